@@ -1,0 +1,207 @@
+/*
+ * smolmc.h -- C-ABI of the MI355X-native ensemble Monte-Carlo engine.
+ *
+ * Drop-in boundary for ONE hot path of CederGroupHub/smol: the
+ * per-flip local correlation / cluster-interaction delta, the Ewald single-flip
+ * delta and the Metropolis / Wang-Landau accept step, batched over independent
+ * replica walkers.  The reference has no C ABI of its own for this path: its
+ * native entry points are the Cython cpdef methods listed below, called from
+ * Python objects.  Each entry point here names the reference interface it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions (same as the reference):
+ *   - occupancies are int32, C-contiguous, values = species codes per site
+ *     (smol/moca/processor/base.py:228-237);
+ *   - index tables are int32 C-contiguous, tensors / outputs are float64;
+ *   - feature vectors handed back are EXTENSIVE (x size) like
+ *     Processor.compute_feature_vector[_change] (processor/expansion.py:184,231);
+ *   - the engine copies every table at smolmc_create(); the caller keeps
+ *     ownership of all buffers it passes; outputs are caller-allocated;
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from smolmc_last_error() (the Python shim raises
+ *     ValueError / RuntimeError like the reference, expansion.py:186-188).
+ *   - a handle is not thread-safe; one host thread drives one device.
+ *
+ * All pointers in this header are HOST pointers unless the name says _dev.
+ */
+#ifndef SMOLMC_H
+#define SMOLMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMOLMC_ABI_VERSION 1
+#define SMOLMC_MAX_CLUSTER_SITES 6 /* largest cluster (sites per cluster) supported */
+
+/* feature_mode */
+#define SMOLMC_FEATURES_CORRELATIONS 0 /* ClusterExpansionProcessor  (expansion.py:39)  */
+#define SMOLMC_FEATURES_INTERACTIONS 1 /* ClusterDecompositionProcessor (expansion.py:243) */
+/* kernel_type (smol/moca/kernel/__init__.py:35-56 mckernel_factory names) */
+#define SMOLMC_KERNEL_METROPOLIS 0 /* kernel/metropolis.py:52 */
+#define SMOLMC_KERNEL_WANGLANDAU 1 /* kernel/wanglandau.py:17 */
+/* step_type (smol/moca/kernel/mcusher.py) */
+#define SMOLMC_STEP_FLIP 0 /* Flip  mcusher.py:151 */
+#define SMOLMC_STEP_SWAP 1 /* Swap  mcusher.py:173 */
+
+/*
+ * Read-only model tables.  Flattened, caller-owned equivalents of the
+ * containers in smol/utils/cluster/container.pyx (OrbitContainer :21,
+ * IntArray2DContainer :287, FloatArray1DContainer :173) and struct.pxd:12-38.
+ */
+typedef struct smolmc_tables {
+    int32_t num_sites;   /* N, length of an occupancy (Processor.num_sites) */
+    int32_t size;        /* P, number of prim cells in the supercell (Processor.size) */
+    int32_t num_orbits;  /* incl. empty cluster (ClusterSubspace.num_orbits) */
+    int32_t num_corr;    /* incl. empty cluster (num_corr_functions) */
+    int32_t max_species; /* largest number of species codes on any site */
+    int32_t n_orb;       /* number of OrbitC records = num_orbits - 1 */
+
+    /* OrbitC records, order of ClusterSubspace.orbits
+     * (struct.pxd:33-38, get_orbit_data smol/utils/cluster/__init__.py:4-15) */
+    const int32_t *orb_id;          /* [n_orb] orbit.id        (>= 1) */
+    const int32_t *orb_bit_id;      /* [n_orb] orbit.bit_id    (>= 1) */
+    const int32_t *orb_nsites;      /* [n_orb] I = tensor_indices.size */
+    const int32_t *orb_nfunc;       /* [n_orb] K = correlation_tensors.size_r */
+    const int32_t *orb_tensor_len;  /* [n_orb] correlation_tensors.size_c */
+    const int32_t *orb_stride_off;  /* [n_orb] offset into tensor_indices[] */
+    const int32_t *tensor_indices;  /* concatenated flat_tensor_indices (orbit.py:268-275) */
+    const int64_t *orb_ctensor_off; /* [n_orb] offset into corr_tensors[] */
+    const double *corr_tensors;     /* concatenated [K x len] row-major (orbit.py:251-266) */
+    const int64_t *orb_itensor_off; /* [n_orb] offset into interaction_tensors[] */
+    const double *interaction_tensors; /* concatenated [len] (expansion.py:186-201) */
+    double offset;                  /* interaction of the empty cluster (evaluator.pxd:20) */
+
+    /* full cluster-site tables: OrbitIndices (clusterspace.py:1329-1366) */
+    const int64_t *full_off; /* [n_orb+1] offsets (int32 entries) into full_idx */
+    const int32_t *full_idx; /* per orbit rows [J_full x I] */
+
+    /* per-site reduced tables: LocalEvalData (processor/expansion.py:24-36,120-156) */
+    const int64_t *site_ptr;  /* [N+1] local-record range of each site (empty if inactive) */
+    const int32_t *loc_orbit; /* [n_loc] index into orb_* records */
+    const double *loc_ratio;  /* [n_loc] cluster_ratio */
+    const int32_t *loc_nrows; /* [n_loc] J_local */
+    const int64_t *loc_off;   /* [n_loc] offset (int32 entries) into loc_idx */
+    const int32_t *loc_idx;   /* rows [J_local x I] */
+
+    /* natural parameters of the cluster-expansion part (Processor.coefs) */
+    int32_t feature_mode;   /* SMOLMC_FEATURES_* */
+    const double *ce_coefs; /* [num_corr] (mode 0) or [num_orbits] (mode 1) */
+
+    /* EwaldProcessor tables (smol/moca/processor/ewald.py:76-101), optional */
+    int32_t has_ewald;
+    int32_t ewald_dim;         /* M */
+    int32_t ewald_width;       /* columns of ewald_inds */
+    const int32_t *ewald_inds; /* [N x ewald_width], -1 = vacancy / absent */
+    const double *ewald_matrix; /* [M x M] */
+    double ewald_coef;          /* coefficient of the Ewald feature (ensemble.py:191-199) */
+
+    /* chemical-potential table (smol/moca/ensemble.py:90-99), optional */
+    int32_t has_mu;
+    int32_t mu_width;
+    const double *mu_table; /* [N x mu_width]; natural parameter -1 appended last */
+
+    /* active sublattices (smol/moca/sublattice.py:23; mcusher.py:55-57) */
+    int32_t n_sublattices;
+    const int64_t *sub_site_ptr;   /* [n_sub+1] ranges into sub_active_sites */
+    const int32_t *sub_active_sites;
+    const int64_t *sub_code_ptr;   /* [n_sub+1] ranges into sub_codes */
+    const int32_t *sub_codes;      /* Sublattice.encoding */
+    const double *sub_probs;       /* [n_sub] sublattice_probabilities (sum to 1) */
+} smolmc_tables;
+
+typedef struct smolmc_config {
+    int32_t n_replicas;  /* walkers owned by this handle (Sampler nwalkers) */
+    int32_t kernel_type; /* SMOLMC_KERNEL_* */
+    int32_t step_type;   /* SMOLMC_STEP_* */
+    int32_t device;      /* HIP device ordinal (ignored by the CPU oracle) */
+    /* Wang-Landau parameters (kernel/wanglandau.py:26-39) */
+    double wl_min_enthalpy, wl_max_enthalpy, wl_bin_size;
+    double wl_flatness, wl_mod_factor, wl_mod_divisor; /* mod_update = m / divisor */
+    int64_t wl_check_period, wl_update_period;
+} smolmc_config;
+
+typedef struct smolmc_handle smolmc_handle;
+
+/* ---- lifetime ----------------------------------------------------------- */
+/* Replaces construction of Processor + Ensemble + one MCKernel per walker
+ * (processor/expansion.py:61-163, ensemble.py:102-217, kernel/base.py:192-239). */
+int smolmc_create(const smolmc_tables *tables, const smolmc_config *config,
+                  smolmc_handle **out);
+int smolmc_destroy(smolmc_handle *h);
+const char *smolmc_last_error(void);
+int smolmc_abi_version(void);
+
+/* ---- sizes -------------------------------------------------------------- */
+int smolmc_num_features(const smolmc_handle *h); /* len(ensemble.natural_parameters) */
+int smolmc_wl_num_levels(const smolmc_handle *h); /* len(np.arange(min,max,bin)) wanglandau.py:107 */
+/* natural parameters vector (Ensemble.natural_parameters, ensemble.py:25,61-65) */
+int smolmc_natural_parameters(const smolmc_handle *h, double *out /*F*/);
+
+/* ---- state: Sampler.setup_sample + MCKernel.compute_initial_trace ------- */
+/* (sampler/sampler.py:386-434, kernel/base.py:345-365, wanglandau.py:290-300).
+ * occ [R x N] int32, seeds [R], temperature [R] (Kelvin; ignored by WL).
+ * Computes the initial features / enthalpy of every walker on the device and
+ * resets step counters.  WL aux arrays are reset only when reset_aux != 0. */
+int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint64_t *seeds,
+                     const double *temperature, int reset_aux);
+/* ThermalKernelMixin.temperature setter (kernel/base.py:418-422), per walker */
+int smolmc_set_temperature(smolmc_handle *h, const double *temperature /*R*/);
+/* any output pointer may be NULL */
+int smolmc_get_state(smolmc_handle *h, int32_t *occ /*RxN*/, double *features /*RxF*/,
+                     double *enthalpy /*R*/, uint64_t *n_accepted /*R*/,
+                     uint64_t *n_steps /*R*/, uint8_t *last_accepted /*R*/);
+/* WangLandau trace extras (wanglandau.py:247-251,268-288); NULLs allowed */
+int smolmc_get_wl(smolmc_handle *h, double *entropy /*RxL*/, int64_t *histogram /*RxL*/,
+                  int64_t *occurrences /*RxL*/, double *mean_features /*RxLxF*/,
+                  double *mod_factor /*R*/);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Advance every walker nsteps MC steps: the body of Sampler.sample
+ * (sampler/sampler.py:195-208) = MCUsher.propose_step + compute_feature_vector_change
+ * + accept + in-place update + trace accumulation, engine RNG (Philox4x32-10
+ * keyed by the walker seed, counter = step index).
+ * Asynchronous on the handle's stream; smolmc_sync() or any get_* waits. */
+int smolmc_run(smolmc_handle *h, int64_t nsteps);
+int smolmc_sync(smolmc_handle *h);
+/* Same loop driven by host-provided proposals ("replay mode"):
+ * steps [R x nsteps x 4] = (site1, code1, site2, code2), -1 = no flip;
+ * uniforms [R x nsteps] = the number rng.random() returned (NaN if not drawn).
+ * accepted_out [R x nsteps] and enthalpy_out [R x nsteps] may be NULL. */
+int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,
+                  const double *uniforms, uint8_t *accepted_out, double *enthalpy_out);
+/* elapsed device time of the last smolmc_run / smolmc_replay launch in ms
+ * (HIP events recorded on the launch stream) */
+int smolmc_last_kernel_ms(smolmc_handle *h, float *ms);
+
+/* ---- evaluator-level entry points (parity + Processor shim) ------------- */
+/* Ensemble.compute_feature_vector (ensemble.py:323-351) for nocc occupancies:
+ * correlations_from_occupancy / interactions_from_occupancy x size
+ * (evaluator.pyx:121-209; expansion.py:165-189,391-414), Ewald feature
+ * (processor/ewald.py:128-145), chemical work.  features [nocc x F]. */
+int smolmc_eval_full(smolmc_handle *h, const int32_t *occ /*nocc x N*/, int nocc,
+                     double *features);
+/* Ensemble.compute_feature_vector_change (ensemble.py:353-376) for nstep steps of
+ * up to 2 sequential flips each on ONE occupancy:
+ * delta_correlations_from_occupancies / delta_interactions_from_occupancies
+ * (evaluator.pyx:211-317) x size with sequential-flip semantics
+ * (expansion.py:217-229), delta_ewald_single_flip (ewald.pyx:9-59), mu table.
+ * flips [nstep x 4] like smolmc_replay; dfeatures [nstep x F]. */
+int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ /*N*/, const int32_t *flips,
+                      int nstep, double *dfeatures);
+
+/* ---- device plumbing (multi-GPU / RCCL glue, optional) ------------------- */
+/* Use an externally created hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int smolmc_set_stream(smolmc_handle *h, void *hip_stream);
+/* Copy per-walker enthalpies (float64[R]) into a DEVICE buffer (for all_gather) */
+int smolmc_export_enthalpy_dev(smolmc_handle *h, double *dst_dev);
+/* Permute per-walker temperatures from a DEVICE or host array after an exchange */
+int smolmc_import_temperature_dev(smolmc_handle *h, const double *src_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOLMC_H */

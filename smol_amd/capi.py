@@ -1,0 +1,408 @@
+"""ctypes mirror of include/smolmc.h (structs + flattening of model tables).
+
+``TableSet`` flattens the Python-side tables (smol_amd.synth / imported arrays)
+into the caller-owned, C-contiguous buffers ``smolmc_tables`` points at, and keeps
+them alive -- the same job smol/utils/cluster/container.pyx does for the
+reference's raw-pointer containers (container.pyx:31-32,99,115-117).
+
+Dtype errors are raised as ``ValueError`` like the reference's typed memoryviews
+("Buffer dtype mismatch", SURVEY.md §8b error conventions).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+FEATURES_CORRELATIONS = 0
+FEATURES_INTERACTIONS = 1
+KERNEL_METROPOLIS = 0
+KERNEL_WANGLANDAU = 1
+STEP_FLIP = 0
+STEP_SWAP = 1
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+class smolmc_tables(C.Structure):
+    _fields_ = [
+        ("num_sites", C.c_int32),
+        ("size", C.c_int32),
+        ("num_orbits", C.c_int32),
+        ("num_corr", C.c_int32),
+        ("max_species", C.c_int32),
+        ("n_orb", C.c_int32),
+        ("orb_id", _i32p),
+        ("orb_bit_id", _i32p),
+        ("orb_nsites", _i32p),
+        ("orb_nfunc", _i32p),
+        ("orb_tensor_len", _i32p),
+        ("orb_stride_off", _i32p),
+        ("tensor_indices", _i32p),
+        ("orb_ctensor_off", _i64p),
+        ("corr_tensors", _f64p),
+        ("orb_itensor_off", _i64p),
+        ("interaction_tensors", _f64p),
+        ("offset", C.c_double),
+        ("full_off", _i64p),
+        ("full_idx", _i32p),
+        ("site_ptr", _i64p),
+        ("loc_orbit", _i32p),
+        ("loc_ratio", _f64p),
+        ("loc_nrows", _i32p),
+        ("loc_off", _i64p),
+        ("loc_idx", _i32p),
+        ("feature_mode", C.c_int32),
+        ("ce_coefs", _f64p),
+        ("has_ewald", C.c_int32),
+        ("ewald_dim", C.c_int32),
+        ("ewald_width", C.c_int32),
+        ("ewald_inds", _i32p),
+        ("ewald_matrix", _f64p),
+        ("ewald_coef", C.c_double),
+        ("has_mu", C.c_int32),
+        ("mu_width", C.c_int32),
+        ("mu_table", _f64p),
+        ("n_sublattices", C.c_int32),
+        ("sub_site_ptr", _i64p),
+        ("sub_active_sites", _i32p),
+        ("sub_code_ptr", _i64p),
+        ("sub_codes", _i32p),
+        ("sub_probs", _f64p),
+    ]
+
+
+class smolmc_config(C.Structure):
+    _fields_ = [
+        ("n_replicas", C.c_int32),
+        ("kernel_type", C.c_int32),
+        ("step_type", C.c_int32),
+        ("device", C.c_int32),
+        ("wl_min_enthalpy", C.c_double),
+        ("wl_max_enthalpy", C.c_double),
+        ("wl_bin_size", C.c_double),
+        ("wl_flatness", C.c_double),
+        ("wl_mod_factor", C.c_double),
+        ("wl_mod_divisor", C.c_double),
+        ("wl_check_period", C.c_int64),
+        ("wl_update_period", C.c_int64),
+    ]
+
+
+def _arr(a, dtype, name):
+    a = np.asarray(a)
+    if a.dtype != dtype:
+        if np.issubdtype(a.dtype, np.integer) and np.issubdtype(dtype, np.integer):
+            a = a.astype(dtype)
+        elif np.issubdtype(dtype, np.floating) and a.dtype.kind in "fiu":
+            a = a.astype(dtype)
+        else:
+            raise ValueError(
+                f"Buffer dtype mismatch for {name}: expected {np.dtype(dtype)} got {a.dtype}"
+            )
+    return np.ascontiguousarray(a)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class TableSet:
+    """Flattened, kept-alive model tables + the ``smolmc_tables`` struct.
+
+    Parameters mirror what the reference assembles across
+    ClusterSubspace / ClusterExpansion / Processor / Ensemble:
+
+    orbit_data       tuple of (id, bit_id, flat_corr_tensors[K,len], strides[I])
+                     -- smol/utils/cluster/__init__.py:4-15
+    full_indices     tuple of int32[J_full, I] per orbit -- clusterspace.py:1329-1366
+    local_tables     dict site -> list of (orbit_pos, rows int32[J,I], ratio)
+                     -- processor/expansion.py:120-138
+    interaction_tensors  list [offset, T_1, ...] -- cofe/expansion.py:186-201
+    coefs            natural parameters of the CE part (num_corr or num_orbits long)
+    sublattices      list of dict(active_sites=int array, codes=int array); inactive
+                     sublattices are simply omitted (mcusher.py:55-57)
+    """
+
+    def __init__(
+        self,
+        num_sites,
+        size,
+        num_orbits,
+        num_corr,
+        orbit_data,
+        full_indices,
+        local_tables,
+        interaction_tensors,
+        coefs,
+        feature_mode,
+        sublattices,
+        nspecies_per_site=None,
+        sublattice_probabilities=None,
+        ewald_inds=None,
+        ewald_matrix=None,
+        ewald_coef=1.0,
+        mu_table=None,
+    ):
+        self._keep = {}
+        k = self._keep
+        t = smolmc_tables()
+        n_orb = len(orbit_data)
+        if n_orb != num_orbits - 1:
+            raise ValueError("orbit_data must hold num_orbits - 1 records")
+        t.num_sites, t.size = int(num_sites), int(size)
+        t.num_orbits, t.num_corr, t.n_orb = int(num_orbits), int(num_corr), n_orb
+        for d in orbit_data:
+            if not isinstance(d[0], (int, np.integer)):
+                raise TypeError("id must be an integer.")  # container.pyx:52-53
+            if not isinstance(d[1], (int, np.integer)):
+                raise TypeError("bit_id must be an integer.")
+            if not isinstance(d[2], np.ndarray) or not isinstance(d[3], np.ndarray):
+                raise TypeError("correlation_tensors / tensor_indices must be numpy arrays.")
+            if d[2].ndim != 2:
+                raise ValueError("correlation_tensors must be 2D.")  # container.pyx:60-61
+            if d[3].ndim != 1:
+                raise ValueError("tensor_indices must be 1D.")
+        k["orb_id"] = np.array([d[0] for d in orbit_data], dtype=np.int32)
+        k["orb_bit_id"] = np.array([d[1] for d in orbit_data], dtype=np.int32)
+        k["orb_nsites"] = np.array([len(d[3]) for d in orbit_data], dtype=np.int32)
+        k["orb_nfunc"] = np.array([d[2].shape[0] for d in orbit_data], dtype=np.int32)
+        k["orb_tensor_len"] = np.array([d[2].shape[1] for d in orbit_data], dtype=np.int32)
+        if k["orb_nsites"].max(initial=0) > 6:
+            raise ValueError("clusters larger than SMOLMC_MAX_CLUSTER_SITES=6 sites")
+        so = np.concatenate(([0], np.cumsum(k["orb_nsites"])))[:-1]
+        k["orb_stride_off"] = so.astype(np.int32)
+        k["tensor_indices"] = np.concatenate(
+            [_arr(d[3], np.int32, "tensor_indices") for d in orbit_data]
+        ).astype(np.int32)
+        lens = k["orb_nfunc"].astype(np.int64) * k["orb_tensor_len"]
+        k["orb_ctensor_off"] = np.concatenate(([0], np.cumsum(lens)))[:-1].astype(np.int64)
+        k["corr_tensors"] = np.concatenate(
+            [_arr(d[2], np.float64, "correlation_tensors").ravel() for d in orbit_data]
+        )
+        k["orb_itensor_off"] = np.concatenate(
+            ([0], np.cumsum(k["orb_tensor_len"].astype(np.int64)))
+        )[:-1].astype(np.int64)
+        if interaction_tensors is None:
+            # evaluator.pyx:58-59 default: sum of correlation tensors over bit combos
+            its = [d[2].sum(axis=0) for d in orbit_data]
+            t.offset = 0.0
+        else:
+            if len(interaction_tensors) != num_orbits:
+                raise ValueError(
+                    "Number of cluster interaction tensors must be equal to the number of orbits."
+                )
+            its = [np.ravel(np.asarray(x, dtype=np.float64)) for x in interaction_tensors[1:]]
+            t.offset = float(interaction_tensors[0])
+        for x, ln in zip(its, k["orb_tensor_len"]):
+            if x.size != ln:
+                raise ValueError("interaction tensor size does not match its orbit")
+        k["interaction_tensors"] = np.ascontiguousarray(np.concatenate(its), dtype=np.float64)
+        # full tables
+        fulls = [_arr(a, np.int32, "cluster indices") for a in full_indices]
+        for a, I in zip(fulls, k["orb_nsites"]):
+            if a.ndim != 2 or a.shape[1] != I:
+                raise ValueError("All arrays must be 2D.")  # container.pyx:309-311
+        k["full_off"] = np.concatenate(([0], np.cumsum([a.size for a in fulls]))).astype(np.int64)
+        k["full_idx"] = (
+            np.concatenate([a.ravel() for a in fulls]) if fulls else np.zeros(0, np.int32)
+        ).astype(np.int32)
+        # local tables
+        site_ptr = np.zeros(num_sites + 1, dtype=np.int64)
+        lo, lr, ln_, loff, lidx = [], [], [], [], []
+        off = 0
+        for s in range(num_sites):
+            for pos, rows, ratio in local_tables.get(s, ()):
+                rows = _arr(rows, np.int32, "local cluster indices")
+                lo.append(pos)
+                lr.append(ratio)
+                ln_.append(rows.shape[0])
+                loff.append(off)
+                lidx.append(rows.ravel())
+                off += rows.size
+            site_ptr[s + 1] = len(lo)
+        k["site_ptr"] = site_ptr
+        k["loc_orbit"] = np.array(lo, dtype=np.int32)
+        k["loc_ratio"] = np.array(lr, dtype=np.float64)
+        k["loc_nrows"] = np.array(ln_, dtype=np.int32)
+        k["loc_off"] = np.array(loff, dtype=np.int64)
+        k["loc_idx"] = (np.concatenate(lidx) if lidx else np.zeros(0, np.int32)).astype(np.int32)
+        # natural parameters
+        t.feature_mode = int(feature_mode)
+        nce = num_corr if feature_mode == FEATURES_CORRELATIONS else num_orbits
+        coefs = _arr(coefs, np.float64, "coefficients")
+        if len(coefs) != nce:
+            raise ValueError(
+                f"The provided coefficients are not the right length. Got {len(coefs)} "
+                f"coefficients, the length must be {nce}"
+            )  # expansion.py:97-103
+        k["ce_coefs"] = coefs
+        # ewald
+        t.has_ewald = 0
+        if ewald_matrix is not None:
+            ei = _arr(ewald_inds, np.int32, "ewald_indices")
+            em = _arr(ewald_matrix, np.float64, "ewald_matrix")
+            if em.ndim != 2 or em.shape[0] != em.shape[1] or ei.shape[0] != num_sites:
+                raise ValueError("malformed Ewald tables")
+            k["ewald_inds"], k["ewald_matrix"] = ei, em
+            t.has_ewald, t.ewald_dim, t.ewald_width = 1, em.shape[0], ei.shape[1]
+            t.ewald_coef = float(ewald_coef)
+        # mu
+        t.has_mu = 0
+        if mu_table is not None:
+            mu = _arr(mu_table, np.float64, "chemical potential table")
+            if mu.ndim != 2 or mu.shape[0] != num_sites:
+                raise ValueError("malformed chemical potential table")
+            k["mu_table"] = mu
+            t.has_mu, t.mu_width = 1, mu.shape[1]
+        # sublattices
+        subs = [s for s in sublattices if len(s["active_sites"]) > 0]
+        t.n_sublattices = len(subs)
+        k["sub_site_ptr"] = np.concatenate(
+            ([0], np.cumsum([len(s["active_sites"]) for s in subs]))
+        ).astype(np.int64)
+        k["sub_active_sites"] = np.concatenate(
+            [np.asarray(s["active_sites"]) for s in subs] or [np.zeros(0)]
+        ).astype(np.int32)
+        k["sub_code_ptr"] = np.concatenate(
+            ([0], np.cumsum([len(s["codes"]) for s in subs]))
+        ).astype(np.int64)
+        k["sub_codes"] = np.concatenate(
+            [np.asarray(s["codes"]) for s in subs] or [np.zeros(0)]
+        ).astype(np.int32)
+        if sublattice_probabilities is None:
+            probs = np.full(len(subs), 1.0 / max(len(subs), 1))
+        else:
+            probs = np.asarray(sublattice_probabilities, dtype=np.float64)
+            if len(probs) != len(subs):
+                raise AttributeError(
+                    "Sublattice probabilities needs to be the same length as sublattices."
+                )  # mcusher.py:62-65
+            if abs(probs.sum() - 1) > 1e-12:
+                raise ValueError("Sublattice probabilities must sum to one.")
+        k["sub_probs"] = np.ascontiguousarray(probs)
+        if nspecies_per_site is None:
+            ms = int(max([len(s["codes"]) for s in subs] + [1]))
+        else:
+            ms = int(np.max(nspecies_per_site))
+        t.max_species = ms
+        self.nspecies_per_site = (
+            None if nspecies_per_site is None else np.asarray(nspecies_per_site, np.int32)
+        )
+        for name, ctype in smolmc_tables._fields_:
+            if name in k:
+                setattr(t, name, _ptr(k[name], ctype._type_))
+        self.struct = t
+        self.sublattices = subs
+        self.num_features = nce + int(t.has_ewald) + int(t.has_mu)
+
+    # convenience -------------------------------------------------------------
+    @property
+    def num_sites(self):
+        return self.struct.num_sites
+
+    @property
+    def natural_parameters(self):
+        p = list(self._keep["ce_coefs"])
+        if self.struct.has_ewald:
+            p.append(self.struct.ewald_coef)
+        if self.struct.has_mu:
+            p.append(-1.0)
+        return np.array(p)
+
+    @classmethod
+    def from_synth(
+        cls,
+        sc,
+        coefs,
+        feature_mode=FEATURES_INTERACTIONS,
+        ewald=None,
+        ewald_coef=1.0,
+        mu_table=None,
+    ):
+        """Build from smol_amd.synth tables (SupercellTables + CE coefficients)."""
+        model = sc.model
+        prim = model.prim
+        its = model.cluster_interaction_tensors(coefs)
+        nsp = np.array([prim.nspecies[b] for b in sc.site_b], dtype=np.int32)
+        subs = []
+        for b in range(prim.nb):
+            sites = np.flatnonzero(sc.site_b == b)
+            S = prim.nspecies[b]
+            subs.append(
+                dict(active_sites=sites if S > 1 else np.zeros(0, int), codes=np.arange(S))
+            )
+        # merge symmetry-equivalent basis sites with identical site spaces into one
+        # sublattice, as Processor.get_sublattices does (processor/base.py).
+        merged = {}
+        for b, s in enumerate(subs):
+            key = prim.labels[b]
+            if key in merged:
+                merged[key]["active_sites"] = np.sort(
+                    np.concatenate((merged[key]["active_sites"], s["active_sites"]))
+                )
+            else:
+                merged[key] = s
+        subs = list(merged.values())
+        ce_coefs = (
+            np.asarray(coefs, float)
+            if feature_mode == FEATURES_CORRELATIONS
+            else model.orbit_multiplicities.astype(float)
+        )
+        return cls(
+            sc.num_sites,
+            sc.size,
+            model.num_orbits,
+            model.num_corr_functions,
+            model.orbit_data(),
+            tuple(sc.full_indices),
+            sc.local_tables(),
+            its,
+            ce_coefs,
+            feature_mode,
+            subs,
+            nspecies_per_site=nsp,
+            ewald_inds=None if ewald is None else ewald[0],
+            ewald_matrix=None if ewald is None else ewald[1],
+            ewald_coef=ewald_coef,
+            mu_table=mu_table,
+        )
+
+
+def make_config(
+    n_replicas,
+    kernel_type=KERNEL_METROPOLIS,
+    step_type=STEP_SWAP,
+    device=0,
+    min_enthalpy=0.0,
+    max_enthalpy=1.0,
+    bin_size=1.0,
+    flatness=0.8,
+    mod_factor=1.0,
+    mod_update=2.0,
+    check_period=1000,
+    update_period=1,
+):
+    """smolmc_config with the WangLandau defaults of kernel/wanglandau.py:34-38,105."""
+    c = smolmc_config()
+    c.n_replicas, c.kernel_type, c.step_type, c.device = (
+        int(n_replicas),
+        int(kernel_type),
+        int(step_type),
+        int(device),
+    )
+    c.wl_min_enthalpy, c.wl_max_enthalpy, c.wl_bin_size = (
+        float(min_enthalpy),
+        float(max_enthalpy),
+        float(bin_size),
+    )
+    c.wl_flatness, c.wl_mod_factor, c.wl_mod_divisor = (
+        float(flatness),
+        float(mod_factor),
+        float(mod_update),
+    )
+    c.wl_check_period, c.wl_update_period = int(check_period), int(update_period)
+    return c

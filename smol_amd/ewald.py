@@ -1,0 +1,229 @@
+"""Own Ewald-summation matrix + index table for the electrostatic term (host setup).
+
+The reference takes the matrix *values* from a third-party package
+(pymatgen.analysis.ewald.EwaldSummation, pinned pymatgen==2025.01.09; call sites
+smol/moca/processor/ewald.py:83-99 and smol/cofe/extern/ewald.py:152-177) which is
+not available here, so absolute values are "parity unpinned" (SURVEY.md §8c).  What
+*is* pinned is everything the hot path does with the matrix: the index table layout
+(smol/cofe/extern/ewald.py:84-97) and the single-flip delta
+(smol/utils/cluster/ewald.pyx:9-59), because oracle, reference core and HIP engine
+are all fed the identical matrix produced here.
+
+Matrix convention (same as the reference's use of it): E = sum_{a,b occupied} M[a,b]
+(smol/moca/processor/ewald.py:141-145), M symmetric, self/point terms on the
+diagonal.  Known-answer check: rocksalt Madelung constant 1.747565.
+"""
+
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+from scipy.special import erfc
+
+CONV_FACT = 14.399645478425668  # e^2 / (4 pi eps0) in eV * Angstrom
+
+
+def ewald_indices(nspecies_per_site, vacancy_codes=None):
+    """Index table int32[N, max_species]: running counter over (site, species),
+    -1 where a site has no such species or the species is a vacancy.
+
+    Restates smol/cofe/extern/ewald.py:84-97.  ``vacancy_codes`` maps site ->
+    set of species codes that are vacancies (skipped, -1).
+    """
+    nsp = np.asarray(nspecies_per_site, dtype=np.int64)
+    width = int(nsp.max())
+    inds = -np.ones((len(nsp), width), dtype=np.int32)
+    c = 0
+    for s, S in enumerate(nsp):
+        vac = () if vacancy_codes is None else vacancy_codes.get(s, ())
+        for code in range(S):
+            if code in vac:
+                continue
+            inds[s, code] = c
+            c += 1
+    return np.ascontiguousarray(inds), c
+
+
+def _geometric_kernel(lattice, frac, eta=None, acc=12.0):
+    """g[i,j] such that E = sum_ij q_i q_j g[i,j] (incl. i==j self-image terms,
+    excluding the -sqrt(eta/pi) point term which is returned separately)."""
+    lattice = np.asarray(lattice, float)
+    frac = np.asarray(frac, float)
+    n = len(frac)
+    vol = abs(np.linalg.det(lattice))
+    if eta is None:
+        eta = (n * 0.01 / vol) ** (1 / 3) * np.pi  # same heuristic family as common codes
+        eta = max(eta, 0.05)
+    sq = np.sqrt(eta)
+    rcut = np.sqrt(acc / eta) if acc else 6.0 / sq
+    gcut = 2 * sq * np.sqrt(acc) if acc else 12.0 * sq
+    cart = frac @ lattice
+    recip = 2 * np.pi * np.linalg.inv(lattice).T  # rows = reciprocal vectors
+    # real space
+    lens = np.linalg.norm(lattice, axis=1)
+    heights = vol / np.array(
+        [
+            np.linalg.norm(np.cross(lattice[1], lattice[2])),
+            np.linalg.norm(np.cross(lattice[2], lattice[0])),
+            np.linalg.norm(np.cross(lattice[0], lattice[1])),
+        ]
+    )
+    nmax = np.ceil(rcut / heights).astype(int) + 1
+    shifts = np.array(
+        list(itertools.product(*[range(-m, m + 1) for m in nmax])), dtype=float
+    ) @ lattice
+    d0 = cart[None, :, :] - cart[:, None, :]  # (n,n,3) r_j - r_i
+    g_real = np.zeros((n, n))
+    for chunk in np.array_split(shifts, max(1, len(shifts) // 64)):
+        d = d0[:, :, None, :] + chunk[None, None, :, :]
+        r = np.linalg.norm(d, axis=-1)
+        mask = (r > 1e-8) & (r <= rcut)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            term = np.where(mask, erfc(sq * r) / r, 0.0)
+        g_real += term.sum(axis=-1)
+    g_real *= 0.5
+    # reciprocal space
+    rheights = 2 * np.pi / lens  # conservative bound on reciprocal spacing
+    rl = np.linalg.norm(recip, axis=1)
+    rvol = abs(np.linalg.det(recip))
+    rh = rvol / np.array(
+        [
+            np.linalg.norm(np.cross(recip[1], recip[2])),
+            np.linalg.norm(np.cross(recip[2], recip[0])),
+            np.linalg.norm(np.cross(recip[0], recip[1])),
+        ]
+    )
+    gmax = np.ceil(gcut / rh).astype(int) + 1
+    hkl = np.array(list(itertools.product(*[range(-m, m + 1) for m in gmax])), dtype=float)
+    hkl = hkl[np.any(hkl != 0, axis=1)]
+    gv = hkl @ recip
+    g2 = np.sum(gv * gv, axis=1)
+    keep = g2 <= gcut * gcut
+    gv, g2 = gv[keep], g2[keep]
+    w = np.exp(-g2 / (4 * eta)) / g2
+    phase = cart @ gv.T  # (n, ng)
+    cs, sn = np.cos(phase), np.sin(phase)
+    g_recip = (cs * w) @ cs.T + (sn * w) @ sn.T
+    g_recip *= 2 * np.pi / vol
+    point = -np.sqrt(eta / np.pi)
+    del rheights, rl
+    return g_real, g_recip, point, eta
+
+
+def ewald_matrix(lattice, frac, charges, eta=None, acc=12.0):
+    """Dense Ewald matrix for point charges ``charges`` at ``frac`` (eV)."""
+    g_real, g_recip, point, _ = _geometric_kernel(lattice, frac, eta, acc)
+    q = np.asarray(charges, float)
+    m = (g_real + g_recip) * np.outer(q, q)
+    m[np.diag_indices_from(m)] += point * q * q
+    m *= CONV_FACT
+    return np.ascontiguousarray(0.5 * (m + m.T))
+
+
+def supercell_ewald(sc, eta=None, acc=12.0):
+    """(ewald_inds int32[N,Smax], matrix float64[M,M]) for a SupercellTables.
+
+    Exploits translation invariance: the geometric kernel is evaluated for the
+    first lattice point of each basis site against all sites (nb x N block), then
+    expanded to the dense (M, M) matrix the reference layout requires.
+    """
+    prim = sc.model.prim
+    P, N = sc.size, sc.num_sites
+    nsp = np.array([prim.nspecies[b] for b in sc.site_b])
+    inds, M = ewald_indices(nsp)
+    # supercell lattice and site fractional coords (in supercell basis)
+    sc_lat = sc.scmatrix.astype(float) @ prim.lattice
+    inv = np.linalg.inv(sc.scmatrix.astype(float))
+    frac_prim = prim.frac_coords[sc.site_b] + sc.lattice_points[sc.site_t]
+    frac_sc = frac_prim @ inv
+    # kernel rows for the representative site of every basis index
+    g_rows = np.zeros((prim.nb, N))
+    point = 0.0
+    for b in range(prim.nb):
+        # place representative first; kernel of (rep, all sites)
+        rep = b * P
+        g_real, g_recip, point, eta = _pair_rows(sc_lat, frac_sc, rep, eta, acc)
+        g_rows[b] = g_real + g_recip
+    # expand by translation: g[s1, s2] = g_rows[b1][ b2*P + idx(t2 - t1) ]
+    pts = sc.lattice_points
+    g_full = np.empty((N, N))
+    for t1 in range(P):
+        rel = sc._point_index(pts - pts[t1][None, :])  # index of (t2 - t1)
+        for b1 in range(prim.nb):
+            row = g_rows[b1].reshape(prim.nb, P)[:, rel].reshape(-1)
+            g_full[b1 * P + t1] = row
+    g_full = 0.5 * (g_full + g_full.T)
+    # species-resolved matrix
+    qs = np.zeros(M)
+    site_of = np.zeros(M, dtype=np.int64)
+    for s in range(N):
+        for code in range(nsp[s]):
+            k = inds[s, code]
+            if k >= 0:
+                qs[k] = prim.charges[sc.site_b[s]][code]
+                site_of[k] = s
+    mat = g_full[np.ix_(site_of, site_of)] * np.outer(qs, qs)
+    # two species on the same site never coexist; keep kernel value (as the
+    # reference's overlapping-site structure would) but the self term only on diag
+    mat[np.diag_indices_from(mat)] += point * qs * qs
+    mat *= CONV_FACT
+    return inds, np.ascontiguousarray(mat)
+
+
+def _pair_rows(lattice, frac, rep, eta, acc):
+    """Kernel row of site ``rep`` against all sites (real, recip, point, eta)."""
+    lattice = np.asarray(lattice, float)
+    n = len(frac)
+    vol = abs(np.linalg.det(lattice))
+    if eta is None:
+        eta = max((n * 0.01 / vol) ** (1 / 3) * np.pi, 0.05)
+    sq = np.sqrt(eta)
+    rcut = np.sqrt(acc / eta)
+    gcut = 2 * sq * np.sqrt(acc)
+    cart = frac @ lattice
+    heights = vol / np.array(
+        [
+            np.linalg.norm(np.cross(lattice[1], lattice[2])),
+            np.linalg.norm(np.cross(lattice[2], lattice[0])),
+            np.linalg.norm(np.cross(lattice[0], lattice[1])),
+        ]
+    )
+    nmax = np.ceil(rcut / heights).astype(int) + 1
+    shifts = np.array(
+        list(itertools.product(*[range(-m, m + 1) for m in nmax])), dtype=float
+    ) @ lattice
+    d0 = cart - cart[rep]
+    g_real = np.zeros(n)
+    for chunk in np.array_split(shifts, max(1, len(shifts) * n // 2_000_000 + 1)):
+        r = np.linalg.norm(d0[:, None, :] + chunk[None, :, :], axis=-1)
+        mask = (r > 1e-8) & (r <= rcut)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g_real += np.where(mask, erfc(sq * r) / r, 0.0).sum(axis=-1)
+    g_real *= 0.5
+    recip = 2 * np.pi * np.linalg.inv(lattice).T
+    rvol = abs(np.linalg.det(recip))
+    rh = rvol / np.array(
+        [
+            np.linalg.norm(np.cross(recip[1], recip[2])),
+            np.linalg.norm(np.cross(recip[2], recip[0])),
+            np.linalg.norm(np.cross(recip[0], recip[1])),
+        ]
+    )
+    gmax = np.ceil(gcut / rh).astype(int) + 1
+    hkl = np.array(list(itertools.product(*[range(-m, m + 1) for m in gmax])), dtype=float)
+    hkl = hkl[np.any(hkl != 0, axis=1)]
+    gv = hkl @ recip
+    g2 = np.sum(gv * gv, axis=1)
+    keep = g2 <= gcut * gcut
+    gv, g2 = gv[keep], g2[keep]
+    w = np.exp(-g2 / (4 * eta)) / g2
+    g_recip = np.zeros(n)
+    for gc, wc in zip(
+        np.array_split(gv, max(1, len(gv) * n // 4_000_000 + 1)),
+        np.array_split(w, max(1, len(gv) * n // 4_000_000 + 1)),
+    ):
+        phase = d0 @ gc.T
+        g_recip += np.cos(phase) @ wc
+    g_recip *= 2 * np.pi / vol
+    return g_real, g_recip, -np.sqrt(eta / np.pi), eta

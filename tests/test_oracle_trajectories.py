@@ -1,0 +1,130 @@
+"""Pin the oracle's kernel-level control flow (Metropolis / Wang-Landau / trace
+accumulation) against trajectories whose every delta came from the reference's
+compiled core (tests/golden/trajectories.npz, made by tests/golden/make_golden.py).
+
+Accept masks and final occupancies: bit-exact.  Running enthalpies: 1e-10 relative
+(BASELINE.json north_star tolerance).
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from smol_amd import capi
+from tests.cases import GOLD, load_case, tables_for
+
+T = np.load(os.path.join(GOLD, "trajectories.npz"))
+MODES = {"int": capi.FEATURES_INTERACTIONS, "corr": capi.FEATURES_CORRELATIONS}
+
+
+def _check(mc, key, H_key="H", rtol=1e-10):
+    acc, H = mc.replay(T[f"{key}_steps"][None], T[f"{key}_u"][None])
+    assert np.array_equal(acc[0], T[f"{key}_accepted"])
+    np.testing.assert_allclose(H[0], T[f"{key}_{H_key}"], rtol=rtol, atol=1e-9)
+    st = mc.get_state()
+    assert np.array_equal(st["occupancy"][0], T[f"{key}_occ_final"])
+    np.testing.assert_allclose(st["features"][0], T[f"{key}_feat_final"], rtol=1e-10, atol=1e-8)
+    assert st["n_accepted"][0] == T[f"{key}_accepted"].sum()
+    return st
+
+
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_metropolis_swap_replay(mode):
+    tab = tables_for("fcc_prim666_triplets", MODES[mode])
+    mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    mc.set_state(T["B_occ0"][None], [0], T["B_T"])
+    _check(mc, f"B_swap_{mode}")
+
+
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_metropolis_semigrand_flip_ewald_replay(mode):
+    tab = tables_for("rocksalt444_ewald", MODES[mode], mu_table=T["C_mu"])
+    mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    mc.set_state(T["C_occ0"][None], [0], T["C_T"])
+    _check(mc, f"C_flip_{mode}")
+
+
+def test_metropolis_swap_ewald_replay():
+    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=T["C_mu"])
+    mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    mc.set_state(T["C_occ0"][None], [0], T["C_T"])
+    _check(mc, "C_swap_int")
+
+
+@pytest.mark.parametrize("tag", ["B_wl", "B_wlflat"])
+def test_wang_landau_replay(tag):
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    w = T[f"{tag}_window"]
+    cfg = capi.make_config(1, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=w[0],
+                           max_enthalpy=w[1], bin_size=w[2], check_period=int(T[f"{tag}_check"][0]))
+    mc = orc.OracleMC(tab, cfg)
+    assert mc.L == len(T[f"{tag}_levels"])
+    mc.set_state(T["B_occ0"][None], [0], [0.0])
+    _check(mc, tag)
+    wl = mc.get_wl()
+    np.testing.assert_allclose(wl["entropy"][0], T[f"{tag}_entropy"], rtol=0, atol=0)
+    assert np.array_equal(wl["histogram"][0], T[f"{tag}_histogram"])
+    assert np.array_equal(wl["occurrences"][0], T[f"{tag}_occurrences"])
+    np.testing.assert_allclose(wl["mean_features"][0], T[f"{tag}_mean_features"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(wl["mod_factor"], T[f"{tag}_mod_factor"])
+
+
+def test_native_stream_invariants():
+    """Kernel stepping invariants of tests/test_moca/test_kernel.py:109-170 and
+    tests/test_moca/test_sampler.py:59-84 on the engine's own RNG stream."""
+    c = load_case("fcc_prim666_triplets")
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    R = 3
+    mc = orc.OracleMC(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    occ0 = np.tile(T["B_occ0"], (R, 1))
+    mc.set_state(occ0, [11, 12, 13], [900.0, 1500.0, 5000.0])
+    ev = orc.OracleEvaluator(tab)
+    nat = ev.natural_parameters()
+    prev = mc.get_state()
+    for _ in range(40):
+        mc.run(1)
+        st = mc.get_state()
+        for r in range(R):
+            changed = not np.array_equal(st["occupancy"][r], prev["occupancy"][r])
+            assert changed == bool(st["accepted"][r]) or not changed
+            f = ev.feature_vector(st["occupancy"][r])
+            np.testing.assert_allclose(st["features"][r], f, rtol=1e-11, atol=5e-10)
+            np.testing.assert_allclose(st["enthalpy"][r], nat @ f, rtol=1e-11, atol=5e-10)
+            # canonical: composition conserved
+            assert st["occupancy"][r].sum() == occ0[r].sum()
+        prev = st
+    mc.run(2000)
+    st = mc.get_state()
+    eff = st["n_accepted"] / st["n_steps"]
+    assert eff[0] < eff[1] < eff[2]  # hotter walkers accept more
+
+
+def test_usher_statistics():
+    """Proposal statistics (tests/test_moca/test_mcushers.py:124-196): sites uniform over
+    the active sublattice, swap partner has a different species, flip code uniform over
+    the alternatives."""
+    c = load_case("rocksalt444_ewald")
+    tab = tables_for("rocksalt444_ewald", MODES["int"])
+    occ0 = T["C_occ0"]
+    nact = c["sc"].size
+    for step_type in (capi.STEP_FLIP, capi.STEP_SWAP):
+        mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, step_type))
+        mc.set_state(occ0[None], [2024], [1000.0])
+        counts = np.zeros(c["sc"].num_sites)
+        codes = np.zeros(3)
+        n = 30000
+        for k in range(n):
+            nf, fl = mc.propose(0, k)
+            counts[fl[0]] += 1
+            if step_type == capi.STEP_FLIP:
+                assert nf == 1 and fl[1] != occ0[fl[0]]
+                codes[fl[1]] += 1
+            else:
+                assert nf == 2
+                assert occ0[fl[2]] != occ0[fl[0]]
+                assert fl[1] == occ0[fl[2]] and fl[3] == occ0[fl[0]]
+        assert counts[nact:].sum() == 0  # anions are never proposed
+        p = counts[:nact] / n
+        assert abs(p - 1 / nact).max() < 5 * np.sqrt(1 / nact / n)
