@@ -1,0 +1,1654 @@
+// smolmc_hip.hip -- MI355X (gfx950) ensemble Monte-Carlo engine: HIP kernels + C-ABI.
+//
+// Hot path: per-flip local cluster-interaction / correlation delta
+// (smol/utils/cluster/evaluator.pyx:211-317), Ewald single-flip delta
+// (smol/utils/cluster/ewald.pyx:9-59), Metropolis / Wang-Landau accept
+// (smol/moca/kernel/metropolis.py:31-49, wanglandau.py:186-266), ushers
+// (smol/moca/kernel/mcusher.py:154-200), batched over independent walkers
+// (smol/moca/sampler/sampler.py:195-208, :436-440).
+//
+// Design (DESIGN.md has the long form):
+//   * one 64-lane wavefront owns one Markov chain for the whole launch; 4 chains
+//     per 256-thread workgroup share the read-only tables staged in LDS;
+//   * the chain's occupancy lives in LDS as one byte per site for the whole launch
+//     (loaded / stored coalesced once per launch); per-site cluster-member index
+//     rows stream coalesced from L2/HBM ([site][member][slot], slot = lane);
+//   * every lane evaluates <= NSLOT clusters of the flipped site, the enthalpy
+//     delta is a DPP wave reduction, the accept decision is wave-uniform;
+//   * feature (trace) deltas are accumulated per lane in LDS and reduced once per
+//     launch; Philox4x32-10 counter RNG generated 16 steps at a time across lanes.
+// MFMA is not used: the work is sparse integer gathers + table lookups.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/smolmc.h"
+#include "philox.h"
+
+// ----------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string &m) {
+    g_err = m;
+    return 1;
+}
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess)                                                             \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+static const double SMOLMC_KB = 8.617333262145e-5; // smol/constants.py:4
+
+// ----------------------------------------------------------------------------
+// device-side parameter block
+// ----------------------------------------------------------------------------
+struct KParams {
+    // model geometry
+    int N, Npad, Fce, F, nclasses, Cpad, Mmax, nsub, step_type;
+    int has_ewald, has_mu, ew_W, ew_M, mu_W, corr_mode;
+    // optimised MC tables
+    const void *idx;              // IdxT [N][Mmax][Cpad]
+    const uint8_t *site_class;    // [N] (255 = no clusters)
+    const uint4 *descA;           // [nclasses][Cpad]  {xoff, u16 strides[6]}
+    const uint4 *descB;           // [nclasses][Cpad]  {foff, tlen, feat|K<<16, 0}
+    const double *slot_fs;        // [nclasses][Cpad]  feature scale size/(ratio*J)
+    const int *cls_niter;         // [nclasses]
+    const double *xt;             // decision tensors (per class), xt_len doubles
+    const double *ft;             // feature tensors, ft_len doubles
+    int xt_len, ft_len;
+    // ewald / mu
+    const int *ew_inds;           // [N][ew_W]
+    const double *ew_Mt;          // [M][M] transposed ewald matrix
+    double ew_coef;
+    const double *mu;             // [N][mu_W]
+    // sublattices
+    const int *sub_ptr;           // [nsub+1]
+    const int *sub_sites;         // concatenated active sites
+    const int *sub_base;          // [nsub] first site if contiguous else -1
+    const int *sub_code_ptr;      // [nsub+1]
+    const int *sub_codes;
+    const double *sub_cum;        // [nsub] cumulative probabilities
+    // walker state
+    int R;
+    uint8_t *occ;                 // [R][Npad]
+    double *enthalpy;             // [R]
+    double *features;             // [R][F]
+    const double *beta;           // [R]
+    const uint64_t *seeds;        // [R]
+    uint64_t *nsteps, *nacc;      // [R]
+    uint8_t *last_acc;            // [R]
+    long long steps_to_run;
+    // replay
+    const int *rp_steps;          // [R][nsteps][4]
+    const double *rp_u;           // [R][nsteps]
+    uint8_t *rp_acc;              // [R][nsteps]
+    double *rp_H;                 // [R][nsteps]
+    // Wang-Landau
+    int L;
+    double wl_min, wl_max, wl_bin, wl_flat, wl_div;
+    long long wl_check, wl_update;
+    double *wl_entropy;           // [R][L]
+    long long *wl_hist;           // [R][L]
+    long long *wl_occur;          // [R][L]
+    double *wl_meanf;             // [R][L][F]
+    double *wl_m;                 // [R]
+    long long *wl_counter;        // [R]
+    // lds layout (bytes)
+    int lds_tables, lds_per_wave;
+};
+
+// ----------------------------------------------------------------------------
+// wave helpers
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    // inclusive DPP scan inside each 16-lane row, then row broadcasts; lane 63 holds
+    // the total, returned wave-uniform.
+#define SMOLMC_DPP_STEP(ctrl, rmask)                                                       \
+    {                                                                                      \
+        int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false); \
+        int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
+        v += __hiloint2double(hi_, lo_);                                                   \
+    }
+    SMOLMC_DPP_STEP(0x111, 0xf) // row_shr:1
+    SMOLMC_DPP_STEP(0x112, 0xf) // row_shr:2
+    SMOLMC_DPP_STEP(0x114, 0xf) // row_shr:4
+    SMOLMC_DPP_STEP(0x118, 0xf) // row_shr:8
+    SMOLMC_DPP_STEP(0x142, 0xa) // row_bcast:15 -> rows 1,3
+    SMOLMC_DPP_STEP(0x143, 0xc) // row_bcast:31 -> rows 2,3
+#undef SMOLMC_DPP_STEP
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ double uni_d(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// exact floor(x / y), y > 0 : Python's float // (wanglandau.py:180)
+__device__ __forceinline__ double floordiv_exact(double x, double y) {
+    double q = floor(x / y);
+    double r = fma(-q, y, x);
+    if (r < 0) q -= 1.0;
+    else if (r >= y) q += 1.0;
+    return q;
+}
+
+struct Lds {
+    const uint4 *descA;
+    const uint4 *descB;
+    const double *slot_fs;
+    const double *xt;
+    const double *ft;
+    const uint8_t *site_class;
+    const int *cls_niter;
+    uint8_t *occ;   // this wave's occupancy bytes
+    double *acc;    // this wave's feature accumulators [Fce][64]  (Metropolis)
+    double *wl_S;   // WL: entropy [L]
+    long long *wl_H; // WL: histogram [L]
+    double *wl_cf;  // WL: current features [F]
+};
+
+// u16 stride m out of the packed descriptor words
+__device__ __forceinline__ int stride_of(const uint4 &a, int m) {
+    uint32_t w = (m < 2) ? a.y : (m < 4 ? a.z : a.w);
+    return (m & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+}
+
+// Evaluate one cluster slot of a flip at site s (old code -> new code).
+//   GENERIC: every member of the cluster row is gathered (the flipped site included)
+//            -> exactly the reference index arithmetic, handles aliased rows.
+//   !GENERIC: the row excludes the flipped site; its stride is st[0].
+//   PATCH: occupancy seen is the LDS state with site ps overridden to pc (second
+//          flip of a swap sees the first, processor/expansion.py:217-229).
+template <typename IdxT, int MM, bool GENERIC, bool PATCH>
+__device__ __forceinline__ double eval_slot(const KParams &P, const Lds &L, int cls, int c, int s,
+                                            int oldc, int newc, int ps, int pc, int &ind_i,
+                                            int &ind_f) {
+    const uint4 a = L.descA[cls * P.Cpad + c];
+    const IdxT *ip = (const IdxT *)P.idx + ((size_t)s * P.Mmax) * P.Cpad + c;
+    int x[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) x[m] = (int)ip[(size_t)m * P.Cpad];
+    int bi = 0, bf = 0;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        int v = L.occ[x[m]];
+        if (PATCH) v = (x[m] == ps) ? pc : v;
+        if (GENERIC) {
+            int st = stride_of(a, m);
+            int vf = (x[m] == s) ? newc : v;
+            bi += st * v;
+            bf += st * vf;
+        } else {
+            bi += stride_of(a, m + 1) * v;
+        }
+    }
+    if (!GENERIC) {
+        int ss = stride_of(a, 0);
+        bf = bi + ss * newc;
+        bi = bi + ss * oldc;
+    }
+    ind_i = bi;
+    ind_f = bf;
+    return L.xt[a.x + bf] - L.xt[a.x + bi];
+}
+
+// feature accumulation of one accepted slot (Metropolis: lane-private LDS cells)
+template <bool WL>
+__device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int cls, int c, int lane,
+                                           int ind_i, int ind_f) {
+    const uint4 b = L.descB[cls * P.Cpad + c];
+    const int K = (int)(b.z >> 16), feat = (int)(b.z & 0xffffu);
+    const double fs = L.slot_fs[cls * P.Cpad + c];
+    for (int k = 0; k < K; ++k) {
+        const double *t = L.ft + b.x + (size_t)k * b.y;
+        double d = t[ind_f] - t[ind_i];
+        if (WL) {
+            // WL needs the reduced current features every step: LDS atomics
+            __hip_atomic_fetch_add(&L.wl_cf[feat + k], fs * d, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            double *cell = L.acc + (size_t)(feat + k) * 64 + lane;
+            *cell = fma(fs, d, *cell);
+        }
+    }
+}
+
+// Ewald delta of one flip (ewald.pyx:38-58), wave-parallel over sites; returns the
+// lane-partial (caller reduces).  Reads ROWS of the transposed matrix, i.e. the same
+// entries M[i, add] / M[j, sub] the reference reads as columns.
+template <bool PATCH>
+__device__ __forceinline__ double ewald_partial(const KParams &P, const Lds &L, int lane, int s,
+                                                int oldc, int newc, int ps, int pc) {
+    const int W = P.ew_W;
+    const int add = P.ew_inds[(size_t)s * W + newc];
+    const int sub = P.ew_inds[(size_t)s * W + oldc];
+    const double *radd = P.ew_Mt + (size_t)(add < 0 ? 0 : add) * P.ew_M;
+    const double *rsub = P.ew_Mt + (size_t)(sub < 0 ? 0 : sub) * P.ew_M;
+    double out = 0;
+    for (int k = lane; k < P.N; k += 64) {
+        int v = L.occ[k];
+        if (PATCH) v = (k == ps) ? pc : v;
+        int vf = (k == s) ? newc : v;
+        int i = P.ew_inds[(size_t)k * W + vf];
+        int j = (k == s) ? P.ew_inds[(size_t)k * W + v] : i;
+        double o = 0;
+        if (i != -1 && add != -1) o += (i != add ? 2.0 : 1.0) * radd[i];
+        if (j != -1 && sub != -1) o -= (j != sub ? 2.0 : 1.0) * rsub[j];
+        out += o;
+    }
+    return out;
+}
+
+// ----------------------------------------------------------------------------
+// the Monte-Carlo kernel
+// ----------------------------------------------------------------------------
+template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
+__global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int replay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+
+    // ---- stage read-only tables in LDS (shared by the workgroup) -------------
+    unsigned char *sp = smem;
+    uint4 *s_descA = (uint4 *)sp;               sp += (size_t)P.nclasses * P.Cpad * 16;
+    uint4 *s_descB = (uint4 *)sp;               sp += (size_t)P.nclasses * P.Cpad * 16;
+    double *s_fs = (double *)sp;                sp += (size_t)P.nclasses * P.Cpad * 8;
+    double *s_xt = (double *)sp;                sp += (size_t)P.xt_len * 8;
+    double *s_ft = (double *)sp;                sp += (size_t)P.ft_len * 8;
+    int *s_niter = (int *)sp;                   sp += (size_t)((P.nclasses + 3) & ~3) * 4;
+    uint8_t *s_cls = (uint8_t *)sp;
+    for (int i = threadIdx.x; i < P.nclasses * P.Cpad; i += blockDim.x) {
+        s_descA[i] = P.descA[i];
+        s_descB[i] = P.descB[i];
+        s_fs[i] = P.slot_fs[i];
+    }
+    for (int i = threadIdx.x; i < P.xt_len; i += blockDim.x) s_xt[i] = P.xt[i];
+    for (int i = threadIdx.x; i < P.ft_len; i += blockDim.x) s_ft[i] = P.ft[i];
+    for (int i = threadIdx.x; i < P.nclasses; i += blockDim.x) s_niter[i] = P.cls_niter[i];
+    if (P.nclasses > 1)
+        for (int i = threadIdx.x; i < P.N; i += blockDim.x) s_cls[i] = P.site_class[i];
+
+    Lds L;
+    L.descA = s_descA; L.descB = s_descB; L.slot_fs = s_fs; L.xt = s_xt; L.ft = s_ft;
+    L.site_class = s_cls; L.cls_niter = s_niter;
+    unsigned char *wp = smem + P.lds_tables + (size_t)wave * P.lds_per_wave;
+    L.occ = wp;
+    wp += P.Npad;
+    L.acc = nullptr; L.wl_S = nullptr; L.wl_H = nullptr; L.wl_cf = nullptr;
+    if (WL) {
+        L.wl_S = (double *)wp;        wp += (size_t)P.L * 8;
+        L.wl_H = (long long *)wp;     wp += (size_t)P.L * 8;
+        L.wl_cf = (double *)wp;
+    } else {
+        L.acc = (double *)wp;
+    }
+
+    // ---- this wave's chain: occupancy -> LDS (coalesced 16-byte loads) --------
+    const bool live = r < P.R;
+    if (live) {
+        const uint4 *src = (const uint4 *)(P.occ + (size_t)r * P.Npad);
+        uint4 *dst = (uint4 *)L.occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+        if (WL) {
+            for (int i = lane; i < P.L; i += 64) {
+                L.wl_S[i] = P.wl_entropy[(size_t)r * P.L + i];
+                L.wl_H[i] = P.wl_hist[(size_t)r * P.L + i];
+            }
+            for (int i = lane; i < P.F; i += 64) L.wl_cf[i] = P.features[(size_t)r * P.F + i];
+        } else {
+            for (int i = lane; i < P.Fce * 64; i += 64) L.acc[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    // ---- chain registers ------------------------------------------------------
+    double H = P.enthalpy[r];
+    const double beta = WL ? 0.0 : P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    double acc_ew = 0.0, acc_mu = 0.0; // Ewald / chemical-work feature deltas (uniform)
+    int last_acc = 1;
+    double wl_m = 0.0;
+    long long wl_counter = 0;
+    if (WL) {
+        wl_m = P.wl_m[r];
+        wl_counter = P.wl_counter[r];
+    }
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0; // RNG batch: lane l = block (l&3) of step base+(l>>2)
+    unsigned long long batch_base = ~0ull;
+
+    for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
+        // ================= proposal =========================================
+        int nfl = 0, s1 = 0, n1 = 0, o1 = 0, s2 = 0, n2 = 0, o2 = 0;
+        double u = 0.0;
+        if (replay) {
+            const int *st = P.rp_steps + ((size_t)r * P.steps_to_run + it_step) * 4;
+            int a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3];
+            u = P.rp_u[(size_t)r * P.steps_to_run + it_step];
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing
+            a0 = uni(a0); a1 = uni(a1); a2 = uni(a2); a3 = uni(a3);
+            u = uni_d(u);
+            if (a0 >= 0) { nfl = 1; s1 = a0; n1 = a1; o1 = uni((int)L.occ[s1]); }
+            if (a2 >= 0) { nfl = 2; s2 = a2; n2 = a3; o2 = uni((int)L.occ[s2]); if (s2 == s1) o2 = n1; }
+        } else {
+            const unsigned long long base = step & ~15ull;
+            if (base != batch_base) {
+                batch_base = base;
+                unsigned long long st = base + (unsigned)(lane >> 2);
+                philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                             0u, key0, key1);
+                W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            }
+            const int l4 = (int)(step & 15ull) * 4;
+            const uint32_t w_sub = rdlane(W0, l4), w_site = rdlane(W1, l4);
+            u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
+            // sublattice: MCUsher.get_random_sublattice (mcusher.py:146-148)
+            int sl = 0;
+            if (P.nsub > 1) {
+                const double x = (double)w_sub * (1.0 / 4294967296.0);
+                sl = P.nsub - 1;
+                for (int q = P.nsub - 2; q >= 0; --q)
+                    if (x < P.sub_cum[q]) sl = q;
+            }
+            const int p0 = P.sub_ptr[sl];
+            const uint32_t nact = (uint32_t)(P.sub_ptr[sl + 1] - p0);
+            const int sbase = P.sub_base[sl];
+            const uint32_t k1 = __umulhi(w_site, nact);
+            s1 = sbase >= 0 ? sbase + (int)k1 : P.sub_sites[p0 + k1];
+            s1 = uni(s1);
+            o1 = uni((int)L.occ[s1]);
+            if (P.step_type == SMOLMC_STEP_FLIP) {
+                // Flip.propose_step (mcusher.py:154-170)
+                const int c0 = P.sub_code_ptr[sl];
+                const uint32_t nc = (uint32_t)(P.sub_code_ptr[sl + 1] - c0);
+                const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), nc - 1);
+                int code = -1;
+                uint32_t seen = 0;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    int cc = P.sub_codes[c0 + c];
+                    if (cc == o1) continue;
+                    if (seen == kk && code < 0) code = cc;
+                    seen++;
+                }
+                n1 = uni(code);
+                nfl = 1;
+            } else {
+                // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate
+                // sequence c_t = W(step, 1 + t/4, t%4)
+                int found = -1;
+                {
+                    int selsite = -1;
+                    const uint32_t ws[4] = {W0, W1, W2, W3};
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const uint32_t kc = __umulhi(ws[j], nact);
+                        const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                        if ((int)L.occ[cs] != o1) selsite = cs;
+                    }
+                    unsigned long long m = __ballot(selsite >= 0) & (0xEull << l4);
+                    if (m) found = (int)rdlane((uint32_t)selsite, __ffsll((long long)m) - 1);
+                }
+                if (found < 0) {
+                    // rare: continue the candidate sequence with blocks 4 + 64 q + lane
+                    for (uint32_t q = 0;; ++q) {
+                        philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                     4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                        int selsite = -1;
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) {
+                            const uint32_t kc = __umulhi(o.w[j], nact);
+                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            if ((int)L.occ[cs] != o1) selsite = cs;
+                        }
+                        unsigned long long m = __ballot(selsite >= 0);
+                        if (m) {
+                            found = (int)rdlane((uint32_t)selsite, __ffsll((long long)m) - 1);
+                            break;
+                        }
+                        if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step (:197-199)
+                            int any = 0;
+                            for (uint32_t a = lane; a < nact; a += 64) {
+                                const int cs = sbase >= 0 ? sbase + (int)a : P.sub_sites[p0 + a];
+                                any |= ((int)L.occ[cs] != o1);
+                            }
+                            if (__ballot(any) == 0ull) break;
+                        }
+                    }
+                }
+                if (found >= 0) {
+                    s2 = uni(found);
+                    o2 = uni((int)L.occ[s2]);
+                    n1 = o2;
+                    n2 = o1;
+                    nfl = 2;
+                }
+            }
+        }
+
+        // ================= enthalpy delta ====================================
+        int ii1[NSLOT], jf1[NSLOT], ii2[NSLOT], jf2[NSLOT];
+        int cls1 = 0, cls2 = 0, nit1 = 0, nit2 = 0;
+        double e = 0.0;
+        if (nfl >= 1) {
+            cls1 = P.nclasses > 1 ? uni((int)L.site_class[s1]) : 0;
+            nit1 = cls1 == 255 ? 0 : uni(L.cls_niter[cls1]);
+        }
+        if (nfl == 2) {
+            cls2 = P.nclasses > 1 ? uni((int)L.site_class[s2]) : 0;
+            nit2 = cls2 == 255 ? 0 : uni(L.cls_niter[cls2]);
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const int c = lane + 64 * it;
+                if (it < nit1)
+                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
+                                                             jf1[it]);
+                if (it < nit2)
+                    e += eval_slot<IdxT, MM, GENERIC, true>(P, L, cls2, c, s2, o2, n2, s1, n1, ii2[it],
+                                                            jf2[it]);
+            }
+        } else if (nfl == 1) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const int c = lane + 64 * it;
+                if (it < nit1)
+                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
+                                                             jf1[it]);
+            }
+        }
+        double dEw = 0.0, dMu = 0.0;
+        if (P.has_ewald && nfl >= 1) {
+            double pe = ewald_partial<false>(P, L, lane, s1, o1, n1, 0, 0);
+            if (nfl == 2) pe += ewald_partial<true>(P, L, lane, s2, o2, n2, s1, n1);
+            dEw = wave_sum(pe);
+        }
+        if (P.has_mu && nfl >= 1) {
+            // delta chemical work against the ORIGINAL occupancy (ensemble.py:368-374)
+            dMu = P.mu[(size_t)s1 * P.mu_W + n1] - P.mu[(size_t)s1 * P.mu_W + o1];
+            if (nfl == 2) {
+                const int orig2 = uni((int)L.occ[s2]);
+                dMu += P.mu[(size_t)s2 * P.mu_W + n2] - P.mu[(size_t)s2 * P.mu_W + orig2];
+            }
+            dMu = uni_d(dMu);
+        }
+        double dH = wave_sum(e);
+        if (P.has_ewald) dH += P.ew_coef * dEw;
+        if (P.has_mu) dH -= dMu;
+
+        // ================= accept ==============================================
+        bool accepted;
+        if (!WL) {
+            // MetropolisAcceptMixin._accept_step (metropolis.py:31-49)
+            const double exponent = -beta * dH + 0.0;
+            accepted = exponent >= 0.0 ? true : (exponent > log(u));
+        } else {
+            // WangLandau._accept_step (wanglandau.py:186-202)
+            const double new_h = H + dH;
+            if (new_h < P.wl_min || new_h >= P.wl_max) {
+                accepted = false;
+            } else {
+                const int b = (int)floordiv_exact(H - P.wl_min, P.wl_bin);
+                const int nb = (int)floordiv_exact(new_h - P.wl_min, P.wl_bin);
+                const double exponent = L.wl_S[b] - L.wl_S[nb] + 0.0;
+                accepted = exponent >= 0.0 ? true : (exponent > log(u));
+            }
+        }
+
+        // ================= update ==============================================
+        if (accepted) {
+            // MCKernel._do_accept_step (kernel/base.py:327-343) + trace += delta
+            // (sampler/sampler.py:204-207)
+            if (nfl >= 1) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    if (it < nit1) accum_slot<WL>(P, L, cls1, lane + 64 * it, lane, ii1[it], jf1[it]);
+            }
+            if (nfl == 2) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    if (it < nit2) accum_slot<WL>(P, L, cls2, lane + 64 * it, lane, ii2[it], jf2[it]);
+            }
+            if (lane == 0) {
+                if (nfl >= 1) L.occ[s1] = (uint8_t)n1;
+                if (nfl == 2) L.occ[s2] = (uint8_t)n2;
+                if (WL) {
+                    if (P.has_ewald) L.wl_cf[P.Fce] += dEw;
+                    if (P.has_mu) L.wl_cf[P.Fce + P.has_ewald] += dMu;
+                }
+            }
+            acc_ew += dEw;
+            acc_mu += dMu;
+            H += dH;
+            nacc++;
+        }
+        last_acc = accepted ? 1 : 0;
+
+        if (WL) {
+            // WangLandau._do_post_step (wanglandau.py:222-266)
+            const double bq = floordiv_exact(H - P.wl_min, P.wl_bin);
+            if (bq >= 0.0 && bq < (double)P.L) {
+                const int b = (int)bq;
+                wl_counter++;
+                const size_t cell = (size_t)r * P.L + b;
+                // lane 0 owns the occurrences counter (single-thread program order for
+                // its own global read-after-write); broadcast to the wave
+                long long total = 0;
+                if (lane == 0) total = P.wl_occur[cell];
+                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
+                        (unsigned)uni((int)(total & 0xffffffffll));
+                if (lane < P.F) {
+                    double *mf = P.wl_meanf + cell * P.F + lane;
+                    const double inv = 1.0 / (double)(total + 1);
+                    *mf = inv * (L.wl_cf[lane] + (double)total * (*mf));
+                }
+                if (wl_counter % P.wl_update == 0) {
+                    if (lane == 0) {
+                        L.wl_S[b] += wl_m;
+                        L.wl_H[b] += 1;
+                        P.wl_occur[cell] = total + 1;
+                    }
+                }
+            }
+            if (wl_counter % P.wl_check == 0) {
+                long cnt = 0;
+                double sum = 0;
+                for (int i = lane; i < P.L; i += 64)
+                    if (L.wl_S[i] > 0) { cnt++; sum += (double)L.wl_H[i]; }
+                const double tcnt = wave_sum((double)cnt), tsum = wave_sum(sum);
+                if (tcnt >= 2.0) {
+                    const double thr = P.wl_flat * (tsum / tcnt);
+                    int bad = 0;
+                    for (int i = lane; i < P.L; i += 64)
+                        if (L.wl_S[i] > 0 && !((double)L.wl_H[i] > thr)) bad = 1;
+                    if (__ballot(bad) == 0ull) {
+                        for (int i = lane; i < P.L; i += 64) L.wl_H[i] = 0;
+                        wl_m = wl_m / P.wl_div;
+                    }
+                }
+            }
+        }
+        if (replay && lane == 0) {
+            if (P.rp_acc) P.rp_acc[(size_t)r * P.steps_to_run + it_step] = (uint8_t)last_acc;
+            if (P.rp_H) P.rp_H[(size_t)r * P.steps_to_run + it_step] = H;
+        }
+    }
+
+    // ---- write the chain back --------------------------------------------------
+    {
+        uint4 *dst = (uint4 *)(P.occ + (size_t)r * P.Npad);
+        const uint4 *src = (const uint4 *)L.occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+    }
+    double *feat = P.features + (size_t)r * P.F;
+    if (WL) {
+        for (int i = lane; i < P.L; i += 64) {
+            P.wl_entropy[(size_t)r * P.L + i] = L.wl_S[i];
+            P.wl_hist[(size_t)r * P.L + i] = L.wl_H[i];
+        }
+        for (int i = lane; i < P.F; i += 64) feat[i] = L.wl_cf[i];
+        if (lane == 0) {
+            P.wl_m[r] = wl_m;
+            P.wl_counter[r] = wl_counter;
+        }
+    } else {
+        for (int f = 0; f < P.Fce; ++f) {
+            const double s = wave_sum(L.acc[(size_t)f * 64 + lane]);
+            if (lane == 0) feat[f] += s;
+        }
+        if (lane == 0) {
+            if (P.has_ewald) feat[P.Fce] += acc_ew;
+            if (P.has_mu) feat[P.Fce + P.has_ewald] += acc_mu;
+        }
+    }
+    if (lane == 0) {
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// reference-layout evaluation kernels (parity API + initial trace)
+// ----------------------------------------------------------------------------
+struct RefTables { // device copies of the smolmc_tables arrays
+    int N, Npad, P, num_orbits, num_corr, n_orb, Fce, F, corr_mode;
+    const int *orb_id, *orb_bit_id, *orb_nsites, *orb_nfunc, *orb_tensor_len, *orb_stride_off,
+        *tensor_indices;
+    const long long *orb_ctensor_off, *orb_itensor_off, *full_off, *site_ptr, *loc_off;
+    const double *corr_tensors, *interaction_tensors, *loc_ratio;
+    const int *full_idx, *loc_orbit, *loc_nrows, *loc_idx;
+    double offset;
+    int has_ewald, ew_W, ew_M, has_mu, mu_W;
+    const int *ew_inds;
+    const double *ew_M_rowmajor; // original matrix (for the full feature)
+    const double *ew_Mt;
+    const double *mu;
+};
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < nw; ++i) s += sh[i];
+    return s;
+}
+
+// Ensemble.compute_feature_vector for one occupancy per block
+// (evaluator.pyx:121-209 x size; processor/ewald.py:128-145; ensemble.py:343-349)
+__global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const uint8_t *occ_all,
+                                                        double *out_all) {
+    __shared__ double sh[8];
+    const uint8_t *occ = occ_all + (size_t)blockIdx.x * T.Npad;
+    double *out = out_all + (size_t)blockIdx.x * T.F;
+    if (threadIdx.x == 0) out[0] = (T.corr_mode ? 1.0 : T.offset) * (double)T.P;
+    for (int n = 0; n < T.n_orb; ++n) {
+        const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1;
+        const int Nt = T.orb_tensor_len[n];
+        const int *st = T.tensor_indices + T.orb_stride_off[n];
+        const int *ind = T.full_idx + T.full_off[n];
+        const long long J = (T.full_off[n + 1] - T.full_off[n]) / I;
+        for (int k = 0; k < K; ++k) {
+            const double *t = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] + (size_t)k * Nt
+                                          : T.interaction_tensors + T.orb_itensor_off[n];
+            double p = 0;
+            for (long long j = threadIdx.x; j < J; j += blockDim.x) {
+                int index = 0;
+                for (int i = 0; i < I; ++i) index += st[i] * (int)occ[ind[j * I + i]];
+                p += t[index];
+            }
+            p = block_sum(p, sh);
+            if (threadIdx.x == 0) {
+                const int o = T.corr_mode ? T.orb_bit_id[n] + k : T.orb_id[n];
+                out[o] = p / (double)J * (double)T.P;
+            }
+        }
+    }
+    int f = T.Fce;
+    if (T.has_ewald) {
+        double s = 0;
+        for (int a = 0; a < T.N; ++a) {
+            const int ia = T.ew_inds[(size_t)a * T.ew_W + occ[a]];
+            if (ia == -1) continue;
+            const double *row = T.ew_M_rowmajor + (size_t)ia * T.ew_M;
+            for (int b = threadIdx.x; b < T.N; b += blockDim.x) {
+                const int ib = T.ew_inds[(size_t)b * T.ew_W + occ[b]];
+                if (ib != -1) s += row[ib];
+            }
+        }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) out[f] = s;
+        f++;
+    }
+    if (T.has_mu) {
+        double s = 0;
+        for (int a = threadIdx.x; a < T.N; a += blockDim.x) s += T.mu[(size_t)a * T.mu_W + occ[a]];
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) out[f] = s;
+    }
+}
+
+// Ensemble.compute_feature_vector_change for one step (<= 2 sequential flips) per
+// wave, reference table layout and arithmetic chain p / ratio / J, x size
+// (evaluator.pyx:244-262, :302-315; expansion.py:217-231).
+__global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const uint8_t *occ,
+                                                        const int *flips, double *out_all) {
+    const int lane = threadIdx.x;
+    const int *fl = flips + (size_t)blockIdx.x * 4;
+    double *out = out_all + (size_t)blockIdx.x * T.F;
+    for (int i = lane; i < T.F; i += 64) out[i] = 0.0;
+    __syncthreads();
+    const int nfl = fl[0] < 0 ? 0 : (fl[2] < 0 ? 1 : 2);
+    double dew = 0, dmu = 0;
+    for (int f = 0; f < nfl; ++f) {
+        const int s = fl[2 * f], newc = fl[2 * f + 1];
+        const int ps = f == 1 ? fl[0] : -1, pc = f == 1 ? fl[1] : 0;
+        for (long long rr = T.site_ptr[s]; rr < T.site_ptr[s + 1]; ++rr) {
+            const int n = T.loc_orbit[rr];
+            const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1, Nt = T.orb_tensor_len[n];
+            const int *st = T.tensor_indices + T.orb_stride_off[n];
+            const int *ind = T.loc_idx + T.loc_off[rr];
+            const int J = T.loc_nrows[rr];
+            for (int k = 0; k < K; ++k) {
+                const double *t = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] + (size_t)k * Nt
+                                              : T.interaction_tensors + T.orb_itensor_off[n];
+                double p = 0;
+                for (int j = lane; j < J; j += 64) {
+                    int ind_i = 0, ind_f = 0;
+                    for (int i = 0; i < I; ++i) {
+                        const int x = ind[j * I + i];
+                        int v = occ[x];
+                        if (x == ps) v = pc;
+                        const int vf = (x == s) ? newc : v;
+                        ind_i += st[i] * v;
+                        ind_f += st[i] * vf;
+                    }
+                    p += t[ind_f] - t[ind_i];
+                }
+                p = wave_sum(p);
+                if (lane == 0) {
+                    const int o = T.corr_mode ? T.orb_bit_id[n] + k : T.orb_id[n];
+                    out[o] += p / T.loc_ratio[rr] / (double)J;
+                }
+            }
+        }
+        if (T.has_ewald) {
+            // ewald.pyx:38-58
+            int oldc = occ[s];
+            if (s == ps) oldc = pc;
+            const int W = T.ew_W;
+            const int add = T.ew_inds[(size_t)s * W + newc], sub = T.ew_inds[(size_t)s * W + oldc];
+            double o = 0;
+            for (int k = lane; k < T.N; k += 64) {
+                int v = occ[k];
+                if (k == ps) v = pc;
+                const int vf = (k == s) ? newc : v;
+                const int i = T.ew_inds[(size_t)k * W + vf], j = T.ew_inds[(size_t)k * W + v];
+                if (i != -1 && add != -1)
+                    o += (i != add ? 2.0 : 1.0) * T.ew_Mt[(size_t)add * T.ew_M + i];
+                if (j != -1 && sub != -1)
+                    o -= (j != sub ? 2.0 : 1.0) * T.ew_Mt[(size_t)sub * T.ew_M + j];
+            }
+            dew += wave_sum(o);
+        }
+        if (T.has_mu)
+            dmu += T.mu[(size_t)s * T.mu_W + newc] - T.mu[(size_t)s * T.mu_W + occ[s]];
+    }
+    __syncthreads();
+    for (int i = lane; i < T.Fce; i += 64) out[i] *= (double)T.P;
+    if (lane == 0) {
+        int f = T.Fce;
+        if (T.has_ewald) out[f++] = dew;
+        if (T.has_mu) out[f++] = dmu;
+    }
+}
+
+__global__ void pack_occ_kernel(const int *occ32, uint8_t *occ8, int N, int Npad, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t rr = i / Npad;
+    const int s = (int)(i % Npad);
+    occ8[i] = s < N ? (uint8_t)occ32[rr * N + s] : 0;
+}
+__global__ void unpack_occ_kernel(const uint8_t *occ8, int *occ32, int N, int Npad, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t rr = i / N;
+    const int s = (int)(i % N);
+    occ32[i] = (int)occ8[rr * Npad + s];
+}
+__global__ void dot_features_kernel(const double *features, const double *natural, double *enthalpy,
+                                    int R, int F) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double s = 0;
+    for (int i = 0; i < F; ++i) s += natural[i] * features[(size_t)r * F + i];
+    enthalpy[r] = s;
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct smolmc_handle {
+    smolmc_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<void *> allocs;
+    KParams kp;
+    RefTables rt;
+    int R = 0, N = 0, Npad = 0, F = 0, Fce = 0, L = 0;
+    std::vector<double> natural;
+    // dispatch
+    int nslot = 0, mm = 0;
+    bool generic = false, idx16 = false;
+    size_t lds_bytes = 0;
+    int waves_per_block = 4;
+    // scratch
+    uint8_t *d_eval_occ = nullptr;
+    size_t eval_occ_cap = 0;
+    double *d_natural = nullptr;
+    double *d_beta = nullptr;
+};
+
+template <typename T>
+static int dev_upload(smolmc_handle *h, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIPCHK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (n) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)p;
+    return 0;
+}
+template <typename T> static int dev_alloc(smolmc_handle *h, size_t n, T **dst, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIPCHK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (zero) HIPCHK(hipMemset(p, 0, bytes));
+    *dst = (T *)p;
+    return 0;
+}
+#define TRY(x)                                                                            \
+    do {                                                                                  \
+        if (int rc_ = (x)) return rc_;                                                    \
+    } while (0)
+
+static int num_ce_features(const smolmc_tables *t) {
+    return t->feature_mode == SMOLMC_FEATURES_CORRELATIONS ? t->num_corr : t->num_orbits;
+}
+
+// Build the MC-optimised tables (classes, slot descriptors, member index rows).
+static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
+    const int N = t->num_sites;
+    const bool corr = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+    // does any local row contain a repeated site (aliased tiny supercells)?
+    bool aliased = false;
+    int maxI = 1;
+    for (int s = 0; s < N && !aliased; ++s)
+        for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1] && !aliased; ++r) {
+            const int o = t->loc_orbit[r], I = t->orb_nsites[o];
+            const int32_t *rows = t->loc_idx + t->loc_off[r];
+            for (int j = 0; j < t->loc_nrows[r] && !aliased; ++j)
+                for (int a = 0; a < I && !aliased; ++a)
+                    for (int b = a + 1; b < I; ++b)
+                        if (rows[j * I + a] == rows[j * I + b]) aliased = true;
+        }
+    for (int o = 0; o < t->n_orb; ++o) maxI = std::max(maxI, (int)t->orb_nsites[o]);
+    if (maxI > SMOLMC_MAX_CLUSTER_SITES) return fail("cluster larger than SMOLMC_MAX_CLUSTER_SITES");
+    for (int o = 0; o < t->n_orb; ++o)
+        for (int i = 0; i < t->orb_nsites[o]; ++i)
+            if (t->tensor_indices[t->orb_stride_off[o] + i] > 65535)
+                return fail("tensor stride exceeds 16 bits");
+    h->generic = aliased;
+    const int need_mm = aliased ? maxI : std::max(1, maxI - 1);
+
+    // per-site slot lists: (orbit, self position p, row pointer, record r)
+    struct Slot {
+        int orbit, p, nmem;
+        int64_t rec;
+        const int32_t *row;
+    };
+    std::vector<std::vector<Slot>> slots(N);
+    std::vector<int> site_class(N, 255);
+    std::map<std::vector<long long>, int> class_of;
+    std::vector<int> class_rep; // representative site per class
+    for (int s = 0; s < N; ++s) {
+        if (t->site_ptr[s] == t->site_ptr[s + 1]) continue;
+        std::vector<Slot> &sl = slots[s];
+        std::vector<long long> sig;
+        for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1]; ++r) {
+            const int o = t->loc_orbit[r], I = t->orb_nsites[o], J = t->loc_nrows[r];
+            const int32_t *rows = t->loc_idx + t->loc_off[r];
+            std::vector<Slot> rec;
+            for (int j = 0; j < J; ++j) {
+                int p = 0;
+                if (!aliased)
+                    for (int a = 0; a < I; ++a)
+                        if (rows[j * I + a] == s) p = a;
+                rec.push_back(Slot{o, p, aliased ? I : I - 1, r, rows + (size_t)j * I});
+            }
+            std::stable_sort(rec.begin(), rec.end(), [](const Slot &a, const Slot &b) { return a.p < b.p; });
+            sig.push_back(o);
+            sig.push_back(J);
+            long long rb;
+            memcpy(&rb, &t->loc_ratio[r], 8);
+            sig.push_back(rb);
+            for (int a = 0; a < I; ++a) {
+                long long cnt = 0;
+                for (auto &q : rec) cnt += q.p == a;
+                sig.push_back(cnt);
+            }
+            sl.insert(sl.end(), rec.begin(), rec.end());
+        }
+        // most members first so that iterations are homogeneous
+        std::stable_sort(sl.begin(), sl.end(), [](const Slot &a, const Slot &b) { return a.nmem > b.nmem; });
+        auto itc = class_of.find(sig);
+        if (itc == class_of.end()) {
+            if (class_rep.size() >= 255) return fail("more than 255 site classes");
+            itc = class_of.emplace(sig, (int)class_rep.size()).first;
+            class_rep.push_back(s);
+        }
+        site_class[s] = itc->second;
+    }
+    const int nclasses = std::max<int>(1, (int)class_rep.size());
+    size_t Cmax = 1;
+    for (int s : class_rep) Cmax = std::max(Cmax, slots[s].size());
+    const int Cpad = (int)((Cmax + 63) / 64 * 64);
+    const int niter_max = Cpad / 64;
+    h->nslot = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
+    if (niter_max > 8) return fail("more than 512 clusters per site are not supported yet");
+    if (aliased)
+        h->mm = need_mm <= 3 ? 3 : 6;
+    else
+        h->mm = need_mm <= 2 ? 2 : (need_mm <= 3 ? 3 : 5);
+    const int MM = h->mm;
+    h->idx16 = (!aliased) && N <= 65535;
+
+    // decision tensors per class, feature tensors shared
+    std::vector<double> ft;
+    std::vector<int> foff(t->n_orb);
+    for (int o = 0; o < t->n_orb; ++o) {
+        foff[o] = (int)ft.size();
+        const int Nt = t->orb_tensor_len[o];
+        if (corr) {
+            const double *ct = t->corr_tensors + t->orb_ctensor_off[o];
+            ft.insert(ft.end(), ct, ct + (size_t)t->orb_nfunc[o] * Nt);
+        } else {
+            const double *it = t->interaction_tensors + t->orb_itensor_off[o];
+            ft.insert(ft.end(), it, it + Nt);
+        }
+    }
+    std::vector<double> xt;
+    std::vector<uint4> descA((size_t)nclasses * Cpad, make_uint4(0, 0, 0, 0));
+    std::vector<uint4> descB((size_t)nclasses * Cpad, make_uint4(0, 0, 0, 0));
+    std::vector<double> slot_fs((size_t)nclasses * Cpad, 0.0);
+    std::vector<int> cls_niter(nclasses, 0);
+    xt.push_back(0.0); // padded slots read xt[0] - xt[0]
+    for (int c = 0; c < (int)class_rep.size(); ++c) {
+        const int s = class_rep[c];
+        const std::vector<Slot> &sl = slots[s];
+        cls_niter[c] = (int)((sl.size() + 63) / 64);
+        std::map<int64_t, int> xoff_of_rec;
+        for (size_t q = 0; q < sl.size(); ++q) {
+            const Slot &k = sl[q];
+            const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
+            const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
+            const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
+            if (!xoff_of_rec.count(k.rec)) {
+                xoff_of_rec[k.rec] = (int)xt.size();
+                for (int i = 0; i < Nt; ++i) {
+                    double v;
+                    if (corr) {
+                        // energy tensor: sum_k coef[bit_id+k] * ct[k][i], times scale
+                        v = 0;
+                        const double *ct = t->corr_tensors + t->orb_ctensor_off[o];
+                        for (int kk = 0; kk < t->orb_nfunc[o]; ++kk)
+                            v += t->ce_coefs[t->orb_bit_id[o] + kk] * ct[(size_t)kk * Nt + i];
+                        v *= scale;
+                    } else {
+                        v = t->ce_coefs[t->orb_id[o]] * scale *
+                            t->interaction_tensors[t->orb_itensor_off[o] + i];
+                    }
+                    xt.push_back(v);
+                }
+            }
+            uint16_t sv[6] = {0, 0, 0, 0, 0, 0};
+            if (aliased) {
+                for (int a = 0; a < I; ++a) sv[a] = (uint16_t)st[a];
+            } else {
+                sv[0] = (uint16_t)st[k.p];
+                int m = 1;
+                for (int a = 0; a < I; ++a)
+                    if (a != k.p) sv[m++] = (uint16_t)st[a];
+            }
+            uint4 A;
+            A.x = (uint32_t)xoff_of_rec[k.rec];
+            A.y = sv[0] | ((uint32_t)sv[1] << 16);
+            A.z = sv[2] | ((uint32_t)sv[3] << 16);
+            A.w = sv[4] | ((uint32_t)sv[5] << 16);
+            descA[(size_t)c * Cpad + q] = A;
+            uint4 B;
+            B.x = (uint32_t)foff[o];
+            B.y = (uint32_t)Nt;
+            const uint32_t feat = corr ? (uint32_t)t->orb_bit_id[o] : (uint32_t)t->orb_id[o];
+            const uint32_t K = corr ? (uint32_t)t->orb_nfunc[o] : 1u;
+            B.z = feat | (K << 16);
+            B.w = 0;
+            descB[(size_t)c * Cpad + q] = B;
+            slot_fs[(size_t)c * Cpad + q] = scale;
+        }
+    }
+    if (xt.size() > 0xffffffffull) return fail("decision tensors too large");
+
+    // member index rows [site][m][Cpad]; padded entries point at the site itself
+    const size_t idx_n = (size_t)N * MM * Cpad;
+    std::vector<int32_t> idx32(idx_n);
+    for (int s = 0; s < N; ++s) {
+        for (int m = 0; m < MM; ++m)
+            for (int c = 0; c < Cpad; ++c) idx32[((size_t)s * MM + m) * Cpad + c] = s;
+        const std::vector<Slot> &sl = slots[s];
+        for (size_t q = 0; q < sl.size(); ++q) {
+            const Slot &k = sl[q];
+            const int I = t->orb_nsites[k.orbit];
+            int m = 0;
+            for (int a = 0; a < I; ++a) {
+                if (!aliased && a == k.p) continue;
+                idx32[((size_t)s * MM + m) * Cpad + q] = k.row[a];
+                m++;
+            }
+        }
+    }
+    KParams &kp = h->kp;
+    if (h->idx16) {
+        std::vector<uint16_t> idx16(idx_n);
+        for (size_t i = 0; i < idx_n; ++i) idx16[i] = (uint16_t)idx32[i];
+        const uint16_t *d;
+        TRY(dev_upload(h, idx16.data(), idx_n, &d));
+        kp.idx = d;
+    } else {
+        const int32_t *d;
+        TRY(dev_upload(h, idx32.data(), idx_n, &d));
+        kp.idx = d;
+    }
+    std::vector<uint8_t> sc8(N);
+    for (int s = 0; s < N; ++s) sc8[s] = (uint8_t)site_class[s];
+    TRY(dev_upload(h, sc8.data(), (size_t)N, &kp.site_class));
+    TRY(dev_upload(h, descA.data(), descA.size(), &kp.descA));
+    TRY(dev_upload(h, descB.data(), descB.size(), &kp.descB));
+    TRY(dev_upload(h, slot_fs.data(), slot_fs.size(), &kp.slot_fs));
+    TRY(dev_upload(h, cls_niter.data(), cls_niter.size(), &kp.cls_niter));
+    TRY(dev_upload(h, xt.data(), xt.size(), &kp.xt));
+    TRY(dev_upload(h, ft.data(), ft.size(), &kp.ft));
+    kp.xt_len = (int)xt.size();
+    kp.ft_len = (int)ft.size();
+    kp.nclasses = nclasses;
+    kp.Cpad = Cpad;
+    kp.Mmax = MM;
+    return 0;
+}
+
+static int build_ref_tables(smolmc_handle *h, const smolmc_tables *t) {
+    RefTables &rt = h->rt;
+    memset(&rt, 0, sizeof(rt));
+    const int n = t->n_orb;
+    rt.N = t->num_sites;
+    rt.Npad = h->Npad;
+    rt.P = t->size;
+    rt.num_orbits = t->num_orbits;
+    rt.num_corr = t->num_corr;
+    rt.n_orb = n;
+    rt.Fce = h->Fce;
+    rt.F = h->F;
+    rt.corr_mode = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+    rt.offset = t->offset;
+    int nstr = 0;
+    long long nct = 0, nit = 0;
+    for (int o = 0; o < n; ++o) {
+        nstr += t->orb_nsites[o];
+        nct += (long long)t->orb_nfunc[o] * t->orb_tensor_len[o];
+        nit += t->orb_tensor_len[o];
+    }
+    const int64_t nloc = t->site_ptr[t->num_sites];
+    int64_t nlocidx = 0;
+    for (int64_t r = 0; r < nloc; ++r)
+        nlocidx += (int64_t)t->loc_nrows[r] * t->orb_nsites[t->loc_orbit[r]];
+    TRY(dev_upload(h, t->orb_id, n, &rt.orb_id));
+    TRY(dev_upload(h, t->orb_bit_id, n, &rt.orb_bit_id));
+    TRY(dev_upload(h, t->orb_nsites, n, &rt.orb_nsites));
+    TRY(dev_upload(h, t->orb_nfunc, n, &rt.orb_nfunc));
+    TRY(dev_upload(h, t->orb_tensor_len, n, &rt.orb_tensor_len));
+    TRY(dev_upload(h, t->orb_stride_off, n, &rt.orb_stride_off));
+    TRY(dev_upload(h, t->tensor_indices, nstr, &rt.tensor_indices));
+    TRY(dev_upload(h, (const long long *)t->orb_ctensor_off, n, &rt.orb_ctensor_off));
+    TRY(dev_upload(h, (const long long *)t->orb_itensor_off, n, &rt.orb_itensor_off));
+    TRY(dev_upload(h, t->corr_tensors, nct, &rt.corr_tensors));
+    TRY(dev_upload(h, t->interaction_tensors, nit, &rt.interaction_tensors));
+    TRY(dev_upload(h, (const long long *)t->full_off, n + 1, &rt.full_off));
+    TRY(dev_upload(h, t->full_idx, t->full_off[n], &rt.full_idx));
+    TRY(dev_upload(h, (const long long *)t->site_ptr, t->num_sites + 1, &rt.site_ptr));
+    TRY(dev_upload(h, t->loc_orbit, nloc, &rt.loc_orbit));
+    TRY(dev_upload(h, t->loc_ratio, nloc, &rt.loc_ratio));
+    TRY(dev_upload(h, t->loc_nrows, nloc, &rt.loc_nrows));
+    TRY(dev_upload(h, (const long long *)t->loc_off, nloc, &rt.loc_off));
+    TRY(dev_upload(h, t->loc_idx, nlocidx, &rt.loc_idx));
+    rt.has_ewald = t->has_ewald;
+    rt.has_mu = t->has_mu;
+    if (t->has_ewald) {
+        const size_t M = t->ewald_dim;
+        rt.ew_W = t->ewald_width;
+        rt.ew_M = (int)M;
+        TRY(dev_upload(h, t->ewald_inds, (size_t)t->num_sites * t->ewald_width, &rt.ew_inds));
+        TRY(dev_upload(h, t->ewald_matrix, M * M, &rt.ew_M_rowmajor));
+        std::vector<double> mt(M * M);
+        const size_t B = 64;
+        for (size_t i0 = 0; i0 < M; i0 += B)
+            for (size_t j0 = 0; j0 < M; j0 += B)
+                for (size_t i = i0; i < std::min(M, i0 + B); ++i)
+                    for (size_t j = j0; j < std::min(M, j0 + B); ++j)
+                        mt[j * M + i] = t->ewald_matrix[i * M + j];
+        TRY(dev_upload(h, mt.data(), M * M, &rt.ew_Mt));
+    }
+    if (t->has_mu) {
+        rt.mu_W = t->mu_width;
+        TRY(dev_upload(h, t->mu_table, (size_t)t->num_sites * t->mu_width, &rt.mu));
+    }
+    return 0;
+}
+
+extern "C" int smolmc_abi_version(void) { return SMOLMC_ABI_VERSION; }
+extern "C" const char *smolmc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, smolmc_handle **out) {
+    if (!t || !cfg || !out) return fail("null argument");
+    if (cfg->n_replicas <= 0) return fail("n_replicas must be positive");
+    if (t->max_species > 255) return fail("more than 255 species codes per site");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: the smol_amd engine requires an AMD GPU (there is no "
+                    "CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("invalid device ordinal");
+    smolmc_handle *h = new smolmc_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    auto bail = [&](int rc) {
+        smolmc_destroy(h);
+        return rc;
+    };
+    if (hipSetDevice(h->device) != hipSuccess) return bail(fail("hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail("hipStreamCreate failed"));
+    h->own_stream = true;
+    hipEventCreate(&h->ev0);
+    hipEventCreate(&h->ev1);
+    h->R = cfg->n_replicas;
+    h->N = t->num_sites;
+    h->Npad = (t->num_sites + 15) / 16 * 16;
+    h->Fce = num_ce_features(t);
+    h->F = h->Fce + (t->has_ewald ? 1 : 0) + (t->has_mu ? 1 : 0);
+    h->natural.assign(t->ce_coefs, t->ce_coefs + h->Fce);
+    if (t->has_ewald) h->natural.push_back(t->ewald_coef);
+    if (t->has_mu) h->natural.push_back(-1.0);
+    const bool wl = cfg->kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    if (wl) {
+        if (cfg->wl_min_enthalpy > cfg->wl_max_enthalpy)
+            return bail(fail("min_enthalpy can not be larger than max_enthalpy.")); // wanglandau.py:82
+        if ((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size <= 1)
+            return bail(fail("The values provided for min and max enthalpy and bin sizer result in a "
+                             "single bin!"));
+        if (cfg->wl_mod_factor <= 0) return bail(fail("mod_factor must be greater than 0."));
+        h->L = (int)ceil((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size);
+    }
+    memset(&h->kp, 0, sizeof(KParams));
+    KParams &kp = h->kp;
+    if (int rc = build_mc_tables(h, t)) return bail(rc);
+    if (int rc = build_ref_tables(h, t)) return bail(rc);
+    kp.N = h->N;
+    kp.Npad = h->Npad;
+    kp.Fce = h->Fce;
+    kp.F = h->F;
+    kp.step_type = cfg->step_type;
+    kp.corr_mode = h->rt.corr_mode;
+    kp.has_ewald = t->has_ewald;
+    kp.has_mu = t->has_mu;
+    kp.ew_W = h->rt.ew_W;
+    kp.ew_M = h->rt.ew_M;
+    kp.mu_W = h->rt.mu_W;
+    kp.ew_inds = h->rt.ew_inds;
+    kp.ew_Mt = h->rt.ew_Mt;
+    kp.ew_coef = t->ewald_coef;
+    kp.mu = h->rt.mu;
+    // sublattices
+    {
+        const int ns = t->n_sublattices;
+        if (ns <= 0) return bail(fail("no active sublattice"));
+        std::vector<int> ptr(ns + 1), cptr(ns + 1), base(ns);
+        std::vector<double> cum(ns);
+        double c = 0;
+        for (int s = 0; s <= ns; ++s) {
+            ptr[s] = (int)t->sub_site_ptr[s];
+            cptr[s] = (int)t->sub_code_ptr[s];
+        }
+        for (int s = 0; s < ns; ++s) {
+            c += t->sub_probs[s];
+            cum[s] = c;
+            const int a = ptr[s], b = ptr[s + 1];
+            if (b <= a) return bail(fail("empty active sublattice"));
+            bool contig = true;
+            for (int i = a + 1; i < b; ++i)
+                if (t->sub_active_sites[i] != t->sub_active_sites[a] + (i - a)) contig = false;
+            base[s] = contig ? t->sub_active_sites[a] : -1;
+            for (int i = a; i < b; ++i)
+                if (t->sub_active_sites[i] < 0 || t->sub_active_sites[i] >= t->num_sites)
+                    return bail(fail("sublattice site index out of range"));
+        }
+        kp.nsub = ns;
+        if (dev_upload(h, ptr.data(), ptr.size(), &kp.sub_ptr) ||
+            dev_upload(h, t->sub_active_sites, (size_t)ptr[ns], &kp.sub_sites) ||
+            dev_upload(h, base.data(), base.size(), &kp.sub_base) ||
+            dev_upload(h, cptr.data(), cptr.size(), &kp.sub_code_ptr) ||
+            dev_upload(h, t->sub_codes, (size_t)cptr[ns], &kp.sub_codes) ||
+            dev_upload(h, cum.data(), cum.size(), &kp.sub_cum))
+            return bail(1);
+    }
+    // walker state
+    const size_t R = h->R;
+    kp.R = h->R;
+    double *dbeta = nullptr;
+    uint64_t *dseeds = nullptr;
+    if (dev_alloc(h, R * h->Npad, &kp.occ) || dev_alloc(h, R, &kp.enthalpy) ||
+        dev_alloc(h, R * h->F, &kp.features) || dev_alloc(h, R, &dbeta) || dev_alloc(h, R, &dseeds) ||
+        dev_alloc(h, R, &kp.nsteps) || dev_alloc(h, R, &kp.nacc) || dev_alloc(h, R, &kp.last_acc))
+        return bail(1);
+    kp.beta = dbeta;
+    h->d_beta = dbeta;
+    kp.seeds = dseeds;
+    if (dev_upload(h, h->natural.data(), h->natural.size(), (const double **)&h->d_natural))
+        return bail(1);
+    if (wl) {
+        kp.L = h->L;
+        kp.wl_min = cfg->wl_min_enthalpy;
+        kp.wl_max = cfg->wl_max_enthalpy;
+        kp.wl_bin = cfg->wl_bin_size;
+        kp.wl_flat = cfg->wl_flatness;
+        kp.wl_div = cfg->wl_mod_divisor;
+        kp.wl_check = cfg->wl_check_period;
+        kp.wl_update = cfg->wl_update_period;
+        if (kp.wl_check <= 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
+        if (h->F > 64) return bail(fail("Wang-Landau supports at most 64 features"));
+        if (dev_alloc(h, R * h->L, &kp.wl_entropy) || dev_alloc(h, R * h->L, &kp.wl_hist) ||
+            dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F, &kp.wl_meanf) ||
+            dev_alloc(h, R, &kp.wl_m) || dev_alloc(h, R, &kp.wl_counter))
+            return bail(1);
+        std::vector<double> m0(R, cfg->wl_mod_factor);
+        if (hipMemcpy(kp.wl_m, m0.data(), R * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail("hipMemcpy failed"));
+    }
+    // LDS layout
+    size_t tb = (size_t)kp.nclasses * kp.Cpad * (16 + 16 + 8) + (size_t)(kp.xt_len + kp.ft_len) * 8 +
+                (size_t)((kp.nclasses + 3) & ~3) * 4 + (kp.nclasses > 1 ? (size_t)h->N : 0);
+    tb = (tb + 15) / 16 * 16;
+    size_t pw = (size_t)h->Npad;
+    if (wl)
+        pw += (size_t)h->L * 16 + (size_t)h->F * 8;
+    else
+        pw += (size_t)h->Fce * 64 * 8;
+    pw = (pw + 15) / 16 * 16;
+    kp.lds_tables = (int)tb;
+    kp.lds_per_wave = (int)pw;
+    h->waves_per_block = 4;
+    while (h->waves_per_block > 1 && tb + pw * h->waves_per_block > 160 * 1024) h->waves_per_block /= 2;
+    h->lds_bytes = tb + pw * h->waves_per_block;
+    if (h->lds_bytes > 160 * 1024)
+        return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
+    *out = h;
+    return 0;
+}
+
+extern "C" int smolmc_destroy(smolmc_handle *h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->d_eval_occ) hipFree(h->d_eval_occ);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int smolmc_num_features(const smolmc_handle *h) { return h ? h->F : -1; }
+extern "C" int smolmc_wl_num_levels(const smolmc_handle *h) { return h ? h->L : -1; }
+extern "C" int smolmc_natural_parameters(const smolmc_handle *h, double *out) {
+    if (!h || !out) return fail("null argument");
+    memcpy(out, h->natural.data(), h->natural.size() * 8);
+    return 0;
+}
+
+extern "C" int smolmc_set_stream(smolmc_handle *h, void *stream) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return 0;
+}
+
+static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, double *d_out) {
+    hipLaunchKernelGGL(eval_full_kernel, dim3(nocc), dim3(256), 0, h->stream, h->rt, d_occ8, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int upload_occ(smolmc_handle *h, const int32_t *occ, size_t nocc, uint8_t *d_occ8) {
+    const size_t n32 = nocc * h->N;
+    for (size_t i = 0; i < n32; ++i)
+        if (occ[i] < 0 || occ[i] > 255) return fail("occupancy code out of range [0, 255]");
+    int *d32 = nullptr;
+    HIPCHK(hipMalloc((void **)&d32, std::max<size_t>(n32 * 4, 16)));
+    hipError_t e = hipMemcpyAsync(d32, occ, n32 * 4, hipMemcpyHostToDevice, h->stream);
+    const size_t total = nocc * h->Npad;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           d32, d_occ8, h->N, h->Npad, total);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d32);
+    if (e != hipSuccess) return fail(std::string("occupancy upload: ") + hipGetErrorString(e));
+    return 0;
+}
+
+static void set_betas(smolmc_handle *h, const double *temperature, std::vector<double> &beta) {
+    beta.resize(h->R);
+    for (int r = 0; r < h->R; ++r) {
+        const double T = temperature ? temperature[r] : 0.0;
+        beta[r] = 1.0 / (SMOLMC_KB * T); // ThermalKernelMixin (kernel/base.py:398)
+    }
+}
+
+extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint64_t *seeds,
+                                const double *temperature, int reset_aux) {
+    if (!h || !occ) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    KParams &kp = h->kp;
+    const size_t R = h->R;
+    TRY(upload_occ(h, occ, R, kp.occ));
+    std::vector<uint64_t> sd(R);
+    for (size_t r = 0; r < R; ++r) sd[r] = seeds ? seeds[r] : (uint64_t)r;
+    HIPCHK(hipMemcpy((void *)kp.seeds, sd.data(), R * 8, hipMemcpyHostToDevice));
+    std::vector<double> beta;
+    set_betas(h, temperature, beta);
+    HIPCHK(hipMemcpy(h->d_beta, beta.data(), R * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(kp.nsteps, 0, R * 8, h->stream));
+    HIPCHK(hipMemsetAsync(kp.nacc, 0, R * 8, h->stream));
+    HIPCHK(hipMemsetAsync(kp.last_acc, 1, R, h->stream));
+    TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));
+    hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,
+                       kp.features, h->d_natural, kp.enthalpy, (int)R, h->F);
+    HIPCHK(hipGetLastError());
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && reset_aux) {
+        const size_t RL = R * h->L;
+        HIPCHK(hipMemsetAsync(kp.wl_entropy, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_hist, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_occur, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_meanf, 0, RL * h->F * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_counter, 0, R * 8, h->stream));
+        std::vector<double> m0(R, h->cfg.wl_mod_factor);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(kp.wl_m, m0.data(), R * 8, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_set_temperature(smolmc_handle *h, const double *temperature) {
+    if (!h || !temperature) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> beta;
+    set_betas(h, temperature, beta);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_beta, beta.data(), (size_t)h->R * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int smolmc_sync(smolmc_handle *h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_get_state(smolmc_handle *h, int32_t *occ, double *features, double *enthalpy,
+                                uint64_t *n_accepted, uint64_t *n_steps, uint8_t *last_accepted) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t R = h->R;
+    KParams &kp = h->kp;
+    if (occ) {
+        int *d32 = nullptr;
+        const size_t total = R * h->N;
+        HIPCHK(hipMalloc((void **)&d32, total * 4));
+        hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, kp.occ, d32, h->N, h->Npad, total);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(occ, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        hipFree(d32);
+        if (e != hipSuccess) return fail(std::string("occupancy download: ") + hipGetErrorString(e));
+    }
+    if (features) HIPCHK(hipMemcpy(features, kp.features, R * h->F * 8, hipMemcpyDeviceToHost));
+    if (enthalpy) HIPCHK(hipMemcpy(enthalpy, kp.enthalpy, R * 8, hipMemcpyDeviceToHost));
+    if (n_accepted) HIPCHK(hipMemcpy(n_accepted, kp.nacc, R * 8, hipMemcpyDeviceToHost));
+    if (n_steps) HIPCHK(hipMemcpy(n_steps, kp.nsteps, R * 8, hipMemcpyDeviceToHost));
+    if (last_accepted) HIPCHK(hipMemcpy(last_accepted, kp.last_acc, R, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int smolmc_get_wl(smolmc_handle *h, double *entropy, int64_t *histogram,
+                             int64_t *occurrences, double *mean_features, double *mod_factor) {
+    if (!h) return fail("null handle");
+    if (h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU) return fail("handle is not a Wang-Landau kernel");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t RL = (size_t)h->R * h->L;
+    KParams &kp = h->kp;
+    if (entropy) HIPCHK(hipMemcpy(entropy, kp.wl_entropy, RL * 8, hipMemcpyDeviceToHost));
+    if (histogram) HIPCHK(hipMemcpy(histogram, kp.wl_hist, RL * 8, hipMemcpyDeviceToHost));
+    if (occurrences) HIPCHK(hipMemcpy(occurrences, kp.wl_occur, RL * 8, hipMemcpyDeviceToHost));
+    if (mean_features)
+        HIPCHK(hipMemcpy(mean_features, kp.wl_meanf, RL * h->F * 8, hipMemcpyDeviceToHost));
+    if (mod_factor) HIPCHK(hipMemcpy(mod_factor, kp.wl_m, (size_t)h->R * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- kernel dispatch ----------------------------------------------------------
+template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
+static int launch_mc_inst(smolmc_handle *h, const KParams &kp, int replay) {
+    auto kern = mc_kernel<IdxT, NSLOT, MM, GENERIC, WL>;
+    if (h->lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes));
+    const int wpb = h->waves_per_block;
+    const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), h->lds_bytes, h->stream, kp, replay);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+template <typename IdxT, int NSLOT, bool GENERIC, bool WL>
+static int launch_mc_mm(smolmc_handle *h, const KParams &kp, int replay) {
+    if (GENERIC) {
+        if (h->mm == 3) return launch_mc_inst<IdxT, NSLOT, 3, GENERIC, WL>(h, kp, replay);
+        return launch_mc_inst<IdxT, NSLOT, 6, GENERIC, WL>(h, kp, replay);
+    }
+    if (h->mm == 2) return launch_mc_inst<IdxT, NSLOT, 2, GENERIC, WL>(h, kp, replay);
+    if (h->mm == 3) return launch_mc_inst<IdxT, NSLOT, 3, GENERIC, WL>(h, kp, replay);
+    return launch_mc_inst<IdxT, NSLOT, 5, GENERIC, WL>(h, kp, replay);
+}
+
+template <typename IdxT, bool GENERIC, bool WL>
+static int launch_mc_slot(smolmc_handle *h, const KParams &kp, int replay) {
+    if (h->nslot == 2) return launch_mc_mm<IdxT, 2, GENERIC, WL>(h, kp, replay);
+#ifndef SMOLMC_FAST_BUILD
+    if (h->nslot == 4) return launch_mc_mm<IdxT, 4, GENERIC, WL>(h, kp, replay);
+    return launch_mc_mm<IdxT, 8, GENERIC, WL>(h, kp, replay);
+#else
+    return fail("this build only carries NSLOT=2 kernels");
+#endif
+}
+
+static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
+    const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    if (h->generic)
+        return wl ? launch_mc_slot<int32_t, true, true>(h, kp, replay)
+                  : launch_mc_slot<int32_t, true, false>(h, kp, replay);
+    if (h->idx16)
+        return wl ? launch_mc_slot<uint16_t, false, true>(h, kp, replay)
+                  : launch_mc_slot<uint16_t, false, false>(h, kp, replay);
+    return wl ? launch_mc_slot<int32_t, false, true>(h, kp, replay)
+              : launch_mc_slot<int32_t, false, false>(h, kp, replay);
+}
+
+extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
+    if (!h) return fail("null handle");
+    if (nsteps < 0) return fail("nsteps must be non-negative");
+    if (nsteps == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    KParams kp = h->kp;
+    kp.steps_to_run = nsteps;
+    return launch_mc(h, kp, 0);
+}
+
+extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,
+                             const double *uniforms, uint8_t *accepted_out, double *enthalpy_out) {
+    if (!h || !steps || !uniforms) return fail("null argument");
+    if (nsteps <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->R * nsteps;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t *st = steps + i * 4;
+        for (int f = 0; f < 2; ++f)
+            if (st[2 * f] >= h->N || (st[2 * f] >= 0 && (st[2 * f + 1] < 0 || st[2 * f + 1] > 255)))
+                return fail("replay step out of range");
+    }
+    int *d_steps = nullptr;
+    double *d_u = nullptr, *d_H = nullptr;
+    uint8_t *d_acc = nullptr;
+    hipError_t e = hipMalloc((void **)&d_steps, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_u, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_H, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_acc, n);
+    if (e == hipSuccess) e = hipMemcpy(d_steps, steps, n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_u, uniforms, n * 8, hipMemcpyHostToDevice);
+    int rc = 0;
+    if (e == hipSuccess) {
+        KParams kp = h->kp;
+        kp.steps_to_run = nsteps;
+        kp.rp_steps = d_steps;
+        kp.rp_u = d_u;
+        kp.rp_acc = d_acc;
+        kp.rp_H = d_H;
+        rc = launch_mc(h, kp, 1);
+        if (!rc) e = hipStreamSynchronize(h->stream);
+        if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_steps);
+    hipFree(d_u);
+    hipFree(d_H);
+    hipFree(d_acc);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(std::string("replay: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_last_kernel_ms(smolmc_handle *h, float *ms) {
+    if (!h || !ms) return fail("null argument");
+    if (!h->timed) return fail("no kernel has been launched yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+static int ensure_eval_occ(smolmc_handle *h, size_t nocc) {
+    const size_t need = nocc * h->Npad;
+    if (need > h->eval_occ_cap) {
+        if (h->d_eval_occ) hipFree(h->d_eval_occ);
+        h->d_eval_occ = nullptr;
+        h->eval_occ_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->d_eval_occ, need));
+        h->eval_occ_cap = need;
+    }
+    return 0;
+}
+
+extern "C" int smolmc_eval_full(smolmc_handle *h, const int32_t *occ, int nocc, double *features) {
+    if (!h || !occ || !features) return fail("null argument");
+    if (nocc <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    TRY(ensure_eval_occ(h, nocc));
+    TRY(upload_occ(h, occ, nocc, h->d_eval_occ));
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, (size_t)nocc * h->F * 8));
+    int rc = launch_eval_full(h, h->d_eval_occ, nocc, d_out);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpy(features, d_out, (size_t)nocc * h->F * 8, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(std::string("eval_full: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ, const int32_t *flips, int nstep,
+                                 double *dfeatures) {
+    if (!h || !occ || !flips || !dfeatures) return fail("null argument");
+    if (nstep <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    for (int i = 0; i < nstep; ++i)
+        for (int f = 0; f < 2; ++f) {
+            const int s = flips[i * 4 + 2 * f], c = flips[i * 4 + 2 * f + 1];
+            if (s >= h->N || (s >= 0 && (c < 0 || c > 255))) return fail("flip out of range");
+        }
+    TRY(ensure_eval_occ(h, 1));
+    TRY(upload_occ(h, occ, 1, h->d_eval_occ));
+    int *d_fl = nullptr;
+    double *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_fl, (size_t)nstep * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)nstep * h->F * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_fl, flips, (size_t)nstep * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(eval_delta_kernel, dim3(nstep), dim3(64), 0, h->stream, h->rt, h->d_eval_occ,
+                           d_fl, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(dfeatures, d_out, (size_t)nstep * h->F * 8, hipMemcpyDeviceToHost);
+    hipFree(d_fl);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(std::string("eval_delta: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_export_enthalpy_dev(smolmc_handle *h, double *dst_dev) {
+    if (!h || !dst_dev) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst_dev, h->kp.enthalpy, (size_t)h->R * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+__global__ void beta_from_T_kernel(const double *T, double *beta, int R, double kB) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) beta[r] = 1.0 / (kB * T[r]);
+}
+
+extern "C" int smolmc_import_temperature_dev(smolmc_handle *h, const double *src_dev) {
+    if (!h || !src_dev) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(beta_from_T_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, src_dev,
+                       h->d_beta, h->R, SMOLMC_KB);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}

@@ -1,0 +1,242 @@
+"""ctypes binding of the MI355X engine (libsmolmc_hip.so, C-ABI in include/smolmc.h).
+
+There is NO CPU fallback: if the HIP library is missing, or no AMD GPU is visible,
+every entry point raises.  (The CPU oracle under oracle/ is test infrastructure and
+is never imported from this package.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmolmc_hip.so")
+_LIB = None
+
+_i32p, _f64p = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+_u64p, _u8p, _i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+
+# every symbol include/smolmc.h declares: (name, restype, argtypes)
+_HP = C.c_void_p
+SYMBOLS = {
+    "smolmc_create": (C.c_int, [C.POINTER(capi.smolmc_tables), C.POINTER(capi.smolmc_config), C.POINTER(_HP)]),
+    "smolmc_destroy": (C.c_int, [_HP]),
+    "smolmc_last_error": (C.c_char_p, []),
+    "smolmc_abi_version": (C.c_int, []),
+    "smolmc_num_features": (C.c_int, [_HP]),
+    "smolmc_wl_num_levels": (C.c_int, [_HP]),
+    "smolmc_natural_parameters": (C.c_int, [_HP, _f64p]),
+    "smolmc_set_state": (C.c_int, [_HP, _i32p, _u64p, _f64p, C.c_int]),
+    "smolmc_set_temperature": (C.c_int, [_HP, _f64p]),
+    "smolmc_get_state": (C.c_int, [_HP, _i32p, _f64p, _f64p, _u64p, _u64p, _u8p]),
+    "smolmc_get_wl": (C.c_int, [_HP, _f64p, _i64p, _i64p, _f64p, _f64p]),
+    "smolmc_run": (C.c_int, [_HP, C.c_int64]),
+    "smolmc_sync": (C.c_int, [_HP]),
+    "smolmc_replay": (C.c_int, [_HP, C.c_int64, _i32p, _f64p, _u8p, _f64p]),
+    "smolmc_last_kernel_ms": (C.c_int, [_HP, C.POINTER(C.c_float)]),
+    "smolmc_eval_full": (C.c_int, [_HP, _i32p, C.c_int, _f64p]),
+    "smolmc_eval_delta": (C.c_int, [_HP, _i32p, _i32p, C.c_int, _f64p]),
+    "smolmc_set_stream": (C.c_int, [_HP, C.c_void_p]),
+    "smolmc_export_enthalpy_dev": (C.c_int, [_HP, C.c_void_p]),
+    "smolmc_import_temperature_dev": (C.c_int, [_HP, C.c_void_p]),
+}
+
+
+def load_library(path=None):
+    """Load libsmolmc_hip.so; raises RuntimeError when it has not been built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C smol_amd/csrc). smol_amd has no CPU fallback."
+        )
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.smolmc_abi_version() != 1:
+        raise RuntimeError("smolmc ABI version mismatch")
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One engine handle = R walkers of one ensemble on one GPU."""
+
+    def __init__(self, tables: capi.TableSet, config: capi.smolmc_config):
+        self._lib = load_library()
+        self.tables, self.config = tables, config
+        self._h = _HP()
+        rc = self._lib.smolmc_create(C.byref(tables.struct), C.byref(config), C.byref(self._h))
+        if rc:
+            msg = self._lib.smolmc_last_error().decode()
+            self._h = None
+            # argument problems are ValueErrors like the reference's (expansion.py:97-103,
+            # wanglandau.py:80-88); device problems are RuntimeErrors
+            if any(k in msg for k in ("enthalpy", "mod_factor", "range", "must be", "larger")):
+                raise ValueError(msg)
+            raise EngineError(msg)
+        self.R = config.n_replicas
+        self.N = tables.struct.num_sites
+        self.F = self._lib.smolmc_num_features(self._h)
+        self.L = self._lib.smolmc_wl_num_levels(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smolmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise EngineError(self._lib.smolmc_last_error().decode())
+
+    @staticmethod
+    def _occ32(occ, shape):
+        occ = np.asarray(occ)
+        if occ.dtype != np.int32:
+            if not np.issubdtype(occ.dtype, np.integer):
+                raise ValueError(
+                    f"occupancy dtype is: {occ.dtype}, but should be integers!"
+                )  # expansion.py:225-228
+            occ = occ.astype(np.int32)
+        return np.ascontiguousarray(occ).reshape(shape)
+
+    # ---- state ----------------------------------------------------------------
+    @property
+    def natural_parameters(self):
+        out = np.zeros(self.F)
+        self._chk(self._lib.smolmc_natural_parameters(self._h, _p(out, C.c_double)))
+        return out
+
+    def set_state(self, occupancies, seeds=None, temperature=None, reset_aux=True):
+        occ = self._occ32(occupancies, (self.R, self.N))
+        seeds = (
+            np.arange(self.R, dtype=np.uint64)
+            if seeds is None
+            else np.ascontiguousarray(seeds, dtype=np.uint64)
+        )
+        if len(seeds) != self.R:
+            raise ValueError("Number of seeds does not match number of kernels!")  # sampler.py:107
+        temp = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(1.0 if temperature is None else temperature, float), (self.R,))
+        )
+        self._chk(
+            self._lib.smolmc_set_state(
+                self._h, _p(occ, C.c_int32), _p(seeds, C.c_uint64), _p(temp, C.c_double), int(reset_aux)
+            )
+        )
+
+    def set_temperature(self, temperature):
+        temp = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, float), (self.R,)))
+        self._chk(self._lib.smolmc_set_temperature(self._h, _p(temp, C.c_double)))
+
+    def get_state(self, occupancy=True):
+        occ = np.zeros((self.R, self.N), dtype=np.int32) if occupancy else None
+        feat = np.zeros((self.R, self.F))
+        H = np.zeros(self.R)
+        na = np.zeros(self.R, dtype=np.uint64)
+        ns = np.zeros(self.R, dtype=np.uint64)
+        la = np.zeros(self.R, dtype=np.uint8)
+        self._chk(
+            self._lib.smolmc_get_state(
+                self._h, _p(occ, C.c_int32), _p(feat, C.c_double), _p(H, C.c_double),
+                _p(na, C.c_uint64), _p(ns, C.c_uint64), _p(la, C.c_uint8),
+            )
+        )
+        return dict(occupancy=occ, features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
+                    accepted=la.astype(bool))
+
+    def get_wl(self):
+        S = np.zeros((self.R, self.L))
+        hist = np.zeros((self.R, self.L), dtype=np.int64)
+        occ = np.zeros((self.R, self.L), dtype=np.int64)
+        mf = np.zeros((self.R, self.L, self.F))
+        m = np.zeros(self.R)
+        self._chk(
+            self._lib.smolmc_get_wl(
+                self._h, _p(S, C.c_double), _p(hist, C.c_int64), _p(occ, C.c_int64),
+                _p(mf, C.c_double), _p(m, C.c_double),
+            )
+        )
+        return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
+
+    # ---- hot path -------------------------------------------------------------
+    def run(self, nsteps, sync=False):
+        self._chk(self._lib.smolmc_run(self._h, int(nsteps)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._chk(self._lib.smolmc_sync(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self._lib.smolmc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def replay(self, steps, uniforms):
+        """steps (R, n, 4) int32, uniforms (R, n) float64 -> (accepted (R,n) bool, H (R,n))."""
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.R, -1)
+        n = uniforms.shape[1]
+        steps = np.ascontiguousarray(steps, dtype=np.int32).reshape(self.R, n, 4)
+        acc = np.zeros((self.R, n), dtype=np.uint8)
+        H = np.zeros((self.R, n))
+        self._chk(
+            self._lib.smolmc_replay(
+                self._h, n, _p(steps, C.c_int32), _p(uniforms, C.c_double), _p(acc, C.c_uint8),
+                _p(H, C.c_double),
+            )
+        )
+        return acc.astype(bool), H
+
+    # ---- evaluator level --------------------------------------------------------
+    def eval_full(self, occupancies):
+        occ = self._occ32(occupancies, (-1, self.N))
+        out = np.zeros((len(occ), self.F))
+        self._chk(self._lib.smolmc_eval_full(self._h, _p(occ, C.c_int32), len(occ), _p(out, C.c_double)))
+        return out
+
+    def eval_delta(self, occupancy, steps):
+        """steps: (n, 4) int32 rows (site1, code1, site2, code2), -1 = absent."""
+        occ = self._occ32(occupancy, (self.N,))
+        steps = np.ascontiguousarray(steps, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((len(steps), self.F))
+        self._chk(
+            self._lib.smolmc_eval_delta(
+                self._h, _p(occ, C.c_int32), _p(steps, C.c_int32), len(steps), _p(out, C.c_double)
+            )
+        )
+        return out
+
+    # ---- device plumbing ----------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.smolmc_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def export_enthalpy(self, dev_ptr):
+        self._chk(self._lib.smolmc_export_enthalpy_dev(self._h, C.c_void_p(int(dev_ptr))))
+
+    def import_temperature(self, dev_ptr):
+        self._chk(self._lib.smolmc_import_temperature_dev(self._h, C.c_void_p(int(dev_ptr))))

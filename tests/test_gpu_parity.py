@@ -1,0 +1,201 @@
+"""GPU parity: the HIP engine (through the C-ABI) against the CPU oracle and the
+committed reference-core fixtures.  Tolerances: accept masks / occupancies bit-exact;
+float64 1e-10 relative (BASELINE.json north_star)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from smol_amd import capi
+from tests.cases import CASES, GOLD, load_case, tables_for
+
+pytestmark = pytest.mark.gpu
+
+T = np.load(os.path.join(GOLD, "trajectories.npz"))
+MODES = {"int": capi.FEATURES_INTERACTIONS, "corr": capi.FEATURES_CORRELATIONS}
+RTOL, ATOL = 1e-10, 1e-9
+
+
+def _engine(tab, cfg):
+    from smol_amd.engine import Engine
+
+    return Engine(tab, cfg)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_eval_full_and_delta_vs_reference_fixtures(name, mode):
+    c = load_case(name)
+    g = c["gold"]
+    tab = tables_for(name, MODES[mode])
+    eng = _engine(tab, capi.make_config(1))
+    nce = c["model"].num_corr_functions if mode == "corr" else c["model"].num_orbits
+    full = eng.eval_full(g["occ"])
+    np.testing.assert_allclose(full[:, :nce], g["full_corr" if mode == "corr" else "full_int"],
+                               rtol=RTOL, atol=ATOL)
+    if c["ewald"] is not None:
+        np.testing.assert_allclose(full[:, nce], g["full_ewald"], rtol=RTOL)
+    nper = len(g["flips"]) // len(g["occ"])
+    for k, occ in enumerate(g["occ"]):
+        rows = g["flips"][k * nper:(k + 1) * nper]
+        d = eng.eval_delta(occ, rows)
+        np.testing.assert_allclose(
+            d[:, :nce], g["delta_corr" if mode == "corr" else "delta_int"][k * nper:(k + 1) * nper],
+            rtol=RTOL, atol=ATOL)
+        if c["ewald"] is not None:
+            np.testing.assert_allclose(d[:, nce], g["delta_ewald"][k * nper:(k + 1) * nper],
+                                       rtol=RTOL, atol=1e-8)
+
+
+def _check_replay(eng, key, R=1):
+    steps = np.tile(T[f"{key}_steps"][None], (R, 1, 1))
+    us = np.tile(T[f"{key}_u"][None], (R, 1))
+    acc, H = eng.replay(steps, us)
+    st = eng.get_state()
+    for r in range(R):
+        assert np.array_equal(acc[r], T[f"{key}_accepted"])
+        np.testing.assert_allclose(H[r], T[f"{key}_H"], rtol=RTOL, atol=ATOL)
+        assert np.array_equal(st["occupancy"][r], T[f"{key}_occ_final"])
+        np.testing.assert_allclose(st["features"][r], T[f"{key}_feat_final"], rtol=RTOL, atol=1e-8)
+        assert st["n_accepted"][r] == T[f"{key}_accepted"].sum()
+    return st
+
+
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_replay_metropolis_swap_vs_reference_trajectory(mode):
+    tab = tables_for("fcc_prim666_triplets", MODES[mode])
+    R = 5
+    eng = _engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    eng.set_state(np.tile(T["B_occ0"], (R, 1)), temperature=T["B_T"][0])
+    _check_replay(eng, f"B_swap_{mode}", R)
+
+
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_replay_semigrand_flip_ewald_mu(mode):
+    tab = tables_for("rocksalt444_ewald", MODES[mode], mu_table=T["C_mu"])
+    eng = _engine(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    eng.set_state(np.tile(T["C_occ0"], (2, 1)), temperature=T["C_T"][0])
+    _check_replay(eng, f"C_flip_{mode}", 2)
+
+
+def test_replay_swap_ewald():
+    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=T["C_mu"])
+    eng = _engine(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    eng.set_state(T["C_occ0"][None], temperature=T["C_T"][0])
+    _check_replay(eng, "C_swap_int")
+
+
+@pytest.mark.parametrize("tag", ["B_wl", "B_wlflat"])
+def test_replay_wang_landau(tag):
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    w = T[f"{tag}_window"]
+    cfg = capi.make_config(3, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=w[0],
+                           max_enthalpy=w[1], bin_size=w[2], check_period=int(T[f"{tag}_check"][0]))
+    eng = _engine(tab, cfg)
+    assert eng.L == len(T[f"{tag}_levels"])
+    eng.set_state(np.tile(T["B_occ0"], (3, 1)))
+    _check_replay(eng, tag, 3)
+    wl = eng.get_wl()
+    for r in range(3):
+        np.testing.assert_allclose(wl["entropy"][r], T[f"{tag}_entropy"], rtol=0, atol=0)
+        assert np.array_equal(wl["histogram"][r], T[f"{tag}_histogram"])
+        assert np.array_equal(wl["occurrences"][r], T[f"{tag}_occurrences"])
+        np.testing.assert_allclose(wl["mean_features"][r], T[f"{tag}_mean_features"], rtol=1e-10,
+                                   atol=1e-9)
+    np.testing.assert_allclose(wl["mod_factor"], np.tile(T[f"{tag}_mod_factor"], 3))
+
+
+CONFIGS = [
+    ("fcc_conv444_pairs", "int", capi.STEP_SWAP, None),
+    ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None),
+    ("fcc_prim666_triplets", "corr", capi.STEP_FLIP, "mu2"),
+    ("rocksalt444_ewald", "int", capi.STEP_FLIP, "mu3"),
+    ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None),
+    ("fcc3_indicator_skew", "corr", capi.STEP_SWAP, None),
+    ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2"),
+]
+
+
+def _mu(kind, c):
+    if kind is None:
+        return None
+    nsp = 2 if kind == "mu2" else 3
+    mu = np.zeros((c["sc"].num_sites, nsp))
+    act = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b]) > 1
+    mu[act] = np.linspace(-0.3, 0.4, nsp)[None, :]
+    return mu
+
+
+@pytest.mark.parametrize("name,mode,step,mukind", CONFIGS)
+def test_native_stream_matches_oracle(name, mode, step, mukind):
+    """Same Philox streams on CPU oracle and GPU: identical trajectories (occupancies,
+    accept counts bit-exact; enthalpy/features 1e-10), across chunked run() calls."""
+    from oracle import oracle as orc
+
+    c = load_case(name)
+    tab = tables_for(name, MODES[mode], mu_table=_mu(mukind, c))
+    R = 9
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(5)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(100, 100 + R, dtype=np.uint64) * np.uint64(7919)
+    temps = np.linspace(400.0, 4000.0, R)
+    eng = _engine(tab, cfg)
+    ora = orc.OracleMC(tab, cfg)
+    eng.set_state(occ0, seeds, temps)
+    ora.set_state(occ0, seeds, temps)
+    s0, o0 = eng.get_state(), ora.get_state()
+    np.testing.assert_allclose(s0["features"], o0["features"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(s0["enthalpy"], o0["enthalpy"], rtol=RTOL, atol=ATOL)
+    for chunk in (1, 7, 16, 33, 500):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        assert np.array_equal(a["n_steps"], b["n_steps"])
+        assert np.array_equal(a["accepted"], b["accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+    # trace consistency: running features == recomputed features (test_sampler.py:59-84)
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+
+
+def test_native_wang_landau_matches_oracle():
+    from oracle import oracle as orc
+
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    w = T["B_wlflat_window"]
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=w[0],
+                           max_enthalpy=w[1], bin_size=0.5, check_period=100)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    occ0 = np.tile(T["B_occ0"], (R, 1))
+    seeds = np.arange(1, R + 1, dtype=np.uint64)
+    eng.set_state(occ0, seeds)
+    ora.set_state(occ0, seeds, 0.0)
+    for chunk in (3, 50, 1000):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=ATOL)
+        wa, wb = eng.get_wl(), ora.get_wl()
+        np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=0, atol=0)
+        assert np.array_equal(wa["histogram"], wb["histogram"])
+        assert np.array_equal(wa["occurrences"], wb["occurrences"])
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"])
+
+
+def test_errors_surface_as_exceptions():
+    tab = tables_for("fcc_prim222_aliased", MODES["int"])
+    eng = _engine(tab, capi.make_config(1))
+    with pytest.raises(ValueError):
+        eng.eval_full(np.zeros((1, 8), dtype=np.float64))
+    with pytest.raises(ValueError):
+        _engine(tab, capi.make_config(1, capi.KERNEL_WANGLANDAU, min_enthalpy=2.0, max_enthalpy=1.0))
