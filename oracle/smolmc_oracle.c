@@ -437,7 +437,7 @@ int orc_mc_get_wl(orc_mc *h, double *entropy, int64_t *hist, int64_t *occur, dou
 /* ---- ushers on the engine stream (distribution of mcusher.py:146-200) ----- */
 /* Random words of one step: W(step, block, j).  block 0: w0 sublattice,
  * w1 site, (w2,w3) acceptance uniform.  block 1+: flip species word (block 1,
- * word 0) or the swap candidate sequence c_t = W(step, 1 + t/4, t%4). */
+ * word 0) or the swap candidate sequence (see propose_step). */
 typedef struct {
     uint32_t key[2];
     uint64_t step;
@@ -487,7 +487,22 @@ static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, u
      * of the sublattice whose species differs; realised as rejection sampling
      * over the candidate sequence (identical distribution). */
     int sp1 = occ[site1];
-    for (uint32_t blk = 1;; ++blk) {
+    /* first 12 candidates: c_t = W(step, 1 + t % 3, t / 3)  (blocks 1..3, word-major:
+     * the order the wavefront tests them, three lanes per LDS read) */
+    {
+        uint32_t w[3][4];
+        for (int b = 0; b < 3; ++b) rng_block(g, 1 + b, w[b]);
+        for (int t = 0; t < 12; ++t) {
+            int site2 = sites[mulhi32(w[t % 3][t / 3], nact)];
+            if (occ[site2] != sp1) {
+                flips[0] = site1; flips[1] = occ[site2];
+                flips[2] = site2; flips[3] = sp1;
+                return 2;
+            }
+        }
+    }
+    /* then c_t = W(step, 4 + (t - 12) / 4, (t - 12) % 4), t >= 12 */
+    for (uint32_t blk = 4;; ++blk) {
         uint32_t w[4];
         rng_block(g, blk, w);
         for (int j = 0; j < 4; ++j) {
@@ -498,7 +513,7 @@ static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, u
                 return 2;
             }
         }
-        if (blk == 16 || (blk & 1023u) == 0) { /* swap_options.size == 0 -> empty step (:197-199) */
+        if (blk == 4 + 63 || ((blk - 4) & 4095u) == 4095u) { /* swap_options.size == 0 -> empty step (:197-199) */
             int any = 0;
             for (uint32_t a = 0; a < nact; ++a)
                 if (occ[sites[a]] != sp1) { any = 1; break; }

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -397,19 +398,22 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                 nfl = 1;
             } else {
                 // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate
-                // sequence c_t = W(step, 1 + t/4, t%4)
+                // sequence ('random stream')
                 int found = -1;
                 {
-                    int selsite = -1;
+                    // first 12 candidates c_t = W(step, 1 + t % 3, t / 3): word-major over the
+                    // three candidate lanes of this step
                     const uint32_t ws[4] = {W0, W1, W2, W3};
 #pragma unroll
-                    for (int j = 3; j >= 0; --j) {
-                        const uint32_t kc = __umulhi(ws[j], nact);
-                        const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
-                        if ((int)L.occ[cs] != o1) selsite = cs;
+                    for (int j = 0; j < 4; ++j) {
+                        if (found < 0) {
+                            const uint32_t kc = __umulhi(ws[j], nact);
+                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            const bool hit = (int)L.occ[cs] != o1;
+                            unsigned long long m = __ballot(hit) & (0xEull << l4);
+                            if (m) found = (int)rdlane((uint32_t)cs, __ffsll((long long)m) - 1);
+                        }
                     }
-                    unsigned long long m = __ballot(selsite >= 0) & (0xEull << l4);
-                    if (m) found = (int)rdlane((uint32_t)selsite, __ffsll((long long)m) - 1);
                 }
                 if (found < 0) {
                     // rare: continue the candidate sequence with blocks 4 + 64 q + lane
@@ -630,6 +634,291 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// lean Metropolis kernel: one site class, one contiguous active sublattice with the
+// default encoding, cluster-interaction features, no Ewald term, engine RNG.
+// This is the shape of BASELINE configs 1/2/4; everything else takes mc_kernel.
+//   * member index rows are lane-packed: idx[site][lane][NSLOT][MM] (u16), one vector
+//     load per flip;
+//   * per-(orbit, self position) DELTA tables dt[(old*S+new)][base] = T[.. new ..] - T[.. old ..]
+//     live in LDS: one 8-byte LDS read per cluster instead of two reads + a subtract
+//     (the subtraction is done once on the host in float64: identical value);
+//   * slot constants and feature accumulators stay in registers for the whole launch.
+// ----------------------------------------------------------------------------
+struct LeanSlot {
+    uint32_t doff8;     // byte offset of the slot's delta table
+    uint32_t nt8;       // 8 * tensor length
+    uint32_t snt8;      // 8 * tensor length * (#species on the flipped site)
+    uint32_t stride8[3]; // 8 * stride of the other members
+    uint32_t feat;      // feature index (orbit id)
+    uint32_t pad;
+    double w;           // natural parameter * size / (ratio * J)
+    double fs;          // size / (ratio * J)
+};
+
+struct LeanParams {
+    const uint16_t *idx;   // [N][64][NSLOT][MM]
+    const double *dt;      // delta tables
+    const LeanSlot *slots; // [NSLOT][64]
+    const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
+    uint8_t *occ;
+    double *enthalpy, *features;
+    const double *beta;
+    const uint64_t *seeds;
+    uint64_t *nsteps, *nacc;
+    uint8_t *last_acc;
+    int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
+    long long steps;
+};
+
+__device__ __forceinline__ bool metropolis_accept(double exponent, double u) {
+    // MetropolisAcceptMixin._accept_step (metropolis.py:46-48):
+    //   True if exponent >= 0 else exponent > log(u)
+    // float32 pre-filter with a guard band; inside the band (and for tiny u) the exact
+    // float64 comparison decides, so the decision is always the float64 one.
+    if (exponent >= 0.0) return true;
+    const float uf = (float)u, ef = (float)exponent;
+    if (uf > 1e-30f) {
+        const float lf = __logf(uf);
+        const float margin = 2e-5f * fmaxf(1.0f, fabsf(lf)) + 1e-6f * fabsf(ef);
+        if (ef > lf + margin) return true;
+        if (ef < lf - margin) return false;
+    }
+    return exponent > log(u);
+}
+
+template <int NSLOT, int MM, int STEP, bool HAS_MU>
+__global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len;               // 8 doubles
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * (P.Npad + 64 * 8);
+    uint8_t *occ = wbase;
+    double *s_feat = (double *)(wbase + P.Npad);  // [<=64] end-of-launch feature reduction
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
+    const bool live = r < P.R;
+    if (live) {
+        const uint4 *src = (const uint4 *)(P.occ + (size_t)r * P.Npad);
+        uint4 *dst = (uint4 *)occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+        s_feat[lane] = 0.0;
+    }
+    __syncthreads();
+    if (!live) return;
+
+    // per-lane slot constants (registers for the whole launch)
+    uint32_t doff8[NSLOT], nt8[NSLOT], snt8[NSLOT], st8[NSLOT][MM];
+    double wgt[NSLOT], acc[NSLOT];
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) {
+        const LeanSlot sl = P.slots[it * 64 + lane];
+        doff8[it] = sl.doff8; nt8[it] = sl.nt8; snt8[it] = sl.snt8;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
+        wgt[it] = sl.w;
+        acc[it] = 0.0;
+    }
+    double H = P.enthalpy[r];
+    const double beta = P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    const uint32_t nact = (uint32_t)P.nact;
+    const int sbase = P.sbase;
+    double acc_mu = 0.0;
+    int last_acc = 1;
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+    int cand[4] = {0, 0, 0, 0};
+    unsigned long long batch_base = ~0ull;
+    constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
+    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+    uint16_t row1[ROW], rown[ROW];
+    bool row1_valid = false;
+
+    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+        // -------- random words of this step (generated 16 steps at a time) --------
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                               0u, key0, key1);
+            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            if (STEP == SMOLMC_STEP_SWAP) {
+                cand[0] = sbase + (int)__umulhi(W0, nact);
+                cand[1] = sbase + (int)__umulhi(W1, nact);
+                cand[2] = sbase + (int)__umulhi(W2, nact);
+                cand[3] = sbase + (int)__umulhi(W3, nact);
+            }
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        const int s1 = sbase + (int)__umulhi(rdlane(W1, l4), nact);
+        const double u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
+        // index row of site 1: normally prefetched by the previous step (it does not
+        // depend on the occupancy, only on the random words)
+        if (!row1_valid) {
+            const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) row1[q] = p[q];
+        }
+        const int o1 = uni((int)occ[s1]);
+        int nfl, s2 = 0, n1, n2 = 0, o2 = 0;
+        if (STEP == SMOLMC_STEP_FLIP) {
+            // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
+            const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
+            n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
+            nfl = 1;
+        } else {
+            // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate sequence
+            int found = -1, fo = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int v = (int)occ[cand[j]];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cand[j], b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                    }
+                }
+            }
+            if (found < 0) {
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                        const int v = (int)occ[cs];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
+                        int any = 0;
+                        for (uint32_t a = lane; a < nact; a += 64) any |= ((int)occ[sbase + (int)a] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) { s2 = found; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
+            else { nfl = 0; n1 = o1; }
+        }
+
+        // issue the data-dependent row of site 2 and next step's row of site 1 before
+        // evaluating, so their L2 latency overlaps the LDS work below
+        uint16_t row2[ROW];
+        if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+            const uint16_t *p = idx_lane + (size_t)s2 * (64 * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) row2[q] = p[q];
+        }
+        const bool next_valid = l4 != 60;
+        if (next_valid) {
+            const int s1n = sbase + (int)__umulhi(rdlane(W1, l4 + 4), nact);
+            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) rown[q] = p[q];
+        }
+
+        // -------- enthalpy delta ---------------------------------------------------
+        double e = 0.0, d1[NSLOT], d2[NSLOT];
+        if (nfl >= 1) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it] + __umul24((uint32_t)o1, snt8[it]) + __umul24((uint32_t)n1, nt8[it]);
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row1[it * MM + m]]);
+                d1[it] = *(const double *)((const unsigned char *)s_dt + a);
+                e = fma(wgt[it], d1[it], e);
+            }
+        }
+        if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it] + __umul24((uint32_t)o2, snt8[it]) + __umul24((uint32_t)n2, nt8[it]);
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const int x = row2[it * MM + m];
+                    int v = (int)occ[x];
+                    v = (x == s1) ? n1 : v; // second flip sees the first (expansion.py:217-229)
+                    a += __umul24(st8[it][m], (uint32_t)v);
+                }
+                d2[it] = *(const double *)((const unsigned char *)s_dt + a);
+                e = fma(wgt[it], d2[it], e);
+            }
+        }
+        double dH = wave_sum(e);
+        double dMu = 0.0;
+        if (HAS_MU && nfl >= 1) {
+            dMu = s_mu[n1] - s_mu[o1];
+            if (nfl == 2) dMu += s_mu[n2] - s_mu[o2];
+            dMu = uni_d(dMu);
+            dH -= dMu;
+        }
+
+        // -------- accept / update --------------------------------------------------
+        const bool accepted = metropolis_accept(-beta * dH + 0.0, u);
+        if (accepted) {
+            if (nfl >= 1) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
+            }
+            if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
+            }
+            if (lane == 0) {
+                if (nfl >= 1) occ[s1] = (uint8_t)n1;
+                if (nfl == 2) occ[s2] = (uint8_t)n2;
+            }
+            acc_mu += dMu;
+            H += dH;
+            nacc++;
+        }
+        last_acc = accepted ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
+        row1_valid = next_valid;
+    }
+
+    // ---- write back ---------------------------------------------------------------
+    {
+        uint4 *dst = (uint4 *)(P.occ + (size_t)r * P.Npad);
+        const uint4 *src = (const uint4 *)occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+    }
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) {
+        const LeanSlot sl = P.slots[it * 64 + lane];
+        if (sl.nt8) // padded slots carry no feature
+            __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    double *feat = P.features + (size_t)r * P.F;
+    if (lane < P.Fce) feat[lane] += s_feat[lane];
+    if (lane == 0) {
+        if (HAS_MU) feat[P.Fce] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // reference-layout evaluation kernels (parity API + initial trace)
 // ----------------------------------------------------------------------------
@@ -836,6 +1125,11 @@ struct smolmc_handle {
     bool generic = false, idx16 = false;
     size_t lds_bytes = 0;
     int waves_per_block = 4;
+    // lean kernel (single class / single contiguous sublattice / interactions / no ewald)
+    bool lean_tables = false, lean = false;
+    int lean_nslot = 0, lean_mm = 0;
+    size_t lean_lds = 0;
+    LeanParams lp;
     // scratch
     uint8_t *d_eval_occ = nullptr;
     size_t eval_occ_cap = 0;
@@ -1078,6 +1372,77 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     kp.nclasses = nclasses;
     kp.Cpad = Cpad;
     kp.Mmax = MM;
+
+    // ---- lean tables (see mc_lean_kernel) ------------------------------------------
+    memset(&h->lp, 0, sizeof(LeanParams));
+    if (class_rep.size() == 1 && !aliased && !corr && N <= 65535 && niter_max <= 4 && need_mm <= 3 &&
+        num_ce_features(t) <= 64) {
+        const int NSL = niter_max <= 2 ? 2 : 4;
+        const int MML = need_mm <= 2 ? 2 : 3;
+        const int ROW = NSL * MML;
+        std::vector<uint16_t> lidx((size_t)N * 64 * ROW);
+        for (int s = 0; s < N; ++s) {
+            for (int q = 0; q < 64 * ROW; ++q) lidx[(size_t)s * 64 * ROW + q] = (uint16_t)s;
+            const std::vector<Slot> &sl = slots[s];
+            for (size_t q = 0; q < sl.size(); ++q) {
+                const Slot &k = sl[q];
+                const int I = t->orb_nsites[k.orbit];
+                const int it = (int)(q / 64), ln = (int)(q % 64);
+                int m = 0;
+                for (int a = 0; a < I; ++a) {
+                    if (a == k.p) continue;
+                    lidx[(((size_t)s * 64 + ln) * NSL + it) * MML + m] = (uint16_t)k.row[a];
+                    m++;
+                }
+            }
+        }
+        std::vector<double> dt(1, 0.0); // dt[0] = 0 for padded slots
+        std::vector<LeanSlot> ls((size_t)NSL * 64);
+        memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
+        std::map<std::pair<int, int>, uint32_t> doff_of;
+        const std::vector<Slot> &sl = slots[class_rep[0]];
+        bool ok = true;
+        for (size_t q = 0; q < sl.size() && ok; ++q) {
+            const Slot &k = sl[q];
+            const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
+            const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
+            const double *T = t->interaction_tensors + t->orb_itensor_off[o];
+            const int ss = st[k.p];
+            const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
+            const auto key = std::make_pair(o, k.p);
+            if (!doff_of.count(key)) {
+                doff_of[key] = (uint32_t)dt.size();
+                for (int pid = 0; pid < Sself * Sself; ++pid) {
+                    const int oldc = pid / Sself, newc = pid % Sself;
+                    for (int b = 0; b < Nt; ++b) {
+                        const int fi = b + ss * newc, ii = b + ss * oldc;
+                        dt.push_back((fi < Nt && ii < Nt) ? T[fi] - T[ii] : 0.0);
+                    }
+                }
+            }
+            const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
+            LeanSlot &L = ls[(q / 64) * 64 + (q % 64)];
+            L.doff8 = doff_of[key] * 8u;
+            L.nt8 = (uint32_t)Nt * 8u;
+            L.snt8 = (uint32_t)Nt * 8u * (uint32_t)Sself;
+            int m = 0;
+            for (int a = 0; a < I; ++a)
+                if (a != k.p) L.stride8[m++] = (uint32_t)st[a] * 8u;
+            L.feat = (uint32_t)t->orb_id[o];
+            L.w = t->ce_coefs[t->orb_id[o]] * scale;
+            L.fs = scale;
+            if (dt.size() > 12000) ok = false; // keep the LDS tables small
+        }
+        if (ok) {
+            TRY(dev_upload(h, lidx.data(), lidx.size(), &h->lp.idx));
+            TRY(dev_upload(h, dt.data(), dt.size(), &h->lp.dt));
+            TRY(dev_upload(h, ls.data(), ls.size(), &h->lp.slots));
+            h->lp.dt_len = (int)dt.size();
+            h->lean_tables = true;
+            h->lean_nslot = NSL;
+            h->lean_mm = MML;
+        }
+    }
     return 0;
 }
 
@@ -1294,6 +1659,53 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     h->lds_bytes = tb + pw * h->waves_per_block;
     if (h->lds_bytes > 160 * 1024)
         return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
+    // lean-kernel eligibility (everything else runs mc_kernel)
+    {
+        bool lean = h->lean_tables && !wl && !t->has_ewald && t->n_sublattices == 1 &&
+                    getenv("SMOLMC_FORCE_GENERAL") == nullptr;
+        int sbase = -1, nact = 0, nc = 0;
+        std::vector<double> mu_row;
+        if (lean) {
+            nact = (int)(t->sub_site_ptr[1] - t->sub_site_ptr[0]);
+            nc = (int)(t->sub_code_ptr[1] - t->sub_code_ptr[0]);
+            sbase = t->sub_active_sites[0];
+            for (int i = 0; i < nact; ++i)
+                if (t->sub_active_sites[i] != sbase + i) lean = false;
+            for (int c = 0; c < nc; ++c)
+                if (t->sub_codes[c] != c) lean = false;
+            if (nc < 2 || nc > 8) lean = false;
+        }
+        if (lean && t->has_mu) {
+            if (t->mu_width < nc) lean = false;
+            for (int c = 0; lean && c < nc; ++c) mu_row.push_back(t->mu_table[(size_t)sbase * t->mu_width + c]);
+            for (int i = 0; lean && i < nact; ++i)
+                for (int c = 0; c < nc; ++c)
+                    if (t->mu_table[(size_t)(sbase + i) * t->mu_width + c] != mu_row[c]) lean = false;
+        }
+        if (lean) {
+            LeanParams &lp = h->lp;
+            if (t->has_mu && dev_upload(h, mu_row.data(), mu_row.size(), &lp.mu_row)) return bail(1);
+            lp.occ = kp.occ;
+            lp.enthalpy = kp.enthalpy;
+            lp.features = kp.features;
+            lp.beta = kp.beta;
+            lp.seeds = kp.seeds;
+            lp.nsteps = kp.nsteps;
+            lp.nacc = kp.nacc;
+            lp.last_acc = kp.last_acc;
+            lp.R = h->R;
+            lp.N = h->N;
+            lp.Npad = h->Npad;
+            lp.F = h->F;
+            lp.Fce = h->Fce;
+            lp.sbase = sbase;
+            lp.nact = nact;
+            lp.ncodes = nc;
+            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 + (size_t)4 * (h->Npad + 64 * 8);
+            if (h->lean_lds > 64 * 1024) lean = false;
+        }
+        h->lean = lean;
+    }
     *out = h;
     return 0;
 }
@@ -1509,11 +1921,40 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
               : launch_mc_slot<int32_t, false, false>(h, kp, replay);
 }
 
+template <int NSLOT, int MM, int STEP, bool MU>
+static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned grid = (unsigned)((h->R + 3) / 4);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL((mc_lean_kernel<NSLOT, MM, STEP, MU>), dim3(grid), dim3(256), h->lean_lds,
+                       h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+template <int NSLOT, int MM>
+static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr;
+    if (h->cfg.step_type == SMOLMC_STEP_SWAP)
+        return mu ? launch_lean_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true>(h, lp)
+              : launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false>(h, lp);
+}
+static int launch_lean(smolmc_handle *h, int64_t nsteps) {
+    LeanParams lp = h->lp;
+    lp.steps = nsteps;
+    if (h->lean_nslot == 2)
+        return h->lean_mm == 2 ? launch_lean_nm<2, 2>(h, lp) : launch_lean_nm<2, 3>(h, lp);
+    return h->lean_mm == 2 ? launch_lean_nm<4, 2>(h, lp) : launch_lean_nm<4, 3>(h, lp);
+}
+
 extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
     if (!h) return fail("null handle");
     if (nsteps < 0) return fail("nsteps must be non-negative");
     if (nsteps == 0) return 0;
     HIPCHK(hipSetDevice(h->device));
+    if (h->lean) return launch_lean(h, nsteps);
     KParams kp = h->kp;
     kp.steps_to_run = nsteps;
     return launch_mc(h, kp, 0);

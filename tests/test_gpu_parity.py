@@ -109,6 +109,9 @@ def test_replay_wang_landau(tag):
 CONFIGS = [
     ("fcc_conv444_pairs", "int", capi.STEP_SWAP, None),
     ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None),
+    ("fcc_prim666_triplets", "int", capi.STEP_FLIP, "mu2"),
+    ("fcc3_indicator_skew", "int", capi.STEP_SWAP, None),
+    ("fcc3_indicator_skew", "int", capi.STEP_FLIP, "mu3"),
     ("fcc_prim666_triplets", "corr", capi.STEP_FLIP, "mu2"),
     ("rocksalt444_ewald", "int", capi.STEP_FLIP, "mu3"),
     ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None),
@@ -127,11 +130,19 @@ def _mu(kind, c):
     return mu
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 @pytest.mark.parametrize("name,mode,step,mukind", CONFIGS)
-def test_native_stream_matches_oracle(name, mode, step, mukind):
+def test_native_stream_matches_oracle(name, mode, step, mukind, general, monkeypatch):
     """Same Philox streams on CPU oracle and GPU: identical trajectories (occupancies,
-    accept counts bit-exact; enthalpy/features 1e-10), across chunked run() calls."""
+    accept counts bit-exact; enthalpy/features 1e-10), across chunked run() calls.
+    "auto" lets the engine pick the lean kernel where eligible; "general-kernel" forces
+    mc_kernel so both code paths are pinned."""
     from oracle import oracle as orc
+
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
 
     c = load_case(name)
     tab = tables_for(name, MODES[mode], mu_table=_mu(mukind, c))
