@@ -647,19 +647,17 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
 //   * slot constants and feature accumulators stay in registers for the whole launch.
 // ----------------------------------------------------------------------------
 struct LeanSlot {
-    uint32_t doff8;     // byte offset of the slot's delta table
-    uint32_t nt8;       // 8 * tensor length
-    uint32_t snt8;      // 8 * tensor length * (#species on the flipped site)
+    uint32_t doff8;      // byte offset of the slot's delta table
     uint32_t stride8[3]; // 8 * stride of the other members
-    uint32_t feat;      // feature index (orbit id)
-    uint32_t pad;
-    double w;           // natural parameter * size / (ratio * J)
-    double fs;          // size / (ratio * J)
+    uint32_t feat;       // feature index (orbit id)
+    uint32_t live;       // 0 for padded slots
+    double w;            // natural parameter * size / (ratio * J)
+    double fs;           // size / (ratio * J)
 };
 
 struct LeanParams {
     const uint16_t *idx;   // [N][64][NSLOT][MM]
-    const double *dt;      // delta tables
+    const double *dt;      // delta tables, all padded to a common [S*S][NTP] shape
     const LeanSlot *slots; // [NSLOT][64]
     const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
     uint8_t *occ;
@@ -669,23 +667,35 @@ struct LeanParams {
     uint64_t *nsteps, *nacc;
     uint8_t *last_acc;
     int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
+    uint32_t nt8, snt8;    // 8*NTP and 8*NTP*S: (old, new) -> byte offset old*snt8 + new*nt8
     long long steps;
 };
 
-__device__ __forceinline__ bool metropolis_accept(double exponent, double u) {
-    // MetropolisAcceptMixin._accept_step (metropolis.py:46-48):
-    //   True if exponent >= 0 else exponent > log(u)
-    // float32 pre-filter with a guard band; inside the band (and for tiny u) the exact
-    // float64 comparison decides, so the decision is always the float64 one.
-    if (exponent >= 0.0) return true;
-    const float uf = (float)u, ef = (float)exponent;
-    if (uf > 1e-30f) {
-        const float lf = __logf(uf);
-        const float margin = 2e-5f * fmaxf(1.0f, fabsf(lf)) + 1e-6f * fabsf(ef);
-        if (ef > lf + margin) return true;
-        if (ef < lf - margin) return false;
+// xor-butterfly inside 16-lane rows (DPP), then gfx950 permlane16/32 swaps: 22 VALU
+// instructions, the total ends up in every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_xor_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = dpp_xor_add<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_xor_add<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_xor_add<0x141>(v); // row_half_mirror
+    v = dpp_xor_add<0x140>(v); // row_mirror
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
     }
-    return exponent > log(u);
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
 }
 
 template <int NSLOT, int MM, int STEP, bool HAS_MU>
@@ -713,28 +723,30 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     if (!live) return;
 
     // per-lane slot constants (registers for the whole launch)
-    uint32_t doff8[NSLOT], nt8[NSLOT], snt8[NSLOT], st8[NSLOT][MM];
+    uint32_t doff8[NSLOT], st8[NSLOT][MM];
     double wgt[NSLOT], acc[NSLOT];
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
-        doff8[it] = sl.doff8; nt8[it] = sl.nt8; snt8[it] = sl.snt8;
+        doff8[it] = sl.doff8;
 #pragma unroll
         for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
         wgt[it] = sl.w;
         acc[it] = 0.0;
     }
     double H = P.enthalpy[r];
-    const double beta = P.beta[r];
+    const double nbeta = -P.beta[r];
     unsigned long long step = P.nsteps[r];
     unsigned long long nacc = P.nacc[r];
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
-    const uint32_t nact = (uint32_t)P.nact;
+    const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
     double acc_mu = 0.0;
     int last_acc = 1;
-    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+    // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
+    uint32_t W0 = 0, W1 = 0;
     int cand[4] = {0, 0, 0, 0};
+    double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
     const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
@@ -749,19 +761,21 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
                                                0u, key0, key1);
-            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            W0 = o.w[0]; W1 = o.w[1];
+            // metropolis.py:46-48 compares the exponent with log(rng.random()): take the
+            // float64 log of all 16 uniforms of the batch at once (lane-parallel)
+            logu = log(philox_u53(o.w[2], o.w[3]));
             if (STEP == SMOLMC_STEP_SWAP) {
-                cand[0] = sbase + (int)__umulhi(W0, nact);
-                cand[1] = sbase + (int)__umulhi(W1, nact);
-                cand[2] = sbase + (int)__umulhi(W2, nact);
-                cand[3] = sbase + (int)__umulhi(W3, nact);
+                cand[0] = sbase + (int)__umulhi(o.w[0], nact);
+                cand[1] = sbase + (int)__umulhi(o.w[1], nact);
+                cand[2] = sbase + (int)__umulhi(o.w[2], nact);
+                cand[3] = sbase + (int)__umulhi(o.w[3], nact);
             }
         }
         const int l4 = (int)(step & 15ull) * 4;
         const int s1 = sbase + (int)__umulhi(rdlane(W1, l4), nact);
-        const double u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
-        // index row of site 1: normally prefetched by the previous step (it does not
-        // depend on the occupancy, only on the random words)
+        // index row of site 1: normally prefetched by the previous step (it depends only
+        // on the random words, not on the occupancy)
         if (!row1_valid) {
             const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
 #pragma unroll
@@ -837,41 +851,43 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // -------- enthalpy delta ---------------------------------------------------
         double e = 0.0, d1[NSLOT], d2[NSLOT];
         if (nfl >= 1) {
+            const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8; // uniform
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
-                uint32_t a = doff8[it] + __umul24((uint32_t)o1, snt8[it]) + __umul24((uint32_t)n1, nt8[it]);
+                uint32_t a = doff8[it];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row1[it * MM + m]]);
-                d1[it] = *(const double *)((const unsigned char *)s_dt + a);
+                d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
                 e = fma(wgt[it], d1[it], e);
             }
         }
         if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+            // the second flip sees the first (expansion.py:217-229): apply it tentatively in
+            // LDS (undone below on rejection) instead of patching every gathered value
+            if (lane == 0) occ[s1] = (uint8_t)n1;
+            const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
-                uint32_t a = doff8[it] + __umul24((uint32_t)o2, snt8[it]) + __umul24((uint32_t)n2, nt8[it]);
+                uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) {
-                    const int x = row2[it * MM + m];
-                    int v = (int)occ[x];
-                    v = (x == s1) ? n1 : v; // second flip sees the first (expansion.py:217-229)
-                    a += __umul24(st8[it][m], (uint32_t)v);
-                }
-                d2[it] = *(const double *)((const unsigned char *)s_dt + a);
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row2[it * MM + m]]);
+                d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
                 e = fma(wgt[it], d2[it], e);
             }
         }
-        double dH = wave_sum(e);
+        double dH = wave_sum_all(e);
         double dMu = 0.0;
         if (HAS_MU && nfl >= 1) {
             dMu = s_mu[n1] - s_mu[o1];
             if (nfl == 2) dMu += s_mu[n2] - s_mu[o2];
-            dMu = uni_d(dMu);
             dH -= dMu;
         }
 
-        // -------- accept / update --------------------------------------------------
-        const bool accepted = metropolis_accept(-beta * dH + 0.0, u);
+        // -------- accept / update (metropolis.py:31-49, kernel/base.py:327-343) --------
+        const double exponent = nbeta * dH + 0.0;
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        const bool accepted = (exponent >= 0.0) || (exponent > lu);
         if (accepted) {
             if (nfl >= 1) {
 #pragma unroll
@@ -882,12 +898,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
             }
             if (lane == 0) {
-                if (nfl >= 1) occ[s1] = (uint8_t)n1;
+                if (STEP == SMOLMC_STEP_FLIP) occ[s1] = (uint8_t)n1;
                 if (nfl == 2) occ[s2] = (uint8_t)n2;
             }
             acc_mu += dMu;
             H += dH;
             nacc++;
+        } else if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+            if (lane == 0) occ[s1] = (uint8_t)o1; // undo the tentative first flip
         }
         last_acc = accepted ? 1 : 0;
 #pragma unroll
@@ -904,7 +922,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
-        if (sl.nt8) // padded slots carry no feature
+        if (sl.live) // padded slots carry no feature
             __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
@@ -1396,7 +1414,11 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 }
             }
         }
-        std::vector<double> dt(1, 0.0); // dt[0] = 0 for padded slots
+        // delta tables, one per (orbit, self position), all padded to [S*S][NTP]
+        int NTP = 1, SMAX = t->max_species;
+        for (int o = 0; o < t->n_orb; ++o) NTP = std::max(NTP, (int)t->orb_tensor_len[o]);
+        const size_t tlen = (size_t)SMAX * SMAX * NTP;
+        std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
         std::vector<LeanSlot> ls((size_t)NSL * 64);
         memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
         std::map<std::pair<int, int>, uint32_t> doff_of;
@@ -1412,27 +1434,29 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             const auto key = std::make_pair(o, k.p);
             if (!doff_of.count(key)) {
                 doff_of[key] = (uint32_t)dt.size();
-                for (int pid = 0; pid < Sself * Sself; ++pid) {
-                    const int oldc = pid / Sself, newc = pid % Sself;
-                    for (int b = 0; b < Nt; ++b) {
-                        const int fi = b + ss * newc, ii = b + ss * oldc;
-                        dt.push_back((fi < Nt && ii < Nt) ? T[fi] - T[ii] : 0.0);
-                    }
-                }
+                dt.resize(dt.size() + tlen, 0.0);
+                double *D = dt.data() + doff_of[key];
+                for (int oldc = 0; oldc < Sself; ++oldc)
+                    for (int newc = 0; newc < Sself; ++newc)
+                        for (int b = 0; b < Nt; ++b) {
+                            const int fi = b + ss * newc, ii = b + ss * oldc;
+                            if (fi < Nt && ii < Nt) D[((size_t)oldc * SMAX + newc) * NTP + b] = T[fi] - T[ii];
+                        }
             }
             const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
             LeanSlot &L = ls[(q / 64) * 64 + (q % 64)];
             L.doff8 = doff_of[key] * 8u;
-            L.nt8 = (uint32_t)Nt * 8u;
-            L.snt8 = (uint32_t)Nt * 8u * (uint32_t)Sself;
             int m = 0;
             for (int a = 0; a < I; ++a)
                 if (a != k.p) L.stride8[m++] = (uint32_t)st[a] * 8u;
             L.feat = (uint32_t)t->orb_id[o];
+            L.live = 1;
             L.w = t->ce_coefs[t->orb_id[o]] * scale;
             L.fs = scale;
-            if (dt.size() > 12000) ok = false; // keep the LDS tables small
+            if (dt.size() > 5500) ok = false; // keep the LDS tables within budget
         }
+        h->lp.nt8 = (uint32_t)NTP * 8u;
+        h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
             TRY(dev_upload(h, lidx.data(), lidx.size(), &h->lp.idx));
             TRY(dev_upload(h, dt.data(), dt.size(), &h->lp.dt));

@@ -22,7 +22,7 @@ def main():
                 rows = con.execute(
                     "select name, total_calls, total_duration, average, percentage from top_kernels"
                 ).fetchall()
-                print("KERNEL_STATS name | calls | total_us | avg_us | pct")
+                print("KERNEL_STATS name | calls | total_ms | avg_ms | pct")
                 for r in rows:
                     print(f"  {r[0]} | {r[1]} | {r[2]/1e3:.3f} | {r[3]/1e3:.3f} | {r[4]:.2f}")
             except sqlite3.Error as e:
