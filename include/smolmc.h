@@ -144,8 +144,11 @@ int smolmc_natural_parameters(const smolmc_handle *h, double *out /*F*/);
 /* ---- state: Sampler.setup_sample + MCKernel.compute_initial_trace ------- */
 /* (sampler/sampler.py:386-434, kernel/base.py:345-365, wanglandau.py:290-300).
  * occ [R x N] int32, seeds [R], temperature [R] (Kelvin; ignored by WL).
- * Computes the initial features / enthalpy of every walker on the device and
- * resets step counters.  WL aux arrays are reset only when reset_aux != 0. */
+ * Computes the initial features / enthalpy of every walker on the device.
+ * reset_aux != 0: fresh kernels -- per-walker RNG counters (= step counters), accept
+ * counters and Wang-Landau aux arrays are reset.  reset_aux == 0: continuation --
+ * counters and WL arrays are kept (a kernel's Generator and aux state persist
+ * across Sampler.run calls in the reference, sampler.py:254-262), seeds are ignored. */
 int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint64_t *seeds,
                      const double *temperature, int reset_aux);
 /* ThermalKernelMixin.temperature setter (kernel/base.py:418-422), per walker */

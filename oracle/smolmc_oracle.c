@@ -381,10 +381,12 @@ int orc_mc_set_state(orc_mc *h, const int32_t *occ, const uint64_t *seeds,
     memcpy(h->work_f, occ, RN * 4);
     memcpy(h->work_i, occ, RN * 4);
     for (int r = 0; r < h->R; ++r) {
-        h->seeds[r] = seeds ? seeds[r] : (uint64_t)r;
         h->temperature[r] = temperature ? temperature[r] : 0.0;
-        h->nsteps[r] = 0;
-        h->naccepted[r] = 0;
+        if (reset_aux) {
+            h->seeds[r] = seeds ? seeds[r] : (uint64_t)r;
+            h->nsteps[r] = 0;
+            h->naccepted[r] = 0;
+        }
         h->last_accepted[r] = 1; /* trace.accepted = True initially (base.py:364) */
         double *f = h->features + (size_t)r * h->F;
         orc_feature_vector(h->t, h->occ + (size_t)r * h->N, f);

@@ -1805,14 +1805,16 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
     KParams &kp = h->kp;
     const size_t R = h->R;
     TRY(upload_occ(h, occ, R, kp.occ));
-    std::vector<uint64_t> sd(R);
-    for (size_t r = 0; r < R; ++r) sd[r] = seeds ? seeds[r] : (uint64_t)r;
-    HIPCHK(hipMemcpy((void *)kp.seeds, sd.data(), R * 8, hipMemcpyHostToDevice));
     std::vector<double> beta;
     set_betas(h, temperature, beta);
     HIPCHK(hipMemcpy(h->d_beta, beta.data(), R * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(kp.nsteps, 0, R * 8, h->stream));
-    HIPCHK(hipMemsetAsync(kp.nacc, 0, R * 8, h->stream));
+    if (reset_aux) {
+        std::vector<uint64_t> sd(R);
+        for (size_t r = 0; r < R; ++r) sd[r] = seeds ? seeds[r] : (uint64_t)r;
+        HIPCHK(hipMemcpy((void *)kp.seeds, sd.data(), R * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(kp.nsteps, 0, R * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.nacc, 0, R * 8, h->stream));
+    }
     HIPCHK(hipMemsetAsync(kp.last_acc, 1, R, h->stream));
     TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));
     hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,

@@ -1,0 +1,940 @@
+"""Host-side mirror of smol.moca's interface for the accelerated path.
+
+Same names, argument meaning and error behaviour as the reference objects they stand
+in for, so user scripts and parity tests read like smol's own:
+
+    Sublattice                      smol/moca/sublattice.py:23
+    ClusterExpansionProcessor       smol/moca/processor/expansion.py:39
+    ClusterDecompositionProcessor   smol/moca/processor/expansion.py:243
+    EwaldProcessor                  smol/moca/processor/ewald.py:26
+    CompositeProcessor              smol/moca/processor/composite.py:18
+    Ensemble                        smol/moca/ensemble.py:102
+    Metropolis / WangLandau         smol/moca/kernel/metropolis.py:52, wanglandau.py:17
+    Trace                           smol/moca/trace.py:8
+    SampleContainer                 smol/moca/sampler/container.py:25
+    Sampler                         smol/moca/sampler/sampler.py:22
+
+What differs, by design: the boundary sits at the *Sampler* level.  A
+Sampler owns ONE engine handle holding all its walkers on one GPU; ``run`` advances
+every walker ``thin_by`` steps per kernel launch instead of looping over Python kernel
+objects one flip at a time.  The per-flip ``Processor`` methods are kept (GPU-backed,
+one launch per call) for parity tests and user-side checks, not for sampling.
+
+Everything here drives the HIP engine through smol_amd.engine; there is no CPU path.
+"""
+
+from __future__ import annotations
+
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import capi
+from .engine import Engine
+
+kB = 8.617333262145e-5  # smol/constants.py:4
+
+
+# --------------------------------------------------------------------------- #
+class Trace(SimpleNamespace):
+    """Namespace of ndarrays recorded during sampling (smol/moca/trace.py:8-46)."""
+
+    def __init__(self, /, **kwargs):
+        if not all(isinstance(v, np.ndarray) for v in kwargs.values()):
+            raise TypeError("Trace only supports attributes of type ndarray.")
+        super().__init__(**kwargs)
+
+    @property
+    def names(self):
+        return tuple(self.__dict__.keys())
+
+    def items(self):
+        yield from self.__dict__.items()
+
+    def __setattr__(self, name, value):
+        if isinstance(value, float):
+            value = np.array([value], dtype=np.float64)
+        if isinstance(value, int):
+            value = np.array([value], dtype=np.int32)
+        if not isinstance(value, np.ndarray):
+            raise TypeError("Trace only supports attributes of type ndarray.")
+        self.__dict__[name] = value
+
+    def as_dict(self):
+        return self.__dict__.copy()
+
+
+class Sublattice:
+    """Sites sharing one site space (smol/moca/sublattice.py:23-107)."""
+
+    def __init__(self, species, sites):
+        self.species = tuple(species)
+        self.sites = np.unique(np.asarray(sites, dtype=np.int64))
+        self.active_sites = self.sites.copy()
+        if len(self.species) <= 1:
+            self.restrict_sites(self.sites)
+        self.encoding = np.arange(len(self.species), dtype=np.int32)
+
+    @property
+    def is_active(self):
+        return len(self.active_sites) > 0
+
+    @property
+    def restricted_sites(self):
+        return np.setdiff1d(self.sites, self.active_sites)
+
+    def restrict_sites(self, sites):
+        sites = set(int(s) for s in sites)
+        self.active_sites = np.array([i for i in self.active_sites if i not in sites], dtype=np.int64)
+
+    def reset_restricted_sites(self):
+        if len(self.species) > 1:
+            self.active_sites = self.sites.copy()
+
+
+# --------------------------------------------------------------------------- #
+# processors
+# --------------------------------------------------------------------------- #
+def default_species(prim):
+    names = []
+    for b, S in enumerate(prim.nspecies):
+        names.append([f"{chr(65 + b)}{c}" for c in range(S)])
+    return names
+
+
+class Processor:
+    """Base of the GPU-backed processors (smol/moca/processor/base.py:26)."""
+
+    def __init__(self, supercell, coefficients):
+        self.supercell = supercell
+        self.cluster_subspace = supercell.model
+        self.coefs = np.asarray(coefficients, dtype=np.float64)
+        self.size = supercell.size
+        self.num_sites = supercell.num_sites
+        self.supercell_matrix = supercell.scmatrix
+        self._eval_engine = None
+        self._eval_tables = None
+
+    # -- pieces of the flattened tables this processor contributes --------------
+    def _table_kwargs(self):
+        raise NotImplementedError
+
+    def _make_tables(self, mu_table=None, sublattices=None):
+        kw = self._table_kwargs()
+        tab = capi.TableSet.from_synth(
+            self.supercell, kw["ce_coefs_expansion"], feature_mode=kw["feature_mode"],
+            ewald=kw.get("ewald"), ewald_coef=kw.get("ewald_coef", 1.0), mu_table=mu_table,
+        )
+        if kw.get("ce_natural") is not None:
+            tab._keep["ce_coefs"][:] = kw["ce_natural"]
+        if kw.get("interaction_tensors") is not None:
+            its = kw["interaction_tensors"]
+            flat = np.concatenate([np.ravel(np.asarray(x, dtype=np.float64)) for x in its[1:]])
+            if flat.size != tab._keep["interaction_tensors"].size:
+                raise ValueError(
+                    "The number of cluster interaction tensors must match the number of orbits"
+                )
+            tab._keep["interaction_tensors"][:] = flat
+            tab.struct.offset = float(its[0])
+        if sublattices is not None:
+            _override_sublattices(tab, sublattices)
+        return tab
+
+    def _engine(self):
+        if self._eval_engine is None:
+            self._eval_tables = self._make_tables()
+            self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
+        return self._eval_engine
+
+    _feature_slice = slice(None)
+
+    # -- reference API -----------------------------------------------------------
+    def compute_feature_vector(self, occupancy):
+        try:
+            occupancy = np.array(occupancy, dtype=np.int32)
+        except ValueError:
+            types = {type(n) for n in occupancy}
+            raise ValueError(f"occupancy contains {types}, but should be integers!")
+        out = self._engine().eval_full(occupancy[None, :])[0][self._feature_slice]
+        return float(out[0]) if self._scalar_feature else out
+
+    _scalar_feature = False
+
+    def compute_feature_vector_change(self, occupancy, flips):
+        try:
+            occupancy = np.array(occupancy, dtype=np.int32)
+        except ValueError:
+            types = {type(n) for n in occupancy}
+            raise ValueError(f"occupancy contains {types}, but should be integers!")
+        flips = list(flips)
+        if len(flips) > 2:
+            # sequential semantics (expansion.py:217-229): chain in pairs
+            total = 0.0
+            occ = occupancy.copy()
+            for i in range(0, len(flips), 2):
+                chunk = flips[i:i + 2]
+                total = total + self.compute_feature_vector_change(occ, chunk)
+                for s, c in chunk:
+                    occ[s] = c
+            return total
+        row = -np.ones(4, dtype=np.int32)
+        for j, (s, c) in enumerate(flips):
+            row[2 * j], row[2 * j + 1] = s, c
+        out = self._engine().eval_delta(occupancy, row[None, :])[0][self._feature_slice]
+        return float(out[0]) if self._scalar_feature else out
+
+    def compute_property(self, occupancy):
+        return np.dot(self.coefs, self.compute_feature_vector(occupancy))
+
+    def compute_property_change(self, occupancy, flips):
+        return np.dot(self.coefs, self.compute_feature_vector_change(occupancy, flips))
+
+    def compute_average_drift(self, iterations=1000, rng=None):
+        """Average forward / reverse drift of local updates (processor/base.py:270-312)."""
+        rng = np.random.default_rng(rng)
+        prim = self.supercell.model.prim
+        nsp = np.array([prim.nspecies[b] for b in self.supercell.site_b])
+        active = np.flatnonzero(nsp > 1)
+        occ = (rng.random(self.num_sites) * nsp).astype(np.int32)
+        fwd = rev = 0.0
+        f_prev = self.compute_feature_vector(occ)
+        for _ in range(iterations):
+            s = int(rng.choice(active))
+            c = int((occ[s] + 1 + rng.integers(0, nsp[s] - 1)) % nsp[s])
+            d = self.compute_feature_vector_change(occ, [(s, c)])
+            new = occ.copy()
+            new[s] = c
+            dr = self.compute_feature_vector_change(new, [(s, int(occ[s]))])
+            f_new = self.compute_feature_vector(new)
+            fwd += np.sum(np.abs(f_new - f_prev - d))
+            rev += np.sum(np.abs(f_prev - f_new - dr))
+            occ, f_prev = new, f_new
+        return fwd / iterations, rev / iterations
+
+    def get_sublattices(self):
+        """One Sublattice per distinct site space (processor/base.py get_sublattices)."""
+        prim = self.supercell.model.prim
+        names = getattr(prim, "species", None) or default_species(prim)
+        groups = {}
+        for b in range(prim.nb):
+            key = prim.labels[b]
+            sites = np.flatnonzero(self.supercell.site_b == b)
+            if key in groups:
+                groups[key][1].append(sites)
+            else:
+                groups[key] = (names[b], [sites])
+        return [Sublattice(sp, np.concatenate(st)) for sp, st in groups.values()]
+
+    def encode_occupancy(self, occupancy):
+        return np.array(occupancy, dtype=np.int32)
+
+
+class ClusterExpansionProcessor(Processor):
+    """Correlation-vector features (smol/moca/processor/expansion.py:39-241)."""
+
+    def __init__(self, supercell, coefficients):
+        if len(coefficients) != supercell.model.num_corr_functions:
+            raise ValueError(
+                f"The provided coefficients are not the right length. Got {len(coefficients)} "
+                f"coefficients, the length must be {supercell.model.num_corr_functions} based on "
+                "the provided cluster subspace."
+            )
+        super().__init__(supercell, coefficients)
+
+    def _table_kwargs(self):
+        return dict(feature_mode=capi.FEATURES_CORRELATIONS, ce_coefs_expansion=self.coefs)
+
+
+class ClusterDecompositionProcessor(Processor):
+    """Cluster-interaction features (smol/moca/processor/expansion.py:243-489)."""
+
+    def __init__(self, supercell, interaction_tensors, coefficients=None):
+        model = supercell.model
+        if len(interaction_tensors) != model.num_orbits:
+            raise ValueError(
+                f"The number of cluster interaction tensors must match the number  of orbits in "
+                f"the subspace. Got {len(interaction_tensors)} interaction tensors, but need "
+                f"{model.num_orbits}  for the given cluster_subspace."
+            )
+        coefficients = model.orbit_multiplicities if coefficients is None else coefficients
+        super().__init__(supercell, np.asarray(coefficients, dtype=np.float64))
+        self._interaction_tensors = interaction_tensors
+
+    def _table_kwargs(self):
+        return dict(
+            feature_mode=capi.FEATURES_INTERACTIONS,
+            ce_coefs_expansion=np.zeros(self.supercell.model.num_corr_functions),
+            ce_natural=self.coefs,
+            interaction_tensors=self._interaction_tensors,
+        )
+
+
+class EwaldProcessor(Processor):
+    """Electrostatic feature (smol/moca/processor/ewald.py:26-203).
+
+    ``ewald_term`` is ``(ewald_inds, ewald_matrix)``; when None it is computed with the
+    build's own Ewald sum (smol_amd.ewald; values unpinned vs pymatgen)."""
+
+    _scalar_feature = True
+
+    def __init__(self, supercell, ewald_term=None, coefficient=1.0):
+        super().__init__(supercell, np.asarray(coefficient, dtype=np.float64))
+        if ewald_term is None:
+            from . import ewald as _ew
+
+            ewald_term = _ew.supercell_ewald(supercell)
+        self._ewald_inds = np.ascontiguousarray(ewald_term[0], dtype=np.int32)
+        self.ewald_matrix = np.ascontiguousarray(ewald_term[1], dtype=np.float64)
+        self._feature_slice = slice(supercell.model.num_orbits, supercell.model.num_orbits + 1)
+
+    def _table_kwargs(self):
+        m = self.supercell.model
+        return dict(
+            feature_mode=capi.FEATURES_INTERACTIONS,
+            ce_coefs_expansion=np.zeros(m.num_corr_functions),
+            ce_natural=np.zeros(m.num_orbits),
+            ewald=(self._ewald_inds, self.ewald_matrix),
+            ewald_coef=float(self.coefs),
+        )
+
+    def compute_property(self, occupancy):
+        return self.coefs * self.compute_feature_vector(occupancy)
+
+    def compute_property_change(self, occupancy, flips):
+        return self.coefs * self.compute_feature_vector_change(occupancy, flips)
+
+
+class CompositeProcessor(Processor):
+    """CE + external term (smol/moca/processor/composite.py:18-190)."""
+
+    def __init__(self, supercell):
+        super().__init__(supercell, np.zeros(0))
+        self._processors = []
+
+    @property
+    def processors(self):
+        return self._processors
+
+    def add_processor(self, processor):
+        if isinstance(processor, CompositeProcessor):
+            raise AttributeError("A CompositeProcessor can not be added into another CompositeProcessor")
+        if processor.supercell is not self.supercell:
+            raise ValueError("processors must share the supercell")
+        if len(self._processors) >= 2 or (self._processors and not isinstance(processor, EwaldProcessor)):
+            raise ValueError("supported composition: one cluster processor followed by one EwaldProcessor")
+        self._processors.append(processor)
+        self.coefs = np.append(self.coefs, processor.coefs)
+        self._eval_engine = None
+
+    def _table_kwargs(self):
+        if not self._processors:
+            raise ValueError("empty CompositeProcessor")
+        kw = dict(self._processors[0]._table_kwargs())
+        if len(self._processors) == 2:
+            ew = self._processors[1]
+            kw["ewald"] = (ew._ewald_inds, ew.ewald_matrix)
+            kw["ewald_coef"] = float(ew.coefs)
+        return kw
+
+
+def _override_sublattices(tab, sublattices):
+    """Re-point a TableSet's sublattice arrays at user-given Sublattice objects."""
+    import ctypes as C
+
+    subs = [s for s in sublattices if s.is_active]
+    k = tab._keep
+    k["sub_site_ptr"] = np.concatenate(([0], np.cumsum([len(s.active_sites) for s in subs]))).astype(np.int64)
+    k["sub_active_sites"] = np.concatenate([s.active_sites for s in subs]).astype(np.int32)
+    k["sub_code_ptr"] = np.concatenate(([0], np.cumsum([len(s.encoding) for s in subs]))).astype(np.int64)
+    k["sub_codes"] = np.concatenate([s.encoding for s in subs]).astype(np.int32)
+    probs = getattr(tab, "_user_probs", None)
+    k["sub_probs"] = np.full(len(subs), 1.0 / len(subs)) if probs is None else np.asarray(probs, float)
+    t = tab.struct
+    t.n_sublattices = len(subs)
+    for name, ct in (("sub_site_ptr", C.c_int64), ("sub_active_sites", C.c_int32),
+                     ("sub_code_ptr", C.c_int64), ("sub_codes", C.c_int32), ("sub_probs", C.c_double)):
+        setattr(t, name, k[name].ctypes.data_as(C.POINTER(ct)))
+
+
+# --------------------------------------------------------------------------- #
+class Ensemble:
+    """Thermodynamic ensemble (smol/moca/ensemble.py:102-430)."""
+
+    def __init__(self, processor, sublattices=None, chemical_potentials=None):
+        self._processor = processor
+        self._sublattices = processor.get_sublattices() if sublattices is None else sublattices
+        self.natural_parameters = np.array(processor.coefs, dtype=np.float64)  # ensemble.py:126
+        self.thermo_boundaries = {}
+        self._chemical_potentials = None
+        self._mu_table = None
+        self.chemical_potentials = chemical_potentials
+
+    @classmethod
+    def from_cluster_expansion(cls, supercell, coefficients, processor_type="decomposition",
+                               ewald_term=None, ewald_coefficient=None, **kwargs):
+        """Counterpart of Ensemble.from_cluster_expansion (ensemble.py:133-217) for the
+        build's own tables: ``supercell`` is a smol_amd.synth.SupercellTables and
+        ``coefficients`` the expansion coefficients (num_corr_functions long).  When
+        ``ewald_coefficient`` is given an EwaldProcessor is composed in."""
+        model = supercell.model
+        if processor_type == "decomposition":
+            ce = ClusterDecompositionProcessor(supercell, model.cluster_interaction_tensors(coefficients))
+        elif processor_type == "expansion":
+            ce = ClusterExpansionProcessor(supercell, coefficients)
+        else:
+            raise ValueError(f"Processor type {processor_type} not supported!")
+        if ewald_coefficient is None:
+            return cls(ce, **kwargs)
+        comp = CompositeProcessor(supercell)
+        comp.add_processor(ce)
+        comp.add_processor(EwaldProcessor(supercell, ewald_term, ewald_coefficient))
+        return cls(comp, **kwargs)
+
+    # -- properties ----------------------------------------------------------------
+    @property
+    def processor(self):
+        return self._processor
+
+    @property
+    def num_sites(self):
+        return self._processor.num_sites
+
+    @property
+    def num_energy_coefs(self):
+        return len(self._processor.coefs)
+
+    @property
+    def system_size(self):
+        return self._processor.size
+
+    @property
+    def sublattices(self):
+        return self._sublattices
+
+    @property
+    def active_sublattices(self):
+        return [s for s in self._sublattices if s.is_active]
+
+    @property
+    def restricted_sites(self):
+        return np.concatenate([s.restricted_sites for s in self._sublattices] + [np.zeros(0, int)])
+
+    @property
+    def species(self):
+        return [sp for s in self.active_sublattices for sp in s.species]
+
+    @property
+    def chemical_potentials(self):
+        return self._chemical_potentials
+
+    @chemical_potentials.setter
+    def chemical_potentials(self, value):
+        """ChemicalPotentialManager.__set__ (ensemble.py:35-73)."""
+        had = self._chemical_potentials is not None
+        if value is None:
+            if had:
+                self.natural_parameters = self.natural_parameters[:-1]
+                self.thermo_boundaries.pop("chemical_potentials", None)
+            self._chemical_potentials, self._mu_table = None, None
+            return
+        value = {k: float(v) for k, v in value.items() if k in self.species}
+        if set(value) != set(self.species):
+            raise ValueError(
+                "Chemical potentials given are missing species. Values must be given for each of "
+                f"the following: {self.species}"
+            )
+        if not had:
+            self.natural_parameters = np.append(self.natural_parameters, -1.0)  # ensemble.py:25,61-65
+        self._chemical_potentials = value
+        num_cols = max(max(s.encoding) for s in self._sublattices) + 1  # _build_table :90-99
+        table = np.zeros((self.num_sites, num_cols))
+        for s in self.active_sublattices:
+            table[s.sites[:, None], s.encoding] = [value[sp] for sp in s.species]
+        self._mu_table = table
+        self.thermo_boundaries["chemical_potentials"] = value
+
+    def restrict_sites(self, sites):
+        for s in self._sublattices:
+            s.restrict_sites(sites)
+
+    def reset_restricted_sites(self):
+        for s in self._sublattices:
+            s.reset_restricted_sites()
+
+    # -- tables for the engine -----------------------------------------------------
+    def make_tables(self):
+        return self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
+
+    def _eval(self):
+        key = (id(self._mu_table), tuple(len(s.active_sites) for s in self._sublattices))
+        if getattr(self, "_eval_key", None) != key:
+            self._eval_tables = self.make_tables()
+            self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
+            self._eval_key = key
+        return self._eval_engine
+
+    def compute_feature_vector(self, occupancy):
+        """ensemble.py:323-351."""
+        return self._eval().eval_full(np.asarray(occupancy, dtype=np.int32)[None, :])[0]
+
+    def compute_feature_vector_change(self, occupancy, step):
+        """ensemble.py:353-376 (steps of up to two flips)."""
+        row = -np.ones(4, dtype=np.int32)
+        for j, (s, c) in enumerate(step):
+            row[2 * j], row[2 * j + 1] = s, c
+        return self._eval().eval_delta(np.asarray(occupancy, dtype=np.int32), row[None, :])[0]
+
+
+# --------------------------------------------------------------------------- #
+# kernels (specifications of what the engine runs for each walker)
+# --------------------------------------------------------------------------- #
+STEP_TYPES = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP}
+
+
+class MCKernel:
+    """Per-walker kernel record (smol/moca/kernel/base.py:169-343).  Holds the parameters
+    the reference keeps per kernel object; the stepping itself happens on the GPU."""
+
+    kernel_type = None
+
+    def __init__(self, ensemble, step_type, *args, seed=None, **kwargs):
+        if step_type not in STEP_TYPES:
+            raise ValueError(
+                f"{step_type} is not a valid MCUsher for this kernel (supported: {sorted(STEP_TYPES)})."
+            )
+        self._ensemble = ensemble
+        self.natural_params = ensemble.natural_parameters
+        self.step_type = step_type
+        self._seed = seed if seed is not None else np.random.SeedSequence().entropy
+        self.spec = dict(kernel=self.__class__.__name__, seed=self._seed, step=step_type)
+
+    @property
+    def ensemble(self):
+        return self._ensemble
+
+    @property
+    def seed(self):
+        return self._seed
+
+    @property
+    def seed64(self):
+        return np.uint64(int(self._seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+class Metropolis(MCKernel):
+    """Metropolis-Hastings kernel (smol/moca/kernel/metropolis.py:52-100)."""
+
+    kernel_type = capi.KERNEL_METROPOLIS
+
+    def __init__(self, ensemble, step_type, temperature, *args, seed=None, **kwargs):
+        super().__init__(ensemble, step_type, *args, seed=seed, **kwargs)
+        self.kB = kB
+        self.temperature = temperature
+
+    @property
+    def temperature(self):
+        return self._temperature
+
+    @temperature.setter
+    def temperature(self, temperature):
+        self._temperature = float(temperature)
+        self.beta = 1.0 / (self.kB * self._temperature)  # kernel/base.py:418-422
+
+
+class WangLandau(MCKernel):
+    """Wang-Landau kernel (smol/moca/kernel/wanglandau.py:17-300)."""
+
+    kernel_type = capi.KERNEL_WANGLANDAU
+
+    def __init__(self, ensemble, step_type, min_enthalpy, max_enthalpy, bin_size, *args,
+                 flatness=0.8, mod_factor=1.0, check_period=1000, update_period=1,
+                 mod_update=None, seed=None, **kwargs):
+        if min_enthalpy > max_enthalpy:
+            raise ValueError("min_enthalpy can not be larger than max_enthalpy.")
+        if (max_enthalpy - min_enthalpy) / bin_size <= 1:
+            raise ValueError(
+                "The values provided for min and max enthalpy and bin sizer result in a single bin!"
+            )
+        if mod_factor <= 0:
+            raise ValueError("mod_factor must be greater than 0.")
+        if callable(mod_update):
+            raise NotImplementedError("callable mod_update is not supported on the device; pass a number")
+        super().__init__(ensemble, step_type, *args, seed=seed, **kwargs)
+        self.flatness, self.check_period, self.update_period = flatness, check_period, update_period
+        self._m0 = mod_factor
+        self._window = (min_enthalpy, max_enthalpy, bin_size)
+        self._mod_divisor = 2.0 if mod_update is None else float(mod_update)
+        self._levels = np.arange(min_enthalpy, max_enthalpy, bin_size)
+        self.spec.update(min_enthalpy=min_enthalpy, max_enthalpy=max_enthalpy, bin_size=bin_size,
+                         flatness=flatness, check_period=check_period, update_period=update_period,
+                         levels=self._levels.tolist())
+
+    @property
+    def bin_size(self):
+        return self._window[2]
+
+
+KERNELS = {"metropolis": Metropolis, "wanglandau": WangLandau, "wang-landau": WangLandau}
+
+
+def mckernel_factory(kernel_type, ensemble, step_type, *args, **kwargs):
+    """smol/moca/kernel/__init__.py:35-56."""
+    key = str(kernel_type).lower().replace("_", "")
+    if key not in KERNELS:
+        raise NotImplementedError(f"{kernel_type} is not implemented on the MI355X engine.")
+    return KERNELS[key](ensemble, step_type, *args, **kwargs)
+
+
+# --------------------------------------------------------------------------- #
+class SampleContainer:
+    """In-memory sample storage (smol/moca/sampler/container.py:25-660, HDF5 parts omitted:
+    h5py is not available; use to_npz / from_npz)."""
+
+    def __init__(self, ensemble, sample_trace, sampling_metadata=None):
+        self._ensemble = ensemble
+        self.natural_parameters = ensemble.natural_parameters
+        self._num_energy_coefs = ensemble.num_energy_coefs
+        self._trace = sample_trace
+        self.metadata = dict(sampling_metadata or {})
+        self._nsamples = 0
+        self._total_steps = 0
+        self._aux_checkpoint = None
+
+    @property
+    def ensemble(self):
+        return self._ensemble
+
+    @property
+    def sublattices(self):
+        return self._ensemble.sublattices
+
+    @property
+    def num_samples(self):
+        return self._nsamples
+
+    @property
+    def total_mc_steps(self):
+        return self._total_steps
+
+    @property
+    def shape(self):
+        return self._trace.occupancy.shape[1:]
+
+    @property
+    def traced_values(self):
+        return self._trace.names
+
+    def __len__(self):
+        return self._nsamples
+
+    def sampling_efficiency(self, discard=0, flat=True):
+        total_accepted = self._trace.accepted[discard:self._nsamples].sum(axis=0)
+        efficiency = total_accepted / (self._nsamples - discard)
+        return efficiency.mean() if flat else efficiency
+
+    @staticmethod
+    def _flatten(traced_values):
+        shape_l = list(traced_values.shape[1:])
+        shape_l[0] = int(np.prod(traced_values.shape[:2]))
+        return np.squeeze(traced_values.reshape(shape_l))
+
+    def get_trace_value(self, name, discard=0, thin_by=1, flat=True):
+        value = getattr(self._trace, name)[: self._nsamples][discard + thin_by - 1:: thin_by]
+        return self._flatten(value) if flat else value
+
+    def mean_trace_value(self, name, discard=0, thin_by=1, flat=True):
+        return self.get_trace_value(name, discard, thin_by, flat).mean(axis=0)
+
+    def trace_value_variance(self, name, discard=0, thin_by=1, flat=True):
+        return self.get_trace_value(name, discard, thin_by, flat).var(axis=0)
+
+    def get_occupancies(self, discard=0, thin_by=1, flat=True):
+        return self.get_trace_value("occupancy", discard, thin_by, flat)
+
+    def get_enthalpies(self, discard=0, thin_by=1, flat=True):
+        return self.get_trace_value("enthalpy", discard, thin_by, flat)
+
+    def get_feature_vectors(self, discard=0, thin_by=1, flat=True):
+        return self.get_trace_value("features", discard, thin_by, flat)
+
+    def get_temperatures(self, discard=0, thin_by=1):
+        return self.get_trace_value("temperature", discard, thin_by)
+
+    def get_energies(self, discard=0, thin_by=1, flat=True):
+        if len(self.natural_parameters) == self._num_energy_coefs:
+            return self.get_enthalpies(discard, thin_by, flat)
+        feats = self.get_feature_vectors(discard, thin_by, flat=False)
+        n = self._num_energy_coefs
+        energies = np.expand_dims(feats[..., :n] @ self.natural_parameters[:n], axis=-1)
+        return self._flatten(energies) if flat else energies
+
+    def mean_enthalpy(self, discard=0, thin_by=1, flat=True):
+        return self.get_enthalpies(discard, thin_by, flat).mean(axis=0)
+
+    def enthalpy_variance(self, discard=0, thin_by=1, flat=True):
+        return self.get_enthalpies(discard, thin_by, flat).var(axis=0)
+
+    def mean_energy(self, discard=0, thin_by=1, flat=True):
+        return self.get_energies(discard, thin_by, flat).mean(axis=0)
+
+    def energy_variance(self, discard=0, thin_by=1, flat=True):
+        return self.get_energies(discard, thin_by, flat).var(axis=0)
+
+    def mean_feature_vector(self, discard=0, thin_by=1, flat=True):
+        return self.get_feature_vectors(discard, thin_by, flat).mean(axis=0)
+
+    def feature_vector_variance(self, discard=0, thin_by=1, flat=True):
+        return self.get_feature_vectors(discard, thin_by, flat).var(axis=0)
+
+    def get_minimum_enthalpy(self, discard=0, thin_by=1, flat=True):
+        return self.get_enthalpies(discard, thin_by, flat).min(axis=0)
+
+    def get_minimum_enthalpy_occupancy(self, discard=0, thin_by=1, flat=True):
+        inds = self.get_enthalpies(discard, thin_by, flat).argmin(axis=0)
+        occ = self.get_occupancies(discard, thin_by, flat)
+        return occ[inds] if flat else occ[inds, np.arange(self.shape[0])][0]
+
+    def get_species_counts(self, discard=0, thin_by=1, flat=True):
+        """Counts of every species code per sublattice (container.py:336-347)."""
+        occ = self.get_occupancies(discard, thin_by, flat)
+        out = {}
+        for s in self.sublattices:
+            sub = occ[..., s.sites]
+            for code, sp in zip(s.encoding, s.species):
+                out[sp] = out.get(sp, 0) + (sub == code).sum(axis=-1)
+        return out
+
+    def save_sampled_trace(self, trace, thinned_by):
+        for name, value in trace.items():
+            getattr(self._trace, name)[self._nsamples] = value
+        self._nsamples += 1
+        self._total_steps += thinned_by
+
+    def clear(self):
+        self._total_steps = 0
+        self._nsamples = 0
+        for name, value in self._trace.items():
+            setattr(self._trace, name, np.empty((0, *value.shape[1:]), dtype=value.dtype))
+
+    def allocate(self, nsamples):
+        for name, value in self._trace.items():
+            arr = np.empty((nsamples, *value.shape[1:]), dtype=value.dtype)
+            setattr(self._trace, name, np.append(value[: self._nsamples], arr, axis=0))
+
+    def vacuum(self):
+        for name, value in self._trace.items():
+            setattr(self._trace, name, value[: self._nsamples])
+
+    def to_npz(self, path):
+        """Checkpoint samples (.npz stand-in for to_hdf5, container.py:615): one array per
+        trace name + nsamples / total_mc_steps, like the HDF5 'trace' group (Appendix D)."""
+        np.savez_compressed(
+            path, nsamples=self._nsamples, total_mc_steps=self._total_steps,
+            **{f"trace/{k}": v[: self._nsamples] for k, v in self._trace.items()},
+        )
+
+    @classmethod
+    def from_npz(cls, path, ensemble):
+        d = np.load(path)
+        trace = Trace(**{k[6:]: d[k] for k in d.files if k.startswith("trace/")})
+        c = cls(ensemble, trace)
+        c._nsamples, c._total_steps = int(d["nsamples"]), int(d["total_mc_steps"])
+        return c
+
+
+# --------------------------------------------------------------------------- #
+class Sampler:
+    """MCMC driver (smol/moca/sampler/sampler.py:22-445) on the batched GPU engine."""
+
+    def __init__(self, kernels, container, engine=None):
+        self._kernels = kernels
+        self._container = container
+        self._container.metadata["kernels"] = [k.spec for k in kernels]
+        self._engine = engine
+        self._engine_key = None
+
+    @classmethod
+    def from_ensemble(cls, ensemble, *args, step_type=None, kernel_type=None, seeds=None,
+                      nwalkers=1, **kwargs):
+        """sampler.py:52-139: default step 'flip' when chemical potentials are set else
+        'swap'; default kernel Metropolis; one kernel (seed) per walker."""
+        if step_type is None:
+            step_type = "flip" if ensemble.chemical_potentials is not None else "swap"
+        if kernel_type is None:
+            kernel_type = "Metropolis"
+        if seeds is not None:
+            if len(seeds) != nwalkers:
+                raise ValueError("Number of seeds does not match number of kernels!")
+        else:
+            seeds = [None for _ in range(nwalkers)]
+        kernels = [mckernel_factory(kernel_type, ensemble, step_type, *args, seed=s, **kwargs)
+                   for s in seeds]
+        k0 = kernels[0]
+        F = len(ensemble.natural_parameters)
+        fields = dict(
+            occupancy=np.empty((0, nwalkers, ensemble.num_sites), dtype=np.int32),
+            features=np.empty((0, nwalkers, F), dtype=np.float64),
+            enthalpy=np.empty((0, nwalkers, 1), dtype=np.float64),
+        )
+        if isinstance(k0, Metropolis):
+            fields["temperature"] = np.empty((0, nwalkers, 1), dtype=np.float64)
+        fields["accepted"] = np.empty((0, nwalkers, 1), dtype=bool)
+        if isinstance(k0, WangLandau):
+            L = len(k0._levels)
+            fields.update(
+                histogram=np.empty((0, nwalkers, L), dtype=np.int64),
+                occurrences=np.empty((0, nwalkers, L), dtype=np.int64),
+                entropy=np.empty((0, nwalkers, L), dtype=np.float64),
+                cumulative_mean_features=np.empty((0, nwalkers, L, F), dtype=np.float64),
+                mod_factor=np.empty((0, nwalkers, 1), dtype=np.float64),
+            )
+        container = SampleContainer(ensemble, Trace(**fields), ensemble.thermo_boundaries)
+        return cls(kernels, container)
+
+    # -- accessors -----------------------------------------------------------------
+    @property
+    def mckernels(self):
+        return self._kernels
+
+    @property
+    def seeds(self):
+        return [k.seed for k in self._kernels]
+
+    @property
+    def samples(self):
+        return self._container
+
+    @property
+    def engine(self):
+        return self._get_engine()
+
+    def efficiency(self, discard=0, flat=True):
+        return self.samples.sampling_efficiency(discard=discard, flat=flat)
+
+    def clear_samples(self):
+        self.samples.clear()
+
+    # -- engine plumbing -------------------------------------------------------------
+    def _get_engine(self, device=0):
+        k0 = self._kernels[0]
+        ens = k0.ensemble
+        key = (id(ens._mu_table), tuple(len(s.active_sites) for s in ens.sublattices), device)
+        if self._engine is None or self._engine_key != key:
+            tables = ens.make_tables()
+            if isinstance(k0, WangLandau):
+                cfg = capi.make_config(
+                    len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], device,
+                    min_enthalpy=k0._window[0], max_enthalpy=k0._window[1], bin_size=k0._window[2],
+                    flatness=k0.flatness, mod_factor=k0._m0, mod_update=k0._mod_divisor,
+                    check_period=k0.check_period, update_period=k0.update_period,
+                )
+            else:
+                cfg = capi.make_config(len(self._kernels), capi.KERNEL_METROPOLIS,
+                                       STEP_TYPES[k0.step_type], device)
+            self._engine = Engine(tables, cfg)
+            self._engine_key = key
+            self._state_loaded = False
+        return self._engine
+
+    def _temperatures(self):
+        return np.array([getattr(k, "temperature", 0.0) for k in self._kernels], dtype=np.float64)
+
+    def _reshape_occu(self, occupancies):
+        """sampler.py:442-end: allow a 1-D occupancy for a single walker."""
+        if occupancies.ndim == 1 and self.samples.shape[0] == 1:
+            return occupancies.reshape(1, -1)
+        raise AttributeError(
+            "The given initial occupancies have incompompatible dimensions. Shape should be "
+            f"{self.samples.shape}."
+        )
+
+    def setup_sample(self, initial_occupancies):
+        """sampler.py:386-434: copy / reshape occupancies, set aux states, initial trace."""
+        occupancies = np.array(initial_occupancies).copy()
+        if occupancies.shape != self.samples.shape:
+            occupancies = self._reshape_occu(occupancies)
+        occupancies = occupancies.astype(np.int32)
+        eng = self._get_engine()
+        seeds = np.array([k.seed64 for k in self._kernels], dtype=np.uint64)
+        # a kernel's Generator, accept counters and WL aux arrays persist across run()
+        # calls of one sampler (sampler.py:254-262): only the first call starts fresh
+        fresh = not getattr(self, "_state_loaded", False)
+        eng.set_state(occupancies, seeds, self._temperatures(), reset_aux=fresh)
+        self._state_loaded = True
+        return occupancies, self._current_trace(eng)
+
+    def _current_trace(self, eng):
+        st = eng.get_state()
+        nw = len(self._kernels)
+        tr = Trace(
+            occupancy=st["occupancy"],
+            features=st["features"],
+            enthalpy=st["enthalpy"].reshape(nw, 1),
+        )
+        if isinstance(self._kernels[0], Metropolis):
+            tr.temperature = self._temperatures().reshape(nw, 1)
+        tr.accepted = st["accepted"].reshape(nw, 1)
+        if isinstance(self._kernels[0], WangLandau):
+            wl = eng.get_wl()
+            tr.histogram = wl["histogram"]
+            tr.occurrences = wl["occurrences"]
+            tr.entropy = wl["entropy"]
+            tr.cumulative_mean_features = wl["mean_features"]
+            tr.mod_factor = wl["mod_factor"].reshape(nw, 1)
+        return tr
+
+    def sample(self, nsteps, initial_occupancies, thin_by=1, progress=False):
+        """Generator over thinned traces (sampler.py:164-210); one launch per yield."""
+        if nsteps % thin_by != 0:
+            warnings.warn(
+                f"The number of steps {nsteps} is not a multiple of thin_by  {thin_by}. The last "
+                f"{nsteps % thin_by} will be ignored.",
+                category=RuntimeWarning,
+            )
+        self.setup_sample(initial_occupancies)
+        eng = self._get_engine()
+        for _ in range(nsteps // thin_by):
+            eng.run(thin_by)
+            yield self._current_trace(eng)
+
+    def run(self, nsteps, initial_occupancies=None, thin_by=1, progress=False, stream_chunk=0,
+            stream_file=None, keep_last_chunk=False, swmr_mode=False):
+        """sampler.py:212-301."""
+        if initial_occupancies is None:
+            try:
+                initial_occupancies = self.samples.get_occupancies(flat=False)[-1]
+            except IndexError as index_error:
+                raise RuntimeError(
+                    "There are no saved samples to obtain the initial occupancies."
+                    "These must be provided."
+                ) from index_error
+        elif self.samples.num_samples > 0:
+            warnings.warn(
+                "Initial occupancies where provided with a pre-existing set of samples.\n Make "
+                "real sure that is what you want. If not, reset the samples in the sampler.",
+                RuntimeWarning,
+            )
+        if stream_chunk > 0:
+            raise NotImplementedError("HDF5 streaming is out of scope here (h5py absent); use to_npz")
+        self.samples.allocate(nsteps // thin_by)
+        for trace in self.sample(nsteps, initial_occupancies, thin_by=thin_by, progress=progress):
+            self.samples.save_sampled_trace(trace, thinned_by=thin_by)
+
+    def anneal(self, temperatures, mcmc_steps, initial_occupancies=None, thin_by=1, progress=False,
+               **kwargs):
+        """Simulated annealing (sampler.py:303-384)."""
+        if not isinstance(self._kernels[0], Metropolis):
+            raise AttributeError("anneal is only available for samplers with a thermal kernel")
+        if temperatures[0] < temperatures[-1]:
+            raise ValueError(
+                "End temperature is greater than start temperature "
+                f"{temperatures[-1]:.2f} > {temperatures[0]:.2f}."
+            )
+        for kernel in self._kernels:
+            kernel.temperature = temperatures[0]
+        self.run(mcmc_steps, initial_occupancies=initial_occupancies, thin_by=thin_by, progress=progress)
+        for temperature in temperatures[1:]:
+            for kernel in self._kernels:
+                kernel.temperature = temperature
+            self.run(mcmc_steps, thin_by=thin_by, progress=progress)

@@ -88,6 +88,7 @@ class PrimCell:
     nspecies: list  # allowed species per basis site (1 => inactive)
     charges: list = None  # per basis site: list of charges per species code
     labels: list = None  # symmetry label per basis site (defaults to nspecies/charges)
+    species: list = None  # species names per basis site, in code order (SiteSpace order)
 
     def __post_init__(self):
         self.lattice = np.asarray(self.lattice, dtype=np.float64)
@@ -585,11 +586,13 @@ def fcc_conventional_prim(a=4.09, nspecies=2):
 def rocksalt_prim(a=4.2, cation_charges=(1.0, 3.0, 4.0), anion_charge=-2.0):
     """Rocksalt primitive cell: cation site (len(cation_charges) species) + fixed anion."""
     lat = 0.5 * a * np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=float)
+    names = ["Li+", "Mn3+", "Ti4+", "Nb5+", "Zr4+"]
     return PrimCell(
         lat,
         [[0, 0, 0], [0.5, 0.5, 0.5]],
         [len(cation_charges), 1],
         charges=[list(cation_charges), [anion_charge]],
+        species=[names[: len(cation_charges)], ["O2-"]],
     )
 
 

@@ -1,0 +1,192 @@
+"""GPU tests of the smol.moca mirror (Sampler / Ensemble / Processors on the engine),
+restating the reference's own invariants:
+  tests/test_moca/test_processor.py:170-231  delta == difference, reversibility, drift
+  tests/test_moca/test_kernel.py:109-170     accepted => occupancy changed, trace deltas
+  tests/test_moca/test_sampler.py:59-129     trace rows == recomputed features, anneal
+"""
+
+import numpy as np
+import pytest
+
+from smol_amd import capi, moca, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+ATOL = 2e4 * np.finfo(float).eps  # tests/test_moca/test_processor.py:27-29
+DRIFT_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def fcc():
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.0, 3: 5.0})
+    sc = synth.build_supercell(model, [5, 5, 5])
+    return model, sc, synth.random_coefs(model, seed=3)
+
+
+@pytest.fixture(scope="module")
+def rocksalt():
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 6.0, 3: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    return model, sc, synth.random_coefs(model, seed=4)
+
+
+def _processors(fcc, rocksalt):
+    model, sc, coefs = fcc
+    yield moca.ClusterExpansionProcessor(sc, coefs)
+    yield moca.ClusterDecompositionProcessor(sc, model.cluster_interaction_tensors(coefs))
+    model, sc, coefs = rocksalt
+    yield moca.EwaldProcessor(sc, coefficient=0.3)
+    comp = moca.CompositeProcessor(sc)
+    comp.add_processor(moca.ClusterExpansionProcessor(sc, coefs))
+    comp.add_processor(moca.EwaldProcessor(sc, coefficient=0.3))
+    yield comp
+
+
+def _rand_occ(rng, sc):
+    nsp = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
+    return (rng.random(sc.num_sites) * nsp).astype(np.int32), nsp
+
+
+def test_processor_delta_is_difference_and_reversible(fcc, rocksalt):
+    rng = np.random.default_rng(0)
+    for proc in _processors(fcc, rocksalt):
+        occ, nsp = _rand_occ(rng, proc.supercell)
+        active = np.flatnonzero(nsp > 1)
+        prop_f = proc.compute_property(occ)
+        for _ in range(15):
+            s1, s2 = rng.choice(active, 2, replace=False)
+            flips = [(int(s1), int((occ[s1] + 1) % nsp[s1])), (int(s2), int((occ[s2] + 1) % nsp[s2]))]
+            new = occ.copy()
+            for s, c in flips:
+                new[s] = c
+            d = proc.compute_feature_vector_change(occ, flips)
+            f0, f1 = proc.compute_feature_vector(occ), proc.compute_feature_vector(new)
+            np.testing.assert_allclose(d, f1 - f0, rtol=1e-8, atol=1e-8)
+            rev = [(s, int(occ[s])) for s, _ in flips][::-1]
+            np.testing.assert_allclose(d, -1 * np.asarray(proc.compute_feature_vector_change(new, rev)),
+                                       rtol=RTOL, atol=1e-9)
+            dprop = proc.compute_property_change(occ, flips)
+            np.testing.assert_allclose(proc.compute_property(new) - prop_f, dprop, rtol=1e-8, atol=1e-8)
+            occ, prop_f = new, proc.compute_property(new)
+
+
+def test_processor_average_drift(fcc):
+    model, sc, coefs = fcc
+    for proc in (moca.ClusterExpansionProcessor(sc, coefs),
+                 moca.ClusterDecompositionProcessor(sc, model.cluster_interaction_tensors(coefs))):
+        fwd, rev = proc.compute_average_drift(iterations=60, rng=1)
+        assert fwd <= DRIFT_TOL and rev <= DRIFT_TOL
+
+
+def test_decomposition_and_expansion_give_same_energy(fcc):
+    """ClusterDecompositionProcessor samples the same ensemble (expansion.py:249-252)."""
+    model, sc, coefs = fcc
+    pe = moca.ClusterExpansionProcessor(sc, coefs)
+    pd = moca.ClusterDecompositionProcessor(sc, model.cluster_interaction_tensors(coefs))
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        occ, _ = _rand_occ(rng, sc)
+        np.testing.assert_allclose(pe.compute_property(occ), pd.compute_property(occ), rtol=1e-10)
+
+
+@pytest.mark.parametrize("kind", ["canonical", "semigrand"])
+def test_sampler_trace_rows_match_recomputed_features(fcc, kind):
+    """tests/test_moca/test_sampler.py:59-84 (ATOL 5e-13 there; rel 1e-10 here)."""
+    model, sc, coefs = fcc
+    mu = {"A0": 0.3, "A1": -0.1} if kind == "semigrand" else None
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, chemical_potentials=mu)
+    nw = 5
+    sampler = moca.Sampler.from_ensemble(ens, temperature=1500, nwalkers=nw, seeds=list(range(1, nw + 1)))
+    rng = np.random.default_rng(3)
+    occu = np.vstack([_rand_occ(rng, sc)[0] for _ in range(nw)])
+    sampler.run(2000, occu, thin_by=50)
+    c = sampler.samples
+    assert c.num_samples == 40 and c.total_mc_steps == 2000
+    occs = c.get_occupancies(flat=False)
+    feats = c.get_feature_vectors(flat=False)
+    enth = c.get_enthalpies(flat=False)
+    for i in (0, 17, 39):
+        for w in range(nw):
+            f = ens.compute_feature_vector(occs[i, w])
+            np.testing.assert_allclose(feats[i, w], f, rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(enth[i, w, 0], ens.natural_parameters @ f, rtol=1e-10, atol=1e-9)
+    if kind == "canonical":  # composition conserved by swaps
+        assert np.all(occs.sum(axis=-1) == occu.sum(axis=-1)[None, :])
+        np.testing.assert_allclose(c.get_energies(), c.get_enthalpies())
+    else:
+        assert not np.all(occs.sum(axis=-1) == occu.sum(axis=-1)[None, :])
+        assert np.abs(c.get_energies() - c.get_enthalpies()).max() > 0
+    assert 0 < sampler.efficiency() <= 1
+    np.testing.assert_allclose(c.get_temperatures(), 1500.0)
+    # continuing a run takes the last sample as the start and keeps the random streams going
+    sampler.run(500, thin_by=50)
+    assert c.num_samples == 50 and c.total_mc_steps == 2500
+
+
+def test_sampler_matches_oracle_stream(fcc):
+    """Same seeds -> same Philox streams as the CPU oracle: identical sampled occupancies."""
+    from oracle import oracle as orc
+
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    nw = 3
+    seeds = [11, 12, 13]
+    sampler = moca.Sampler.from_ensemble(ens, temperature=1200, nwalkers=nw, seeds=seeds)
+    rng = np.random.default_rng(8)
+    occu = np.vstack([_rand_occ(rng, sc)[0] for _ in range(nw)])
+    sampler.run(300, occu, thin_by=100)
+    sampler.run(200, thin_by=100)  # continuation keeps the stream position
+    tab = ens.make_tables()
+    ora = orc.OracleMC(tab, capi.make_config(nw))
+    ora.set_state(occu, np.array(seeds, dtype=np.uint64), 1200.0)
+    occs = sampler.samples.get_occupancies(flat=False)
+    for i in range(5):
+        ora.run(100)
+        st = ora.get_state()
+        assert np.array_equal(occs[i], st["occupancy"])
+        np.testing.assert_allclose(sampler.samples.get_enthalpies(flat=False)[i, :, 0], st["enthalpy"],
+                                   rtol=1e-10, atol=1e-9)
+
+
+def test_anneal(fcc):
+    """tests/test_moca/test_sampler.py:89-113."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    sampler = moca.Sampler.from_ensemble(ens, temperature=5000, nwalkers=2, seeds=[5, 6])
+    occu = np.vstack([_rand_occ(np.random.default_rng(4), sc)[0] for _ in range(2)])
+    temps = np.linspace(2000, 500, 4)
+    with pytest.raises(ValueError):
+        sampler.anneal(temps[::-1], 100, occu)
+    sampler.anneal(temps, 400, occu, thin_by=100)
+    c = sampler.samples
+    assert c.num_samples == 16
+    np.testing.assert_allclose(c.get_temperatures(flat=False) if False else c.get_trace_value(
+        "temperature", flat=False)[:, 0, 0], np.repeat(temps, 4))
+    # cooling lowers the energy on average
+    e = c.get_enthalpies(flat=False)[:, :, 0].mean(axis=1)
+    assert e[-1] < e[0]
+
+
+def test_wang_landau_sampler(fcc):
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = _rand_occ(np.random.default_rng(5), sc)[0]
+    h0 = float(ens.natural_parameters @ ens.compute_feature_vector(occu))
+    sampler = moca.Sampler.from_ensemble(
+        ens, h0 - 8.0, h0 + 8.0, 0.5, kernel_type="Wang-Landau", nwalkers=2, seeds=[1, 2],
+        check_period=200, flatness=0.2,
+    )
+    assert "entropy" in sampler.samples.traced_values
+    sampler.run(4000, np.vstack([occu, occu]), thin_by=1000)
+    c = sampler.samples
+    ent = c.get_trace_value("entropy", flat=False)
+    hist = c.get_trace_value("histogram", flat=False)
+    assert ent.shape == (4, 2, 32) and (ent[-1] > 0).sum() >= 2
+    assert np.all(np.diff(ent.sum(axis=-1), axis=0) > 0)  # entropy only grows
+    assert np.all(hist >= 0)
+    enth = c.get_enthalpies(flat=False)
+    assert np.all((enth >= h0 - 8.0) & (enth < h0 + 8.0))  # never leaves the window
+    feats = c.get_feature_vectors(flat=False)
+    occs = c.get_occupancies(flat=False)
+    np.testing.assert_allclose(feats[-1, 0], ens.compute_feature_vector(occs[-1, 0]), rtol=1e-10, atol=1e-9)

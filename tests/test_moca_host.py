@@ -1,0 +1,151 @@
+"""Host-side logic of the smol.moca mirror that needs no GPU: container / trace
+bookkeeping, argument validation and error behaviour (same messages and exception
+types as the reference objects)."""
+
+import numpy as np
+import pytest
+
+from smol_amd import moca, synth
+
+
+@pytest.fixture(scope="module")
+def ensemble():
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    return moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model))
+
+
+def test_trace_only_accepts_ndarrays():  # smol/moca/trace.py:16-43
+    with pytest.raises(TypeError):
+        moca.Trace(a=1.0)
+    t = moca.Trace(a=np.zeros(2))
+    t.b = 2.0
+    t.c = 3
+    assert t.b.dtype == np.float64 and t.c.dtype == np.int32
+    with pytest.raises(TypeError):
+        t.d = "x"
+    assert t.names == ("a", "b", "c")
+
+
+def test_ensemble_natural_parameters_and_mu_table(ensemble):
+    ens = ensemble
+    n0 = len(ens.natural_parameters)
+    assert n0 == ens.processor.cluster_subspace.num_orbits  # decomposition processor
+    np.testing.assert_array_equal(ens.natural_parameters,
+                                  ens.processor.cluster_subspace.orbit_multiplicities)
+    with pytest.raises(ValueError, match="missing species"):
+        ens.chemical_potentials = {"A0": 0.1}
+    ens.chemical_potentials = {"A0": 0.1, "A1": -0.2}
+    assert len(ens.natural_parameters) == n0 + 1 and ens.natural_parameters[-1] == -1.0
+    np.testing.assert_allclose(ens._mu_table[0], [0.1, -0.2])  # ensemble.py:90-99
+    ens.chemical_potentials = {"A0": 0.3, "A1": 0.3}
+    assert len(ens.natural_parameters) == n0 + 1  # not appended twice
+    ens.chemical_potentials = None
+    assert len(ens.natural_parameters) == n0
+
+
+def test_processor_argument_errors():
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    with pytest.raises(ValueError, match="not the right length"):
+        moca.ClusterExpansionProcessor(sc, np.zeros(2))
+    with pytest.raises(ValueError, match="interaction tensors"):
+        moca.ClusterDecompositionProcessor(sc, [0.0])
+    with pytest.raises(ValueError, match="not supported"):
+        moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model), processor_type="x")
+
+
+def test_sampler_from_ensemble_defaults_and_errors(ensemble):
+    s = moca.Sampler.from_ensemble(ensemble, temperature=500, nwalkers=3)
+    assert [type(k).__name__ for k in s.mckernels] == ["Metropolis"] * 3
+    assert s.mckernels[0].step_type == "swap"  # no chemical potentials -> swap
+    assert s.samples.shape == (3, ensemble.num_sites)
+    assert s.samples.traced_values == ("occupancy", "features", "enthalpy", "temperature", "accepted")
+    np.testing.assert_allclose(s.mckernels[0].beta, 1.0 / (moca.kB * 500))
+    with pytest.raises(ValueError, match="seeds"):
+        moca.Sampler.from_ensemble(ensemble, temperature=500, nwalkers=2, seeds=[1])
+    with pytest.raises(RuntimeError, match="no saved samples"):
+        s.run(10)
+    ensemble.chemical_potentials = {"A0": 0.0, "A1": 0.1}
+    try:
+        s2 = moca.Sampler.from_ensemble(ensemble, temperature=500)
+        assert s2.mckernels[0].step_type == "flip"
+    finally:
+        ensemble.chemical_potentials = None
+    with pytest.raises(ValueError):
+        moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="table-flip")
+    with pytest.raises(NotImplementedError):
+        moca.Sampler.from_ensemble(ensemble, temperature=500, kernel_type="UniformlyRandom")
+
+
+def test_kb_value():  # tests/test_moca/test_kernel.py:191-197
+    assert moca.kB == 8.617333262145e-5
+
+
+def test_wang_landau_argument_errors(ensemble):  # wanglandau.py:80-90
+    with pytest.raises(ValueError, match="larger than max"):
+        moca.WangLandau(ensemble, "swap", 2.0, 1.0, 0.1)
+    with pytest.raises(ValueError, match="single bin"):
+        moca.WangLandau(ensemble, "swap", 0.0, 1.0, 5.0)
+    with pytest.raises(ValueError, match="mod_factor"):
+        moca.WangLandau(ensemble, "swap", 0.0, 1.0, 0.1, mod_factor=0.0)
+    k = moca.WangLandau(ensemble, "swap", 0.0, 1.0, 0.1)
+    assert len(k._levels) == 10 and k.bin_size == 0.1
+
+
+def test_sample_container_bookkeeping(ensemble):
+    """container.py:131-142,181-233,384-413,514-519 on synthetic traces."""
+    nw, N, F = 2, ensemble.num_sites, len(ensemble.natural_parameters)
+    s = moca.Sampler.from_ensemble(ensemble, temperature=500, nwalkers=nw)
+    c = s.samples
+    c.allocate(6)
+    rng = np.random.default_rng(0)
+    for i in range(5):
+        tr = moca.Trace(
+            occupancy=rng.integers(0, 2, (nw, N)).astype(np.int32),
+            features=rng.random((nw, F)), enthalpy=np.full((nw, 1), float(i)),
+            temperature=np.full((nw, 1), 500.0), accepted=np.array([[i % 2 == 0], [True]]),
+        )
+        c.save_sampled_trace(tr, thinned_by=10)
+    assert c.num_samples == len(c) == 5 and c.total_mc_steps == 50
+    assert c.get_occupancies().shape == (10, N)  # flattened, sample-major
+    assert c.get_occupancies(flat=False).shape == (5, nw, N)
+    assert c.get_enthalpies(discard=1, thin_by=2).shape == (4,)
+    np.testing.assert_allclose(c.get_enthalpies(flat=False)[:, 0, 0], np.arange(5.0))
+    np.testing.assert_allclose(c.sampling_efficiency(flat=False).ravel(), [0.6, 1.0])
+    assert np.isclose(c.sampling_efficiency(), 0.8)
+    assert np.isclose(c.mean_enthalpy(), 2.0)
+    np.testing.assert_allclose(c.get_energies(), c.get_enthalpies())  # no mu -> same
+    c.vacuum()
+    assert c._trace.occupancy.shape[0] == 5
+    c.clear()
+    assert c.num_samples == 0 and c._trace.occupancy.shape == (0, nw, N)
+
+
+def test_sample_container_npz_roundtrip(ensemble, tmp_path):
+    s = moca.Sampler.from_ensemble(ensemble, temperature=500, nwalkers=1)
+    c = s.samples
+    c.allocate(2)
+    for i in range(2):
+        c.save_sampled_trace(moca.Trace(
+            occupancy=np.full((1, ensemble.num_sites), i, np.int32),
+            features=np.zeros((1, len(ensemble.natural_parameters))),
+            enthalpy=np.array([[1.5 * i]]), temperature=np.array([[500.0]]),
+            accepted=np.array([[True]])), thinned_by=3)
+    path = str(tmp_path / "samples.npz")
+    c.to_npz(path)
+    d = moca.SampleContainer.from_npz(path, ensemble)
+    assert d.num_samples == 2 and d.total_mc_steps == 6
+    np.testing.assert_array_equal(d.get_occupancies(flat=False), c.get_occupancies(flat=False))
+
+
+def test_sublattice_restriction(ensemble):  # sublattice.py:84-107
+    sub = ensemble.sublattices[0]
+    assert sub.is_active and len(sub.active_sites) == ensemble.num_sites
+    ensemble.restrict_sites([0, 1, 2])
+    try:
+        assert len(sub.active_sites) == ensemble.num_sites - 3
+        np.testing.assert_array_equal(sub.restricted_sites, [0, 1, 2])
+    finally:
+        ensemble.reset_restricted_sites()
+    assert len(sub.active_sites) == ensemble.num_sites
