@@ -1,0 +1,112 @@
+"""The N>1 path on CPU: world_size-2 gloo process groups exercising the sharding,
+the global-average all-reduce and the replica-exchange protocol (the only places the
+multi-GPU run communicates).  Replica exchange is NEW functionality without a reference
+counterpart: it is validated by invariants (rank agreement, permutation, detailed
+balance), not parity."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smol_amd import parallel
+
+
+def test_shard_covers_everything():
+    for total in (1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            got = [parallel.shard(total, r, world) for r in range(world)]
+            assert sum(c for _, c in got) == total
+            assert got[0][0] == 0
+            for (a, c), (b, _) in zip(got, got[1:]):
+                assert a + c == b
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ---- global sums ------------------------------------------------------------
+        local = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 1.0], dtype=torch.float64)
+        tot = parallel.global_sums(local.clone()).numpy()
+        # ---- replica exchange over 2 ranks x 4 walkers ------------------------------
+        per = 4
+        ladder = parallel.geometric_ladder(400.0, 2000.0, per * world)
+        rex = parallel.ReplicaExchange(ladder, per, rank, world, seed=99)
+        rng = np.random.default_rng(5)  # same stream on both ranks -> a shared "truth"
+        history = []
+        for it in range(40):
+            H_all = rng.normal(0.0, 0.5, per * world) - 3.0 / rex.temperatures * 1000.0
+            mine = torch.tensor(H_all[rank * per:(rank + 1) * per], dtype=torch.float64)
+            gathered = rex.gather(mine)
+            assert np.array_equal(gathered, H_all)
+            rex.decide(gathered)
+            history.append(rex.rung_of.copy())
+        q.put((rank, tot, np.array(history), rex.local_temperatures(), rex.accepted.copy(),
+               rex.attempted.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_protocol():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, tot0, h0, t0, acc0, att0), (r1, tot1, h1, t1, acc1, att1) = res
+    np.testing.assert_allclose(tot0, [3.0, 30.0, 2.0])
+    np.testing.assert_allclose(tot0, tot1)
+    assert np.array_equal(h0, h1)  # every rank took identical decisions
+    for row in h0:
+        assert sorted(row) == list(range(8))  # rungs stay a permutation of the walkers
+    assert np.array_equal(acc0, acc1) and att0.sum() > 0
+    ladder = parallel.geometric_ladder(400.0, 2000.0, 8)
+    np.testing.assert_allclose(np.concatenate([t0, t1]), ladder[h0[-1]])
+    assert acc0.sum() > 0  # swaps do happen
+
+
+def test_exchange_rule_is_metropolis_for_two_rungs():
+    """Acceptance frequency of a fixed pair equals min(1, exp((b0-b1)(H_a-H_b)))."""
+    ladder = np.array([500.0, 1000.0])
+    beta = 1.0 / (parallel.kB * ladder)
+    dH = 0.05
+    expect = min(1.0, np.exp((beta[0] - beta[1]) * (-dH)))
+    hits, n = 0, 4000
+    for s in range(n):
+        rex = parallel.ReplicaExchange(ladder, 2, seed=s)
+        hits += len(rex.decide(np.array([0.0, dH])))  # walker 0 (cold) lower by dH: unfavourable
+    assert abs(hits / n - expect) < 4 * np.sqrt(expect * (1 - expect) / n)
+    rex = parallel.ReplicaExchange(ladder, 2, seed=1)
+    assert rex.decide(np.array([dH, 0.0])) == [(0, 1)]  # favourable swaps are always taken
+
+
+def test_identical_ladder_leaves_temperatures_unchanged():
+    """SURVEY 8e invariant: with equal temperatures every swap is accepted and changes
+    nothing observable."""
+    rex = parallel.ReplicaExchange(np.full(6, 800.0), 6, seed=3)
+    for _ in range(10):
+        rex.decide(np.random.default_rng(0).normal(size=6))
+    np.testing.assert_allclose(rex.local_temperatures(), 800.0)
+    assert rex.accepted.sum() == rex.attempted.sum()
+
+
+def test_ladder_length_mismatch():
+    with pytest.raises(ValueError):
+        parallel.ReplicaExchange(np.ones(5), 2, 0, 2)
