@@ -53,13 +53,38 @@ def initial_occupancies(sc, first, count):
     return occ
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 hardware threads but grants a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# HBM bytes per launch of the default configuration from the PMC passes committed under
+# profiles/ (FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 correction + WRITE_SIZE): the
+# occupancies in and out; everything else is cache-resident.
+MEASURED_TRAFFIC_BYTES = {(4096, 10000): 5.08e7}
+
+
 def cpu_baseline(tab, sc, seconds=12.0):
     """The CPU oracle (port of the reference's compiled core + kernel logic) timed on the
     host cores of this box with OpenMP over walkers, on a bounded sample of the workload."""
+    cores = usable_cores()
+    # before the oracle library is loaded; bound, passive-wait threads are ~2.3x faster than
+    # libgomp's defaults under this box's cgroup quota (tools/cpu_baseline_probe.py)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import oracle as orc
     from smol_amd import capi
 
-    cores = os.cpu_count() or 1
     R = max(cores, 1) * 4
     cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
     mc = orc.OracleMC(tab, cfg)
@@ -184,12 +209,14 @@ def main():
             "mean_enthalpy_per_site_eV": stats[1] / stats[3] / sc.num_sites,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mc_kernel<uint16,NSLOT=2,MM=2> (Metropolis swap)",
+                "kernel": "mc_lean_kernel<NSLOT=2,MM=2,SWAP,noMU>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": MEASURED_TRAFFIC_BYTES.get((R, args.mc_per_step)),
+                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_bytes_per_launch": flips_per_launch * ALGO_BYTES_PER_FLIP,
                 "kernel_ms_avg": k_ms,
                 "algorithmic_bytes_per_flip": ALGO_BYTES_PER_FLIP,
                 "lds_gathers_per_s": flips_per_launch * 174.0 / (k_ms * 1e-3),
