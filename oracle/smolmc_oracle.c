@@ -438,7 +438,9 @@ int orc_mc_get_wl(orc_mc *h, double *entropy, int64_t *hist, int64_t *occur, dou
 
 /* ---- ushers on the engine stream (distribution of mcusher.py:146-200) ----- */
 /* Random words of one step: W(step, block, j).  block 0: w0 sublattice,
- * w1 site, (w2,w3) acceptance uniform.  block 1+: flip species word (block 1,
+ * (w2,w3) acceptance uniform; the SITE of step k is drawn from W(k-1, 0, 1), i.e.
+ * from the previous step's block (so a wavefront can prefetch the next step's index
+ * row while it evaluates the current one).  block 1+: flip species word (block 1,
  * word 0) or the swap candidate sequence (see propose_step). */
 typedef struct {
     uint32_t key[2];
@@ -463,12 +465,12 @@ static int pick_sublattice(const smolmc_tables *t, uint32_t w0) {
 
 /* returns number of flips (0, 1 or 2) written to flips[4] */
 static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, uint32_t w0[4],
-                        int32_t flips[4]) {
+                        uint32_t w_site, int32_t flips[4]) {
     const smolmc_tables *t = h->t;
     int sl = pick_sublattice(t, w0[0]);
     const int32_t *sites = t->sub_active_sites + t->sub_site_ptr[sl];
     uint32_t nact = (uint32_t)(t->sub_site_ptr[sl + 1] - t->sub_site_ptr[sl]);
-    int site1 = sites[mulhi32(w0[1], nact)];
+    int site1 = sites[mulhi32(w_site, nact)];
     if (h->cfg.step_type == SMOLMC_STEP_FLIP) {
         /* Flip.propose_step (mcusher.py:154-170): uniform among the other codes */
         const int32_t *codes = t->sub_codes + t->sub_code_ptr[sl];
@@ -624,13 +626,17 @@ int orc_mc_run(orc_mc *h, int64_t nsteps) {
         rng_ctx g;
         g.key[0] = (uint32_t)h->seeds[r];
         g.key[1] = (uint32_t)(h->seeds[r] >> 32);
+        uint32_t wprev[4];
+        g.step = h->nsteps[r] - 1; /* wraps to 2^64-1 for the very first step */
+        rng_block(&g, 0, wprev);
         for (int64_t k = 0; k < nsteps; ++k) {
             g.step = h->nsteps[r];
             uint32_t w0[4];
             int32_t flips[4] = {-1, -1, -1, -1};
             rng_block(&g, 0, w0);
-            int nf = propose_step(h, h->occ + (size_t)r * h->N, &g, w0, flips);
+            int nf = propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
             do_step(h, r, flips, nf, u53(w0[2], w0[3]), dfeat);
+            memcpy(wprev, w0, sizeof(w0));
         }
         free(dfeat);
     }
@@ -664,9 +670,11 @@ int orc_mc_propose(orc_mc *h, int r, uint64_t step, int32_t flips[4]) {
     rng_ctx g;
     g.key[0] = (uint32_t)h->seeds[r];
     g.key[1] = (uint32_t)(h->seeds[r] >> 32);
+    uint32_t w0[4], wprev[4];
+    g.step = step - 1;
+    rng_block(&g, 0, wprev);
     g.step = step;
-    uint32_t w0[4];
     rng_block(&g, 0, w0);
     flips[0] = flips[1] = flips[2] = flips[3] = -1;
-    return propose_step(h, h->occ + (size_t)r * h->N, &g, w0, flips);
+    return propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
 }

@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         wl_counter = P.wl_counter[r];
     }
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0; // RNG batch: lane l = block (l&3) of step base+(l>>2)
-    unsigned long long batch_base = ~0ull;
+    uint32_t w_site_carry = 0;
+    unsigned long long batch_base = ~0ull - 64ull;
 
     for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
         // ================= proposal =========================================
@@ -357,6 +358,14 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         } else {
             const unsigned long long base = step & ~15ull;
             if (base != batch_base) {
+                // the site word of a step comes from the PREVIOUS step's block 0 (word 1)
+                if (batch_base == base - 16) {
+                    w_site_carry = rdlane(W1, 60);
+                } else {
+                    const unsigned long long sp = base - 1ull;
+                    w_site_carry = uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                          key0, key1).w[1]);
+                }
                 batch_base = base;
                 unsigned long long st = base + (unsigned)(lane >> 2);
                 philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
@@ -364,7 +373,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                 W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
             }
             const int l4 = (int)(step & 15ull) * 4;
-            const uint32_t w_sub = rdlane(W0, l4), w_site = rdlane(W1, l4);
+            const uint32_t w_sub = rdlane(W0, l4);
+            const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
             u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
             // sublattice: MCUsher.get_random_sublattice (mcusher.py:146-148)
             int sl = 0;
@@ -750,8 +760,20 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
     const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
-    uint16_t row1[ROW], rown[ROW];
-    bool row1_valid = false;
+
+    // software pipeline: the site of step k comes from W(k-1, 0, 1), so the index row of
+    // the NEXT step is always known one step ahead and is fetched while this step runs.
+    int s1;
+    uint16_t row1[ROW];
+    {
+        const unsigned long long sp = step - 1ull;
+        const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                            key0, key1).w[1]);
+        s1 = sbase + (int)__umulhi(w, nact);
+        const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
+#pragma unroll
+        for (int q = 0; q < ROW; ++q) row1[q] = p[q];
+    }
 
     for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
         // -------- random words of this step (generated 16 steps at a time) --------
@@ -773,16 +795,16 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
         const int l4 = (int)(step & 15ull) * 4;
-        const int s1 = sbase + (int)__umulhi(rdlane(W1, l4), nact);
-        // index row of site 1: normally prefetched by the previous step (it depends only
-        // on the random words, not on the occupancy)
-        if (!row1_valid) {
-            const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
+        // prefetch the index row of the next step's site (depends only on random words)
+        const int s1n = sbase + (int)__umulhi(rdlane(W1, l4), nact);
+        uint16_t rown[ROW];
+        {
+            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
 #pragma unroll
-            for (int q = 0; q < ROW; ++q) row1[q] = p[q];
+            for (int q = 0; q < ROW; ++q) rown[q] = p[q];
         }
         const int o1 = uni((int)occ[s1]);
-        int nfl, s2 = 0, n1, n2 = 0, o2 = 0;
+        int nfl, s2 = s1, n1, n2 = 0, o2 = 0;
         if (STEP == SMOLMC_STEP_FLIP) {
             // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
@@ -829,28 +851,21 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 }
             }
             if (found >= 0) { s2 = found; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
-            else { nfl = 0; n1 = o1; }
+            else { nfl = 0; n1 = o1; s2 = s1; o2 = o1; n2 = o1; } // empty step: both 'flips' are no-ops
         }
 
-        // issue the data-dependent row of site 2 and next step's row of site 1 before
-        // evaluating, so their L2 latency overlaps the LDS work below
+        // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
+        // rare empty step, the loaded row is then unused)
         uint16_t row2[ROW];
-        if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+        if (STEP == SMOLMC_STEP_SWAP) {
             const uint16_t *p = idx_lane + (size_t)s2 * (64 * ROW);
 #pragma unroll
             for (int q = 0; q < ROW; ++q) row2[q] = p[q];
         }
-        const bool next_valid = l4 != 60;
-        if (next_valid) {
-            const int s1n = sbase + (int)__umulhi(rdlane(W1, l4 + 4), nact);
-            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
-#pragma unroll
-            for (int q = 0; q < ROW; ++q) rown[q] = p[q];
-        }
 
         // -------- enthalpy delta ---------------------------------------------------
         double e = 0.0, d1[NSLOT], d2[NSLOT];
-        if (nfl >= 1) {
+        {
             const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8; // uniform
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
@@ -861,7 +876,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 e = fma(wgt[it], d1[it], e);
             }
         }
-        if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+        if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
             if (lane == 0) occ[s1] = (uint8_t)n1;
@@ -889,28 +904,26 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                            (int)rdlane((uint32_t)__double2loint(logu), l4));
         const bool accepted = (exponent >= 0.0) || (exponent > lu);
         if (accepted) {
-            if (nfl >= 1) {
 #pragma unroll
-                for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
-            }
-            if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+            for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
+            if (STEP == SMOLMC_STEP_SWAP) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
             }
             if (lane == 0) {
                 if (STEP == SMOLMC_STEP_FLIP) occ[s1] = (uint8_t)n1;
-                if (nfl == 2) occ[s2] = (uint8_t)n2;
+                if (STEP == SMOLMC_STEP_SWAP) occ[s2] = (uint8_t)n2; // (n2 == o1 == occ[s1] when empty)
             }
             acc_mu += dMu;
             H += dH;
             nacc++;
-        } else if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+        } else if (STEP == SMOLMC_STEP_SWAP) {
             if (lane == 0) occ[s1] = (uint8_t)o1; // undo the tentative first flip
         }
         last_acc = accepted ? 1 : 0;
+        s1 = s1n;
 #pragma unroll
         for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
-        row1_valid = next_valid;
     }
 
     // ---- write back ---------------------------------------------------------------
