@@ -678,8 +678,13 @@ struct LeanParams {
     uint8_t *last_acc;
     int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
     uint32_t nt8, snt8;    // 8*NTP and 8*NTP*S: (old, new) -> byte offset old*snt8 + new*nt8
+    // LDS address of site s = s ^ (((s >> swz_a) & swz_m) << swz_b): a bank swizzle chosen on
+    // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
+    int swz_a, swz_m, swz_b, Nlds;
     long long steps;
 };
+
+__device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
 
 // xor-butterfly inside 16-lane rows (DPP), then gfx950 permlane16/32 swaps: 22 VALU
 // instructions, the total ends up in every lane.
@@ -708,6 +713,26 @@ __device__ __forceinline__ double wave_sum_all(double v) {
     return v;
 }
 
+// The same sum on the matrix pipe: two v_mfma_f64_16x16x4_f64 with B = ones
+// (D[i][j] = sum_k A[i][k], lane l holds A[l & 15][l >> 4]; C/D: col = lane & 15,
+// row = (lane >> 4) + 4 * reg) and three VALU adds in between.  Frees ~19 VALU issue
+// slots per step but MEASURED SLOWER (9.87 ms vs 8.46 ms per 10^4 steps, same session):
+// the two dependent f64 MFMAs lengthen the per-step dependency chain more than the VALU
+// slots they free.  Kept behind -DSMOLMC_MFMA_REDUCE as a documented negative result.
+typedef double smolmc_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+    const smolmc_v4d z = {0.0, 0.0, 0.0, 0.0};
+    const smolmc_v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
+    const double t = (d[0] + d[1]) + (d[2] + d[3]);
+    const smolmc_v4d d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
+    return d2[0];
+}
+#ifdef SMOLMC_MFMA_REDUCE
+#define LEAN_WAVE_SUM wave_sum_mfma
+#else
+#define LEAN_WAVE_SUM wave_sum_all
+#endif
+
 template <int NSLOT, int MM, int STEP, bool HAS_MU>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -717,16 +742,18 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int r = uni(blockIdx.x * nwaves + wave);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len;               // 8 doubles
-    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * (P.Npad + 64 * 8);
-    uint8_t *occ = wbase;
-    double *s_feat = (double *)(wbase + P.Npad);  // [<=64] end-of-launch feature reduction
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * (P.Nlds + 64 * 8);
+    uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
+    double *s_feat = (double *)(wbase + P.Nlds);  // [<=64] end-of-launch feature reduction
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
     const bool live = r < P.R;
     if (live) {
-        const uint4 *src = (const uint4 *)(P.occ + (size_t)r * P.Npad);
-        uint4 *dst = (uint4 *)occ;
-        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+        // the swizzle only touches address bits >= 2: move whole dwords
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = 0.0;
     }
     __syncthreads();
@@ -755,7 +782,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     int last_acc = 1;
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
     uint32_t W0 = 0, W1 = 0;
-    int cand[4] = {0, 0, 0, 0};
+    int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
     double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
@@ -792,6 +819,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 cand[1] = sbase + (int)__umulhi(o.w[1], nact);
                 cand[2] = sbase + (int)__umulhi(o.w[2], nact);
                 cand[3] = sbase + (int)__umulhi(o.w[3], nact);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
             }
         }
         const int l4 = (int)(step & 15ull) * 4;
@@ -803,8 +832,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
             for (int q = 0; q < ROW; ++q) rown[q] = p[q];
         }
-        const int o1 = uni((int)occ[s1]);
-        int nfl, s2 = s1, n1, n2 = 0, o2 = 0;
+        const int a1 = lean_swz(s1, swa, swm, swb);
+        const int o1 = uni((int)occ[a1]);
+        int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         if (STEP == SMOLMC_STEP_FLIP) {
             // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
@@ -812,15 +842,16 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             nfl = 1;
         } else {
             // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate sequence
-            int found = -1, fo = 0;
+            int found = -1, fo = 0, fa = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (found < 0) {
-                    const int v = (int)occ[cand[j]];
+                    const int v = (int)occ[canda[j]];
                     const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
                     if (m) {
                         const int b = __ffsll((long long)m) - 1;
                         found = (int)rdlane((uint32_t)cand[j], b);
+                        fa = (int)rdlane((uint32_t)canda[j], b);
                         fo = (int)rdlane((uint32_t)v, b);
                     }
                 }
@@ -833,25 +864,27 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
                         const int cs = sbase + (int)__umulhi(o.w[j], nact);
-                        const int v = (int)occ[cs];
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
                         if (v != o1) { selsite = cs; selv = v; }
                     }
                     const unsigned long long m = __ballot(selsite >= 0);
                     if (m) {
                         const int b = __ffsll((long long)m) - 1;
                         found = (int)rdlane((uint32_t)selsite, b);
+                        fa = lean_swz(found, swa, swm, swb);
                         fo = (int)rdlane((uint32_t)selv, b);
                         break;
                     }
                     if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
                         int any = 0;
-                        for (uint32_t a = lane; a < nact; a += 64) any |= ((int)occ[sbase + (int)a] != o1);
+                        for (uint32_t a = lane; a < nact; a += 64)
+                            any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
                         if (__ballot(any) == 0ull) break;
                     }
                 }
             }
-            if (found >= 0) { s2 = found; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
-            else { nfl = 0; n1 = o1; s2 = s1; o2 = o1; n2 = o1; } // empty step: both 'flips' are no-ops
+            if (found >= 0) { s2 = found; a2 = fa; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
+            else { nfl = 0; n1 = o1; s2 = s1; a2 = a1; o2 = o1; n2 = o1; } // empty step: no-op 'flips'
         }
 
         // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
@@ -879,7 +912,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
-            if (lane == 0) occ[s1] = (uint8_t)n1;
+            if (lane == 0) occ[a1] = (uint8_t)n1;
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
@@ -890,7 +923,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 e = fma(wgt[it], d2[it], e);
             }
         }
-        double dH = wave_sum_all(e);
+        double dH = LEAN_WAVE_SUM(e);
         double dMu = 0.0;
         if (HAS_MU && nfl >= 1) {
             dMu = s_mu[n1] - s_mu[o1];
@@ -911,14 +944,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
             }
             if (lane == 0) {
-                if (STEP == SMOLMC_STEP_FLIP) occ[s1] = (uint8_t)n1;
-                if (STEP == SMOLMC_STEP_SWAP) occ[s2] = (uint8_t)n2; // (n2 == o1 == occ[s1] when empty)
+                if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+                if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             }
             acc_mu += dMu;
             H += dH;
             nacc++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
-            if (lane == 0) occ[s1] = (uint8_t)o1; // undo the tentative first flip
+            if (lane == 0) occ[a1] = (uint8_t)o1; // undo the tentative first flip
         }
         last_acc = accepted ? 1 : 0;
         s1 = s1n;
@@ -928,9 +961,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 
     // ---- write back ---------------------------------------------------------------
     {
-        uint4 *dst = (uint4 *)(P.occ + (size_t)r * P.Npad);
-        const uint4 *src = (const uint4 *)occ;
-        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
@@ -1427,10 +1460,68 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 }
             }
         }
+        // ---- LDS bank swizzle: pick the address permutation s ^ (((s >> a) & m) << b) that
+        // minimises the modelled bank-conflict cycles of the occupancy gathers (each
+        // ds_read_u8 is served in two 32-lane groups; a group costs the max number of
+        // distinct dwords on one of the 32 banks).  See tools/lds_conflict_model.py.
+        int Nlds = 16;
+        while (Nlds < h->Npad) Nlds <<= 1;
+        int best_a = 0, best_m = 0, best_b = 0;
+        {
+            auto model_cost = [&](int a, int m, int b) {
+                double tot = 0;
+                const int nsamp = std::min(N, 48);
+                for (int k = 0; k < nsamp; ++k) {
+                    const int s = (int)(((long long)k * 2654435761ll) % N);
+                    if (slots[s].empty()) continue;
+                    for (int q = 0; q < ROW; ++q)
+                        for (int g = 0; g < 2; ++g) {
+                            int cnt[32] = {0};
+                            int seen[32];
+                            int nseen = 0;
+                            for (int ln = 32 * g; ln < 32 * g + 32; ++ln) {
+                                const int x = lidx[((size_t)s * 64 + ln) * ROW + q];
+                                const int dw = (x ^ (((x >> a) & m) << b)) >> 2;
+                                bool dup = false;
+                                for (int z = 0; z < nseen; ++z) dup |= seen[z] == dw;
+                                if (!dup) { seen[nseen++] = dw; cnt[dw & 31]++; }
+                            }
+                            int mx = 0;
+                            for (int z = 0; z < 32; ++z) mx = std::max(mx, cnt[z]);
+                            tot += mx;
+                        }
+                }
+                return tot;
+            };
+            double best = model_cost(0, 0, 0);
+            const int amax = getenv("SMOLMC_NO_SWIZZLE") ? 0 : 12; // A/B switch for profiling
+            for (int a = 3; a <= amax; ++a)
+                for (int b = 2; b <= 5; ++b)
+                    for (int m : {3, 7, 15, 31}) {
+                        // bijection on [0, Nlds): source bits [a, a+k) above the destination
+                        // bits [b, b+k) and inside the (power-of-two) array
+                        const int k = m == 3 ? 2 : (m == 7 ? 3 : (m == 15 ? 4 : 5));
+                        if (a < b + k || (1 << (a + k)) > Nlds) continue;
+                        const double c = model_cost(a, m, b);
+                        if (c < best * 0.97) { best = c; best_a = a; best_m = m; best_b = b; }
+                    }
+        }
+        if (best_m == 0) Nlds = h->Npad; // identity: no power-of-two padding needed
+        for (size_t i = 0; i < lidx.size(); ++i) {
+            const int x = lidx[i];
+            lidx[i] = (uint16_t)(x ^ (((x >> best_a) & best_m) << best_b));
+        }
+        h->lp.swz_a = best_a; h->lp.swz_m = best_m; h->lp.swz_b = best_b; h->lp.Nlds = Nlds;
+
         // delta tables, one per (orbit, self position), all padded to [S*S][NTP]
         int NTP = 1, SMAX = t->max_species;
         for (int o = 0; o < t->n_orb; ++o) NTP = std::max(NTP, (int)t->orb_tensor_len[o]);
-        const size_t tlen = (size_t)SMAX * SMAX * NTP;
+        // one table = S*S*NTP doubles; the stride between tables is padded so that it is
+        // not a multiple of the 64-dword LDS bank period (lanes of one wave read the same
+        // (pair, base) entry of DIFFERENT tables: an unpadded power-of-two stride makes
+        // them all collide on one bank pair)
+        size_t tlen = (size_t)SMAX * SMAX * NTP;
+        if ((tlen & 1) == 0) tlen += 1;
         std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
         std::vector<LeanSlot> ls((size_t)NSL * 64);
         memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
@@ -1738,7 +1829,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             lp.sbase = sbase;
             lp.nact = nact;
             lp.ncodes = nc;
-            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 + (size_t)4 * (h->Npad + 64 * 8);
+            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 + (size_t)4 * (lp.Nlds + 64 * 8);
             if (h->lean_lds > 64 * 1024) lean = false;
         }
         h->lean = lean;
