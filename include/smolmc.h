@@ -170,6 +170,16 @@ int smolmc_get_wl(smolmc_handle *h, double *entropy /*RxL*/, int64_t *histogram 
  * Asynchronous on the handle's stream; smolmc_sync() or any get_* waits. */
 int smolmc_run(smolmc_handle *h, int64_t nsteps);
 int smolmc_sync(smolmc_handle *h);
+/* Device-side thinning: advance nsamples x thin_by steps and record, after every thin_by
+ * steps, one row per walker -- what Sampler.sample yields and
+ * SampleContainer.save_sampled_trace stores (sampler/sampler.py:195-210,
+ * container.py:384-397): enthalpy, features, the accept flag of the last step of the
+ * block, and (flags bit 0) the occupancy.  Buffers live on the device until the next
+ * smolmc_run_sampled / smolmc_destroy; smolmc_get_samples copies them out
+ * ([nsamples x R (x F | x N)], NULLs allowed). */
+int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags);
+int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
+                       uint8_t *accepted, int32_t *occupancy);
 /* Same loop driven by host-provided proposals ("replay mode"):
  * steps [R x nsteps x 4] = (site1, code1, site2, code2), -1 = no flip;
  * uniforms [R x nsteps] = the number rng.random() returned (NaN if not drawn).

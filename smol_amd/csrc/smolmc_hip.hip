@@ -54,6 +54,16 @@ static const double SMOLMC_KB = 8.617333262145e-5; // smol/constants.py:4
 // ----------------------------------------------------------------------------
 // device-side parameter block
 // ----------------------------------------------------------------------------
+// device-side sample recording (Sampler.sample + SampleContainer.save_sampled_trace,
+// sampler/sampler.py:195-210, container.py:384-397): every `every` steps one row per walker
+struct SampleBufs {
+    long long every;   // 0 = off
+    double *H;         // [nsamples][R]
+    double *feat;      // [nsamples][R][F]
+    uint8_t *acc;      // [nsamples][R]
+    uint8_t *occ;      // [nsamples][R][Npad] or null
+};
+
 struct KParams {
     // model geometry
     int N, Npad, Fce, F, nclasses, Cpad, Mmax, nsub, step_type;
@@ -107,6 +117,7 @@ struct KParams {
     long long *wl_counter;        // [R]
     // lds layout (bytes)
     int lds_tables, lds_per_wave;
+    SampleBufs smp;
 };
 
 // ----------------------------------------------------------------------------
@@ -341,6 +352,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0; // RNG batch: lane l = block (l&3) of step base+(l>>2)
     uint32_t w_site_carry = 0;
     unsigned long long batch_base = ~0ull - 64ull;
+    long long smp_countdown = P.smp.every, smp_index = 0;
 
     for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
         // ================= proposal =========================================
@@ -607,6 +619,34 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             if (P.rp_acc) P.rp_acc[(size_t)r * P.steps_to_run + it_step] = (uint8_t)last_acc;
             if (P.rp_H) P.rp_H[(size_t)r * P.steps_to_run + it_step] = H;
         }
+        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
+            smp_countdown = P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            double *dstf = P.smp.feat + row * P.F;
+            const double *base = P.features + (size_t)r * P.F;
+            if (WL) {
+                for (int i = lane; i < P.F; i += 64) dstf[i] = L.wl_cf[i];
+            } else {
+                for (int f = 0; f < P.Fce; ++f) {
+                    const double sm = wave_sum(L.acc[(size_t)f * 64 + lane]);
+                    if (lane == 0) dstf[f] = base[f] + sm;
+                }
+                if (lane == 0) {
+                    if (P.has_ewald) dstf[P.Fce] = base[P.Fce] + acc_ew;
+                    if (P.has_mu) dstf[P.Fce + P.has_ewald] = base[P.Fce + P.has_ewald] + acc_mu;
+                }
+            }
+            if (lane == 0) {
+                P.smp.H[row] = H;
+                P.smp.acc[row] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint4 *dst = (uint4 *)(P.smp.occ + row * P.Npad);
+                const uint4 *src = (const uint4 *)L.occ;
+                for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+            }
+        }
     }
 
     // ---- write the chain back --------------------------------------------------
@@ -682,6 +722,7 @@ struct LeanParams {
     // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
     int swz_a, swz_m, swz_b, Nlds;
     long long steps;
+    SampleBufs smp;
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -780,6 +821,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int sbase = P.sbase;
     double acc_mu = 0.0;
     int last_acc = 1;
+    // trace at launch start; features of a sample = base + sum over lanes of fs * acc
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    long long smp_countdown = P.smp.every, smp_index = 0;
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
     uint32_t W0 = 0, W1 = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
@@ -957,6 +1002,31 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         s1 = s1n;
 #pragma unroll
         for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
+
+        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
+            smp_countdown = P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            s_feat[lane] = 0.0;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const LeanSlot sl = P.slots[it * 64 + lane];
+                if (sl.live)
+                    __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
+            if (HAS_MU && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            if (lane == 0) {
+                P.smp.H[row] = H;
+                P.smp.acc[row] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
     }
 
     // ---- write back ---------------------------------------------------------------
@@ -965,6 +1035,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         for (int i = lane; i < P.Npad / 4; i += 64)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
+    s_feat[lane] = 0.0;
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
@@ -972,10 +1043,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    double *feat = P.features + (size_t)r * P.F;
-    if (lane < P.Fce) feat[lane] += s_feat[lane];
+    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     if (lane == 0) {
-        if (HAS_MU) feat[P.Fce] += acc_mu;
+        if (HAS_MU) featp[P.Fce] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
@@ -1194,12 +1264,18 @@ struct smolmc_handle {
     int lean_nslot = 0, lean_mm = 0;
     size_t lean_lds = 0;
     LeanParams lp;
+    // device-side samples of the last smolmc_run_sampled
+    SampleBufs smp;
+    long long smp_n = 0;
+    bool smp_has_occ = false;
     // scratch
     uint8_t *d_eval_occ = nullptr;
     size_t eval_occ_cap = 0;
     double *d_natural = nullptr;
     double *d_beta = nullptr;
 };
+
+static void free_samples(smolmc_handle *h);
 
 template <typename T>
 static int dev_upload(smolmc_handle *h, const T *src, size_t n, const T **dst) {
@@ -1686,6 +1762,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         h->L = (int)ceil((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size);
     }
     memset(&h->kp, 0, sizeof(KParams));
+    memset(&h->smp, 0, sizeof(SampleBufs));
     KParams &kp = h->kp;
     if (int rc = build_mc_tables(h, t)) return bail(rc);
     if (int rc = build_ref_tables(h, t)) return bail(rc);
@@ -1844,6 +1921,7 @@ extern "C" int smolmc_destroy(smolmc_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     if (h->d_eval_occ) hipFree(h->d_eval_occ);
+    free_samples(h);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -2071,12 +2149,33 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     return mu ? launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true>(h, lp)
               : launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false>(h, lp);
 }
-static int launch_lean(smolmc_handle *h, int64_t nsteps) {
-    LeanParams lp = h->lp;
+static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
     if (h->lean_nslot == 2)
         return h->lean_mm == 2 ? launch_lean_nm<2, 2>(h, lp) : launch_lean_nm<2, 3>(h, lp);
     return h->lean_mm == 2 ? launch_lean_nm<4, 2>(h, lp) : launch_lean_nm<4, 3>(h, lp);
+}
+
+static void free_samples(smolmc_handle *h) {
+    if (h->smp.H) hipFree(h->smp.H);
+    if (h->smp.feat) hipFree(h->smp.feat);
+    if (h->smp.acc) hipFree(h->smp.acc);
+    if (h->smp.occ) hipFree(h->smp.occ);
+    memset(&h->smp, 0, sizeof(SampleBufs));
+    h->smp_n = 0;
+    h->smp_has_occ = false;
+}
+
+static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
+    if (h->lean) {
+        LeanParams lp = h->lp;
+        lp.smp = smp;
+        return launch_lean(h, lp, nsteps);
+    }
+    KParams kp = h->kp;
+    kp.steps_to_run = nsteps;
+    kp.smp = smp;
+    return launch_mc(h, kp, 0);
 }
 
 extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
@@ -2084,10 +2183,54 @@ extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
     if (nsteps < 0) return fail("nsteps must be non-negative");
     if (nsteps == 0) return 0;
     HIPCHK(hipSetDevice(h->device));
-    if (h->lean) return launch_lean(h, nsteps);
-    KParams kp = h->kp;
-    kp.steps_to_run = nsteps;
-    return launch_mc(h, kp, 0);
+    SampleBufs none;
+    memset(&none, 0, sizeof(none));
+    return run_steps(h, nsteps, none);
+}
+
+extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags) {
+    if (!h) return fail("null handle");
+    if (nsamples <= 0 || thin_by <= 0) return fail("nsamples and thin_by must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_samples(h);
+    const size_t rows = (size_t)nsamples * h->R;
+    HIPCHK(hipMalloc((void **)&h->smp.H, rows * 8));
+    HIPCHK(hipMalloc((void **)&h->smp.feat, rows * h->F * 8));
+    HIPCHK(hipMalloc((void **)&h->smp.acc, rows));
+    if (flags & 1) {
+        HIPCHK(hipMalloc((void **)&h->smp.occ, rows * h->Npad));
+        h->smp_has_occ = true;
+    }
+    h->smp.every = thin_by;
+    h->smp_n = nsamples;
+    return run_steps(h, nsamples * thin_by, h->smp);
+}
+
+extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
+                                  uint8_t *accepted, int32_t *occupancy) {
+    if (!h) return fail("null handle");
+    if (h->smp_n == 0) return fail("no samples recorded: call smolmc_run_sampled first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t rows = (size_t)h->smp_n * h->R;
+    if (enthalpy) HIPCHK(hipMemcpy(enthalpy, h->smp.H, rows * 8, hipMemcpyDeviceToHost));
+    if (features) HIPCHK(hipMemcpy(features, h->smp.feat, rows * h->F * 8, hipMemcpyDeviceToHost));
+    if (accepted) HIPCHK(hipMemcpy(accepted, h->smp.acc, rows, hipMemcpyDeviceToHost));
+    if (occupancy) {
+        if (!h->smp_has_occ) return fail("occupancies were not recorded (flags bit 0)");
+        int *d32 = nullptr;
+        const size_t total = rows * h->N;
+        HIPCHK(hipMalloc((void **)&d32, total * 4));
+        hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, h->smp.occ, d32, h->N, h->Npad, total);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(occupancy, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        hipFree(d32);
+        if (e != hipSuccess) return fail(std::string("sample download: ") + hipGetErrorString(e));
+    }
+    return 0;
 }
 
 extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,

@@ -894,9 +894,29 @@ class Sampler:
             )
         self.setup_sample(initial_occupancies)
         eng = self._get_engine()
-        for _ in range(nsteps // thin_by):
-            eng.run(thin_by)
-            yield self._current_trace(eng)
+        nsamples = nsteps // thin_by
+        if isinstance(self._kernels[0], WangLandau):
+            # WL traces carry per-walker L x F arrays: fetched per sample
+            for _ in range(nsamples):
+                eng.run(thin_by)
+                yield self._current_trace(eng)
+            return
+        # Metropolis: samples are recorded on the device (smolmc_run_sampled) and fetched in
+        # chunks sized to ~256 MiB of occupancies, one launch per chunk
+        nw, N = len(self._kernels), self._kernels[0].ensemble.num_sites
+        chunk = max(1, min(nsamples, (256 << 20) // max(1, nw * N * 4)))
+        temps = self._temperatures().reshape(nw, 1)
+        done = 0
+        while done < nsamples:
+            n = min(chunk, nsamples - done)
+            smp = eng.run_sampled(n, thin_by, occupancy=True)
+            for i in range(n):
+                yield Trace(
+                    occupancy=smp["occupancy"][i], features=smp["features"][i],
+                    enthalpy=smp["enthalpy"][i].reshape(nw, 1), temperature=temps,
+                    accepted=smp["accepted"][i].reshape(nw, 1),
+                )
+            done += n
 
     def run(self, nsteps, initial_occupancies=None, thin_by=1, progress=False, stream_chunk=0,
             stream_file=None, keep_last_chunk=False, swmr_mode=False):

@@ -210,3 +210,46 @@ def test_errors_surface_as_exceptions():
         eng.eval_full(np.zeros((1, 8), dtype=np.float64))
     with pytest.raises(ValueError):
         _engine(tab, capi.make_config(1, capi.KERNEL_WANGLANDAU, min_enthalpy=2.0, max_enthalpy=1.0))
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
+@pytest.mark.parametrize("name,mode,step,mukind", [
+    ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None),
+    ("fcc3_indicator_skew", "int", capi.STEP_FLIP, "mu3"),
+    ("rocksalt444_ewald", "corr", capi.STEP_FLIP, "mu3"),
+])
+def test_device_side_sampling_equals_stepwise(name, mode, step, mukind, general, monkeypatch):
+    """smolmc_run_sampled records exactly what repeated run(thin_by) + get_state returns
+    (the rows Sampler.sample yields, sampler.py:195-210)."""
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    c = load_case(name)
+    tab = tables_for(name, MODES[mode], mu_table=_mu(mukind, c))
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(11)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(42)
+    a, b = _engine(tab, cfg), _engine(tab, cfg)
+    a.set_state(occ0, seeds, 1500.0)
+    b.set_state(occ0, seeds, 1500.0)
+    a.run(5)
+    b.run(5)  # samples must continue from a non-trivial state / stream position
+    ns, thin = 7, 23
+    smp = a.run_sampled(ns, thin, occupancy=True)
+    for i in range(ns):
+        b.run(thin)
+        st = b.get_state()
+        assert np.array_equal(smp["occupancy"][i], st["occupancy"])
+        assert np.array_equal(smp["accepted"][i], st["accepted"])
+        np.testing.assert_allclose(smp["enthalpy"][i], st["enthalpy"], rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(smp["features"][i], st["features"], rtol=1e-12, atol=1e-9)
+    fa, fb = a.get_state(), b.get_state()
+    assert np.array_equal(fa["occupancy"], fb["occupancy"])
+    np.testing.assert_allclose(fa["features"], fb["features"], rtol=1e-12, atol=1e-9)
+    assert np.array_equal(fa["n_steps"], fb["n_steps"])
+    smp2 = a.run_sampled(2, 10, occupancy=False)
+    assert smp2["occupancy"] is None and smp2["enthalpy"].shape == (2, R)
