@@ -111,6 +111,14 @@ typedef struct smolmc_tables {
     const int64_t *sub_code_ptr;   /* [n_sub+1] ranges into sub_codes */
     const int32_t *sub_codes;      /* Sublattice.encoding */
     const double *sub_probs;       /* [n_sub] sublattice_probabilities (sum to 1) */
+
+    /* Optional: charge of every Ewald index, [ewald_dim] (the oxidation states of
+     * EwaldProcessor._ewald_structure, processor/ewald.py:76-78).  When given, the engine
+     * checks that ewald_matrix[a][b] == q_a q_b G[site_a][site_b] off the diagonal (what
+     * pymatgen's EwaldSummation builds) and, if it holds to 1e-12, evaluates single-flip
+     * deltas from the N x N site kernel G (4x less memory traffic than two matrix rows);
+     * otherwise it silently uses the dense rows.  NULL = dense. */
+    const double *ewald_charges;
 } smolmc_tables;
 
 typedef struct smolmc_config {

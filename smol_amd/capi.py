@@ -72,6 +72,7 @@ class smolmc_tables(C.Structure):
         ("sub_code_ptr", _i64p),
         ("sub_codes", _i32p),
         ("sub_probs", _f64p),
+        ("ewald_charges", _f64p),
     ]
 
 
@@ -146,6 +147,7 @@ class TableSet:
         ewald_matrix=None,
         ewald_coef=1.0,
         mu_table=None,
+        ewald_charges=None,
     ):
         self._keep = {}
         k = self._keep
@@ -250,6 +252,11 @@ class TableSet:
             k["ewald_inds"], k["ewald_matrix"] = ei, em
             t.has_ewald, t.ewald_dim, t.ewald_width = 1, em.shape[0], ei.shape[1]
             t.ewald_coef = float(ewald_coef)
+            if ewald_charges is not None:
+                ec = _arr(ewald_charges, np.float64, "ewald_charges")
+                if ec.shape != (em.shape[0],):
+                    raise ValueError("ewald_charges must have one entry per Ewald index")
+                k["ewald_charges"] = ec
         # mu
         t.has_mu = 0
         if mu_table is not None:
@@ -322,6 +329,7 @@ class TableSet:
         ewald=None,
         ewald_coef=1.0,
         mu_table=None,
+        ewald_charges="auto",
     ):
         """Build from smol_amd.synth tables (SupercellTables + CE coefficients)."""
         model = sc.model
@@ -369,7 +377,23 @@ class TableSet:
             ewald_matrix=None if ewald is None else ewald[1],
             ewald_coef=ewald_coef,
             mu_table=mu_table,
+            ewald_charges=cls._synth_charges(sc, ewald, ewald_charges),
         )
+
+    @staticmethod
+    def _synth_charges(sc, ewald, ewald_charges):
+        if ewald is None or ewald_charges is None:
+            return None
+        if isinstance(ewald_charges, str):  # "auto": the oxidation states of the prim cell
+            prim = sc.model.prim
+            inds = ewald[0]
+            q = np.zeros(ewald[1].shape[0])
+            for s in range(sc.num_sites):
+                for code in range(prim.nspecies[sc.site_b[s]]):
+                    if inds[s, code] >= 0:
+                        q[inds[s, code]] = prim.charges[sc.site_b[s]][code]
+            return q
+        return ewald_charges
 
 
 def make_config(

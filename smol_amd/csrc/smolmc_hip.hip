@@ -82,6 +82,14 @@ struct KParams {
     const int *ew_inds;           // [N][ew_W]
     const double *ew_Mt;          // [M][M] transposed ewald matrix
     double ew_coef;
+    // compact Ewald (when the matrix factorises as q_a q_b G[site_a][site_b]):
+    int ew_compact, ew_nact;      // ew_nact = number of sites whose species can change
+    int ew_act_base;              // first such site when they are contiguous, else -1
+    const int *ew_act;            // [ew_nact] those sites
+    const double *ew_frozen;      // [N] sum over single-species sites k of q_k G[s][k]
+    const double *ew_G;           // [N][ew_nact] site kernel restricted to changeable sites
+    const double *ew_qs;          // [N][ew_W] charge of (site, code), 0 for vacancies
+    const double *ew_dg;          // [N][ew_W] diagonal entry M[a][a] of (site, code)
     const double *mu;             // [N][mu_W]
     // sublattices
     const int *sub_ptr;           // [nsub+1]
@@ -266,6 +274,29 @@ __device__ __forceinline__ double ewald_partial(const KParams &P, const Lds &L, 
         if (i != -1 && add != -1) o += (i != add ? 2.0 : 1.0) * radd[i];
         if (j != -1 && sub != -1) o -= (j != sub ? 2.0 : 1.0) * rsub[j];
         out += o;
+    }
+    return out;
+}
+
+// Compact form of the same delta when M[a][b] = q_a q_b G[site_a][site_b] (a != b):
+//   sum_k [2 M[i_k, add] - 2 M[i_k, sub]]  (k != s, i_k = j_k)  + M[add,add] - M[sub,sub]
+//     = 2 (q_add - q_sub) * sum_{k != s} q(k, occ_k) G[s][k] + diag(add) - diag(sub)
+// One fully-used row of G (N x 8 B) streams per flip instead of two strided matrix rows.
+template <bool PATCH>
+__device__ __forceinline__ double ewald_compact_partial(const KParams &P, const Lds &L, int lane, int s,
+                                                        int ps, int pc) {
+    // sites with a single allowed species never change: their part of the sum is the
+    // precomputed ew_frozen[s]; only the changeable sites are streamed
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int W = P.ew_W, abase = P.ew_act_base;
+    double out = 0;
+#pragma unroll 4
+    for (int j = lane; j < P.ew_nact; j += 64) {
+        const int k = abase >= 0 ? abase + j : P.ew_act[j];
+        int v = L.occ[k];
+        if (PATCH) v = (k == ps) ? pc : v;
+        const double q = P.ew_qs[(size_t)k * W + v];
+        out = fma(k == s ? 0.0 : q, g[j], out);
     }
     return out;
 }
@@ -506,9 +537,22 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         }
         double dEw = 0.0, dMu = 0.0;
         if (P.has_ewald && nfl >= 1) {
-            double pe = ewald_partial<false>(P, L, lane, s1, o1, n1, 0, 0);
-            if (nfl == 2) pe += ewald_partial<true>(P, L, lane, s2, o2, n2, s1, n1);
-            dEw = wave_sum(pe);
+            if (P.ew_compact) {
+                const int W = P.ew_W;
+                const double s1sum = P.ew_frozen[s1] + wave_sum(ewald_compact_partial<false>(P, L, lane, s1, 0, 0));
+                dEw = 2.0 * (P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1]) * s1sum +
+                      (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+                if (nfl == 2) {
+                    const double s2sum = P.ew_frozen[s2] + wave_sum(ewald_compact_partial<true>(P, L, lane, s2, s1, n1));
+                    dEw += 2.0 * (P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2]) * s2sum +
+                           (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+                }
+                dEw = uni_d(dEw);
+            } else {
+                double pe = ewald_partial<false>(P, L, lane, s1, o1, n1, 0, 0);
+                if (nfl == 2) pe += ewald_partial<true>(P, L, lane, s2, o2, n2, s1, n1);
+                dEw = wave_sum(pe);
+            }
         }
         if (P.has_mu && nfl >= 1) {
             // delta chemical work against the ORIGINAL occupancy (ensemble.py:368-374)
@@ -723,6 +767,11 @@ struct LeanParams {
     int swz_a, swz_m, swz_b, Nlds;
     long long steps;
     SampleBufs smp;
+    // compact Ewald term (see build_compact_ewald); feature index Fce, coefficient ew_coef
+    int ew_W, ew_nact, ew_act_base;
+    const int *ew_act;
+    const double *ew_G, *ew_qs, *ew_dg, *ew_frozen;
+    double ew_coef;
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -774,7 +823,37 @@ __device__ __forceinline__ double wave_sum_mfma(double v) {
 #define LEAN_WAVE_SUM wave_sum_all
 #endif
 
-template <int NSLOT, int MM, int STEP, bool HAS_MU>
+// sum over the changeable sites k != s of q(k, occ_k) * G[s][k] (lane partial), eight sites
+// per lane in flight so that the dependent latencies (index -> LDS species byte -> charge)
+// of different sites overlap; the occupancy is read from LDS, so a tentatively applied
+// first flip of a swap is seen without patching.
+__device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const uint8_t *occ, int lane,
+                                                     int s, int swa, int swm, int swb) {
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int W = P.ew_W, na = P.ew_nact;
+    double out = 0;
+    for (int j0 = lane; j0 < na; j0 += 64 * 8) {
+        // branch-free: out-of-range lanes re-read the last element and are masked at the end
+        // (conditional loads would put a full s_waitcnt between the eight loads)
+        int k[8];
+        double gk[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = min(j0 + 64 * u, na - 1);
+            k[u] = P.ew_act[jj];
+            gk[u] = g[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            q[u] = P.ew_qs[(size_t)k[u] * W + (int)occ[lean_swz(k[u], swa, swm, swb)]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            out = fma((j0 + 64 * u < na && k[u] != s) ? q[u] : 0.0, gk[u], out);
+    }
+    return out;
+}
+
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -819,7 +898,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
-    double acc_mu = 0.0;
+    double acc_mu = 0.0, acc_ew = 0.0;
     int last_acc = 1;
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
     double *featp = P.features + (size_t)r * P.F;
@@ -954,6 +1033,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 e = fma(wgt[it], d1[it], e);
             }
         }
+        double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
+        if (HAS_EW) {
+            const int W = P.ew_W;
+            const double dq = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
+            ew_part = 2.0 * dq * lean_ewald_partial(P, occ, lane, s1, swa, swm, swb);
+            ew_uni = 2.0 * dq * P.ew_frozen[s1] +
+                     (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+        }
         if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
@@ -967,8 +1054,20 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
                 e = fma(wgt[it], d2[it], e);
             }
+            if (HAS_EW) {
+                const int W = P.ew_W;
+                const double dq = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
+                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s2, swa, swm, swb);
+                ew_uni += 2.0 * dq * P.ew_frozen[s2] +
+                          (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+            }
         }
         double dH = LEAN_WAVE_SUM(e);
+        double dEw = 0.0;
+        if (HAS_EW) {
+            dEw = LEAN_WAVE_SUM(ew_part) + ew_uni;
+            dH += P.ew_coef * dEw;
+        }
         double dMu = 0.0;
         if (HAS_MU && nfl >= 1) {
             dMu = s_mu[n1] - s_mu[o1];
@@ -993,6 +1092,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             }
             acc_mu += dMu;
+            acc_ew += dEw;
             H += dH;
             nacc++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
@@ -1016,7 +1116,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
-            if (HAS_MU && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            if (HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
+            if (HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
             if (lane == 0) {
                 P.smp.H[row] = H;
                 P.smp.acc[row] = (uint8_t)last_acc;
@@ -1045,7 +1146,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
     if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     if (lane == 0) {
-        if (HAS_MU) featp[P.Fce] += acc_mu;
+        if (HAS_EW) featp[P.Fce] += acc_ew;
+        if (HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
@@ -1718,6 +1820,82 @@ static int build_ref_tables(smolmc_handle *h, const smolmc_tables *t) {
     return 0;
 }
 
+// Check M[a][b] == q_a q_b G[site_a][site_b] (a, b on different sites) and build G.
+static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
+    const int N = t->num_sites, W = t->ewald_width;
+    const size_t M = (size_t)t->ewald_dim;
+    const double *Mx = t->ewald_matrix, *q = t->ewald_charges;
+    std::vector<double> G((size_t)N * N, 0.0), qs((size_t)N * W, 0.0), dg((size_t)N * W, 0.0);
+    double mmax = 0;
+    for (size_t i = 0; i < M * M; ++i) mmax = std::max(mmax, fabs(Mx[i]));
+    const double tol = 1e-12 * std::max(mmax, 1e-300);
+    for (int s = 0; s < N; ++s)
+        for (int c = 0; c < W; ++c) {
+            const int a = t->ewald_inds[(size_t)s * W + c];
+            if (a < 0) continue;
+            qs[(size_t)s * W + c] = q[a];
+            dg[(size_t)s * W + c] = Mx[(size_t)a * M + a];
+        }
+    bool ok = true;
+    for (int s = 0; s < N && ok; ++s)
+        for (int u = 0; u < N && ok; ++u) {
+            if (s == u) continue;
+            double g = 0;
+            bool have = false;
+            for (int c = 0; c < W && !have; ++c)
+                for (int d = 0; d < W && !have; ++d) {
+                    const int a = t->ewald_inds[(size_t)s * W + c], b = t->ewald_inds[(size_t)u * W + d];
+                    if (a < 0 || b < 0 || q[a] == 0.0 || q[b] == 0.0) continue;
+                    g = Mx[(size_t)b * M + a] / (q[a] * q[b]); // the entry ewald.pyx reads: M[i_k, add]
+                    have = true;
+                }
+            for (int c = 0; c < W && ok; ++c)
+                for (int d = 0; d < W && ok; ++d) {
+                    const int a = t->ewald_inds[(size_t)s * W + c], b = t->ewald_inds[(size_t)u * W + d];
+                    if (a < 0 || b < 0) continue;
+                    if (fabs(Mx[(size_t)b * M + a] - q[a] * q[b] * g) > tol) ok = false;
+                }
+            G[(size_t)s * N + u] = g; // row s: kernel between the flipped site s and site u
+        }
+    if (!ok) return 0; // not of product form: keep the dense rows
+    // split sites into changeable ones and single-species ("frozen") ones
+    std::vector<int> act;
+    std::vector<char> frozen(N, 0);
+    for (int s = 0; s < N; ++s) {
+        int nvalid = 0, ncodes = 0;
+        for (int c = 0; c < W; ++c) nvalid += t->ewald_inds[(size_t)s * W + c] >= 0;
+        (void)ncodes;
+        // a site is frozen when it is in no active sublattice (its code never changes) and
+        // carries exactly one Ewald species (code 0)
+        bool in_active = false;
+        for (int64_t i = 0; i < t->sub_site_ptr[t->n_sublattices] && !in_active; ++i)
+            in_active = t->sub_active_sites[i] == s;
+        frozen[s] = (!in_active && nvalid == 1 && t->ewald_inds[(size_t)s * W] >= 0) ? 1 : 0;
+        if (!frozen[s]) act.push_back(s);
+    }
+    const size_t na = act.size();
+    std::vector<double> Gact((size_t)N * std::max<size_t>(na, 1), 0.0), fz(N, 0.0);
+    for (int s = 0; s < N; ++s) {
+        for (size_t j = 0; j < na; ++j) Gact[(size_t)s * na + j] = G[(size_t)s * N + act[j]];
+        double c = 0;
+        for (int u = 0; u < N; ++u)
+            if (frozen[u] && u != s) c += qs[(size_t)u * W] * G[(size_t)s * N + u];
+        fz[s] = c;
+    }
+    TRY(dev_upload(h, act.data(), act.size(), &h->kp.ew_act));
+    TRY(dev_upload(h, fz.data(), fz.size(), &h->kp.ew_frozen));
+    h->kp.ew_nact = (int)na;
+    h->kp.ew_act_base = na ? act[0] : -1;
+    for (size_t j = 0; j < na; ++j)
+        if (act[j] != act[0] + (int)j) h->kp.ew_act_base = -1;
+    G.swap(Gact);
+    TRY(dev_upload(h, G.data(), G.size(), &h->kp.ew_G));
+    TRY(dev_upload(h, qs.data(), qs.size(), &h->kp.ew_qs));
+    TRY(dev_upload(h, dg.data(), dg.size(), &h->kp.ew_dg));
+    h->kp.ew_compact = 1;
+    return 0;
+}
+
 extern "C" int smolmc_abi_version(void) { return SMOLMC_ABI_VERSION; }
 extern "C" const char *smolmc_last_error(void) { return g_err.c_str(); }
 
@@ -1781,6 +1959,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     kp.ew_Mt = h->rt.ew_Mt;
     kp.ew_coef = t->ewald_coef;
     kp.mu = h->rt.mu;
+    if (t->has_ewald && t->ewald_charges && getenv("SMOLMC_DENSE_EWALD") == nullptr)
+        if (int rc = build_compact_ewald(h, t)) return bail(rc);
     // sublattices
     {
         const int ns = t->n_sublattices;
@@ -1866,7 +2046,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
-        bool lean = h->lean_tables && !wl && !t->has_ewald && t->n_sublattices == 1 &&
+        bool lean = h->lean_tables && h->F <= 64 && !wl && (!t->has_ewald || kp.ew_compact) &&
+                    t->n_sublattices == 1 &&
                     getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
         std::vector<double> mu_row;
@@ -1906,6 +2087,17 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             lp.sbase = sbase;
             lp.nact = nact;
             lp.ncodes = nc;
+            if (t->has_ewald) {
+                lp.ew_W = kp.ew_W;
+                lp.ew_nact = kp.ew_nact;
+                lp.ew_act_base = kp.ew_act_base;
+                lp.ew_act = kp.ew_act;
+                lp.ew_G = kp.ew_G;
+                lp.ew_qs = kp.ew_qs;
+                lp.ew_dg = kp.ew_dg;
+                lp.ew_frozen = kp.ew_frozen;
+                lp.ew_coef = kp.ew_coef;
+            }
             h->lean_lds = ((size_t)lp.dt_len + 8) * 8 + (size_t)4 * (lp.Nlds + 64 * 8);
             if (h->lean_lds > 64 * 1024) lean = false;
         }
@@ -2129,25 +2321,30 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
               : launch_mc_slot<int32_t, false, false>(h, kp, replay);
 }
 
-template <int NSLOT, int MM, int STEP, bool MU>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL((mc_lean_kernel<NSLOT, MM, STEP, MU>), dim3(grid), dim3(256), h->lean_lds,
+    hipLaunchKernelGGL((mc_lean_kernel<NSLOT, MM, STEP, MU, EW>), dim3(grid), dim3(256), h->lean_lds,
                        h->stream, lp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return 0;
 }
+template <int NSLOT, int MM, int STEP>
+static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (ew)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, true>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, false>(h, lp);
+}
 template <int NSLOT, int MM>
 static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
-    const bool mu = lp.mu_row != nullptr;
-    if (h->cfg.step_type == SMOLMC_STEP_SWAP)
-        return mu ? launch_lean_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false>(h, lp);
-    return mu ? launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true>(h, lp)
-              : launch_lean_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false>(h, lp);
+    if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
+    return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;

@@ -253,3 +253,36 @@ def test_device_side_sampling_equals_stepwise(name, mode, step, mukind, general,
     assert np.array_equal(fa["n_steps"], fb["n_steps"])
     smp2 = a.run_sampled(2, 10, occupancy=False)
     assert smp2["occupancy"] is None and smp2["enthalpy"].shape == (2, R)
+
+
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP])
+def test_compact_ewald_matches_dense_rows_and_oracle(step, monkeypatch):
+    """The factorised Ewald delta (site kernel G, enabled when ewald_charges are given and
+    the matrix is of product form) against the dense two-row form of ewald.pyx:38-58 and
+    the CPU oracle: same accept decisions, enthalpies to 1e-10."""
+    from oracle import oracle as orc
+
+    c = load_case("rocksalt444_ewald")
+    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=_mu("mu3", c))
+    assert tab.struct.ewald_charges  # charges travel with the synthetic tables
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(21)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(9)
+    compact = _engine(tab, cfg)
+    monkeypatch.setenv("SMOLMC_DENSE_EWALD", "1")
+    dense = _engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_DENSE_EWALD")
+    ora = orc.OracleMC(tab, cfg)
+    for e in (compact, dense, ora):
+        e.set_state(occ0, seeds, 2500.0)
+        e.run(400)
+    a, b, o = compact.get_state(), dense.get_state(), ora.get_state()
+    for x in (b, o):
+        assert np.array_equal(a["occupancy"], x["occupancy"])
+        assert np.array_equal(a["n_accepted"], x["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(a["features"], x["features"], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
