@@ -740,6 +740,18 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
 //     (the subtraction is done once on the host in float64: identical value);
 //   * slot constants and feature accumulators stay in registers for the whole launch.
 // ----------------------------------------------------------------------------
+struct WlParams { // Wang-Landau state of the walkers (kernel/wanglandau.py:107-122)
+    int L;
+    double vmin, vmax, bin, flat, div;
+    long long check, update;
+    double *entropy;     // [R][L]
+    long long *hist;     // [R][L]
+    long long *occur;    // [R][L]
+    double *meanf;       // [R][L][F]
+    double *m;           // [R]
+    long long *counter;  // [R]
+};
+
 struct LeanSlot {
     uint32_t doff8;      // byte offset of the slot's delta table
     uint32_t stride8[3]; // 8 * stride of the other members
@@ -772,6 +784,7 @@ struct LeanParams {
     const int *ew_act;
     const double *ew_G, *ew_qs, *ew_dg, *ew_frozen;
     double ew_coef;
+    WlParams wl;
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -853,7 +866,7 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
     return out;
 }
 
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW>
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -862,9 +875,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int r = uni(blockIdx.x * nwaves + wave);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len;               // 8 doubles
-    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * (P.Nlds + 64 * 8);
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0);
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
-    double *s_feat = (double *)(wbase + P.Nlds);  // [<=64] end-of-launch feature reduction
+    // Metropolis: scratch for the feature reduction; Wang-Landau: the CURRENT features
+    // (wanglandau.py:216-218 needs them every step for the per-bin running mean)
+    double *s_feat = (double *)(wbase + P.Nlds);
+    double *wl_S = s_feat + 64;                   // WL: entropy [L]
+    long long *wl_Hh = (long long *)(wl_S + (WL ? P.wl.L : 0)); // WL: histogram [L]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
@@ -874,25 +892,34 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
         for (int i = lane; i < P.Npad / 4; i += 64)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
-        s_feat[lane] = 0.0;
+        s_feat[lane] = (WL && lane < P.F) ? P.features[(size_t)r * P.F + lane] : 0.0;
+        if (WL)
+            for (int i = lane; i < P.wl.L; i += 64) {
+                wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+                wl_Hh[i] = P.wl.hist[(size_t)r * P.wl.L + i];
+            }
     }
     __syncthreads();
     if (!live) return;
 
     // per-lane slot constants (registers for the whole launch)
-    uint32_t doff8[NSLOT], st8[NSLOT][MM];
-    double wgt[NSLOT], acc[NSLOT];
+    uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
+    double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
         doff8[it] = sl.doff8;
+        sfeat[it] = sl.feat;      // only used by the Wang-Landau variant
+        sfs[it] = sl.live ? sl.fs : 0.0;
 #pragma unroll
         for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
         wgt[it] = sl.w;
         acc[it] = 0.0;
     }
     double H = P.enthalpy[r];
-    const double nbeta = -P.beta[r];
+    const double nbeta = WL ? 0.0 : -P.beta[r];
+    double wl_m = WL ? P.wl.m[r] : 0.0;
+    long long wl_counter = WL ? P.wl.counter[r] : 0;
     unsigned long long step = P.nsteps[r];
     unsigned long long nacc = P.nacc[r];
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
@@ -1076,16 +1103,40 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
 
         // -------- accept / update (metropolis.py:31-49, kernel/base.py:327-343) --------
-        const double exponent = nbeta * dH + 0.0;
         const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
                                            (int)rdlane((uint32_t)__double2loint(logu), l4));
-        const bool accepted = (exponent >= 0.0) || (exponent > lu);
+        bool accepted;
+        if (!WL) {
+            const double exponent = nbeta * dH + 0.0;
+            accepted = (exponent >= 0.0) || (exponent > lu);
+        } else {
+            // WangLandau._accept_step (wanglandau.py:186-202)
+            const double new_h = H + dH;
+            if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
+                accepted = false;
+            } else {
+                const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
+                const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                const double exponent = wl_S[b] - wl_S[nb] + 0.0;
+                accepted = (exponent >= 0.0) || (exponent > lu);
+            }
+        }
         if (accepted) {
+            if (!WL) {
 #pragma unroll
-            for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
-            if (STEP == SMOLMC_STEP_SWAP) {
+                for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
+                if (STEP == SMOLMC_STEP_SWAP) {
 #pragma unroll
-                for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
+                    for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
+                }
+            } else {
+                // _do_accept_step (wanglandau.py:204-220): current features += delta features
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    const double dd = STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * dd, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
             if (lane == 0) {
                 if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
@@ -1103,21 +1154,64 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
         for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
 
+        if (WL) {
+            // WangLandau._do_post_step (wanglandau.py:222-266)
+            const double bq = floordiv_exact(H - P.wl.vmin, P.wl.bin);
+            if (bq >= 0.0 && bq < (double)P.wl.L) {
+                const int b = (int)bq;
+                wl_counter++;
+                const size_t cell = (size_t)r * P.wl.L + b;
+                long long total = 0;
+                if (lane == 0) total = P.wl.occur[cell];
+                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
+                        (unsigned)uni((int)(total & 0xffffffffll));
+                if (lane < P.F) {
+                    double *mf = P.wl.meanf + cell * P.F + lane;
+                    const double inv = 1.0 / (double)(total + 1);
+                    *mf = inv * (s_feat[lane] + (double)total * (*mf));
+                }
+                if (wl_counter % P.wl.update == 0 && lane == 0) {
+                    wl_S[b] += wl_m;
+                    wl_Hh[b] += 1;
+                    P.wl.occur[cell] = total + 1;
+                }
+            }
+            if (wl_counter % P.wl.check == 0) {
+                long cnt = 0;
+                double sum = 0;
+                for (int i = lane; i < P.wl.L; i += 64)
+                    if (wl_S[i] > 0) { cnt++; sum += (double)wl_Hh[i]; }
+                const double tcnt = wave_sum_all((double)cnt), tsum = wave_sum_all(sum);
+                if (tcnt >= 2.0) {
+                    const double thr = P.wl.flat * (tsum / tcnt);
+                    int bad = 0;
+                    for (int i = lane; i < P.wl.L; i += 64)
+                        if (wl_S[i] > 0 && !((double)wl_Hh[i] > thr)) bad = 1;
+                    if (__ballot(bad) == 0ull) {
+                        for (int i = lane; i < P.wl.L; i += 64) wl_Hh[i] = 0;
+                        wl_m = wl_m / P.wl.div;
+                    }
+                }
+            }
+        }
+
         if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
             smp_countdown = P.smp.every;
             const size_t row = (size_t)smp_index * P.R + r;
             smp_index++;
-            s_feat[lane] = 0.0;
+            if (WL) {
+                if (lane < P.F) P.smp.feat[row * P.F + lane] = s_feat[lane];
+            } else {
+                s_feat[lane] = 0.0;
 #pragma unroll
-            for (int it = 0; it < NSLOT; ++it) {
-                const LeanSlot sl = P.slots[it * 64 + lane];
-                if (sl.live)
-                    __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
+                for (int it = 0; it < NSLOT; ++it)
+                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
             }
-            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
-            if (HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
-            if (HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            if (!WL && HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
+            if (!WL && HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0))
+                P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
             if (lane == 0) {
                 P.smp.H[row] = H;
                 P.smp.acc[row] = (uint8_t)last_acc;
@@ -1136,18 +1230,27 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         for (int i = lane; i < P.Npad / 4; i += 64)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
-    s_feat[lane] = 0.0;
+    if (WL) {
+        if (lane < P.F) featp[lane] = s_feat[lane];
+        for (int i = lane; i < P.wl.L; i += 64) {
+            P.wl.entropy[(size_t)r * P.wl.L + i] = wl_S[i];
+            P.wl.hist[(size_t)r * P.wl.L + i] = wl_Hh[i];
+        }
+        if (lane == 0) {
+            P.wl.m[r] = wl_m;
+            P.wl.counter[r] = wl_counter;
+        }
+    } else {
+        s_feat[lane] = 0.0;
 #pragma unroll
-    for (int it = 0; it < NSLOT; ++it) {
-        const LeanSlot sl = P.slots[it * 64 + lane];
-        if (sl.live) // padded slots carry no feature
-            __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * acc[it], __ATOMIC_RELAXED,
+        for (int it = 0; it < NSLOT; ++it)
+            __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     }
-    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     if (lane == 0) {
-        if (HAS_EW) featp[P.Fce] += acc_ew;
-        if (HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
+        if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
+        if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
@@ -2046,8 +2149,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
-        bool lean = h->lean_tables && h->F <= 64 && !wl && (!t->has_ewald || kp.ew_compact) &&
-                    t->n_sublattices == 1 &&
+        bool lean = h->lean_tables && h->F <= 64 && (!wl || (!t->has_ewald && !t->has_mu)) &&
+                    (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
                     getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
         std::vector<double> mu_row;
@@ -2098,8 +2201,17 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.ew_frozen = kp.ew_frozen;
                 lp.ew_coef = kp.ew_coef;
             }
-            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 + (size_t)4 * (lp.Nlds + 64 * 8);
-            if (h->lean_lds > 64 * 1024) lean = false;
+            if (wl) {
+                lp.wl.L = h->L;
+                lp.wl.vmin = kp.wl_min; lp.wl.vmax = kp.wl_max; lp.wl.bin = kp.wl_bin;
+                lp.wl.flat = kp.wl_flat; lp.wl.div = kp.wl_div;
+                lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
+                lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
+                lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
+            }
+            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 +
+                          (size_t)4 * (lp.Nlds + 64 * 8 + (wl ? (size_t)h->L * 16 : 0));
+            if (h->lean_lds > 150 * 1024) lean = false;
         }
         h->lean = lean;
     }
@@ -2321,12 +2433,15 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
               : launch_mc_slot<int32_t, false, false>(h, kp, replay);
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL((mc_lean_kernel<NSLOT, MM, STEP, MU, EW>), dim3(grid), dim3(256), h->lean_lds,
-                       h->stream, lp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -2335,11 +2450,13 @@ static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
 template <int NSLOT, int MM, int STEP>
 static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU)
+        return launch_lean_inst<NSLOT, MM, STEP, false, false, true>(h, lp);
     if (ew)
-        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, STEP, false, true>(h, lp);
-    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false>(h, lp)
-              : launch_lean_inst<NSLOT, MM, STEP, false, false>(h, lp);
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, false, false>(h, lp);
 }
 template <int NSLOT, int MM>
 static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {

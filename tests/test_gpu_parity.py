@@ -175,8 +175,14 @@ def test_native_stream_matches_oracle(name, mode, step, mukind, general, monkeyp
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
 
 
-def test_native_wang_landau_matches_oracle():
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
+def test_native_wang_landau_matches_oracle(general, monkeypatch):
     from oracle import oracle as orc
+
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
 
     tab = tables_for("fcc_prim666_triplets", MODES["int"])
     w = T["B_wlflat_window"]
