@@ -46,6 +46,8 @@ extern "C" {
 /* step_type (smol/moca/kernel/mcusher.py) */
 #define SMOLMC_STEP_FLIP 0 /* Flip  mcusher.py:151 */
 #define SMOLMC_STEP_SWAP 1 /* Swap  mcusher.py:173 */
+#define SMOLMC_STEP_TABLE_FLIP 2 /* TableFlip mcusher.py:397 (charge-neutral semigrand) */
+#define SMOLMC_MAX_STEP_FLIPS 8  /* most single-site flips in one TableFlip step */
 
 /*
  * Read-only model tables.  Flattened, caller-owned equivalents of the
@@ -119,6 +121,15 @@ typedef struct smolmc_tables {
      * deltas from the N x N site kernel G (4x less memory traffic than two matrix rows);
      * otherwise it silently uses the dense rows.  NULL = dense. */
     const double *ewald_charges;
+
+    /* TableFlip (smol/moca/kernel/mcusher.py:397-711), used with SMOLMC_STEP_TABLE_FLIP.
+     * flip_table rows are flip vectors in "counts" format over the ACTIVE sublattices'
+     * species, concatenated in sub_* order (the reference's dims of inactive sublattices
+     * are always zero and are dropped); directions 2i / 2i+1 are +row i / -row i. */
+    int32_t n_flip_vectors;
+    const int32_t *flip_table;   /* [n_flip_vectors x sum(codes of active sublattices)] */
+    const double *flip_weights;  /* [2 x n_flip_vectors] (mcusher.py:519-538) */
+    double swap_weight;          /* probability of a canonical Swap instead (mcusher.py:540) */
 } smolmc_tables;
 
 typedef struct smolmc_config {

@@ -58,7 +58,7 @@ def lib():
         L.orc_mc_get_wl.argtypes = [C.c_void_p, f64p, i64p, i64p, f64p, f64p]
         L.orc_mc_run.argtypes = [C.c_void_p, C.c_int64]
         L.orc_mc_replay.argtypes = [C.c_void_p, C.c_int64, i32p, f64p, u8p, f64p]
-        L.orc_mc_propose.argtypes = [C.c_void_p, C.c_int, C.c_uint64, i32p]
+        L.orc_mc_propose.argtypes = [C.c_void_p, C.c_int, C.c_uint64, i32p, f64p]
         _LIB = L
     return _LIB
 
@@ -205,7 +205,8 @@ class OracleMC:
         )
         return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
 
-    def propose(self, r, step):
-        fl = np.zeros(4, dtype=np.int32)
-        n = lib().orc_mc_propose(self.h, int(r), int(step), _p(fl, C.c_int32))
-        return n, fl
+    def propose(self, r, step, with_priori=False):
+        fl = np.zeros(16, dtype=np.int32)
+        lp = C.c_double(0.0)
+        n = lib().orc_mc_propose(self.h, int(r), int(step), _p(fl, C.c_int32), C.byref(lp))
+        return (n, fl, lp.value) if with_priori else (n, fl)

@@ -463,6 +463,9 @@ static int pick_sublattice(const smolmc_tables *t, uint32_t w0) {
     return t->n_sublattices - 1;
 }
 
+static int propose_swap_in(const orc_mc *h, const int32_t *occ, const rng_ctx *g, int sl,
+                           uint32_t w_site, int32_t *flips);
+
 /* returns number of flips (0, 1 or 2) written to flips[4] */
 static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, uint32_t w0[4],
                         uint32_t w_site, int32_t flips[4]) {
@@ -487,9 +490,18 @@ static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, u
         flips[0] = site1; flips[1] = code;
         return 1;
     }
-    /* Swap.propose_step (mcusher.py:176-200): site2 uniform over active sites
-     * of the sublattice whose species differs; realised as rejection sampling
-     * over the candidate sequence (identical distribution). */
+    return propose_swap_in(h, occ, g, sl, w_site, flips);
+}
+
+/* Swap.propose_step (mcusher.py:176-200): site2 uniform over active sites of the sublattice
+ * whose species differs; realised as rejection sampling over the candidate sequence
+ * (identical distribution). */
+static int propose_swap_in(const orc_mc *h, const int32_t *occ, const rng_ctx *g, int sl,
+                           uint32_t w_site, int32_t *flips) {
+    const smolmc_tables *t = h->t;
+    const int32_t *sites = t->sub_active_sites + t->sub_site_ptr[sl];
+    uint32_t nact = (uint32_t)(t->sub_site_ptr[sl + 1] - t->sub_site_ptr[sl]);
+    int site1 = sites[mulhi32(w_site, nact)];
     int sp1 = occ[site1];
     /* first 12 candidates: c_t = W(step, 1 + t % 3, t / 3)  (blocks 1..3, word-major:
      * the order the wavefront tests them, three lanes per LDS read) */
@@ -526,13 +538,152 @@ static int propose_step(const orc_mc *h, const int32_t *occ, const rng_ctx *g, u
     }
 }
 
+/* ---- TableFlip (smol/moca/kernel/mcusher.py:397-711) on the engine stream ---------- */
+/* species counts over the ACTIVE sites, "counts" format over the active sublattices
+ * (occu_to_counts, smol/moca/occu_utils.py:103-135) */
+static void table_counts(const smolmc_tables *t, const int32_t *occ, int *n) {
+    int d = (int)t->sub_code_ptr[t->n_sublattices];
+    for (int i = 0; i < d; ++i) n[i] = 0;
+    for (int sl = 0; sl < t->n_sublattices; ++sl) {
+        const int32_t *codes = t->sub_codes + t->sub_code_ptr[sl];
+        int nc = (int)(t->sub_code_ptr[sl + 1] - t->sub_code_ptr[sl]);
+        for (int64_t a = t->sub_site_ptr[sl]; a < t->sub_site_ptr[sl + 1]; ++a) {
+            int v = occ[t->sub_active_sites[a]];
+            for (int c = 0; c < nc; ++c)
+                if (codes[c] == v) n[t->sub_code_ptr[sl] + c]++;
+        }
+    }
+}
+
+/* flip_weights_mask (smol/utils/math.py:832-867): sum of the weights of feasible directions */
+static double table_masked_weights(const smolmc_tables *t, const int *n, double *mw) {
+    int d = (int)t->sub_code_ptr[t->n_sublattices];
+    double sum = 0;
+    for (int idx = 0; idx < 2 * t->n_flip_vectors; ++idx) {
+        const int32_t *row = t->flip_table + (size_t)(idx / 2) * d;
+        int sgn = (idx & 1) ? -1 : 1, ok = 1;
+        for (int i = 0; i < d && ok; ++i) {
+            int sl = 0;
+            while (t->sub_code_ptr[sl + 1] <= i) sl++;
+            int max_n = (int)(t->sub_site_ptr[sl + 1] - t->sub_site_ptr[sl]); /* mcusher.py:497-501 */
+            int v = n[i] + sgn * row[i];
+            if (v < 0 || v > max_n) ok = 0;
+        }
+        mw[idx] = ok ? t->flip_weights[idx] : 0.0;
+        sum += mw[idx];
+    }
+    return sum;
+}
+
+/* compute_log_priori_factor (mcusher.py:656-711) for direction idx at counts n */
+static double table_log_priori(const smolmc_tables *t, const int *n, int idx, double sum_now,
+                               const double *mw_now) {
+    int d = (int)t->sub_code_ptr[t->n_sublattices];
+    int n_next[64];
+    double mw_next[128];
+    const int32_t *row = t->flip_table + (size_t)(idx / 2) * d;
+    int sgn = (idx & 1) ? -1 : 1;
+    for (int i = 0; i < d; ++i) n_next[i] = n[i] + sgn * row[i];
+    double sum_next = table_masked_weights(t, n_next, mw_next);
+    double sw = t->swap_weight;
+    double p_now = (1 - sw) * mw_now[idx] / sum_now;
+    double p_next = (1 - sw) * mw_next[idx ^ 1] / sum_next;
+    double lf = log(p_next / p_now);
+    for (int i = 0; i < d; ++i) { /* ln(n_now!) - ln(n_next!) as sums of logs */
+        int u = sgn * row[i];
+        for (int k = 1; k <= u; ++k) lf -= log((double)(n[i] + k));
+        for (int k = 0; k < -u; ++k) lf += log((double)(n[i] - k));
+    }
+    return lf;
+}
+
+/* TableFlip.propose_step (mcusher.py:553-639).  Stream: W(step,0,0) swap-or-table,
+ * W(step,1,0) direction, W(step,1,1) sublattice of the swap branch, blocks 2-3 the
+ * assignment draws, blocks 4+ the site candidate sequence.  Returns the number of flips;
+ * *log_priori receives compute_log_priori_factor of the proposed step. */
+static int propose_table_flip(const orc_mc *h, const int32_t *occ, const rng_ctx *g, uint32_t w0[4],
+                              uint32_t w_site, int32_t *flips, double *log_priori) {
+    const smolmc_tables *t = h->t;
+    int d = (int)t->sub_code_ptr[t->n_sublattices];
+    uint32_t w1[4];
+    rng_block(g, 1, w1);
+    *log_priori = 0.0;
+    int n[64];
+    double mw[128];
+    double sumw = 0;
+    int do_swap = (double)w0[0] * (1.0 / 4294967296.0) < t->swap_weight; /* mcusher.py:577-578 */
+    if (!do_swap) {
+        table_counts(t, occ, n);
+        sumw = table_masked_weights(t, n, mw);
+        if (!(sumw > 0)) do_swap = 1; /* no feasible flip: canonical swap only (:604-611) */
+    }
+    if (do_swap) return propose_swap_in(h, occ, g, pick_sublattice(t, w1[1]), w_site, flips);
+    /* choose_section_from_partition (math.py:870-893) */
+    double target = (double)w1[0] * (1.0 / 4294967296.0) * sumw, cum = 0;
+    int idx = -1, last = -1;
+    for (int i = 0; i < 2 * t->n_flip_vectors; ++i) {
+        if (mw[i] <= 0) continue;
+        last = i;
+        cum += mw[i];
+        if (target < cum) { idx = i; break; }
+    }
+    if (idx < 0) idx = last;
+    const int32_t *row = t->flip_table + (size_t)(idx / 2) * d;
+    int sgn = (idx & 1) ? -1 : 1;
+    *log_priori = table_log_priori(t, n, idx, sumw, mw);
+    uint32_t tcand = 0, qdraw = 0, wc[4], wd[4];
+    uint32_t wc_blk = 0xffffffffu, wd_blk = 0xffffffffu;
+    int nfl = 0;
+    for (int sl = 0; sl < t->n_sublattices; ++sl) {
+        const int32_t *sites = t->sub_active_sites + t->sub_site_ptr[sl];
+        uint32_t nact = (uint32_t)(t->sub_site_ptr[sl + 1] - t->sub_site_ptr[sl]);
+        const int32_t *codes = t->sub_codes + t->sub_code_ptr[sl];
+        int nc = (int)(t->sub_code_ptr[sl + 1] - t->sub_code_ptr[sl]);
+        int base = (int)t->sub_code_ptr[sl];
+        int collected[SMOLMC_MAX_STEP_FLIPS], ncol = 0;
+        for (int c = 0; c < nc; ++c) { /* depleted species: pick -u sites without replacement */
+            int u = sgn * row[base + c];
+            for (int k = 0; k < -u; ++k) {
+                for (;;) {
+                    uint32_t blk = 4u + tcand / 4u;
+                    if (blk != wc_blk) { rng_block(g, blk, wc); wc_blk = blk; }
+                    int site = sites[mulhi32(wc[tcand % 4u], nact)];
+                    tcand++;
+                    if (occ[site] != codes[c]) continue;
+                    int dup = 0;
+                    for (int z = 0; z < ncol; ++z) dup |= collected[z] == site;
+                    if (dup) continue;
+                    collected[ncol++] = site;
+                    break;
+                }
+            }
+        }
+        for (int c = 0; c < nc; ++c) { /* enriched species: random assignment (:627-631) */
+            int u = sgn * row[base + c];
+            for (int k = 0; k < u; ++k) {
+                uint32_t blk = 2u + qdraw / 4u;
+                if (blk != wd_blk) { rng_block(g, blk, wd); wd_blk = blk; }
+                uint32_t rr = mulhi32(wd[qdraw % 4u], (uint32_t)ncol);
+                qdraw++;
+                flips[2 * nfl] = collected[rr];
+                flips[2 * nfl + 1] = codes[c];
+                nfl++;
+                for (int z = (int)rr; z + 1 < ncol; ++z) collected[z] = collected[z + 1];
+                ncol--;
+            }
+        }
+    }
+    return nfl;
+}
+
 /* one MC step of walker r given its proposal; follows
  * StandardSingleStepMixin.single_step (kernel/base.py:145-166),
  * MCKernel._compute_step_trace (:291-311), Metropolis _accept_step
  * (metropolis.py:31-49) / WangLandau (wanglandau.py:186-266), _do_accept_step
  * (base.py:327-343) and the trace accumulation of Sampler.sample
  * (sampler/sampler.py:199-207). */
-static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u, double *dfeat) {
+static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u, double log_priori,
+                   double *dfeat) {
     const smolmc_tables *t = h->t;
     int32_t *occ = h->occ + (size_t)r * h->N;
     int F = h->F;
@@ -542,7 +693,7 @@ static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u,
     int accepted;
     if (h->cfg.kernel_type == SMOLMC_KERNEL_METROPOLIS) {
         double beta = 1.0 / (ORC_KB * h->temperature[r]); /* base.py:398 */
-        double exponent = -beta * dH + 0.0;                /* metropolis.py:42 (log_priori = 0) */
+        double exponent = -beta * dH + log_priori;         /* metropolis.py:41-42 */
         accepted = exponent >= 0 ? 1 : (exponent > log(u)); /* :46-48 */
     } else {
         double emin = h->cfg.wl_min_enthalpy, emax = h->cfg.wl_max_enthalpy, bsz = h->cfg.wl_bin_size;
@@ -554,7 +705,7 @@ static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u,
             long b = (long)floordiv_exact(cur - emin, bsz); /* :187,:180 */
             long nb = (long)floordiv_exact(new_h - emin, bsz);
             const double *S = h->wl_entropy + (size_t)r * h->L;
-            double exponent = S[b] - S[nb] + 0.0; /* :198 */
+            double exponent = S[b] - S[nb] + log_priori; /* :197-198 */
             accepted = exponent >= 0 ? 1 : (exponent > log(u));
         }
     }
@@ -632,10 +783,16 @@ int orc_mc_run(orc_mc *h, int64_t nsteps) {
         for (int64_t k = 0; k < nsteps; ++k) {
             g.step = h->nsteps[r];
             uint32_t w0[4];
-            int32_t flips[4] = {-1, -1, -1, -1};
+            int32_t flips[2 * SMOLMC_MAX_STEP_FLIPS];
+            for (int z = 0; z < 2 * SMOLMC_MAX_STEP_FLIPS; ++z) flips[z] = -1;
+            double lp = 0.0;
             rng_block(&g, 0, w0);
-            int nf = propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
-            do_step(h, r, flips, nf, u53(w0[2], w0[3]), dfeat);
+            int nf;
+            if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+                nf = propose_table_flip(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips, &lp);
+            else
+                nf = propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
+            do_step(h, r, flips, nf, u53(w0[2], w0[3]), lp, dfeat);
             memcpy(wprev, w0, sizeof(w0));
         }
         free(dfeat);
@@ -654,7 +811,7 @@ int orc_mc_replay(orc_mc *h, int64_t nsteps, const int32_t *steps, const double 
             int nf = st[0] < 0 ? 0 : (st[2] < 0 ? 1 : 2);
             double u = uniforms[(size_t)r * nsteps + k];
             if (isnan(u)) u = 0.0; /* not drawn by the reference => it accepted without a draw */
-            int a = do_step(h, r, st, nf, u, dfeat);
+            int a = do_step(h, r, st, nf, u, 0.0, dfeat);
             if (accepted_out) accepted_out[(size_t)r * nsteps + k] = (uint8_t)a;
             if (enthalpy_out)
                 enthalpy_out[(size_t)r * nsteps + k] =
@@ -666,7 +823,8 @@ int orc_mc_replay(orc_mc *h, int64_t nsteps, const int32_t *steps, const double 
 }
 
 /* proposal only (for usher statistics tests, tests/test_moca/test_mcushers.py:124-196) */
-int orc_mc_propose(orc_mc *h, int r, uint64_t step, int32_t flips[4]) {
+int orc_mc_propose(orc_mc *h, int r, uint64_t step, int32_t *flips /* 2*SMOLMC_MAX_STEP_FLIPS */,
+                   double *log_priori) {
     rng_ctx g;
     g.key[0] = (uint32_t)h->seeds[r];
     g.key[1] = (uint32_t)(h->seeds[r] >> 32);
@@ -675,6 +833,13 @@ int orc_mc_propose(orc_mc *h, int r, uint64_t step, int32_t flips[4]) {
     rng_block(&g, 0, wprev);
     g.step = step;
     rng_block(&g, 0, w0);
-    flips[0] = flips[1] = flips[2] = flips[3] = -1;
-    return propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
+    for (int z = 0; z < 2 * SMOLMC_MAX_STEP_FLIPS; ++z) flips[z] = -1;
+    double lp = 0.0;
+    int nf;
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+        nf = propose_table_flip(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips, &lp);
+    else
+        nf = propose_step(h, h->occ + (size_t)r * h->N, &g, w0, wprev[1], flips);
+    if (log_priori) *log_priori = lp;
+    return nf;
 }

@@ -21,6 +21,7 @@ KERNEL_METROPOLIS = 0
 KERNEL_WANGLANDAU = 1
 STEP_FLIP = 0
 STEP_SWAP = 1
+STEP_TABLE_FLIP = 2
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -73,6 +74,10 @@ class smolmc_tables(C.Structure):
         ("sub_codes", _i32p),
         ("sub_probs", _f64p),
         ("ewald_charges", _f64p),
+        ("n_flip_vectors", C.c_int32),
+        ("flip_table", _i32p),
+        ("flip_weights", _f64p),
+        ("swap_weight", C.c_double),
     ]
 
 
@@ -148,6 +153,9 @@ class TableSet:
         ewald_coef=1.0,
         mu_table=None,
         ewald_charges=None,
+        flip_table=None,
+        flip_weights=None,
+        swap_weight=0.1,
     ):
         self._keep = {}
         k = self._keep
@@ -299,6 +307,29 @@ class TableSet:
         self.nspecies_per_site = (
             None if nspecies_per_site is None else np.asarray(nspecies_per_site, np.int32)
         )
+        # TableFlip table (mcusher.py:489-551)
+        t.n_flip_vectors = 0
+        t.swap_weight = float(swap_weight)
+        if flip_table is not None:
+            ft = _arr(np.atleast_2d(flip_table), np.int32, "flip_table")
+            d = int(k["sub_code_ptr"][-1])
+            if ft.shape[1] != d:
+                raise ValueError(f"flip_table must have {d} columns (species of the active sublattices)")
+            if flip_weights is None:
+                fw = np.ones(2 * len(ft))
+            else:
+                fw = np.asarray(flip_weights, dtype=np.float64)
+                if len(fw) == len(ft):
+                    fw = np.repeat(fw, 2)
+                if len(fw) != 2 * len(ft):
+                    raise ValueError(
+                        f"{len(fw)} weights provided. You must provide either 1* or 2* weights "
+                        f"given {len(ft)} flip vectors!"
+                    )  # mcusher.py:523-530
+            if np.any(np.abs(ft).sum(axis=1) // 2 > 8):
+                raise ValueError("flip vectors changing more than 8 sites are not supported")
+            k["flip_table"], k["flip_weights"] = ft, np.ascontiguousarray(fw)
+            t.n_flip_vectors = len(ft)
         for name, ctype in smolmc_tables._fields_:
             if name in k:
                 setattr(t, name, _ptr(k[name], ctype._type_))
@@ -330,6 +361,9 @@ class TableSet:
         ewald_coef=1.0,
         mu_table=None,
         ewald_charges="auto",
+        flip_table=None,
+        flip_weights=None,
+        swap_weight=0.1,
     ):
         """Build from smol_amd.synth tables (SupercellTables + CE coefficients)."""
         model = sc.model
@@ -378,6 +412,9 @@ class TableSet:
             ewald_coef=ewald_coef,
             mu_table=mu_table,
             ewald_charges=cls._synth_charges(sc, ewald, ewald_charges),
+            flip_table=flip_table,
+            flip_weights=flip_weights,
+            swap_weight=swap_weight,
         )
 
     @staticmethod

@@ -785,6 +785,11 @@ struct LeanParams {
     const double *ew_G, *ew_qs, *ew_dg, *ew_frozen;
     double ew_coef;
     WlParams wl;
+    // TableFlip (mcusher.py:397-711) for the single active sublattice
+    int tf_n;               // number of flip vectors
+    const int *tf_table;    // [tf_n][ncodes]
+    const double *tf_w;     // [2 tf_n]
+    double tf_sw;           // swap_weight
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -1251,6 +1256,386 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
         if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
+
+// ----------------------------------------------------------------------------
+// TableFlip kernel (charge-neutral semigrand steps, smol/moca/kernel/mcusher.py:397-711)
+// for lean-eligible models: one site class, one contiguous active sublattice, interaction
+// features, optional mu row and compact Ewald.  A step is either a canonical Swap (with
+// probability swap_weight, or when no table direction is feasible) or a flip-table
+// direction u: -u[c] random sites of every depleted species are picked without
+// replacement (rejection over the candidate stream, 256 candidates per wave round) and
+// randomly re-assigned to the enriched species; the a-priori factor
+// log(p_next/p_now) + sum ln n_now! - ln n_next! enters the Metropolis exponent.
+// Flips of a step are evaluated sequentially against the LDS occupancy with each flip
+// applied tentatively (expansion.py:217-229) and undone on rejection.
+// ----------------------------------------------------------------------------
+template <int NSLOT, int MM>
+__global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len; // 8 doubles
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64;
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
+    uint8_t *occ = wbase;
+    double *s_feat = (double *)(wbase + P.Nlds);
+    int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
+    const bool has_mu = P.mu_row != nullptr, has_ew = P.ew_G != nullptr;
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (threadIdx.x < 8) s_mu[threadIdx.x] = (has_mu && threadIdx.x < P.ncodes) ? P.mu_row[threadIdx.x] : 0.0;
+    const bool live = r < P.R;
+    if (live) {
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
+        s_feat[lane] = 0.0;
+        if (lane < 16) s_cnt[lane] = 0;
+    }
+    __syncthreads();
+    if (!live) return;
+    const int nc = P.ncodes, sbase = P.sbase;
+    const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
+    for (int a = lane; a < (int)nact; a += 64)
+        atomicAdd(&s_cnt[(int)occ[lean_swz(sbase + a, swa, swm, swb)]], 1);
+
+    uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
+    double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) {
+        const LeanSlot sl = P.slots[it * 64 + lane];
+        doff8[it] = sl.doff8;
+        sfeat[it] = sl.feat;
+        sfs[it] = sl.live ? sl.fs : 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
+        wgt[it] = sl.w;
+        acc[it] = 0.0;
+    }
+    double H = P.enthalpy[r];
+    const double nbeta = -P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    double acc_mu = 0.0, acc_ew = 0.0;
+    int last_acc = 1;
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    long long smp_countdown = P.smp.every, smp_index = 0;
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+    double logu = 0.0;
+    unsigned long long batch_base = ~0ull;
+    uint32_t w_site_carry = 0;
+    constexpr int ROW = NSLOT * MM;
+    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+    const int nf2 = 2 * P.tf_n;
+
+    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            if (batch_base == base - 16) {
+                w_site_carry = rdlane(W1, 60);
+            } else {
+                const unsigned long long sp = base - 1ull;
+                w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                                key0, key1).w[1]);
+            }
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                               0u, key0, key1);
+            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            logu = log(philox_u53(o.w[2], o.w[3]));
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
+
+        // flips of this step live lane-indexed: lane f holds flip f
+        int vsite = 0, vnew = 0, vold = 0;
+        int nfl = 0, dir = -1;
+        double log_priori = 0.0;
+        bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
+        double sumw = 0.0;
+        if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
+            for (int idx = 0; idx < nf2; ++idx) {
+                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int sg = (idx & 1) ? -1 : 1;
+                bool ok = true;
+                for (int c = 0; c < nc; ++c) {
+                    const int v = s_cnt[c] + sg * row[c];
+                    ok = ok && v >= 0 && v <= (int)nact;
+                }
+                sumw += ok ? P.tf_w[idx] : 0.0;
+            }
+            sumw = uni_d(sumw);
+            if (!(sumw > 0.0)) do_swap = true;
+        }
+        if (do_swap) {
+            // Swap.propose_step (mcusher.py:176-200)
+            const int s1 = sbase + (int)__umulhi(w_site, nact);
+            const int o1 = uni((int)occ[lean_swz(s1, swa, swm, swb)]);
+            int found = -1, fo = 0;
+            const uint32_t ws[4] = {W0, W1, W2, W3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int cs = sbase + (int)__umulhi(ws[j], nact);
+                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cs, b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                    }
+                }
+            }
+            if (found < 0) {
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) {
+                        int any = 0;
+                        for (uint32_t a = lane; a < nact; a += 64)
+                            any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) {
+                nfl = 2;
+                vsite = lane == 0 ? s1 : found;
+                vnew = lane == 0 ? fo : o1;
+                vold = lane == 0 ? o1 : fo;
+            }
+        } else {
+            // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
+            const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
+            double cum = 0.0;
+            int last = -1;
+            for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
+                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int sg = (idx & 1) ? -1 : 1;
+                bool ok = true;
+                for (int c = 0; c < nc; ++c) {
+                    const int v = s_cnt[c] + sg * row[c];
+                    ok = ok && v >= 0 && v <= (int)nact;
+                }
+                if (!ok) continue;
+                last = idx;
+                cum += P.tf_w[idx];
+                if (target < cum) dir = idx;
+            }
+            if (dir < 0) dir = last;
+            dir = uni(dir);
+            const int *urow = P.tf_table + (dir >> 1) * nc;
+            const int usg = (dir & 1) ? -1 : 1;
+            // compute_log_priori_factor (mcusher.py:656-711)
+            {
+                double sum_next = 0.0;
+                for (int idx = 0; idx < nf2; ++idx) {
+                    const int *row = P.tf_table + (idx >> 1) * nc;
+                    const int sg = (idx & 1) ? -1 : 1;
+                    bool ok = true;
+                    for (int c = 0; c < nc; ++c) {
+                        const int v = s_cnt[c] + usg * urow[c] + sg * row[c];
+                        ok = ok && v >= 0 && v <= (int)nact;
+                    }
+                    sum_next += ok ? P.tf_w[idx] : 0.0;
+                }
+                const double p_now = (1.0 - P.tf_sw) * P.tf_w[dir] / sumw;
+                const double p_next = (1.0 - P.tf_sw) * P.tf_w[dir ^ 1] / sum_next;
+                double lf = log(p_next / p_now);
+                for (int c = 0; c < nc; ++c) {
+                    const int u = usg * urow[c], n0 = s_cnt[c];
+                    for (int k = 1; k <= u; ++k) lf -= log((double)(n0 + k));
+                    for (int k = 0; k < -u; ++k) lf += log((double)(n0 - k));
+                }
+                log_priori = uni_d(lf);
+            }
+            // pick the sites of the depleted species from the candidate stream
+            // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round
+            int vcol = 0, ncol = 0; // collected sites, lane-indexed
+            long long tlast = -1;
+            uint32_t round = 0;
+            int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
+            bool have_round = false;
+            for (int c = 0; c < nc; ++c) {
+                int need = -(usg * urow[c]);
+                while (need > 0) {
+                    if (!have_round) {
+                        const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                           4u + 64u * round + (uint32_t)lane, 0u, key0, key1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            cs[j] = sbase + (int)__umulhi(o.w[j], nact);
+                            cv[j] = (int)occ[lean_swz(cs[j], swa, swm, swb)];
+                        }
+                        have_round = true;
+                    }
+                    // smallest stream position t > tlast in this lane that holds species c and
+                    // was not collected yet
+                    long long mint = -1;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const long long t = (long long)round * 256 + 4 * lane + j;
+                        bool ok = cv[j] == c && t > tlast;
+                        for (int z = 0; z < ncol; ++z) ok = ok && cs[j] != (int)rdlane((uint32_t)vcol, z);
+                        if (ok) mint = t;
+                    }
+                    const unsigned long long m = __ballot(mint >= 0);
+                    if (!m) { round++; have_round = false; continue; }
+                    const int b = __ffsll((long long)m) - 1;
+                    const int tj = (int)(((unsigned)rdlane((uint32_t)(int)(mint & 0xffffffffll), b)) & 3u);
+                    tlast = (long long)round * 256 + 4 * b + tj;
+                    const int picked = (int)rdlane((uint32_t)(tj == 0 ? cs[0] : tj == 1 ? cs[1] : tj == 2 ? cs[2] : cs[3]), b);
+                    if (lane == ncol) vcol = picked;
+                    ncol++;
+                    need--;
+                }
+            }
+            // random assignment of the collected sites to the enriched species (:627-631)
+            int qdraw = 0;
+            for (int c = 0; c < nc; ++c) {
+                const int u = usg * urow[c];
+                for (int k = 0; k < u; ++k) {
+                    const int wl = l4 + 2 + (qdraw >> 2);
+                    const int wj = qdraw & 3;
+                    const uint32_t word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
+                    qdraw++;
+                    const int rr = (int)__umulhi(word, (uint32_t)ncol);
+                    const int site = (int)rdlane((uint32_t)vcol, rr);
+                    const int od = uni((int)occ[lean_swz(site, swa, swm, swb)]);
+                    if (lane == nfl) { vsite = site; vnew = c; vold = od; }
+                    nfl++;
+                    const int nxt = __shfl_down(vcol, 1);
+                    if (lane >= rr) vcol = nxt; // list.remove keeps the order of the rest
+                    ncol--;
+                }
+            }
+        }
+
+        // -------- sequential evaluation of the flips of this step -----------------------
+        double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
+        for (int f = 0; f < nfl; ++f) {
+            const int s = (int)rdlane((uint32_t)vsite, f), nw = (int)rdlane((uint32_t)vnew, f);
+            const int od = (int)rdlane((uint32_t)vold, f);
+            const uint16_t *p = idx_lane + (size_t)s * (64 * ROW);
+            uint16_t row[ROW];
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) row[q] = p[q];
+            const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row[it * MM + m]]);
+                const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
+                e = fma(wgt[it], d, e);
+                pend[it] += d;
+            }
+            if (has_ew) {
+                const int W = P.ew_W;
+                const double dq = P.ew_qs[(size_t)s * W + nw] - P.ew_qs[(size_t)s * W + od];
+                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s, swa, swm, swb);
+                ew_uni += 2.0 * dq * P.ew_frozen[s] + (P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od]);
+            }
+            if (has_mu) dMu += s_mu[nw] - s_mu[od];
+            if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative
+        }
+        double dH = wave_sum_all(e);
+        double dEw = 0.0;
+        if (has_ew) {
+            dEw = wave_sum_all(ew_part) + ew_uni;
+            dH += P.ew_coef * dEw;
+        }
+        if (has_mu) dH -= dMu;
+        const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        const bool accepted = (exponent >= 0.0) || (exponent > lu);
+        if (accepted) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
+            if (dir >= 0 && lane < nc) {
+                const int *urow = P.tf_table + (dir >> 1) * nc;
+                s_cnt[lane] += ((dir & 1) ? -1 : 1) * urow[lane];
+            }
+            acc_mu += dMu;
+            acc_ew += dEw;
+            H += dH;
+            nacc++;
+        } else {
+            for (int f = nfl - 1; f >= 0; --f) { // undo the tentative flips
+                const int s = (int)rdlane((uint32_t)vsite, f), od = (int)rdlane((uint32_t)vold, f);
+                if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
+            }
+        }
+        last_acc = accepted ? 1 : 0;
+
+        if (P.smp.every && --smp_countdown == 0) {
+            smp_countdown = P.smp.every;
+            const size_t rowi = (size_t)smp_index * P.R + r;
+            smp_index++;
+            s_feat[lane] = 0.0;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it)
+                __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (lane < P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + s_feat[lane];
+            if (has_ew && lane == P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + acc_ew;
+            if (has_mu && lane == P.Fce + (has_ew ? 1 : 0)) P.smp.feat[rowi * P.F + lane] = base_feat + acc_mu;
+            if (lane == 0) {
+                P.smp.H[rowi] = H;
+                P.smp.acc[rowi] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + rowi * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
+    }
+
+    {
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+    }
+    s_feat[lane] = 0.0;
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it)
+        __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    if (lane == 0) {
+        if (has_ew) featp[P.Fce] += acc_ew;
+        if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
@@ -2201,6 +2586,13 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.ew_frozen = kp.ew_frozen;
                 lp.ew_coef = kp.ew_coef;
             }
+            if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
+                if (dev_upload(h, t->flip_table, (size_t)t->n_flip_vectors * nc, &lp.tf_table) ||
+                    dev_upload(h, t->flip_weights, (size_t)2 * t->n_flip_vectors, &lp.tf_w))
+                    return bail(1);
+                lp.tf_n = t->n_flip_vectors;
+                lp.tf_sw = t->swap_weight;
+            }
             if (wl) {
                 lp.wl.L = h->L;
                 lp.wl.vmin = kp.wl_min; lp.wl.vmax = kp.wl_max; lp.wl.bin = kp.wl_bin;
@@ -2210,10 +2602,20 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
             }
             h->lean_lds = ((size_t)lp.dt_len + 8) * 8 +
-                          (size_t)4 * (lp.Nlds + 64 * 8 + (wl ? (size_t)h->L * 16 : 0));
+                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
         }
         h->lean = lean;
+        if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
+            if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
+                return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
+                                 "smol/moca/composition/space.py:404-429)"));
+            if (!lean || wl)
+                return bail(fail("TableFlip is implemented for single-class, single-sublattice "
+                                 "Metropolis models (the lean path) only"));
+            if (!(t->swap_weight >= 0.0 && t->swap_weight < 1.0))
+                return bail(fail("swap_weight must be in [0, 1)"));
+        }
     }
     *out = h;
     return 0;
@@ -2463,8 +2865,28 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
     return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
+template <int NSLOT, int MM>
+static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned grid = (unsigned)((h->R + 3) / 4);
+    auto kern = mc_table_kernel<NSLOT, MM>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) {
+        if (h->lean_nslot == 2)
+            return h->lean_mm == 2 ? launch_table_inst<2, 2>(h, lp) : launch_table_inst<2, 3>(h, lp);
+        return h->lean_mm == 2 ? launch_table_inst<4, 2>(h, lp) : launch_table_inst<4, 3>(h, lp);
+    }
     if (h->lean_nslot == 2)
         return h->lean_mm == 2 ? launch_lean_nm<2, 2>(h, lp) : launch_lean_nm<2, 3>(h, lp);
     return h->lean_mm == 2 ? launch_lean_nm<4, 2>(h, lp) : launch_lean_nm<4, 3>(h, lp);

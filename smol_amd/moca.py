@@ -463,8 +463,47 @@ class Ensemble:
             s.reset_restricted_sites()
 
     # -- tables for the engine -----------------------------------------------------
-    def make_tables(self):
-        return self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
+    def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1):
+        tab = self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
+        if flip_table is not None:
+            tab = self._with_flip_table(tab, flip_table, flip_weights, swap_weight)
+        return tab
+
+    def _with_flip_table(self, tab, flip_table, flip_weights, swap_weight):
+        """Attach a TableFlip table.  The reference's flip vectors span the species of ALL
+        sublattices in order (mcusher.py:489-503); the engine wants the active ones only."""
+        import ctypes as C
+
+        ft = np.atleast_2d(np.asarray(flip_table, dtype=np.int64))
+        widths = [len(s.species) for s in self._sublattices]
+        act = [s.is_active for s in self._sublattices]
+        if ft.shape[1] == sum(widths):
+            cols, off = [], 0
+            for w, a in zip(widths, act):
+                if a:
+                    cols += list(range(off, off + w))
+                elif np.any(ft[:, off:off + w] != 0):
+                    raise ValueError("flip table changes species on an inactive sublattice")
+                off += w
+            ft = ft[:, cols]
+        elif ft.shape[1] != sum(w for w, a in zip(widths, act) if a):
+            raise ValueError("flip_table width does not match the sublattice species")
+        ft = np.ascontiguousarray(ft, dtype=np.int32)
+        fw = np.ones(2 * len(ft)) if flip_weights is None else np.asarray(flip_weights, dtype=np.float64)
+        if len(fw) == len(ft):
+            fw = np.repeat(fw, 2)
+        if len(fw) != 2 * len(ft):
+            raise ValueError(
+                f"{len(fw)} weights provided. You must provide either 1* or 2* weights given "
+                f"{len(ft)} flip vectors!"
+            )
+        tab._keep["flip_table"], tab._keep["flip_weights"] = ft, np.ascontiguousarray(fw)
+        t = tab.struct
+        t.n_flip_vectors = len(ft)
+        t.swap_weight = float(swap_weight)
+        t.flip_table = ft.ctypes.data_as(C.POINTER(C.c_int32))
+        t.flip_weights = tab._keep["flip_weights"].ctypes.data_as(C.POINTER(C.c_double))
+        return tab
 
     def _eval(self):
         key = (id(self._mu_table), tuple(len(s.active_sites) for s in self._sublattices))
@@ -489,7 +528,8 @@ class Ensemble:
 # --------------------------------------------------------------------------- #
 # kernels (specifications of what the engine runs for each walker)
 # --------------------------------------------------------------------------- #
-STEP_TYPES = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP}
+STEP_TYPES = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP, "table-flip": capi.STEP_TABLE_FLIP,
+              "tableflip": capi.STEP_TABLE_FLIP}
 
 
 class MCKernel:
@@ -506,6 +546,14 @@ class MCKernel:
         self._ensemble = ensemble
         self.natural_params = ensemble.natural_parameters
         self.step_type = step_type
+        # MCUsher arguments (TableFlip: flip_table, flip_weights, swap_weight; mcusher.py:414-426)
+        self.usher_kwargs = {k: kwargs[k] for k in ("flip_table", "flip_weights", "swap_weight")
+                             if k in kwargs}
+        if STEP_TYPES[step_type] == capi.STEP_TABLE_FLIP and "flip_table" not in self.usher_kwargs:
+            raise NotImplementedError(
+                "TableFlip needs an explicit flip_table: CompositionSpace (automatic flip-table "
+                "generation, smol/moca/composition/space.py) is not part of this engine yet"
+            )
         self._seed = seed if seed is not None else np.random.SeedSequence().entropy
         self.spec = dict(kernel=self.__class__.__name__, seed=self._seed, step=step_type)
 
@@ -821,7 +869,7 @@ class Sampler:
         ens = k0.ensemble
         key = (id(ens._mu_table), tuple(len(s.active_sites) for s in ens.sublattices), device)
         if self._engine is None or self._engine_key != key:
-            tables = ens.make_tables()
+            tables = ens.make_tables(**k0.usher_kwargs)
             if isinstance(k0, WangLandau):
                 cfg = capi.make_config(
                     len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], device,

@@ -1,0 +1,96 @@
+"""GPU TableFlip kernel against the CPU oracle (identical Philox streams -> identical
+trajectories) and the detailed-balance histogram of tests/test_moca/test_mcushers.py:237-319."""
+
+from math import comb
+
+import numpy as np
+import pytest
+
+from smol_amd import capi
+from tests.test_table_flip import FLIP_TABLE, _model, _neutral_occ
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05]),
+    dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=True),
+], ids=["zero-H", "ce+mu", "ce+mu+ewald"])
+def test_table_flip_matches_oracle(kw):
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    sc, tab = _model(3, **kw)
+    R = 7
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    rng = np.random.default_rng(4)
+    occ = np.array([_neutral_occ(sc, 1 + 2 * (r % 5), rng) for r in range(R)])
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(100)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ, seeds, 2500.0)
+    ora.set_state(occ, seeds, 2500.0)
+    for chunk in (1, 5, 16, 200):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        assert np.array_equal(a["accepted"], b["accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    # the composition moved along the flip direction only
+    n = np.array([[(o[: sc.size] == c).sum() for c in range(3)] for o in a["occupancy"]])
+    n0 = np.array([[(o[: sc.size] == c).sum() for c in range(3)] for o in occ])
+    k = (n - n0)[:, 0]
+    assert np.array_equal(n - n0, k[:, None] * FLIP_TABLE[0][None, :])
+
+
+def test_table_flip_detailed_balance_on_gpu():
+    from smol_amd.engine import Engine
+
+    sc, tab = _model(3)
+    R = 2048
+    eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP))
+    rng = np.random.default_rng(6)
+    occ = np.array([_neutral_occ(sc, 1 + 2 * (r % 5), rng) for r in range(R)])
+    eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(5), 1000.0)
+    eng.run(2000)
+    counts = np.zeros(10)
+    for _ in range(10):
+        eng.run(200)
+        o = eng.get_state()["occupancy"]
+        counts += np.bincount((o[:, : sc.size] == 2).sum(axis=1), minlength=10)
+    P = sc.size
+    w = {k: comb(P, k) * comb(P - k, (P - 3 * k) // 2) for k in (1, 3, 5, 7, 9)}
+    tot = sum(w.values())
+    for k, wt in w.items():
+        p = wt / tot
+        assert counts[k] / counts.sum() == pytest.approx(p, abs=max(0.01, 5 * np.sqrt(p / counts.sum())))
+    assert counts[[0, 2, 4, 6, 8]].sum() == 0
+
+
+def test_table_flip_through_sampler():
+    from smol_amd import moca, synth
+
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 3.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(
+        sc, synth.random_coefs(model, seed=5, scale=0.05),
+        chemical_potentials={"Li+": 0.1, "Mn3+": -0.2, "Ti4+": 0.05})
+    with pytest.raises(NotImplementedError):
+        moca.Sampler.from_ensemble(ens, temperature=2000, step_type="table-flip")
+    # reference-style table: columns for ALL sublattices (cations, then the inactive anions)
+    sampler = moca.Sampler.from_ensemble(ens, temperature=2000, step_type="table-flip", nwalkers=3,
+                                         seeds=[1, 2, 3], flip_table=[[1, -3, 2, 0]], swap_weight=0.2)
+    rng = np.random.default_rng(8)
+    occ = np.array([_neutral_occ(sc, 3, rng) for _ in range(3)])
+    sampler.run(600, occ, thin_by=100)
+    c = sampler.samples
+    occs = c.get_occupancies(flat=False)
+    charge = np.array([1, 3, 4])
+    assert np.all(charge[occs[..., : sc.size]].sum(axis=-1) == 2 * sc.size)  # neutral throughout
+    f = ens.compute_feature_vector(occs[-1, 0])
+    np.testing.assert_allclose(c.get_feature_vectors(flat=False)[-1, 0], f, rtol=1e-10, atol=1e-8)
