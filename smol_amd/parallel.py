@@ -133,16 +133,26 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None):
     """Alternate ``steps_between`` MC steps on every walker with one exchange attempt.
 
     ``engine`` is a smol_amd.engine.Engine holding this rank's ``rex.per_rank`` walkers.
-    The enthalpies are exported device-to-device into a torch tensor (the all-gather
-    runs on RCCL without staging through the host); the new temperatures are uploaded
-    with set_temperature (per_rank doubles)."""
-    import torch
+    Multi-rank: the enthalpies are exported device-to-device into a torch tensor (the
+    all-gather runs on RCCL without staging through the host; initialise torch.cuda /
+    the process group BEFORE creating the engine, as bench.py does).  Single rank: no
+    collective is needed and the enthalpies are read back directly.  The new temperatures
+    are uploaded with set_temperature (per_rank doubles)."""
+    dist = _dist()
+    multi = rex.world > 1 and dist.is_available() and dist.is_initialized()
+    buf = None
+    if multi:
+        import torch
 
-    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    buf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        buf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
     engine.set_temperature(rex.local_temperatures())
     for _ in range(n_exchanges):
         engine.run(steps_between)
-        engine.export_enthalpy(buf.data_ptr())
-        engine.set_temperature(rex.exchange(buf))
+        if multi:
+            engine.export_enthalpy(buf.data_ptr())
+            engine.set_temperature(rex.exchange(buf))
+        else:
+            rex.decide(engine.get_state(occupancy=False)["enthalpy"])
+            engine.set_temperature(rex.local_temperatures())
     return rex

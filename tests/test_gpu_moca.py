@@ -190,3 +190,30 @@ def test_wang_landau_sampler(fcc):
     feats = c.get_feature_vectors(flat=False)
     occs = c.get_occupancies(flat=False)
     np.testing.assert_allclose(feats[-1, 0], ens.compute_feature_vector(occs[-1, 0]), rtol=1e-10, atol=1e-9)
+
+
+def test_replica_exchange_on_engine(fcc):
+    """Config-5 style ladder on one rank: temperatures stay a permutation of the ladder, the
+    coldest rungs end up lowest in enthalpy, traces stay consistent."""
+    import torch
+
+    from smol_amd import parallel
+    from smol_amd.engine import Engine
+
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    tab = ens.make_tables()
+    R = 16
+    eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    rng = np.random.default_rng(12)
+    occ = np.vstack([_rand_occ(rng, sc)[0] for _ in range(R)])
+    ladder = parallel.geometric_ladder(300.0, 6000.0, R)
+    eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(1), ladder)
+    rex = parallel.ReplicaExchange(ladder, R, seed=3)
+    parallel.run_replica_exchange(eng, rex, 60, 250)
+    assert sorted(rex.rung_of) == list(range(R))
+    assert rex.accepted.sum() > 0
+    st = eng.get_state()
+    np.testing.assert_allclose(st["features"], eng.eval_full(st["occupancy"]), rtol=1e-10, atol=1e-8)
+    H_by_rung = st["enthalpy"][np.argsort(rex.rung_of)]
+    assert H_by_rung[:4].mean() < H_by_rung[-4:].mean()  # cold rungs sit lower

@@ -78,8 +78,55 @@ def main():
                                max_enthalpy=h0 + 96.0, bin_size=0.5, flatness=0.8, check_period=1000)
         T, flips_per_step = 0.0, 2
         name = "config4: binary FCC 16^3 pair+triplet, Wang-Landau swap, 512 bins"
+    elif a.config == 5:
+        # config-3 lattice, charge-neutral TableFlip (3 Mn3+ <-> Li+ + 2 Ti4+) + replica-exchange
+        # ladder (one rank here; bench.py-style multi-rank launch shards the ladder)
+        import torch
+
+        from smol_amd import parallel
+
+        d = a.dim or 12
+        model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 6.0, 3: 5.0})
+        sc = synth.build_supercell(model, [d] * 3)
+        ew = ewald.supercell_ewald(sc)
+        mu = np.zeros((sc.num_sites, 3))
+        mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
+        tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1,
+                                       mu_table=mu, flip_table=[[1, -3, 2]], swap_weight=0.1)
+        R, mc = a.replicas or 2048, a.mc or sc.num_sites
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+        P = sc.size
+        n_ti = 2 * (P // 12)  # neutral: 2 n_Mn + 3 n_Ti = P
+        n_mn = (P - 3 * n_ti) // 2
+        rng = np.random.default_rng(5)
+        occ = np.zeros((R, sc.num_sites), np.int32)
+        for r in range(R):
+            perm = rng.permutation(P)
+            occ[r, perm[:n_mn]] = 1
+            occ[r, perm[n_mn:n_mn + n_ti]] = 2
+        ladder = parallel.geometric_ladder(400.0, 2000.0, R)
+        eng = Engine(tab, cfg)
+        eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(777), ladder)
+        rex = parallel.ReplicaExchange(ladder, R, seed=11)
+        parallel.run_replica_exchange(eng, rex, 1, mc)
+        s0 = eng.get_state(occupancy=False)
+        t1 = time.time()
+        parallel.run_replica_exchange(eng, rex, a.launches, mc)
+        eng.sync()
+        wall = time.time() - t1
+        s1 = eng.get_state(occupancy=False)
+        steps = R * mc * a.launches
+        print(json.dumps(dict(
+            config=f"config5: ternary rocksalt {d}^3 + Ewald, charge-neutral TableFlip, replica-exchange "
+                   f"ladder 400-2000 K over {R} walkers, exchange every {mc} steps",
+            replicas=R, mc_steps_between_exchanges=mc, exchanges=a.launches, wall_s=wall,
+            mc_steps_per_s=steps / wall, kernel_ms_last=eng.last_kernel_ms(),
+            acceptance=float((s1["n_accepted"] - s0["n_accepted"]).sum()) / steps,
+            exchange_acceptance_mean=float(rex.acceptance.mean()),
+        )))
+        return
     else:
-        raise SystemExit("config must be 1, 3 or 4")
+        raise SystemExit("config must be 1, 3, 4 or 5")
     setup_s = time.time() - t0
     eng = Engine(tab, cfg)
     eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(777), T)
