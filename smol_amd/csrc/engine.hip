@@ -1,0 +1,1292 @@
+// engine.hip -- C-ABI (include/smolmc.h), host-side table preparation and the evaluation kernels.
+#include "smolmc_common.h"
+
+thread_local std::string smolmc_g_err;
+
+// ----------------------------------------------------------------------------
+// reference-layout evaluation kernels (parity API + initial trace)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < nw; ++i) s += sh[i];
+    return s;
+}
+
+// Ensemble.compute_feature_vector for one occupancy per block
+// (evaluator.pyx:121-209 x size; processor/ewald.py:128-145; ensemble.py:343-349)
+__global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const uint8_t *occ_all,
+                                                        double *out_all) {
+    __shared__ double sh[8];
+    const uint8_t *occ = occ_all + (size_t)blockIdx.x * T.Npad;
+    double *out = out_all + (size_t)blockIdx.x * T.F;
+    if (threadIdx.x == 0) out[0] = (T.corr_mode ? 1.0 : T.offset) * (double)T.P;
+    for (int n = 0; n < T.n_orb; ++n) {
+        const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1;
+        const int Nt = T.orb_tensor_len[n];
+        const int *st = T.tensor_indices + T.orb_stride_off[n];
+        const int *ind = T.full_idx + T.full_off[n];
+        const long long J = (T.full_off[n + 1] - T.full_off[n]) / I;
+        for (int k = 0; k < K; ++k) {
+            const double *t = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] + (size_t)k * Nt
+                                          : T.interaction_tensors + T.orb_itensor_off[n];
+            double p = 0;
+            for (long long j = threadIdx.x; j < J; j += blockDim.x) {
+                int index = 0;
+                for (int i = 0; i < I; ++i) index += st[i] * (int)occ[ind[j * I + i]];
+                p += t[index];
+            }
+            p = block_sum(p, sh);
+            if (threadIdx.x == 0) {
+                const int o = T.corr_mode ? T.orb_bit_id[n] + k : T.orb_id[n];
+                out[o] = p / (double)J * (double)T.P;
+            }
+        }
+    }
+    int f = T.Fce;
+    if (T.has_ewald) {
+        double s = 0;
+        for (int a = 0; a < T.N; ++a) {
+            const int ia = T.ew_inds[(size_t)a * T.ew_W + occ[a]];
+            if (ia == -1) continue;
+            const double *row = T.ew_M_rowmajor + (size_t)ia * T.ew_M;
+            for (int b = threadIdx.x; b < T.N; b += blockDim.x) {
+                const int ib = T.ew_inds[(size_t)b * T.ew_W + occ[b]];
+                if (ib != -1) s += row[ib];
+            }
+        }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) out[f] = s;
+        f++;
+    }
+    if (T.has_mu) {
+        double s = 0;
+        for (int a = threadIdx.x; a < T.N; a += blockDim.x) s += T.mu[(size_t)a * T.mu_W + occ[a]];
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) out[f] = s;
+    }
+}
+
+// Ensemble.compute_feature_vector_change for one step (<= 2 sequential flips) per
+// wave, reference table layout and arithmetic chain p / ratio / J, x size
+// (evaluator.pyx:244-262, :302-315; expansion.py:217-231).
+__global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const uint8_t *occ,
+                                                        const int *flips, double *out_all) {
+    const int lane = threadIdx.x;
+    const int *fl = flips + (size_t)blockIdx.x * 4;
+    double *out = out_all + (size_t)blockIdx.x * T.F;
+    for (int i = lane; i < T.F; i += 64) out[i] = 0.0;
+    __syncthreads();
+    const int nfl = fl[0] < 0 ? 0 : (fl[2] < 0 ? 1 : 2);
+    double dew = 0, dmu = 0;
+    for (int f = 0; f < nfl; ++f) {
+        const int s = fl[2 * f], newc = fl[2 * f + 1];
+        const int ps = f == 1 ? fl[0] : -1, pc = f == 1 ? fl[1] : 0;
+        for (long long rr = T.site_ptr[s]; rr < T.site_ptr[s + 1]; ++rr) {
+            const int n = T.loc_orbit[rr];
+            const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1, Nt = T.orb_tensor_len[n];
+            const int *st = T.tensor_indices + T.orb_stride_off[n];
+            const int *ind = T.loc_idx + T.loc_off[rr];
+            const int J = T.loc_nrows[rr];
+            for (int k = 0; k < K; ++k) {
+                const double *t = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] + (size_t)k * Nt
+                                              : T.interaction_tensors + T.orb_itensor_off[n];
+                double p = 0;
+                for (int j = lane; j < J; j += 64) {
+                    int ind_i = 0, ind_f = 0;
+                    for (int i = 0; i < I; ++i) {
+                        const int x = ind[j * I + i];
+                        int v = occ[x];
+                        if (x == ps) v = pc;
+                        const int vf = (x == s) ? newc : v;
+                        ind_i += st[i] * v;
+                        ind_f += st[i] * vf;
+                    }
+                    p += t[ind_f] - t[ind_i];
+                }
+                p = wave_sum(p);
+                if (lane == 0) {
+                    const int o = T.corr_mode ? T.orb_bit_id[n] + k : T.orb_id[n];
+                    out[o] += p / T.loc_ratio[rr] / (double)J;
+                }
+            }
+        }
+        if (T.has_ewald) {
+            // ewald.pyx:38-58
+            int oldc = occ[s];
+            if (s == ps) oldc = pc;
+            const int W = T.ew_W;
+            const int add = T.ew_inds[(size_t)s * W + newc], sub = T.ew_inds[(size_t)s * W + oldc];
+            double o = 0;
+            for (int k = lane; k < T.N; k += 64) {
+                int v = occ[k];
+                if (k == ps) v = pc;
+                const int vf = (k == s) ? newc : v;
+                const int i = T.ew_inds[(size_t)k * W + vf], j = T.ew_inds[(size_t)k * W + v];
+                if (i != -1 && add != -1)
+                    o += (i != add ? 2.0 : 1.0) * T.ew_Mt[(size_t)add * T.ew_M + i];
+                if (j != -1 && sub != -1)
+                    o -= (j != sub ? 2.0 : 1.0) * T.ew_Mt[(size_t)sub * T.ew_M + j];
+            }
+            dew += wave_sum(o);
+        }
+        if (T.has_mu)
+            dmu += T.mu[(size_t)s * T.mu_W + newc] - T.mu[(size_t)s * T.mu_W + occ[s]];
+    }
+    __syncthreads();
+    for (int i = lane; i < T.Fce; i += 64) out[i] *= (double)T.P;
+    if (lane == 0) {
+        int f = T.Fce;
+        if (T.has_ewald) out[f++] = dew;
+        if (T.has_mu) out[f++] = dmu;
+    }
+}
+
+__global__ void pack_occ_kernel(const int *occ32, uint8_t *occ8, int N, int Npad, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t rr = i / Npad;
+    const int s = (int)(i % Npad);
+    occ8[i] = s < N ? (uint8_t)occ32[rr * N + s] : 0;
+}
+__global__ void unpack_occ_kernel(const uint8_t *occ8, int *occ32, int N, int Npad, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t rr = i / N;
+    const int s = (int)(i % N);
+    occ32[i] = (int)occ8[rr * Npad + s];
+}
+__global__ void dot_features_kernel(const double *features, const double *natural, double *enthalpy,
+                                    int R, int F) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double s = 0;
+    for (int i = 0; i < F; ++i) s += natural[i] * features[(size_t)r * F + i];
+    enthalpy[r] = s;
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+static int num_ce_features(const smolmc_tables *t) {
+    return t->feature_mode == SMOLMC_FEATURES_CORRELATIONS ? t->num_corr : t->num_orbits;
+}
+
+// Build the MC-optimised tables (classes, slot descriptors, member index rows).
+static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
+    const int N = t->num_sites;
+    const bool corr = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+    // does any local row contain a repeated site (aliased tiny supercells)?
+    bool aliased = false;
+    int maxI = 1;
+    for (int s = 0; s < N && !aliased; ++s)
+        for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1] && !aliased; ++r) {
+            const int o = t->loc_orbit[r], I = t->orb_nsites[o];
+            const int32_t *rows = t->loc_idx + t->loc_off[r];
+            for (int j = 0; j < t->loc_nrows[r] && !aliased; ++j)
+                for (int a = 0; a < I && !aliased; ++a)
+                    for (int b = a + 1; b < I; ++b)
+                        if (rows[j * I + a] == rows[j * I + b]) aliased = true;
+        }
+    for (int o = 0; o < t->n_orb; ++o) maxI = std::max(maxI, (int)t->orb_nsites[o]);
+    if (maxI > SMOLMC_MAX_CLUSTER_SITES) return fail("cluster larger than SMOLMC_MAX_CLUSTER_SITES");
+    for (int o = 0; o < t->n_orb; ++o)
+        for (int i = 0; i < t->orb_nsites[o]; ++i)
+            if (t->tensor_indices[t->orb_stride_off[o] + i] > 65535)
+                return fail("tensor stride exceeds 16 bits");
+    h->generic = aliased;
+    const int need_mm = aliased ? maxI : std::max(1, maxI - 1);
+
+    // per-site slot lists: (orbit, self position p, row pointer, record r)
+    struct Slot {
+        int orbit, p, nmem;
+        int64_t rec;
+        const int32_t *row;
+    };
+    std::vector<std::vector<Slot>> slots(N);
+    std::vector<int> site_class(N, 255);
+    std::map<std::vector<long long>, int> class_of;
+    std::vector<int> class_rep; // representative site per class
+    for (int s = 0; s < N; ++s) {
+        if (t->site_ptr[s] == t->site_ptr[s + 1]) continue;
+        std::vector<Slot> &sl = slots[s];
+        std::vector<long long> sig;
+        for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1]; ++r) {
+            const int o = t->loc_orbit[r], I = t->orb_nsites[o], J = t->loc_nrows[r];
+            const int32_t *rows = t->loc_idx + t->loc_off[r];
+            std::vector<Slot> rec;
+            for (int j = 0; j < J; ++j) {
+                int p = 0;
+                if (!aliased)
+                    for (int a = 0; a < I; ++a)
+                        if (rows[j * I + a] == s) p = a;
+                rec.push_back(Slot{o, p, aliased ? I : I - 1, r, rows + (size_t)j * I});
+            }
+            std::stable_sort(rec.begin(), rec.end(), [](const Slot &a, const Slot &b) { return a.p < b.p; });
+            sig.push_back(o);
+            sig.push_back(J);
+            long long rb;
+            memcpy(&rb, &t->loc_ratio[r], 8);
+            sig.push_back(rb);
+            for (int a = 0; a < I; ++a) {
+                long long cnt = 0;
+                for (auto &q : rec) cnt += q.p == a;
+                sig.push_back(cnt);
+            }
+            sl.insert(sl.end(), rec.begin(), rec.end());
+        }
+        // most members first so that iterations are homogeneous
+        std::stable_sort(sl.begin(), sl.end(), [](const Slot &a, const Slot &b) { return a.nmem > b.nmem; });
+        auto itc = class_of.find(sig);
+        if (itc == class_of.end()) {
+            if (class_rep.size() >= 255) return fail("more than 255 site classes");
+            itc = class_of.emplace(sig, (int)class_rep.size()).first;
+            class_rep.push_back(s);
+        }
+        site_class[s] = itc->second;
+    }
+    const int nclasses = std::max<int>(1, (int)class_rep.size());
+    size_t Cmax = 1;
+    for (int s : class_rep) Cmax = std::max(Cmax, slots[s].size());
+    const int Cpad = (int)((Cmax + 63) / 64 * 64);
+    const int niter_max = Cpad / 64;
+    h->nslot = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : (niter_max <= 8 ? 8 : 16));
+    if (niter_max > 16) return fail("more than 1024 clusters per site are not supported yet");
+    if (aliased)
+        h->mm = need_mm <= 3 ? 3 : 6;
+    else
+        h->mm = need_mm <= 2 ? 2 : (need_mm <= 3 ? 3 : 5);
+    const int MM = h->mm;
+    h->idx16 = (!aliased) && N <= 65535;
+
+    // decision tensors per class, feature tensors shared
+    std::vector<double> ft;
+    std::vector<int> foff(t->n_orb);
+    for (int o = 0; o < t->n_orb; ++o) {
+        foff[o] = (int)ft.size();
+        const int Nt = t->orb_tensor_len[o];
+        if (corr) {
+            const double *ct = t->corr_tensors + t->orb_ctensor_off[o];
+            ft.insert(ft.end(), ct, ct + (size_t)t->orb_nfunc[o] * Nt);
+        } else {
+            const double *it = t->interaction_tensors + t->orb_itensor_off[o];
+            ft.insert(ft.end(), it, it + Nt);
+        }
+    }
+    std::vector<double> xt;
+    std::vector<uint4> descA((size_t)nclasses * Cpad, make_uint4(0, 0, 0, 0));
+    std::vector<uint4> descB((size_t)nclasses * Cpad, make_uint4(0, 0, 0, 0));
+    std::vector<double> slot_fs((size_t)nclasses * Cpad, 0.0);
+    std::vector<int> cls_niter(nclasses, 0);
+    xt.push_back(0.0); // padded slots read xt[0] - xt[0]
+    for (int c = 0; c < (int)class_rep.size(); ++c) {
+        const int s = class_rep[c];
+        const std::vector<Slot> &sl = slots[s];
+        cls_niter[c] = (int)((sl.size() + 63) / 64);
+        std::map<int64_t, int> xoff_of_rec;
+        for (size_t q = 0; q < sl.size(); ++q) {
+            const Slot &k = sl[q];
+            const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
+            const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
+            const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
+            if (!xoff_of_rec.count(k.rec)) {
+                xoff_of_rec[k.rec] = (int)xt.size();
+                for (int i = 0; i < Nt; ++i) {
+                    double v;
+                    if (corr) {
+                        // energy tensor: sum_k coef[bit_id+k] * ct[k][i], times scale
+                        v = 0;
+                        const double *ct = t->corr_tensors + t->orb_ctensor_off[o];
+                        for (int kk = 0; kk < t->orb_nfunc[o]; ++kk)
+                            v += t->ce_coefs[t->orb_bit_id[o] + kk] * ct[(size_t)kk * Nt + i];
+                        v *= scale;
+                    } else {
+                        v = t->ce_coefs[t->orb_id[o]] * scale *
+                            t->interaction_tensors[t->orb_itensor_off[o] + i];
+                    }
+                    xt.push_back(v);
+                }
+            }
+            uint16_t sv[6] = {0, 0, 0, 0, 0, 0};
+            if (aliased) {
+                for (int a = 0; a < I; ++a) sv[a] = (uint16_t)st[a];
+            } else {
+                sv[0] = (uint16_t)st[k.p];
+                int m = 1;
+                for (int a = 0; a < I; ++a)
+                    if (a != k.p) sv[m++] = (uint16_t)st[a];
+            }
+            uint4 A;
+            A.x = (uint32_t)xoff_of_rec[k.rec];
+            A.y = sv[0] | ((uint32_t)sv[1] << 16);
+            A.z = sv[2] | ((uint32_t)sv[3] << 16);
+            A.w = sv[4] | ((uint32_t)sv[5] << 16);
+            descA[(size_t)c * Cpad + q] = A;
+            uint4 B;
+            B.x = (uint32_t)foff[o];
+            B.y = (uint32_t)Nt;
+            const uint32_t feat = corr ? (uint32_t)t->orb_bit_id[o] : (uint32_t)t->orb_id[o];
+            const uint32_t K = corr ? (uint32_t)t->orb_nfunc[o] : 1u;
+            B.z = feat | (K << 16);
+            B.w = 0;
+            descB[(size_t)c * Cpad + q] = B;
+            slot_fs[(size_t)c * Cpad + q] = scale;
+        }
+    }
+    if (xt.size() > 0xffffffffull) return fail("decision tensors too large");
+
+    // member index rows [site][m][Cpad]; padded entries point at the site itself
+    const size_t idx_n = (size_t)N * MM * Cpad;
+    std::vector<int32_t> idx32(idx_n);
+    for (int s = 0; s < N; ++s) {
+        for (int m = 0; m < MM; ++m)
+            for (int c = 0; c < Cpad; ++c) idx32[((size_t)s * MM + m) * Cpad + c] = s;
+        const std::vector<Slot> &sl = slots[s];
+        for (size_t q = 0; q < sl.size(); ++q) {
+            const Slot &k = sl[q];
+            const int I = t->orb_nsites[k.orbit];
+            int m = 0;
+            for (int a = 0; a < I; ++a) {
+                if (!aliased && a == k.p) continue;
+                idx32[((size_t)s * MM + m) * Cpad + q] = k.row[a];
+                m++;
+            }
+        }
+    }
+    KParams &kp = h->kp;
+    if (h->idx16) {
+        std::vector<uint16_t> idx16(idx_n);
+        for (size_t i = 0; i < idx_n; ++i) idx16[i] = (uint16_t)idx32[i];
+        const uint16_t *d;
+        TRY(dev_upload(h, idx16.data(), idx_n, &d));
+        kp.idx = d;
+    } else {
+        const int32_t *d;
+        TRY(dev_upload(h, idx32.data(), idx_n, &d));
+        kp.idx = d;
+    }
+    std::vector<uint8_t> sc8(N);
+    for (int s = 0; s < N; ++s) sc8[s] = (uint8_t)site_class[s];
+    TRY(dev_upload(h, sc8.data(), (size_t)N, &kp.site_class));
+    TRY(dev_upload(h, descA.data(), descA.size(), &kp.descA));
+    TRY(dev_upload(h, descB.data(), descB.size(), &kp.descB));
+    TRY(dev_upload(h, slot_fs.data(), slot_fs.size(), &kp.slot_fs));
+    TRY(dev_upload(h, cls_niter.data(), cls_niter.size(), &kp.cls_niter));
+    TRY(dev_upload(h, xt.data(), xt.size(), &kp.xt));
+    TRY(dev_upload(h, ft.data(), ft.size(), &kp.ft));
+    kp.xt_len = (int)xt.size();
+    kp.ft_len = (int)ft.size();
+    kp.nclasses = nclasses;
+    kp.Cpad = Cpad;
+    kp.Mmax = MM;
+
+    // ---- lean tables (see mc_lean_kernel) ------------------------------------------
+    memset(&h->lp, 0, sizeof(LeanParams));
+    if (class_rep.size() == 1 && !aliased && !corr && N <= 65535 && niter_max <= 4 && need_mm <= 3 &&
+        num_ce_features(t) <= 64) {
+        const int NSL = niter_max <= 2 ? 2 : 4;
+        const int MML = need_mm <= 2 ? 2 : 3;
+        const int ROW = NSL * MML;
+        std::vector<uint16_t> lidx((size_t)N * 64 * ROW);
+        for (int s = 0; s < N; ++s) {
+            for (int q = 0; q < 64 * ROW; ++q) lidx[(size_t)s * 64 * ROW + q] = (uint16_t)s;
+            const std::vector<Slot> &sl = slots[s];
+            for (size_t q = 0; q < sl.size(); ++q) {
+                const Slot &k = sl[q];
+                const int I = t->orb_nsites[k.orbit];
+                const int it = (int)(q / 64), ln = (int)(q % 64);
+                int m = 0;
+                for (int a = 0; a < I; ++a) {
+                    if (a == k.p) continue;
+                    lidx[(((size_t)s * 64 + ln) * NSL + it) * MML + m] = (uint16_t)k.row[a];
+                    m++;
+                }
+            }
+        }
+        // ---- LDS bank swizzle: pick the address permutation s ^ (((s >> a) & m) << b) that
+        // minimises the modelled bank-conflict cycles of the occupancy gathers (each
+        // ds_read_u8 is served in two 32-lane groups; a group costs the max number of
+        // distinct dwords on one of the 32 banks).  See tools/lds_conflict_model.py.
+        int Nlds = 16;
+        while (Nlds < h->Npad) Nlds <<= 1;
+        int best_a = 0, best_m = 0, best_b = 0;
+        {
+            auto model_cost = [&](int a, int m, int b) {
+                double tot = 0;
+                const int nsamp = std::min(N, 48);
+                for (int k = 0; k < nsamp; ++k) {
+                    const int s = (int)(((long long)k * 2654435761ll) % N);
+                    if (slots[s].empty()) continue;
+                    for (int q = 0; q < ROW; ++q)
+                        for (int g = 0; g < 2; ++g) {
+                            int cnt[32] = {0};
+                            int seen[32];
+                            int nseen = 0;
+                            for (int ln = 32 * g; ln < 32 * g + 32; ++ln) {
+                                const int x = lidx[((size_t)s * 64 + ln) * ROW + q];
+                                const int dw = (x ^ (((x >> a) & m) << b)) >> 2;
+                                bool dup = false;
+                                for (int z = 0; z < nseen; ++z) dup |= seen[z] == dw;
+                                if (!dup) { seen[nseen++] = dw; cnt[dw & 31]++; }
+                            }
+                            int mx = 0;
+                            for (int z = 0; z < 32; ++z) mx = std::max(mx, cnt[z]);
+                            tot += mx;
+                        }
+                }
+                return tot;
+            };
+            double best = model_cost(0, 0, 0);
+            const int amax = getenv("SMOLMC_NO_SWIZZLE") ? 0 : 12; // A/B switch for profiling
+            for (int a = 3; a <= amax; ++a)
+                for (int b = 2; b <= 5; ++b)
+                    for (int m : {3, 7, 15, 31}) {
+                        // bijection on [0, Nlds): source bits [a, a+k) above the destination
+                        // bits [b, b+k) and inside the (power-of-two) array
+                        const int k = m == 3 ? 2 : (m == 7 ? 3 : (m == 15 ? 4 : 5));
+                        if (a < b + k || (1 << (a + k)) > Nlds) continue;
+                        const double c = model_cost(a, m, b);
+                        if (c < best * 0.97) { best = c; best_a = a; best_m = m; best_b = b; }
+                    }
+        }
+        if (best_m == 0) Nlds = h->Npad; // identity: no power-of-two padding needed
+        for (size_t i = 0; i < lidx.size(); ++i) {
+            const int x = lidx[i];
+            lidx[i] = (uint16_t)(x ^ (((x >> best_a) & best_m) << best_b));
+        }
+        h->lp.swz_a = best_a; h->lp.swz_m = best_m; h->lp.swz_b = best_b; h->lp.Nlds = Nlds;
+
+        // delta tables, one per (orbit, self position), all padded to [S*S][NTP]
+        int NTP = 1, SMAX = t->max_species;
+        for (int o = 0; o < t->n_orb; ++o) NTP = std::max(NTP, (int)t->orb_tensor_len[o]);
+        // one table = S*S*NTP doubles; the stride between tables is padded so that it is
+        // not a multiple of the 64-dword LDS bank period (lanes of one wave read the same
+        // (pair, base) entry of DIFFERENT tables: an unpadded power-of-two stride makes
+        // them all collide on one bank pair)
+        size_t tlen = (size_t)SMAX * SMAX * NTP;
+        if ((tlen & 1) == 0) tlen += 1;
+        std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
+        std::vector<LeanSlot> ls((size_t)NSL * 64);
+        memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
+        std::map<std::pair<int, int>, uint32_t> doff_of;
+        const std::vector<Slot> &sl = slots[class_rep[0]];
+        bool ok = true;
+        for (size_t q = 0; q < sl.size() && ok; ++q) {
+            const Slot &k = sl[q];
+            const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
+            const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
+            const double *T = t->interaction_tensors + t->orb_itensor_off[o];
+            const int ss = st[k.p];
+            const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
+            const auto key = std::make_pair(o, k.p);
+            if (!doff_of.count(key)) {
+                doff_of[key] = (uint32_t)dt.size();
+                dt.resize(dt.size() + tlen, 0.0);
+                double *D = dt.data() + doff_of[key];
+                for (int oldc = 0; oldc < Sself; ++oldc)
+                    for (int newc = 0; newc < Sself; ++newc)
+                        for (int b = 0; b < Nt; ++b) {
+                            const int fi = b + ss * newc, ii = b + ss * oldc;
+                            if (fi < Nt && ii < Nt) D[((size_t)oldc * SMAX + newc) * NTP + b] = T[fi] - T[ii];
+                        }
+            }
+            const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
+            LeanSlot &L = ls[(q / 64) * 64 + (q % 64)];
+            L.doff8 = doff_of[key] * 8u;
+            int m = 0;
+            for (int a = 0; a < I; ++a)
+                if (a != k.p) L.stride8[m++] = (uint32_t)st[a] * 8u;
+            L.feat = (uint32_t)t->orb_id[o];
+            L.live = 1;
+            L.w = t->ce_coefs[t->orb_id[o]] * scale;
+            L.fs = scale;
+            if (dt.size() > 5500) ok = false; // keep the LDS tables within budget
+        }
+        h->lp.nt8 = (uint32_t)NTP * 8u;
+        h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
+        if (ok) {
+            TRY(dev_upload(h, lidx.data(), lidx.size(), &h->lp.idx));
+            TRY(dev_upload(h, dt.data(), dt.size(), &h->lp.dt));
+            TRY(dev_upload(h, ls.data(), ls.size(), &h->lp.slots));
+            h->lp.dt_len = (int)dt.size();
+            h->lean_tables = true;
+            h->lean_nslot = NSL;
+            h->lean_mm = MML;
+        }
+    }
+    return 0;
+}
+
+static int build_ref_tables(smolmc_handle *h, const smolmc_tables *t) {
+    RefTables &rt = h->rt;
+    memset(&rt, 0, sizeof(rt));
+    const int n = t->n_orb;
+    rt.N = t->num_sites;
+    rt.Npad = h->Npad;
+    rt.P = t->size;
+    rt.num_orbits = t->num_orbits;
+    rt.num_corr = t->num_corr;
+    rt.n_orb = n;
+    rt.Fce = h->Fce;
+    rt.F = h->F;
+    rt.corr_mode = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+    rt.offset = t->offset;
+    int nstr = 0;
+    long long nct = 0, nit = 0;
+    for (int o = 0; o < n; ++o) {
+        nstr += t->orb_nsites[o];
+        nct += (long long)t->orb_nfunc[o] * t->orb_tensor_len[o];
+        nit += t->orb_tensor_len[o];
+    }
+    const int64_t nloc = t->site_ptr[t->num_sites];
+    int64_t nlocidx = 0;
+    for (int64_t r = 0; r < nloc; ++r)
+        nlocidx += (int64_t)t->loc_nrows[r] * t->orb_nsites[t->loc_orbit[r]];
+    TRY(dev_upload(h, t->orb_id, n, &rt.orb_id));
+    TRY(dev_upload(h, t->orb_bit_id, n, &rt.orb_bit_id));
+    TRY(dev_upload(h, t->orb_nsites, n, &rt.orb_nsites));
+    TRY(dev_upload(h, t->orb_nfunc, n, &rt.orb_nfunc));
+    TRY(dev_upload(h, t->orb_tensor_len, n, &rt.orb_tensor_len));
+    TRY(dev_upload(h, t->orb_stride_off, n, &rt.orb_stride_off));
+    TRY(dev_upload(h, t->tensor_indices, nstr, &rt.tensor_indices));
+    TRY(dev_upload(h, (const long long *)t->orb_ctensor_off, n, &rt.orb_ctensor_off));
+    TRY(dev_upload(h, (const long long *)t->orb_itensor_off, n, &rt.orb_itensor_off));
+    TRY(dev_upload(h, t->corr_tensors, nct, &rt.corr_tensors));
+    TRY(dev_upload(h, t->interaction_tensors, nit, &rt.interaction_tensors));
+    TRY(dev_upload(h, (const long long *)t->full_off, n + 1, &rt.full_off));
+    TRY(dev_upload(h, t->full_idx, t->full_off[n], &rt.full_idx));
+    TRY(dev_upload(h, (const long long *)t->site_ptr, t->num_sites + 1, &rt.site_ptr));
+    TRY(dev_upload(h, t->loc_orbit, nloc, &rt.loc_orbit));
+    TRY(dev_upload(h, t->loc_ratio, nloc, &rt.loc_ratio));
+    TRY(dev_upload(h, t->loc_nrows, nloc, &rt.loc_nrows));
+    TRY(dev_upload(h, (const long long *)t->loc_off, nloc, &rt.loc_off));
+    TRY(dev_upload(h, t->loc_idx, nlocidx, &rt.loc_idx));
+    rt.has_ewald = t->has_ewald;
+    rt.has_mu = t->has_mu;
+    if (t->has_ewald) {
+        const size_t M = t->ewald_dim;
+        rt.ew_W = t->ewald_width;
+        rt.ew_M = (int)M;
+        TRY(dev_upload(h, t->ewald_inds, (size_t)t->num_sites * t->ewald_width, &rt.ew_inds));
+        TRY(dev_upload(h, t->ewald_matrix, M * M, &rt.ew_M_rowmajor));
+        std::vector<double> mt(M * M);
+        const size_t B = 64;
+        for (size_t i0 = 0; i0 < M; i0 += B)
+            for (size_t j0 = 0; j0 < M; j0 += B)
+                for (size_t i = i0; i < std::min(M, i0 + B); ++i)
+                    for (size_t j = j0; j < std::min(M, j0 + B); ++j)
+                        mt[j * M + i] = t->ewald_matrix[i * M + j];
+        TRY(dev_upload(h, mt.data(), M * M, &rt.ew_Mt));
+    }
+    if (t->has_mu) {
+        rt.mu_W = t->mu_width;
+        TRY(dev_upload(h, t->mu_table, (size_t)t->num_sites * t->mu_width, &rt.mu));
+    }
+    return 0;
+}
+
+// Check M[a][b] == q_a q_b G[site_a][site_b] (a, b on different sites) and build G.
+static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
+    const int N = t->num_sites, W = t->ewald_width;
+    const size_t M = (size_t)t->ewald_dim;
+    const double *Mx = t->ewald_matrix, *q = t->ewald_charges;
+    std::vector<double> G((size_t)N * N, 0.0), qs((size_t)N * W, 0.0), dg((size_t)N * W, 0.0);
+    double mmax = 0;
+    for (size_t i = 0; i < M * M; ++i) mmax = std::max(mmax, fabs(Mx[i]));
+    const double tol = 1e-12 * std::max(mmax, 1e-300);
+    for (int s = 0; s < N; ++s)
+        for (int c = 0; c < W; ++c) {
+            const int a = t->ewald_inds[(size_t)s * W + c];
+            if (a < 0) continue;
+            qs[(size_t)s * W + c] = q[a];
+            dg[(size_t)s * W + c] = Mx[(size_t)a * M + a];
+        }
+    bool ok = true;
+    for (int s = 0; s < N && ok; ++s)
+        for (int u = 0; u < N && ok; ++u) {
+            if (s == u) continue;
+            double g = 0;
+            bool have = false;
+            for (int c = 0; c < W && !have; ++c)
+                for (int d = 0; d < W && !have; ++d) {
+                    const int a = t->ewald_inds[(size_t)s * W + c], b = t->ewald_inds[(size_t)u * W + d];
+                    if (a < 0 || b < 0 || q[a] == 0.0 || q[b] == 0.0) continue;
+                    g = Mx[(size_t)b * M + a] / (q[a] * q[b]); // the entry ewald.pyx reads: M[i_k, add]
+                    have = true;
+                }
+            for (int c = 0; c < W && ok; ++c)
+                for (int d = 0; d < W && ok; ++d) {
+                    const int a = t->ewald_inds[(size_t)s * W + c], b = t->ewald_inds[(size_t)u * W + d];
+                    if (a < 0 || b < 0) continue;
+                    if (fabs(Mx[(size_t)b * M + a] - q[a] * q[b] * g) > tol) ok = false;
+                }
+            G[(size_t)s * N + u] = g; // row s: kernel between the flipped site s and site u
+        }
+    if (!ok) return 0; // not of product form: keep the dense rows
+    // split sites into changeable ones and single-species ("frozen") ones
+    std::vector<int> act;
+    std::vector<char> frozen(N, 0);
+    for (int s = 0; s < N; ++s) {
+        int nvalid = 0, ncodes = 0;
+        for (int c = 0; c < W; ++c) nvalid += t->ewald_inds[(size_t)s * W + c] >= 0;
+        (void)ncodes;
+        // a site is frozen when it is in no active sublattice (its code never changes) and
+        // carries exactly one Ewald species (code 0)
+        bool in_active = false;
+        for (int64_t i = 0; i < t->sub_site_ptr[t->n_sublattices] && !in_active; ++i)
+            in_active = t->sub_active_sites[i] == s;
+        frozen[s] = (!in_active && nvalid == 1 && t->ewald_inds[(size_t)s * W] >= 0) ? 1 : 0;
+        if (!frozen[s]) act.push_back(s);
+    }
+    const size_t na = act.size();
+    std::vector<double> Gact((size_t)N * std::max<size_t>(na, 1), 0.0), fz(N, 0.0);
+    for (int s = 0; s < N; ++s) {
+        for (size_t j = 0; j < na; ++j) Gact[(size_t)s * na + j] = G[(size_t)s * N + act[j]];
+        double c = 0;
+        for (int u = 0; u < N; ++u)
+            if (frozen[u] && u != s) c += qs[(size_t)u * W] * G[(size_t)s * N + u];
+        fz[s] = c;
+    }
+    TRY(dev_upload(h, act.data(), act.size(), &h->kp.ew_act));
+    TRY(dev_upload(h, fz.data(), fz.size(), &h->kp.ew_frozen));
+    h->kp.ew_nact = (int)na;
+    h->kp.ew_act_base = na ? act[0] : -1;
+    for (size_t j = 0; j < na; ++j)
+        if (act[j] != act[0] + (int)j) h->kp.ew_act_base = -1;
+    G.swap(Gact);
+    TRY(dev_upload(h, G.data(), G.size(), &h->kp.ew_G));
+    TRY(dev_upload(h, qs.data(), qs.size(), &h->kp.ew_qs));
+    TRY(dev_upload(h, dg.data(), dg.size(), &h->kp.ew_dg));
+    h->kp.ew_compact = 1;
+    return 0;
+}
+
+extern "C" int smolmc_abi_version(void) { return SMOLMC_ABI_VERSION; }
+extern "C" const char *smolmc_last_error(void) { return smolmc_g_err.c_str(); }
+
+extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, smolmc_handle **out) {
+    if (!t || !cfg || !out) return fail("null argument");
+    if (cfg->n_replicas <= 0) return fail("n_replicas must be positive");
+    if (t->max_species > 255) return fail("more than 255 species codes per site");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: the smol_amd engine requires an AMD GPU (there is no "
+                    "CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("invalid device ordinal");
+    smolmc_handle *h = new smolmc_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    auto bail = [&](int rc) {
+        smolmc_destroy(h);
+        return rc;
+    };
+    if (hipSetDevice(h->device) != hipSuccess) return bail(fail("hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail("hipStreamCreate failed"));
+    h->own_stream = true;
+    hipEventCreate(&h->ev0);
+    hipEventCreate(&h->ev1);
+    h->R = cfg->n_replicas;
+    h->N = t->num_sites;
+    h->Npad = (t->num_sites + 15) / 16 * 16;
+    h->Fce = num_ce_features(t);
+    h->F = h->Fce + (t->has_ewald ? 1 : 0) + (t->has_mu ? 1 : 0);
+    h->natural.assign(t->ce_coefs, t->ce_coefs + h->Fce);
+    if (t->has_ewald) h->natural.push_back(t->ewald_coef);
+    if (t->has_mu) h->natural.push_back(-1.0);
+    const bool wl = cfg->kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    if (wl) {
+        if (cfg->wl_min_enthalpy > cfg->wl_max_enthalpy)
+            return bail(fail("min_enthalpy can not be larger than max_enthalpy.")); // wanglandau.py:82
+        if ((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size <= 1)
+            return bail(fail("The values provided for min and max enthalpy and bin sizer result in a "
+                             "single bin!"));
+        if (cfg->wl_mod_factor <= 0) return bail(fail("mod_factor must be greater than 0."));
+        h->L = (int)ceil((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size);
+    }
+    memset(&h->kp, 0, sizeof(KParams));
+    memset(&h->smp, 0, sizeof(SampleBufs));
+    KParams &kp = h->kp;
+    if (int rc = build_mc_tables(h, t)) return bail(rc);
+    if (int rc = build_ref_tables(h, t)) return bail(rc);
+    kp.N = h->N;
+    kp.Npad = h->Npad;
+    kp.Fce = h->Fce;
+    kp.F = h->F;
+    kp.step_type = cfg->step_type;
+    kp.corr_mode = h->rt.corr_mode;
+    kp.has_ewald = t->has_ewald;
+    kp.has_mu = t->has_mu;
+    kp.ew_W = h->rt.ew_W;
+    kp.ew_M = h->rt.ew_M;
+    kp.mu_W = h->rt.mu_W;
+    kp.ew_inds = h->rt.ew_inds;
+    kp.ew_Mt = h->rt.ew_Mt;
+    kp.ew_coef = t->ewald_coef;
+    kp.mu = h->rt.mu;
+    if (t->has_ewald && t->ewald_charges && getenv("SMOLMC_DENSE_EWALD") == nullptr)
+        if (int rc = build_compact_ewald(h, t)) return bail(rc);
+    // sublattices
+    {
+        const int ns = t->n_sublattices;
+        if (ns <= 0) return bail(fail("no active sublattice"));
+        std::vector<int> ptr(ns + 1), cptr(ns + 1), base(ns);
+        std::vector<double> cum(ns);
+        double c = 0;
+        for (int s = 0; s <= ns; ++s) {
+            ptr[s] = (int)t->sub_site_ptr[s];
+            cptr[s] = (int)t->sub_code_ptr[s];
+        }
+        for (int s = 0; s < ns; ++s) {
+            c += t->sub_probs[s];
+            cum[s] = c;
+            const int a = ptr[s], b = ptr[s + 1];
+            if (b <= a) return bail(fail("empty active sublattice"));
+            bool contig = true;
+            for (int i = a + 1; i < b; ++i)
+                if (t->sub_active_sites[i] != t->sub_active_sites[a] + (i - a)) contig = false;
+            base[s] = contig ? t->sub_active_sites[a] : -1;
+            for (int i = a; i < b; ++i)
+                if (t->sub_active_sites[i] < 0 || t->sub_active_sites[i] >= t->num_sites)
+                    return bail(fail("sublattice site index out of range"));
+        }
+        kp.nsub = ns;
+        if (dev_upload(h, ptr.data(), ptr.size(), &kp.sub_ptr) ||
+            dev_upload(h, t->sub_active_sites, (size_t)ptr[ns], &kp.sub_sites) ||
+            dev_upload(h, base.data(), base.size(), &kp.sub_base) ||
+            dev_upload(h, cptr.data(), cptr.size(), &kp.sub_code_ptr) ||
+            dev_upload(h, t->sub_codes, (size_t)cptr[ns], &kp.sub_codes) ||
+            dev_upload(h, cum.data(), cum.size(), &kp.sub_cum))
+            return bail(1);
+    }
+    // walker state
+    const size_t R = h->R;
+    kp.R = h->R;
+    double *dbeta = nullptr;
+    uint64_t *dseeds = nullptr;
+    if (dev_alloc(h, R * h->Npad, &kp.occ) || dev_alloc(h, R, &kp.enthalpy) ||
+        dev_alloc(h, R * h->F, &kp.features) || dev_alloc(h, R, &dbeta) || dev_alloc(h, R, &dseeds) ||
+        dev_alloc(h, R, &kp.nsteps) || dev_alloc(h, R, &kp.nacc) || dev_alloc(h, R, &kp.last_acc))
+        return bail(1);
+    kp.beta = dbeta;
+    h->d_beta = dbeta;
+    kp.seeds = dseeds;
+    if (dev_upload(h, h->natural.data(), h->natural.size(), (const double **)&h->d_natural))
+        return bail(1);
+    if (wl) {
+        kp.L = h->L;
+        kp.wl_min = cfg->wl_min_enthalpy;
+        kp.wl_max = cfg->wl_max_enthalpy;
+        kp.wl_bin = cfg->wl_bin_size;
+        kp.wl_flat = cfg->wl_flatness;
+        kp.wl_div = cfg->wl_mod_divisor;
+        kp.wl_check = cfg->wl_check_period;
+        kp.wl_update = cfg->wl_update_period;
+        if (kp.wl_check <= 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
+        if (h->F > 64) return bail(fail("Wang-Landau supports at most 64 features"));
+        if (dev_alloc(h, R * h->L, &kp.wl_entropy) || dev_alloc(h, R * h->L, &kp.wl_hist) ||
+            dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F, &kp.wl_meanf) ||
+            dev_alloc(h, R, &kp.wl_m) || dev_alloc(h, R, &kp.wl_counter))
+            return bail(1);
+        std::vector<double> m0(R, cfg->wl_mod_factor);
+        if (hipMemcpy(kp.wl_m, m0.data(), R * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail("hipMemcpy failed"));
+    }
+    // LDS layout
+    size_t tb = (size_t)kp.nclasses * kp.Cpad * (16 + 16 + 8) + (size_t)(kp.xt_len + kp.ft_len) * 8 +
+                (size_t)((kp.nclasses + 3) & ~3) * 4 + (kp.nclasses > 1 ? (size_t)h->N : 0);
+    tb = (tb + 15) / 16 * 16;
+    size_t pw = (size_t)h->Npad;
+    if (wl)
+        pw += (size_t)h->L * 16 + (size_t)h->F * 8;
+    else
+        pw += (size_t)h->Fce * 64 * 8;
+    pw = (pw + 15) / 16 * 16;
+    kp.lds_tables = (int)tb;
+    kp.lds_per_wave = (int)pw;
+    h->waves_per_block = 4;
+    while (h->waves_per_block > 1 && tb + pw * h->waves_per_block > 160 * 1024) h->waves_per_block /= 2;
+    h->lds_bytes = tb + pw * h->waves_per_block;
+    if (h->lds_bytes > 160 * 1024)
+        return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
+    // lean-kernel eligibility (everything else runs mc_kernel)
+    {
+        bool lean = h->lean_tables && h->F <= 64 && (!wl || (!t->has_ewald && !t->has_mu)) &&
+                    (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
+                    getenv("SMOLMC_FORCE_GENERAL") == nullptr;
+        int sbase = -1, nact = 0, nc = 0;
+        std::vector<double> mu_row;
+        if (lean) {
+            nact = (int)(t->sub_site_ptr[1] - t->sub_site_ptr[0]);
+            nc = (int)(t->sub_code_ptr[1] - t->sub_code_ptr[0]);
+            sbase = t->sub_active_sites[0];
+            for (int i = 0; i < nact; ++i)
+                if (t->sub_active_sites[i] != sbase + i) lean = false;
+            for (int c = 0; c < nc; ++c)
+                if (t->sub_codes[c] != c) lean = false;
+            if (nc < 2 || nc > 8) lean = false;
+        }
+        if (lean && t->has_mu) {
+            if (t->mu_width < nc) lean = false;
+            for (int c = 0; lean && c < nc; ++c) mu_row.push_back(t->mu_table[(size_t)sbase * t->mu_width + c]);
+            for (int i = 0; lean && i < nact; ++i)
+                for (int c = 0; c < nc; ++c)
+                    if (t->mu_table[(size_t)(sbase + i) * t->mu_width + c] != mu_row[c]) lean = false;
+        }
+        if (lean) {
+            LeanParams &lp = h->lp;
+            if (t->has_mu && dev_upload(h, mu_row.data(), mu_row.size(), &lp.mu_row)) return bail(1);
+            lp.occ = kp.occ;
+            lp.enthalpy = kp.enthalpy;
+            lp.features = kp.features;
+            lp.beta = kp.beta;
+            lp.seeds = kp.seeds;
+            lp.nsteps = kp.nsteps;
+            lp.nacc = kp.nacc;
+            lp.last_acc = kp.last_acc;
+            lp.R = h->R;
+            lp.N = h->N;
+            lp.Npad = h->Npad;
+            lp.F = h->F;
+            lp.Fce = h->Fce;
+            lp.sbase = sbase;
+            lp.nact = nact;
+            lp.ncodes = nc;
+            if (t->has_ewald) {
+                lp.ew_W = kp.ew_W;
+                lp.ew_nact = kp.ew_nact;
+                lp.ew_act_base = kp.ew_act_base;
+                lp.ew_act = kp.ew_act;
+                lp.ew_G = kp.ew_G;
+                lp.ew_qs = kp.ew_qs;
+                lp.ew_dg = kp.ew_dg;
+                lp.ew_frozen = kp.ew_frozen;
+                lp.ew_coef = kp.ew_coef;
+            }
+            if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
+                if (dev_upload(h, t->flip_table, (size_t)t->n_flip_vectors * nc, &lp.tf_table) ||
+                    dev_upload(h, t->flip_weights, (size_t)2 * t->n_flip_vectors, &lp.tf_w))
+                    return bail(1);
+                lp.tf_n = t->n_flip_vectors;
+                lp.tf_sw = t->swap_weight;
+            }
+            if (wl) {
+                lp.wl.L = h->L;
+                lp.wl.vmin = kp.wl_min; lp.wl.vmax = kp.wl_max; lp.wl.bin = kp.wl_bin;
+                lp.wl.flat = kp.wl_flat; lp.wl.div = kp.wl_div;
+                lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
+                lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
+                lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
+            }
+            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 +
+                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
+            if (h->lean_lds > 150 * 1024) lean = false;
+        }
+        h->lean = lean;
+        if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
+            if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
+                return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
+                                 "smol/moca/composition/space.py:404-429)"));
+            if (!lean || wl)
+                return bail(fail("TableFlip is implemented for single-class, single-sublattice "
+                                 "Metropolis models (the lean path) only"));
+            if (!(t->swap_weight >= 0.0 && t->swap_weight < 1.0))
+                return bail(fail("swap_weight must be in [0, 1)"));
+        }
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int smolmc_destroy(smolmc_handle *h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->d_eval_occ) hipFree(h->d_eval_occ);
+    free_samples(h);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int smolmc_num_features(const smolmc_handle *h) { return h ? h->F : -1; }
+extern "C" int smolmc_wl_num_levels(const smolmc_handle *h) { return h ? h->L : -1; }
+extern "C" int smolmc_natural_parameters(const smolmc_handle *h, double *out) {
+    if (!h || !out) return fail("null argument");
+    memcpy(out, h->natural.data(), h->natural.size() * 8);
+    return 0;
+}
+
+extern "C" int smolmc_set_stream(smolmc_handle *h, void *stream) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return 0;
+}
+
+static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, double *d_out) {
+    hipLaunchKernelGGL(eval_full_kernel, dim3(nocc), dim3(256), 0, h->stream, h->rt, d_occ8, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int upload_occ(smolmc_handle *h, const int32_t *occ, size_t nocc, uint8_t *d_occ8) {
+    const size_t n32 = nocc * h->N;
+    for (size_t i = 0; i < n32; ++i)
+        if (occ[i] < 0 || occ[i] > 255) return fail("occupancy code out of range [0, 255]");
+    int *d32 = nullptr;
+    HIPCHK(hipMalloc((void **)&d32, std::max<size_t>(n32 * 4, 16)));
+    hipError_t e = hipMemcpyAsync(d32, occ, n32 * 4, hipMemcpyHostToDevice, h->stream);
+    const size_t total = nocc * h->Npad;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           d32, d_occ8, h->N, h->Npad, total);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d32);
+    if (e != hipSuccess) return fail(std::string("occupancy upload: ") + hipGetErrorString(e));
+    return 0;
+}
+
+static void set_betas(smolmc_handle *h, const double *temperature, std::vector<double> &beta) {
+    beta.resize(h->R);
+    for (int r = 0; r < h->R; ++r) {
+        const double T = temperature ? temperature[r] : 0.0;
+        beta[r] = 1.0 / (SMOLMC_KB * T); // ThermalKernelMixin (kernel/base.py:398)
+    }
+}
+
+extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint64_t *seeds,
+                                const double *temperature, int reset_aux) {
+    if (!h || !occ) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    KParams &kp = h->kp;
+    const size_t R = h->R;
+    TRY(upload_occ(h, occ, R, kp.occ));
+    std::vector<double> beta;
+    set_betas(h, temperature, beta);
+    HIPCHK(hipMemcpy(h->d_beta, beta.data(), R * 8, hipMemcpyHostToDevice));
+    if (reset_aux) {
+        std::vector<uint64_t> sd(R);
+        for (size_t r = 0; r < R; ++r) sd[r] = seeds ? seeds[r] : (uint64_t)r;
+        HIPCHK(hipMemcpy((void *)kp.seeds, sd.data(), R * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(kp.nsteps, 0, R * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.nacc, 0, R * 8, h->stream));
+    }
+    HIPCHK(hipMemsetAsync(kp.last_acc, 1, R, h->stream));
+    TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));
+    hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,
+                       kp.features, h->d_natural, kp.enthalpy, (int)R, h->F);
+    HIPCHK(hipGetLastError());
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && reset_aux) {
+        const size_t RL = R * h->L;
+        HIPCHK(hipMemsetAsync(kp.wl_entropy, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_hist, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_occur, 0, RL * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_meanf, 0, RL * h->F * 8, h->stream));
+        HIPCHK(hipMemsetAsync(kp.wl_counter, 0, R * 8, h->stream));
+        std::vector<double> m0(R, h->cfg.wl_mod_factor);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(kp.wl_m, m0.data(), R * 8, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_set_temperature(smolmc_handle *h, const double *temperature) {
+    if (!h || !temperature) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> beta;
+    set_betas(h, temperature, beta);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_beta, beta.data(), (size_t)h->R * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int smolmc_sync(smolmc_handle *h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_get_state(smolmc_handle *h, int32_t *occ, double *features, double *enthalpy,
+                                uint64_t *n_accepted, uint64_t *n_steps, uint8_t *last_accepted) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t R = h->R;
+    KParams &kp = h->kp;
+    if (occ) {
+        int *d32 = nullptr;
+        const size_t total = R * h->N;
+        HIPCHK(hipMalloc((void **)&d32, total * 4));
+        hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, kp.occ, d32, h->N, h->Npad, total);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(occ, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        hipFree(d32);
+        if (e != hipSuccess) return fail(std::string("occupancy download: ") + hipGetErrorString(e));
+    }
+    if (features) HIPCHK(hipMemcpy(features, kp.features, R * h->F * 8, hipMemcpyDeviceToHost));
+    if (enthalpy) HIPCHK(hipMemcpy(enthalpy, kp.enthalpy, R * 8, hipMemcpyDeviceToHost));
+    if (n_accepted) HIPCHK(hipMemcpy(n_accepted, kp.nacc, R * 8, hipMemcpyDeviceToHost));
+    if (n_steps) HIPCHK(hipMemcpy(n_steps, kp.nsteps, R * 8, hipMemcpyDeviceToHost));
+    if (last_accepted) HIPCHK(hipMemcpy(last_accepted, kp.last_acc, R, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int smolmc_get_wl(smolmc_handle *h, double *entropy, int64_t *histogram,
+                             int64_t *occurrences, double *mean_features, double *mod_factor) {
+    if (!h) return fail("null handle");
+    if (h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU) return fail("handle is not a Wang-Landau kernel");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t RL = (size_t)h->R * h->L;
+    KParams &kp = h->kp;
+    if (entropy) HIPCHK(hipMemcpy(entropy, kp.wl_entropy, RL * 8, hipMemcpyDeviceToHost));
+    if (histogram) HIPCHK(hipMemcpy(histogram, kp.wl_hist, RL * 8, hipMemcpyDeviceToHost));
+    if (occurrences) HIPCHK(hipMemcpy(occurrences, kp.wl_occur, RL * 8, hipMemcpyDeviceToHost));
+    if (mean_features)
+        HIPCHK(hipMemcpy(mean_features, kp.wl_meanf, RL * h->F * 8, hipMemcpyDeviceToHost));
+    if (mod_factor) HIPCHK(hipMemcpy(mod_factor, kp.wl_m, (size_t)h->R * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- kernel dispatch (instantiations live in general_n*.hip / lean_n*.hip) --------------
+static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
+    switch (h->nslot) {
+    case 2: return smolmc_launch_general_2(h, kp, replay);
+    case 4: return smolmc_launch_general_4(h, kp, replay);
+    case 8: return smolmc_launch_general_8(h, kp, replay);
+    default: return smolmc_launch_general_16(h, kp, replay);
+    }
+}
+
+static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
+    lp.steps = nsteps;
+    return h->lean_nslot == 2 ? smolmc_launch_lean_2(h, lp) : smolmc_launch_lean_4(h, lp);
+}
+
+static void free_samples(smolmc_handle *h) {
+    if (h->smp.H) hipFree(h->smp.H);
+    if (h->smp.feat) hipFree(h->smp.feat);
+    if (h->smp.acc) hipFree(h->smp.acc);
+    if (h->smp.occ) hipFree(h->smp.occ);
+    memset(&h->smp, 0, sizeof(SampleBufs));
+    h->smp_n = 0;
+    h->smp_has_occ = false;
+}
+
+static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
+    if (h->lean) {
+        LeanParams lp = h->lp;
+        lp.smp = smp;
+        return launch_lean(h, lp, nsteps);
+    }
+    KParams kp = h->kp;
+    kp.steps_to_run = nsteps;
+    kp.smp = smp;
+    return launch_mc(h, kp, 0);
+}
+
+extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
+    if (!h) return fail("null handle");
+    if (nsteps < 0) return fail("nsteps must be non-negative");
+    if (nsteps == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    SampleBufs none;
+    memset(&none, 0, sizeof(none));
+    return run_steps(h, nsteps, none);
+}
+
+extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags) {
+    if (!h) return fail("null handle");
+    if (nsamples <= 0 || thin_by <= 0) return fail("nsamples and thin_by must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_samples(h);
+    const size_t rows = (size_t)nsamples * h->R;
+    HIPCHK(hipMalloc((void **)&h->smp.H, rows * 8));
+    HIPCHK(hipMalloc((void **)&h->smp.feat, rows * h->F * 8));
+    HIPCHK(hipMalloc((void **)&h->smp.acc, rows));
+    if (flags & 1) {
+        HIPCHK(hipMalloc((void **)&h->smp.occ, rows * h->Npad));
+        h->smp_has_occ = true;
+    }
+    h->smp.every = thin_by;
+    h->smp_n = nsamples;
+    return run_steps(h, nsamples * thin_by, h->smp);
+}
+
+extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
+                                  uint8_t *accepted, int32_t *occupancy) {
+    if (!h) return fail("null handle");
+    if (h->smp_n == 0) return fail("no samples recorded: call smolmc_run_sampled first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t rows = (size_t)h->smp_n * h->R;
+    if (enthalpy) HIPCHK(hipMemcpy(enthalpy, h->smp.H, rows * 8, hipMemcpyDeviceToHost));
+    if (features) HIPCHK(hipMemcpy(features, h->smp.feat, rows * h->F * 8, hipMemcpyDeviceToHost));
+    if (accepted) HIPCHK(hipMemcpy(accepted, h->smp.acc, rows, hipMemcpyDeviceToHost));
+    if (occupancy) {
+        if (!h->smp_has_occ) return fail("occupancies were not recorded (flags bit 0)");
+        int *d32 = nullptr;
+        const size_t total = rows * h->N;
+        HIPCHK(hipMalloc((void **)&d32, total * 4));
+        hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, h->smp.occ, d32, h->N, h->Npad, total);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(occupancy, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        hipFree(d32);
+        if (e != hipSuccess) return fail(std::string("sample download: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,
+                             const double *uniforms, uint8_t *accepted_out, double *enthalpy_out) {
+    if (!h || !steps || !uniforms) return fail("null argument");
+    if (nsteps <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->R * nsteps;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t *st = steps + i * 4;
+        for (int f = 0; f < 2; ++f)
+            if (st[2 * f] >= h->N || (st[2 * f] >= 0 && (st[2 * f + 1] < 0 || st[2 * f + 1] > 255)))
+                return fail("replay step out of range");
+    }
+    int *d_steps = nullptr;
+    double *d_u = nullptr, *d_H = nullptr;
+    uint8_t *d_acc = nullptr;
+    hipError_t e = hipMalloc((void **)&d_steps, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_u, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_H, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_acc, n);
+    if (e == hipSuccess) e = hipMemcpy(d_steps, steps, n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_u, uniforms, n * 8, hipMemcpyHostToDevice);
+    int rc = 0;
+    if (e == hipSuccess) {
+        KParams kp = h->kp;
+        kp.steps_to_run = nsteps;
+        kp.rp_steps = d_steps;
+        kp.rp_u = d_u;
+        kp.rp_acc = d_acc;
+        kp.rp_H = d_H;
+        rc = launch_mc(h, kp, 1);
+        if (!rc) e = hipStreamSynchronize(h->stream);
+        if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_steps);
+    hipFree(d_u);
+    hipFree(d_H);
+    hipFree(d_acc);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(std::string("replay: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_last_kernel_ms(smolmc_handle *h, float *ms) {
+    if (!h || !ms) return fail("null argument");
+    if (!h->timed) return fail("no kernel has been launched yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+static int ensure_eval_occ(smolmc_handle *h, size_t nocc) {
+    const size_t need = nocc * h->Npad;
+    if (need > h->eval_occ_cap) {
+        if (h->d_eval_occ) hipFree(h->d_eval_occ);
+        h->d_eval_occ = nullptr;
+        h->eval_occ_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->d_eval_occ, need));
+        h->eval_occ_cap = need;
+    }
+    return 0;
+}
+
+extern "C" int smolmc_eval_full(smolmc_handle *h, const int32_t *occ, int nocc, double *features) {
+    if (!h || !occ || !features) return fail("null argument");
+    if (nocc <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    TRY(ensure_eval_occ(h, nocc));
+    TRY(upload_occ(h, occ, nocc, h->d_eval_occ));
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, (size_t)nocc * h->F * 8));
+    int rc = launch_eval_full(h, h->d_eval_occ, nocc, d_out);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpy(features, d_out, (size_t)nocc * h->F * 8, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(std::string("eval_full: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ, const int32_t *flips, int nstep,
+                                 double *dfeatures) {
+    if (!h || !occ || !flips || !dfeatures) return fail("null argument");
+    if (nstep <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    for (int i = 0; i < nstep; ++i)
+        for (int f = 0; f < 2; ++f) {
+            const int s = flips[i * 4 + 2 * f], c = flips[i * 4 + 2 * f + 1];
+            if (s >= h->N || (s >= 0 && (c < 0 || c > 255))) return fail("flip out of range");
+        }
+    TRY(ensure_eval_occ(h, 1));
+    TRY(upload_occ(h, occ, 1, h->d_eval_occ));
+    int *d_fl = nullptr;
+    double *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_fl, (size_t)nstep * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)nstep * h->F * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_fl, flips, (size_t)nstep * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(eval_delta_kernel, dim3(nstep), dim3(64), 0, h->stream, h->rt, h->d_eval_occ,
+                           d_fl, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(dfeatures, d_out, (size_t)nstep * h->F * 8, hipMemcpyDeviceToHost);
+    hipFree(d_fl);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(std::string("eval_delta: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int smolmc_export_enthalpy_dev(smolmc_handle *h, double *dst_dev) {
+    if (!h || !dst_dev) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst_dev, h->kp.enthalpy, (size_t)h->R * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+__global__ void beta_from_T_kernel(const double *T, double *beta, int R, double kB) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) beta[r] = 1.0 / (kB * T[r]);
+}
+
+extern "C" int smolmc_import_temperature_dev(smolmc_handle *h, const double *src_dev) {
+    if (!h || !src_dev) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(beta_from_T_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, src_dev,
+                       h->d_beta, h->R, SMOLMC_KB);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}

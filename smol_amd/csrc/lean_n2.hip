@@ -1,0 +1,6 @@
+// mc_lean_kernel / mc_table_kernel instantiations for NSLOT = 2
+#include "mc_lean.h"
+
+int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp) {
+    return launch_lean_nslot<2>(h, lp);
+}

@@ -1,0 +1,603 @@
+// mc_general.h -- the general Monte-Carlo kernel (mc_kernel) and its launch templates.
+#pragma once
+#include "smolmc_common.h"
+
+struct Lds {
+    const uint4 *descA;
+    const uint4 *descB;
+    const double *slot_fs;
+    const double *xt;
+    const double *ft;
+    const uint8_t *site_class;
+    const int *cls_niter;
+    uint8_t *occ;   // this wave's occupancy bytes
+    double *acc;    // this wave's feature accumulators [Fce][64]  (Metropolis)
+    double *wl_S;   // WL: entropy [L]
+    long long *wl_H; // WL: histogram [L]
+    double *wl_cf;  // WL: current features [F]
+};
+
+// u16 stride m out of the packed descriptor words
+__device__ __forceinline__ int stride_of(const uint4 &a, int m) {
+    uint32_t w = (m < 2) ? a.y : (m < 4 ? a.z : a.w);
+    return (m & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+}
+
+// Evaluate one cluster slot of a flip at site s (old code -> new code).
+//   GENERIC: every member of the cluster row is gathered (the flipped site included)
+//            -> exactly the reference index arithmetic, handles aliased rows.
+//   !GENERIC: the row excludes the flipped site; its stride is st[0].
+//   PATCH: occupancy seen is the LDS state with site ps overridden to pc (second
+//          flip of a swap sees the first, processor/expansion.py:217-229).
+template <typename IdxT, int MM, bool GENERIC, bool PATCH>
+__device__ __forceinline__ double eval_slot(const KParams &P, const Lds &L, int cls, int c, int s,
+                                            int oldc, int newc, int ps, int pc, int &ind_i,
+                                            int &ind_f) {
+    const uint4 a = L.descA[cls * P.Cpad + c];
+    const IdxT *ip = (const IdxT *)P.idx + ((size_t)s * P.Mmax) * P.Cpad + c;
+    int x[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) x[m] = (int)ip[(size_t)m * P.Cpad];
+    int bi = 0, bf = 0;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        int v = L.occ[x[m]];
+        if (PATCH) v = (x[m] == ps) ? pc : v;
+        if (GENERIC) {
+            int st = stride_of(a, m);
+            int vf = (x[m] == s) ? newc : v;
+            bi += st * v;
+            bf += st * vf;
+        } else {
+            bi += stride_of(a, m + 1) * v;
+        }
+    }
+    if (!GENERIC) {
+        int ss = stride_of(a, 0);
+        bf = bi + ss * newc;
+        bi = bi + ss * oldc;
+    }
+    ind_i = bi;
+    ind_f = bf;
+    return L.xt[a.x + bf] - L.xt[a.x + bi];
+}
+
+// feature accumulation of one accepted slot (Metropolis: lane-private LDS cells)
+template <bool WL>
+__device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int cls, int c, int lane,
+                                           int ind_i, int ind_f) {
+    const uint4 b = L.descB[cls * P.Cpad + c];
+    const int K = (int)(b.z >> 16), feat = (int)(b.z & 0xffffu);
+    const double fs = L.slot_fs[cls * P.Cpad + c];
+    for (int k = 0; k < K; ++k) {
+        const double *t = L.ft + b.x + (size_t)k * b.y;
+        double d = t[ind_f] - t[ind_i];
+        if (WL) {
+            // WL needs the reduced current features every step: LDS atomics
+            __hip_atomic_fetch_add(&L.wl_cf[feat + k], fs * d, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            double *cell = L.acc + (size_t)(feat + k) * 64 + lane;
+            *cell = fma(fs, d, *cell);
+        }
+    }
+}
+
+// Ewald delta of one flip (ewald.pyx:38-58), wave-parallel over sites; returns the
+// lane-partial (caller reduces).  Reads ROWS of the transposed matrix, i.e. the same
+// entries M[i, add] / M[j, sub] the reference reads as columns.
+template <bool PATCH>
+__device__ __forceinline__ double ewald_partial(const KParams &P, const Lds &L, int lane, int s,
+                                                int oldc, int newc, int ps, int pc) {
+    const int W = P.ew_W;
+    const int add = P.ew_inds[(size_t)s * W + newc];
+    const int sub = P.ew_inds[(size_t)s * W + oldc];
+    const double *radd = P.ew_Mt + (size_t)(add < 0 ? 0 : add) * P.ew_M;
+    const double *rsub = P.ew_Mt + (size_t)(sub < 0 ? 0 : sub) * P.ew_M;
+    double out = 0;
+    for (int k = lane; k < P.N; k += 64) {
+        int v = L.occ[k];
+        if (PATCH) v = (k == ps) ? pc : v;
+        int vf = (k == s) ? newc : v;
+        int i = P.ew_inds[(size_t)k * W + vf];
+        int j = (k == s) ? P.ew_inds[(size_t)k * W + v] : i;
+        double o = 0;
+        if (i != -1 && add != -1) o += (i != add ? 2.0 : 1.0) * radd[i];
+        if (j != -1 && sub != -1) o -= (j != sub ? 2.0 : 1.0) * rsub[j];
+        out += o;
+    }
+    return out;
+}
+
+// Compact form of the same delta when M[a][b] = q_a q_b G[site_a][site_b] (a != b):
+//   sum_k [2 M[i_k, add] - 2 M[i_k, sub]]  (k != s, i_k = j_k)  + M[add,add] - M[sub,sub]
+//     = 2 (q_add - q_sub) * sum_{k != s} q(k, occ_k) G[s][k] + diag(add) - diag(sub)
+// One fully-used row of G (N x 8 B) streams per flip instead of two strided matrix rows.
+template <bool PATCH>
+__device__ __forceinline__ double ewald_compact_partial(const KParams &P, const Lds &L, int lane, int s,
+                                                        int ps, int pc) {
+    // sites with a single allowed species never change: their part of the sum is the
+    // precomputed ew_frozen[s]; only the changeable sites are streamed
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int W = P.ew_W, abase = P.ew_act_base;
+    double out = 0;
+#pragma unroll 4
+    for (int j = lane; j < P.ew_nact; j += 64) {
+        const int k = abase >= 0 ? abase + j : P.ew_act[j];
+        int v = L.occ[k];
+        if (PATCH) v = (k == ps) ? pc : v;
+        const double q = P.ew_qs[(size_t)k * W + v];
+        out = fma(k == s ? 0.0 : q, g[j], out);
+    }
+    return out;
+}
+
+// ----------------------------------------------------------------------------
+// the Monte-Carlo kernel
+// ----------------------------------------------------------------------------
+template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
+__global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int replay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+
+    // ---- stage read-only tables in LDS (shared by the workgroup) -------------
+    unsigned char *sp = smem;
+    uint4 *s_descA = (uint4 *)sp;               sp += (size_t)P.nclasses * P.Cpad * 16;
+    uint4 *s_descB = (uint4 *)sp;               sp += (size_t)P.nclasses * P.Cpad * 16;
+    double *s_fs = (double *)sp;                sp += (size_t)P.nclasses * P.Cpad * 8;
+    double *s_xt = (double *)sp;                sp += (size_t)P.xt_len * 8;
+    double *s_ft = (double *)sp;                sp += (size_t)P.ft_len * 8;
+    int *s_niter = (int *)sp;                   sp += (size_t)((P.nclasses + 3) & ~3) * 4;
+    uint8_t *s_cls = (uint8_t *)sp;
+    for (int i = threadIdx.x; i < P.nclasses * P.Cpad; i += blockDim.x) {
+        s_descA[i] = P.descA[i];
+        s_descB[i] = P.descB[i];
+        s_fs[i] = P.slot_fs[i];
+    }
+    for (int i = threadIdx.x; i < P.xt_len; i += blockDim.x) s_xt[i] = P.xt[i];
+    for (int i = threadIdx.x; i < P.ft_len; i += blockDim.x) s_ft[i] = P.ft[i];
+    for (int i = threadIdx.x; i < P.nclasses; i += blockDim.x) s_niter[i] = P.cls_niter[i];
+    if (P.nclasses > 1)
+        for (int i = threadIdx.x; i < P.N; i += blockDim.x) s_cls[i] = P.site_class[i];
+
+    Lds L;
+    L.descA = s_descA; L.descB = s_descB; L.slot_fs = s_fs; L.xt = s_xt; L.ft = s_ft;
+    L.site_class = s_cls; L.cls_niter = s_niter;
+    unsigned char *wp = smem + P.lds_tables + (size_t)wave * P.lds_per_wave;
+    L.occ = wp;
+    wp += P.Npad;
+    L.acc = nullptr; L.wl_S = nullptr; L.wl_H = nullptr; L.wl_cf = nullptr;
+    if (WL) {
+        L.wl_S = (double *)wp;        wp += (size_t)P.L * 8;
+        L.wl_H = (long long *)wp;     wp += (size_t)P.L * 8;
+        L.wl_cf = (double *)wp;
+    } else {
+        L.acc = (double *)wp;
+    }
+
+    // ---- this wave's chain: occupancy -> LDS (coalesced 16-byte loads) --------
+    const bool live = r < P.R;
+    if (live) {
+        const uint4 *src = (const uint4 *)(P.occ + (size_t)r * P.Npad);
+        uint4 *dst = (uint4 *)L.occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+        if (WL) {
+            for (int i = lane; i < P.L; i += 64) {
+                L.wl_S[i] = P.wl_entropy[(size_t)r * P.L + i];
+                L.wl_H[i] = P.wl_hist[(size_t)r * P.L + i];
+            }
+            for (int i = lane; i < P.F; i += 64) L.wl_cf[i] = P.features[(size_t)r * P.F + i];
+        } else {
+            for (int i = lane; i < P.Fce * 64; i += 64) L.acc[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    // ---- chain registers ------------------------------------------------------
+    double H = P.enthalpy[r];
+    const double beta = WL ? 0.0 : P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    double acc_ew = 0.0, acc_mu = 0.0; // Ewald / chemical-work feature deltas (uniform)
+    int last_acc = 1;
+    double wl_m = 0.0;
+    long long wl_counter = 0;
+    if (WL) {
+        wl_m = P.wl_m[r];
+        wl_counter = P.wl_counter[r];
+    }
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0; // RNG batch: lane l = block (l&3) of step base+(l>>2)
+    uint32_t w_site_carry = 0;
+    unsigned long long batch_base = ~0ull - 64ull;
+    long long smp_countdown = P.smp.every, smp_index = 0;
+
+    for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
+        // ================= proposal =========================================
+        int nfl = 0, s1 = 0, n1 = 0, o1 = 0, s2 = 0, n2 = 0, o2 = 0;
+        double u = 0.0;
+        if (replay) {
+            const int *st = P.rp_steps + ((size_t)r * P.steps_to_run + it_step) * 4;
+            int a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3];
+            u = P.rp_u[(size_t)r * P.steps_to_run + it_step];
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing
+            a0 = uni(a0); a1 = uni(a1); a2 = uni(a2); a3 = uni(a3);
+            u = uni_d(u);
+            if (a0 >= 0) { nfl = 1; s1 = a0; n1 = a1; o1 = uni((int)L.occ[s1]); }
+            if (a2 >= 0) { nfl = 2; s2 = a2; n2 = a3; o2 = uni((int)L.occ[s2]); if (s2 == s1) o2 = n1; }
+        } else {
+            const unsigned long long base = step & ~15ull;
+            if (base != batch_base) {
+                // the site word of a step comes from the PREVIOUS step's block 0 (word 1)
+                if (batch_base == base - 16) {
+                    w_site_carry = rdlane(W1, 60);
+                } else {
+                    const unsigned long long sp = base - 1ull;
+                    w_site_carry = uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                          key0, key1).w[1]);
+                }
+                batch_base = base;
+                unsigned long long st = base + (unsigned)(lane >> 2);
+                philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                             0u, key0, key1);
+                W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            }
+            const int l4 = (int)(step & 15ull) * 4;
+            const uint32_t w_sub = rdlane(W0, l4);
+            const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
+            u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
+            // sublattice: MCUsher.get_random_sublattice (mcusher.py:146-148)
+            int sl = 0;
+            if (P.nsub > 1) {
+                const double x = (double)w_sub * (1.0 / 4294967296.0);
+                sl = P.nsub - 1;
+                for (int q = P.nsub - 2; q >= 0; --q)
+                    if (x < P.sub_cum[q]) sl = q;
+            }
+            const int p0 = P.sub_ptr[sl];
+            const uint32_t nact = (uint32_t)(P.sub_ptr[sl + 1] - p0);
+            const int sbase = P.sub_base[sl];
+            const uint32_t k1 = __umulhi(w_site, nact);
+            s1 = sbase >= 0 ? sbase + (int)k1 : P.sub_sites[p0 + k1];
+            s1 = uni(s1);
+            o1 = uni((int)L.occ[s1]);
+            if (P.step_type == SMOLMC_STEP_FLIP) {
+                // Flip.propose_step (mcusher.py:154-170)
+                const int c0 = P.sub_code_ptr[sl];
+                const uint32_t nc = (uint32_t)(P.sub_code_ptr[sl + 1] - c0);
+                const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), nc - 1);
+                int code = -1;
+                uint32_t seen = 0;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    int cc = P.sub_codes[c0 + c];
+                    if (cc == o1) continue;
+                    if (seen == kk && code < 0) code = cc;
+                    seen++;
+                }
+                n1 = uni(code);
+                nfl = 1;
+            } else {
+                // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate
+                // sequence ('random stream')
+                int found = -1;
+                {
+                    // first 12 candidates c_t = W(step, 1 + t % 3, t / 3): word-major over the
+                    // three candidate lanes of this step
+                    const uint32_t ws[4] = {W0, W1, W2, W3};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (found < 0) {
+                            const uint32_t kc = __umulhi(ws[j], nact);
+                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            const bool hit = (int)L.occ[cs] != o1;
+                            unsigned long long m = __ballot(hit) & (0xEull << l4);
+                            if (m) found = (int)rdlane((uint32_t)cs, __ffsll((long long)m) - 1);
+                        }
+                    }
+                }
+                if (found < 0) {
+                    // rare: continue the candidate sequence with blocks 4 + 64 q + lane
+                    for (uint32_t q = 0;; ++q) {
+                        philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                     4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                        int selsite = -1;
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) {
+                            const uint32_t kc = __umulhi(o.w[j], nact);
+                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            if ((int)L.occ[cs] != o1) selsite = cs;
+                        }
+                        unsigned long long m = __ballot(selsite >= 0);
+                        if (m) {
+                            found = (int)rdlane((uint32_t)selsite, __ffsll((long long)m) - 1);
+                            break;
+                        }
+                        if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step (:197-199)
+                            int any = 0;
+                            for (uint32_t a = lane; a < nact; a += 64) {
+                                const int cs = sbase >= 0 ? sbase + (int)a : P.sub_sites[p0 + a];
+                                any |= ((int)L.occ[cs] != o1);
+                            }
+                            if (__ballot(any) == 0ull) break;
+                        }
+                    }
+                }
+                if (found >= 0) {
+                    s2 = uni(found);
+                    o2 = uni((int)L.occ[s2]);
+                    n1 = o2;
+                    n2 = o1;
+                    nfl = 2;
+                }
+            }
+        }
+
+        // ================= enthalpy delta ====================================
+        int ii1[NSLOT], jf1[NSLOT], ii2[NSLOT], jf2[NSLOT];
+        int cls1 = 0, cls2 = 0, nit1 = 0, nit2 = 0;
+        double e = 0.0;
+        if (nfl >= 1) {
+            cls1 = P.nclasses > 1 ? uni((int)L.site_class[s1]) : 0;
+            nit1 = cls1 == 255 ? 0 : uni(L.cls_niter[cls1]);
+        }
+        if (nfl == 2) {
+            cls2 = P.nclasses > 1 ? uni((int)L.site_class[s2]) : 0;
+            nit2 = cls2 == 255 ? 0 : uni(L.cls_niter[cls2]);
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const int c = lane + 64 * it;
+                if (it < nit1)
+                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
+                                                             jf1[it]);
+                if (it < nit2)
+                    e += eval_slot<IdxT, MM, GENERIC, true>(P, L, cls2, c, s2, o2, n2, s1, n1, ii2[it],
+                                                            jf2[it]);
+            }
+        } else if (nfl == 1) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const int c = lane + 64 * it;
+                if (it < nit1)
+                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
+                                                             jf1[it]);
+            }
+        }
+        double dEw = 0.0, dMu = 0.0;
+        if (P.has_ewald && nfl >= 1) {
+            if (P.ew_compact) {
+                const int W = P.ew_W;
+                const double s1sum = P.ew_frozen[s1] + wave_sum(ewald_compact_partial<false>(P, L, lane, s1, 0, 0));
+                dEw = 2.0 * (P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1]) * s1sum +
+                      (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+                if (nfl == 2) {
+                    const double s2sum = P.ew_frozen[s2] + wave_sum(ewald_compact_partial<true>(P, L, lane, s2, s1, n1));
+                    dEw += 2.0 * (P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2]) * s2sum +
+                           (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+                }
+                dEw = uni_d(dEw);
+            } else {
+                double pe = ewald_partial<false>(P, L, lane, s1, o1, n1, 0, 0);
+                if (nfl == 2) pe += ewald_partial<true>(P, L, lane, s2, o2, n2, s1, n1);
+                dEw = wave_sum(pe);
+            }
+        }
+        if (P.has_mu && nfl >= 1) {
+            // delta chemical work against the ORIGINAL occupancy (ensemble.py:368-374)
+            dMu = P.mu[(size_t)s1 * P.mu_W + n1] - P.mu[(size_t)s1 * P.mu_W + o1];
+            if (nfl == 2) {
+                const int orig2 = uni((int)L.occ[s2]);
+                dMu += P.mu[(size_t)s2 * P.mu_W + n2] - P.mu[(size_t)s2 * P.mu_W + orig2];
+            }
+            dMu = uni_d(dMu);
+        }
+        double dH = wave_sum(e);
+        if (P.has_ewald) dH += P.ew_coef * dEw;
+        if (P.has_mu) dH -= dMu;
+
+        // ================= accept ==============================================
+        bool accepted;
+        if (!WL) {
+            // MetropolisAcceptMixin._accept_step (metropolis.py:31-49)
+            const double exponent = -beta * dH + 0.0;
+            accepted = exponent >= 0.0 ? true : (exponent > log(u));
+        } else {
+            // WangLandau._accept_step (wanglandau.py:186-202)
+            const double new_h = H + dH;
+            if (new_h < P.wl_min || new_h >= P.wl_max) {
+                accepted = false;
+            } else {
+                const int b = (int)floordiv_exact(H - P.wl_min, P.wl_bin);
+                const int nb = (int)floordiv_exact(new_h - P.wl_min, P.wl_bin);
+                const double exponent = L.wl_S[b] - L.wl_S[nb] + 0.0;
+                accepted = exponent >= 0.0 ? true : (exponent > log(u));
+            }
+        }
+
+        // ================= update ==============================================
+        if (accepted) {
+            // MCKernel._do_accept_step (kernel/base.py:327-343) + trace += delta
+            // (sampler/sampler.py:204-207)
+            if (nfl >= 1) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    if (it < nit1) accum_slot<WL>(P, L, cls1, lane + 64 * it, lane, ii1[it], jf1[it]);
+            }
+            if (nfl == 2) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    if (it < nit2) accum_slot<WL>(P, L, cls2, lane + 64 * it, lane, ii2[it], jf2[it]);
+            }
+            if (lane == 0) {
+                if (nfl >= 1) L.occ[s1] = (uint8_t)n1;
+                if (nfl == 2) L.occ[s2] = (uint8_t)n2;
+                if (WL) {
+                    if (P.has_ewald) L.wl_cf[P.Fce] += dEw;
+                    if (P.has_mu) L.wl_cf[P.Fce + P.has_ewald] += dMu;
+                }
+            }
+            acc_ew += dEw;
+            acc_mu += dMu;
+            H += dH;
+            nacc++;
+        }
+        last_acc = accepted ? 1 : 0;
+
+        if (WL) {
+            // WangLandau._do_post_step (wanglandau.py:222-266)
+            const double bq = floordiv_exact(H - P.wl_min, P.wl_bin);
+            if (bq >= 0.0 && bq < (double)P.L) {
+                const int b = (int)bq;
+                wl_counter++;
+                const size_t cell = (size_t)r * P.L + b;
+                // lane 0 owns the occurrences counter (single-thread program order for
+                // its own global read-after-write); broadcast to the wave
+                long long total = 0;
+                if (lane == 0) total = P.wl_occur[cell];
+                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
+                        (unsigned)uni((int)(total & 0xffffffffll));
+                if (lane < P.F) {
+                    double *mf = P.wl_meanf + cell * P.F + lane;
+                    const double inv = 1.0 / (double)(total + 1);
+                    *mf = inv * (L.wl_cf[lane] + (double)total * (*mf));
+                }
+                if (wl_counter % P.wl_update == 0) {
+                    if (lane == 0) {
+                        L.wl_S[b] += wl_m;
+                        L.wl_H[b] += 1;
+                        P.wl_occur[cell] = total + 1;
+                    }
+                }
+            }
+            if (wl_counter % P.wl_check == 0) {
+                long cnt = 0;
+                double sum = 0;
+                for (int i = lane; i < P.L; i += 64)
+                    if (L.wl_S[i] > 0) { cnt++; sum += (double)L.wl_H[i]; }
+                const double tcnt = wave_sum((double)cnt), tsum = wave_sum(sum);
+                if (tcnt >= 2.0) {
+                    const double thr = P.wl_flat * (tsum / tcnt);
+                    int bad = 0;
+                    for (int i = lane; i < P.L; i += 64)
+                        if (L.wl_S[i] > 0 && !((double)L.wl_H[i] > thr)) bad = 1;
+                    if (__ballot(bad) == 0ull) {
+                        for (int i = lane; i < P.L; i += 64) L.wl_H[i] = 0;
+                        wl_m = wl_m / P.wl_div;
+                    }
+                }
+            }
+        }
+        if (replay && lane == 0) {
+            if (P.rp_acc) P.rp_acc[(size_t)r * P.steps_to_run + it_step] = (uint8_t)last_acc;
+            if (P.rp_H) P.rp_H[(size_t)r * P.steps_to_run + it_step] = H;
+        }
+        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
+            smp_countdown = P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            double *dstf = P.smp.feat + row * P.F;
+            const double *base = P.features + (size_t)r * P.F;
+            if (WL) {
+                for (int i = lane; i < P.F; i += 64) dstf[i] = L.wl_cf[i];
+            } else {
+                for (int f = 0; f < P.Fce; ++f) {
+                    const double sm = wave_sum(L.acc[(size_t)f * 64 + lane]);
+                    if (lane == 0) dstf[f] = base[f] + sm;
+                }
+                if (lane == 0) {
+                    if (P.has_ewald) dstf[P.Fce] = base[P.Fce] + acc_ew;
+                    if (P.has_mu) dstf[P.Fce + P.has_ewald] = base[P.Fce + P.has_ewald] + acc_mu;
+                }
+            }
+            if (lane == 0) {
+                P.smp.H[row] = H;
+                P.smp.acc[row] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint4 *dst = (uint4 *)(P.smp.occ + row * P.Npad);
+                const uint4 *src = (const uint4 *)L.occ;
+                for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+            }
+        }
+    }
+
+    // ---- write the chain back --------------------------------------------------
+    {
+        uint4 *dst = (uint4 *)(P.occ + (size_t)r * P.Npad);
+        const uint4 *src = (const uint4 *)L.occ;
+        for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+    }
+    double *feat = P.features + (size_t)r * P.F;
+    if (WL) {
+        for (int i = lane; i < P.L; i += 64) {
+            P.wl_entropy[(size_t)r * P.L + i] = L.wl_S[i];
+            P.wl_hist[(size_t)r * P.L + i] = L.wl_H[i];
+        }
+        for (int i = lane; i < P.F; i += 64) feat[i] = L.wl_cf[i];
+        if (lane == 0) {
+            P.wl_m[r] = wl_m;
+            P.wl_counter[r] = wl_counter;
+        }
+    } else {
+        for (int f = 0; f < P.Fce; ++f) {
+            const double s = wave_sum(L.acc[(size_t)f * 64 + lane]);
+            if (lane == 0) feat[f] += s;
+        }
+        if (lane == 0) {
+            if (P.has_ewald) feat[P.Fce] += acc_ew;
+            if (P.has_mu) feat[P.Fce + P.has_ewald] += acc_mu;
+        }
+    }
+    if (lane == 0) {
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
+
+// ---- kernel dispatch ----------------------------------------------------------
+template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
+static int launch_mc_inst(smolmc_handle *h, const KParams &kp, int replay) {
+    auto kern = mc_kernel<IdxT, NSLOT, MM, GENERIC, WL>;
+    if (h->lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes));
+    const int wpb = h->waves_per_block;
+    const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), h->lds_bytes, h->stream, kp, replay);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+template <typename IdxT, int NSLOT, bool GENERIC, bool WL>
+static int launch_mc_mm(smolmc_handle *h, const KParams &kp, int replay) {
+    if (GENERIC) {
+        if (h->mm == 3) return launch_mc_inst<IdxT, NSLOT, 3, GENERIC, WL>(h, kp, replay);
+        return launch_mc_inst<IdxT, NSLOT, 6, GENERIC, WL>(h, kp, replay);
+    }
+    if (h->mm == 2) return launch_mc_inst<IdxT, NSLOT, 2, GENERIC, WL>(h, kp, replay);
+    if (h->mm == 3) return launch_mc_inst<IdxT, NSLOT, 3, GENERIC, WL>(h, kp, replay);
+    return launch_mc_inst<IdxT, NSLOT, 5, GENERIC, WL>(h, kp, replay);
+}
+
+
+// all (index type, GENERIC, WL) combinations of one NSLOT
+template <int NSLOT> static int launch_general_nslot(smolmc_handle *h, const KParams &kp, int replay) {
+    const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    if (h->generic)
+        return wl ? launch_mc_mm<int32_t, NSLOT, true, true>(h, kp, replay)
+                  : launch_mc_mm<int32_t, NSLOT, true, false>(h, kp, replay);
+    if (h->idx16)
+        return wl ? launch_mc_mm<uint16_t, NSLOT, false, true>(h, kp, replay)
+                  : launch_mc_mm<uint16_t, NSLOT, false, false>(h, kp, replay);
+    return wl ? launch_mc_mm<int32_t, NSLOT, false, true>(h, kp, replay)
+              : launch_mc_mm<int32_t, NSLOT, false, false>(h, kp, replay);
+}

@@ -1,0 +1,905 @@
+// mc_lean.h -- lean Metropolis / Wang-Landau kernel, TableFlip kernel and their launch templates.
+#pragma once
+#include "smolmc_common.h"
+
+// xor-butterfly inside 16-lane rows (DPP), then gfx950 permlane16/32 swaps: 22 VALU
+// instructions, the total ends up in every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_xor_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = dpp_xor_add<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_xor_add<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_xor_add<0x141>(v); // row_half_mirror
+    v = dpp_xor_add<0x140>(v); // row_mirror
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+}
+
+// The same sum on the matrix pipe: two v_mfma_f64_16x16x4_f64 with B = ones
+// (D[i][j] = sum_k A[i][k], lane l holds A[l & 15][l >> 4]; C/D: col = lane & 15,
+// row = (lane >> 4) + 4 * reg) and three VALU adds in between.  Frees ~19 VALU issue
+// slots per step but MEASURED SLOWER (9.87 ms vs 8.46 ms per 10^4 steps, same session):
+// the two dependent f64 MFMAs lengthen the per-step dependency chain more than the VALU
+// slots they free.  Kept behind -DSMOLMC_MFMA_REDUCE as a documented negative result.
+typedef double smolmc_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+    const smolmc_v4d z = {0.0, 0.0, 0.0, 0.0};
+    const smolmc_v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
+    const double t = (d[0] + d[1]) + (d[2] + d[3]);
+    const smolmc_v4d d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
+    return d2[0];
+}
+#ifdef SMOLMC_MFMA_REDUCE
+#define LEAN_WAVE_SUM wave_sum_mfma
+#else
+#define LEAN_WAVE_SUM wave_sum_all
+#endif
+
+// sum over the changeable sites k != s of q(k, occ_k) * G[s][k] (lane partial), eight sites
+// per lane in flight so that the dependent latencies (index -> LDS species byte -> charge)
+// of different sites overlap; the occupancy is read from LDS, so a tentatively applied
+// first flip of a swap is seen without patching.
+__device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const uint8_t *occ, int lane,
+                                                     int s, int swa, int swm, int swb) {
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int W = P.ew_W, na = P.ew_nact;
+    double out = 0;
+    for (int j0 = lane; j0 < na; j0 += 64 * 8) {
+        // branch-free: out-of-range lanes re-read the last element and are masked at the end
+        // (conditional loads would put a full s_waitcnt between the eight loads)
+        int k[8];
+        double gk[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = min(j0 + 64 * u, na - 1);
+            k[u] = P.ew_act[jj];
+            gk[u] = g[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            q[u] = P.ew_qs[(size_t)k[u] * W + (int)occ[lean_swz(k[u], swa, swm, swb)]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            out = fma((j0 + 64 * u < na && k[u] != s) ? q[u] : 0.0, gk[u], out);
+    }
+    return out;
+}
+
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL>
+__global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len;               // 8 doubles
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0);
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
+    uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
+    // Metropolis: scratch for the feature reduction; Wang-Landau: the CURRENT features
+    // (wanglandau.py:216-218 needs them every step for the per-bin running mean)
+    double *s_feat = (double *)(wbase + P.Nlds);
+    double *wl_S = s_feat + 64;                   // WL: entropy [L]
+    long long *wl_Hh = (long long *)(wl_S + (WL ? P.wl.L : 0)); // WL: histogram [L]
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
+    const bool live = r < P.R;
+    if (live) {
+        // the swizzle only touches address bits >= 2: move whole dwords
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
+        s_feat[lane] = (WL && lane < P.F) ? P.features[(size_t)r * P.F + lane] : 0.0;
+        if (WL)
+            for (int i = lane; i < P.wl.L; i += 64) {
+                wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+                wl_Hh[i] = P.wl.hist[(size_t)r * P.wl.L + i];
+            }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    // per-lane slot constants (registers for the whole launch)
+    uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
+    double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) {
+        const LeanSlot sl = P.slots[it * 64 + lane];
+        doff8[it] = sl.doff8;
+        sfeat[it] = sl.feat;      // only used by the Wang-Landau variant
+        sfs[it] = sl.live ? sl.fs : 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
+        wgt[it] = sl.w;
+        acc[it] = 0.0;
+    }
+    double H = P.enthalpy[r];
+    const double nbeta = WL ? 0.0 : -P.beta[r];
+    double wl_m = WL ? P.wl.m[r] : 0.0;
+    long long wl_counter = WL ? P.wl.counter[r] : 0;
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
+    const int sbase = P.sbase;
+    double acc_mu = 0.0, acc_ew = 0.0;
+    int last_acc = 1;
+    // trace at launch start; features of a sample = base + sum over lanes of fs * acc
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    long long smp_countdown = P.smp.every, smp_index = 0;
+    // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
+    uint32_t W0 = 0, W1 = 0;
+    int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
+    double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
+    unsigned long long batch_base = ~0ull;
+    constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
+    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+
+    // software pipeline: the site of step k comes from W(k-1, 0, 1), so the index row of
+    // the NEXT step is always known one step ahead and is fetched while this step runs.
+    int s1;
+    uint16_t row1[ROW];
+    {
+        const unsigned long long sp = step - 1ull;
+        const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                            key0, key1).w[1]);
+        s1 = sbase + (int)__umulhi(w, nact);
+        const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
+#pragma unroll
+        for (int q = 0; q < ROW; ++q) row1[q] = p[q];
+    }
+
+    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+        // -------- random words of this step (generated 16 steps at a time) --------
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                               0u, key0, key1);
+            W0 = o.w[0]; W1 = o.w[1];
+            // metropolis.py:46-48 compares the exponent with log(rng.random()): take the
+            // float64 log of all 16 uniforms of the batch at once (lane-parallel)
+            logu = log(philox_u53(o.w[2], o.w[3]));
+            if (STEP == SMOLMC_STEP_SWAP) {
+                cand[0] = sbase + (int)__umulhi(o.w[0], nact);
+                cand[1] = sbase + (int)__umulhi(o.w[1], nact);
+                cand[2] = sbase + (int)__umulhi(o.w[2], nact);
+                cand[3] = sbase + (int)__umulhi(o.w[3], nact);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
+            }
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        // prefetch the index row of the next step's site (depends only on random words)
+        const int s1n = sbase + (int)__umulhi(rdlane(W1, l4), nact);
+        uint16_t rown[ROW];
+        {
+            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) rown[q] = p[q];
+        }
+        const int a1 = lean_swz(s1, swa, swm, swb);
+        const int o1 = uni((int)occ[a1]);
+        int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
+        if (STEP == SMOLMC_STEP_FLIP) {
+            // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
+            const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
+            n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
+            nfl = 1;
+        } else {
+            // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate sequence
+            int found = -1, fo = 0, fa = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int v = (int)occ[canda[j]];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cand[j], b);
+                        fa = (int)rdlane((uint32_t)canda[j], b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                    }
+                }
+            }
+            if (found < 0) {
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fa = lean_swz(found, swa, swm, swb);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
+                        int any = 0;
+                        for (uint32_t a = lane; a < nact; a += 64)
+                            any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) { s2 = found; a2 = fa; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
+            else { nfl = 0; n1 = o1; s2 = s1; a2 = a1; o2 = o1; n2 = o1; } // empty step: no-op 'flips'
+        }
+
+        // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
+        // rare empty step, the loaded row is then unused)
+        uint16_t row2[ROW];
+        if (STEP == SMOLMC_STEP_SWAP) {
+            const uint16_t *p = idx_lane + (size_t)s2 * (64 * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) row2[q] = p[q];
+        }
+
+        // -------- enthalpy delta ---------------------------------------------------
+        double e = 0.0, d1[NSLOT], d2[NSLOT];
+        {
+            const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8; // uniform
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row1[it * MM + m]]);
+                d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
+                e = fma(wgt[it], d1[it], e);
+            }
+        }
+        double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
+        if (HAS_EW) {
+            const int W = P.ew_W;
+            const double dq = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
+            ew_part = 2.0 * dq * lean_ewald_partial(P, occ, lane, s1, swa, swm, swb);
+            ew_uni = 2.0 * dq * P.ew_frozen[s1] +
+                     (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+        }
+        if (STEP == SMOLMC_STEP_SWAP) {
+            // the second flip sees the first (expansion.py:217-229): apply it tentatively in
+            // LDS (undone below on rejection) instead of patching every gathered value
+            if (lane == 0) occ[a1] = (uint8_t)n1;
+            const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row2[it * MM + m]]);
+                d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
+                e = fma(wgt[it], d2[it], e);
+            }
+            if (HAS_EW) {
+                const int W = P.ew_W;
+                const double dq = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
+                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s2, swa, swm, swb);
+                ew_uni += 2.0 * dq * P.ew_frozen[s2] +
+                          (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+            }
+        }
+        double dH = LEAN_WAVE_SUM(e);
+        double dEw = 0.0;
+        if (HAS_EW) {
+            dEw = LEAN_WAVE_SUM(ew_part) + ew_uni;
+            dH += P.ew_coef * dEw;
+        }
+        double dMu = 0.0;
+        if (HAS_MU && nfl >= 1) {
+            dMu = s_mu[n1] - s_mu[o1];
+            if (nfl == 2) dMu += s_mu[n2] - s_mu[o2];
+            dH -= dMu;
+        }
+
+        // -------- accept / update (metropolis.py:31-49, kernel/base.py:327-343) --------
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        bool accepted;
+        if (!WL) {
+            const double exponent = nbeta * dH + 0.0;
+            accepted = (exponent >= 0.0) || (exponent > lu);
+        } else {
+            // WangLandau._accept_step (wanglandau.py:186-202)
+            const double new_h = H + dH;
+            if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
+                accepted = false;
+            } else {
+                const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
+                const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                const double exponent = wl_S[b] - wl_S[nb] + 0.0;
+                accepted = (exponent >= 0.0) || (exponent > lu);
+            }
+        }
+        if (accepted) {
+            if (!WL) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
+                if (STEP == SMOLMC_STEP_SWAP) {
+#pragma unroll
+                    for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
+                }
+            } else {
+                // _do_accept_step (wanglandau.py:204-220): current features += delta features
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    const double dd = STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * dd, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            if (lane == 0) {
+                if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+                if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
+            }
+            acc_mu += dMu;
+            acc_ew += dEw;
+            H += dH;
+            nacc++;
+        } else if (STEP == SMOLMC_STEP_SWAP) {
+            if (lane == 0) occ[a1] = (uint8_t)o1; // undo the tentative first flip
+        }
+        last_acc = accepted ? 1 : 0;
+        s1 = s1n;
+#pragma unroll
+        for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
+
+        if (WL) {
+            // WangLandau._do_post_step (wanglandau.py:222-266)
+            const double bq = floordiv_exact(H - P.wl.vmin, P.wl.bin);
+            if (bq >= 0.0 && bq < (double)P.wl.L) {
+                const int b = (int)bq;
+                wl_counter++;
+                const size_t cell = (size_t)r * P.wl.L + b;
+                long long total = 0;
+                if (lane == 0) total = P.wl.occur[cell];
+                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
+                        (unsigned)uni((int)(total & 0xffffffffll));
+                if (lane < P.F) {
+                    double *mf = P.wl.meanf + cell * P.F + lane;
+                    const double inv = 1.0 / (double)(total + 1);
+                    *mf = inv * (s_feat[lane] + (double)total * (*mf));
+                }
+                if (wl_counter % P.wl.update == 0 && lane == 0) {
+                    wl_S[b] += wl_m;
+                    wl_Hh[b] += 1;
+                    P.wl.occur[cell] = total + 1;
+                }
+            }
+            if (wl_counter % P.wl.check == 0) {
+                long cnt = 0;
+                double sum = 0;
+                for (int i = lane; i < P.wl.L; i += 64)
+                    if (wl_S[i] > 0) { cnt++; sum += (double)wl_Hh[i]; }
+                const double tcnt = wave_sum_all((double)cnt), tsum = wave_sum_all(sum);
+                if (tcnt >= 2.0) {
+                    const double thr = P.wl.flat * (tsum / tcnt);
+                    int bad = 0;
+                    for (int i = lane; i < P.wl.L; i += 64)
+                        if (wl_S[i] > 0 && !((double)wl_Hh[i] > thr)) bad = 1;
+                    if (__ballot(bad) == 0ull) {
+                        for (int i = lane; i < P.wl.L; i += 64) wl_Hh[i] = 0;
+                        wl_m = wl_m / P.wl.div;
+                    }
+                }
+            }
+        }
+
+        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
+            smp_countdown = P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            if (WL) {
+                if (lane < P.F) P.smp.feat[row * P.F + lane] = s_feat[lane];
+            } else {
+                s_feat[lane] = 0.0;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
+            }
+            if (!WL && HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
+            if (!WL && HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0))
+                P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            if (lane == 0) {
+                P.smp.H[row] = H;
+                P.smp.acc[row] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
+    }
+
+    // ---- write back ---------------------------------------------------------------
+    {
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+    }
+    if (WL) {
+        if (lane < P.F) featp[lane] = s_feat[lane];
+        for (int i = lane; i < P.wl.L; i += 64) {
+            P.wl.entropy[(size_t)r * P.wl.L + i] = wl_S[i];
+            P.wl.hist[(size_t)r * P.wl.L + i] = wl_Hh[i];
+        }
+        if (lane == 0) {
+            P.wl.m[r] = wl_m;
+            P.wl.counter[r] = wl_counter;
+        }
+    } else {
+        s_feat[lane] = 0.0;
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it)
+            __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    }
+    if (lane == 0) {
+        if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
+        if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
+
+// ----------------------------------------------------------------------------
+// TableFlip kernel (charge-neutral semigrand steps, smol/moca/kernel/mcusher.py:397-711)
+// for lean-eligible models: one site class, one contiguous active sublattice, interaction
+// features, optional mu row and compact Ewald.  A step is either a canonical Swap (with
+// probability swap_weight, or when no table direction is feasible) or a flip-table
+// direction u: -u[c] random sites of every depleted species are picked without
+// replacement (rejection over the candidate stream, 256 candidates per wave round) and
+// randomly re-assigned to the enriched species; the a-priori factor
+// log(p_next/p_now) + sum ln n_now! - ln n_next! enters the Metropolis exponent.
+// Flips of a step are evaluated sequentially against the LDS occupancy with each flip
+// applied tentatively (expansion.py:217-229) and undone on rejection.
+// ----------------------------------------------------------------------------
+template <int NSLOT, int MM>
+__global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len; // 8 doubles
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64;
+    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
+    uint8_t *occ = wbase;
+    double *s_feat = (double *)(wbase + P.Nlds);
+    int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
+    const bool has_mu = P.mu_row != nullptr, has_ew = P.ew_G != nullptr;
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (threadIdx.x < 8) s_mu[threadIdx.x] = (has_mu && threadIdx.x < P.ncodes) ? P.mu_row[threadIdx.x] : 0.0;
+    const bool live = r < P.R;
+    if (live) {
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
+        s_feat[lane] = 0.0;
+        if (lane < 16) s_cnt[lane] = 0;
+    }
+    __syncthreads();
+    if (!live) return;
+    const int nc = P.ncodes, sbase = P.sbase;
+    const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
+    for (int a = lane; a < (int)nact; a += 64)
+        atomicAdd(&s_cnt[(int)occ[lean_swz(sbase + a, swa, swm, swb)]], 1);
+
+    uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
+    double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) {
+        const LeanSlot sl = P.slots[it * 64 + lane];
+        doff8[it] = sl.doff8;
+        sfeat[it] = sl.feat;
+        sfs[it] = sl.live ? sl.fs : 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
+        wgt[it] = sl.w;
+        acc[it] = 0.0;
+    }
+    double H = P.enthalpy[r];
+    const double nbeta = -P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    unsigned long long nacc = P.nacc[r];
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    double acc_mu = 0.0, acc_ew = 0.0;
+    int last_acc = 1;
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    long long smp_countdown = P.smp.every, smp_index = 0;
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+    double logu = 0.0;
+    unsigned long long batch_base = ~0ull;
+    uint32_t w_site_carry = 0;
+    constexpr int ROW = NSLOT * MM;
+    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+    const int nf2 = 2 * P.tf_n;
+
+    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            if (batch_base == base - 16) {
+                w_site_carry = rdlane(W1, 60);
+            } else {
+                const unsigned long long sp = base - 1ull;
+                w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                                key0, key1).w[1]);
+            }
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
+                                               0u, key0, key1);
+            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            logu = log(philox_u53(o.w[2], o.w[3]));
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
+
+        // flips of this step live lane-indexed: lane f holds flip f
+        int vsite = 0, vnew = 0, vold = 0;
+        int nfl = 0, dir = -1;
+        double log_priori = 0.0;
+        bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
+        double sumw = 0.0;
+        if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
+            for (int idx = 0; idx < nf2; ++idx) {
+                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int sg = (idx & 1) ? -1 : 1;
+                bool ok = true;
+                for (int c = 0; c < nc; ++c) {
+                    const int v = s_cnt[c] + sg * row[c];
+                    ok = ok && v >= 0 && v <= (int)nact;
+                }
+                sumw += ok ? P.tf_w[idx] : 0.0;
+            }
+            sumw = uni_d(sumw);
+            if (!(sumw > 0.0)) do_swap = true;
+        }
+        if (do_swap) {
+            // Swap.propose_step (mcusher.py:176-200)
+            const int s1 = sbase + (int)__umulhi(w_site, nact);
+            const int o1 = uni((int)occ[lean_swz(s1, swa, swm, swb)]);
+            int found = -1, fo = 0;
+            const uint32_t ws[4] = {W0, W1, W2, W3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int cs = sbase + (int)__umulhi(ws[j], nact);
+                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cs, b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                    }
+                }
+            }
+            if (found < 0) {
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) {
+                        int any = 0;
+                        for (uint32_t a = lane; a < nact; a += 64)
+                            any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) {
+                nfl = 2;
+                vsite = lane == 0 ? s1 : found;
+                vnew = lane == 0 ? fo : o1;
+                vold = lane == 0 ? o1 : fo;
+            }
+        } else {
+            // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
+            const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
+            double cum = 0.0;
+            int last = -1;
+            for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
+                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int sg = (idx & 1) ? -1 : 1;
+                bool ok = true;
+                for (int c = 0; c < nc; ++c) {
+                    const int v = s_cnt[c] + sg * row[c];
+                    ok = ok && v >= 0 && v <= (int)nact;
+                }
+                if (!ok) continue;
+                last = idx;
+                cum += P.tf_w[idx];
+                if (target < cum) dir = idx;
+            }
+            if (dir < 0) dir = last;
+            dir = uni(dir);
+            const int *urow = P.tf_table + (dir >> 1) * nc;
+            const int usg = (dir & 1) ? -1 : 1;
+            // compute_log_priori_factor (mcusher.py:656-711)
+            {
+                double sum_next = 0.0;
+                for (int idx = 0; idx < nf2; ++idx) {
+                    const int *row = P.tf_table + (idx >> 1) * nc;
+                    const int sg = (idx & 1) ? -1 : 1;
+                    bool ok = true;
+                    for (int c = 0; c < nc; ++c) {
+                        const int v = s_cnt[c] + usg * urow[c] + sg * row[c];
+                        ok = ok && v >= 0 && v <= (int)nact;
+                    }
+                    sum_next += ok ? P.tf_w[idx] : 0.0;
+                }
+                const double p_now = (1.0 - P.tf_sw) * P.tf_w[dir] / sumw;
+                const double p_next = (1.0 - P.tf_sw) * P.tf_w[dir ^ 1] / sum_next;
+                double lf = log(p_next / p_now);
+                for (int c = 0; c < nc; ++c) {
+                    const int u = usg * urow[c], n0 = s_cnt[c];
+                    for (int k = 1; k <= u; ++k) lf -= log((double)(n0 + k));
+                    for (int k = 0; k < -u; ++k) lf += log((double)(n0 - k));
+                }
+                log_priori = uni_d(lf);
+            }
+            // pick the sites of the depleted species from the candidate stream
+            // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round
+            int vcol = 0, ncol = 0; // collected sites, lane-indexed
+            long long tlast = -1;
+            uint32_t round = 0;
+            int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
+            bool have_round = false;
+            for (int c = 0; c < nc; ++c) {
+                int need = -(usg * urow[c]);
+                while (need > 0) {
+                    if (!have_round) {
+                        const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                           4u + 64u * round + (uint32_t)lane, 0u, key0, key1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            cs[j] = sbase + (int)__umulhi(o.w[j], nact);
+                            cv[j] = (int)occ[lean_swz(cs[j], swa, swm, swb)];
+                        }
+                        have_round = true;
+                    }
+                    // smallest stream position t > tlast in this lane that holds species c and
+                    // was not collected yet
+                    long long mint = -1;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const long long t = (long long)round * 256 + 4 * lane + j;
+                        bool ok = cv[j] == c && t > tlast;
+                        for (int z = 0; z < ncol; ++z) ok = ok && cs[j] != (int)rdlane((uint32_t)vcol, z);
+                        if (ok) mint = t;
+                    }
+                    const unsigned long long m = __ballot(mint >= 0);
+                    if (!m) { round++; have_round = false; continue; }
+                    const int b = __ffsll((long long)m) - 1;
+                    const int tj = (int)(((unsigned)rdlane((uint32_t)(int)(mint & 0xffffffffll), b)) & 3u);
+                    tlast = (long long)round * 256 + 4 * b + tj;
+                    const int picked = (int)rdlane((uint32_t)(tj == 0 ? cs[0] : tj == 1 ? cs[1] : tj == 2 ? cs[2] : cs[3]), b);
+                    if (lane == ncol) vcol = picked;
+                    ncol++;
+                    need--;
+                }
+            }
+            // random assignment of the collected sites to the enriched species (:627-631)
+            int qdraw = 0;
+            for (int c = 0; c < nc; ++c) {
+                const int u = usg * urow[c];
+                for (int k = 0; k < u; ++k) {
+                    const int wl = l4 + 2 + (qdraw >> 2);
+                    const int wj = qdraw & 3;
+                    const uint32_t word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
+                    qdraw++;
+                    const int rr = (int)__umulhi(word, (uint32_t)ncol);
+                    const int site = (int)rdlane((uint32_t)vcol, rr);
+                    const int od = uni((int)occ[lean_swz(site, swa, swm, swb)]);
+                    if (lane == nfl) { vsite = site; vnew = c; vold = od; }
+                    nfl++;
+                    const int nxt = __shfl_down(vcol, 1);
+                    if (lane >= rr) vcol = nxt; // list.remove keeps the order of the rest
+                    ncol--;
+                }
+            }
+        }
+
+        // -------- sequential evaluation of the flips of this step -----------------------
+        double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
+        for (int f = 0; f < nfl; ++f) {
+            const int s = (int)rdlane((uint32_t)vsite, f), nw = (int)rdlane((uint32_t)vnew, f);
+            const int od = (int)rdlane((uint32_t)vold, f);
+            const uint16_t *p = idx_lane + (size_t)s * (64 * ROW);
+            uint16_t row[ROW];
+#pragma unroll
+            for (int q = 0; q < ROW; ++q) row[q] = p[q];
+            const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                uint32_t a = doff8[it];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row[it * MM + m]]);
+                const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
+                e = fma(wgt[it], d, e);
+                pend[it] += d;
+            }
+            if (has_ew) {
+                const int W = P.ew_W;
+                const double dq = P.ew_qs[(size_t)s * W + nw] - P.ew_qs[(size_t)s * W + od];
+                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s, swa, swm, swb);
+                ew_uni += 2.0 * dq * P.ew_frozen[s] + (P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od]);
+            }
+            if (has_mu) dMu += s_mu[nw] - s_mu[od];
+            if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative
+        }
+        double dH = wave_sum_all(e);
+        double dEw = 0.0;
+        if (has_ew) {
+            dEw = wave_sum_all(ew_part) + ew_uni;
+            dH += P.ew_coef * dEw;
+        }
+        if (has_mu) dH -= dMu;
+        const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        const bool accepted = (exponent >= 0.0) || (exponent > lu);
+        if (accepted) {
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
+            if (dir >= 0 && lane < nc) {
+                const int *urow = P.tf_table + (dir >> 1) * nc;
+                s_cnt[lane] += ((dir & 1) ? -1 : 1) * urow[lane];
+            }
+            acc_mu += dMu;
+            acc_ew += dEw;
+            H += dH;
+            nacc++;
+        } else {
+            for (int f = nfl - 1; f >= 0; --f) { // undo the tentative flips
+                const int s = (int)rdlane((uint32_t)vsite, f), od = (int)rdlane((uint32_t)vold, f);
+                if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
+            }
+        }
+        last_acc = accepted ? 1 : 0;
+
+        if (P.smp.every && --smp_countdown == 0) {
+            smp_countdown = P.smp.every;
+            const size_t rowi = (size_t)smp_index * P.R + r;
+            smp_index++;
+            s_feat[lane] = 0.0;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it)
+                __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (lane < P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + s_feat[lane];
+            if (has_ew && lane == P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + acc_ew;
+            if (has_mu && lane == P.Fce + (has_ew ? 1 : 0)) P.smp.feat[rowi * P.F + lane] = base_feat + acc_mu;
+            if (lane == 0) {
+                P.smp.H[rowi] = H;
+                P.smp.acc[rowi] = (uint8_t)last_acc;
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + rowi * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
+    }
+
+    {
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+    }
+    s_feat[lane] = 0.0;
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it)
+        __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    if (lane == 0) {
+        if (has_ew) featp[P.Fce] += acc_ew;
+        if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] = nacc;
+        P.last_acc[r] = (uint8_t)last_acc;
+    }
+}
+
+
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL>
+static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned grid = (unsigned)((h->R + 3) / 4);
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+template <int NSLOT, int MM, int STEP>
+static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU)
+        return launch_lean_inst<NSLOT, MM, STEP, false, false, true>(h, lp);
+    if (ew)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, false, false>(h, lp);
+}
+template <int NSLOT, int MM>
+static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
+    if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
+    return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
+}
+template <int NSLOT, int MM>
+static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned grid = (unsigned)((h->R + 3) / 4);
+    auto kern = mc_table_kernel<NSLOT, MM>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+
+template <int NSLOT> static int launch_lean_nslot(smolmc_handle *h, const LeanParams &lp) {
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+        return h->lean_mm == 2 ? launch_table_inst<NSLOT, 2>(h, lp) : launch_table_inst<NSLOT, 3>(h, lp);
+    return h->lean_mm == 2 ? launch_lean_nm<NSLOT, 2>(h, lp) : launch_lean_nm<NSLOT, 3>(h, lp);
+}

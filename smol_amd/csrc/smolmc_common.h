@@ -1,0 +1,332 @@
+// smolmc_common.h -- shared declarations of the MI355X (gfx950) ensemble Monte-Carlo engine.
+// Translation units: engine.hip (C-ABI, table preparation, evaluation kernels),
+// general_n{2,4,8,16}.hip (mc_kernel instantiations), lean_n{2,4}.hip (mc_lean_kernel and
+// mc_table_kernel instantiations).  mc_general.h / mc_lean.h hold the kernel templates.
+//
+// Hot path: per-flip local cluster-interaction / correlation delta
+// (smol/utils/cluster/evaluator.pyx:211-317), Ewald single-flip delta
+// (smol/utils/cluster/ewald.pyx:9-59), Metropolis / Wang-Landau accept
+// (smol/moca/kernel/metropolis.py:31-49, wanglandau.py:186-266), ushers
+// (smol/moca/kernel/mcusher.py:154-200), batched over independent walkers
+// (smol/moca/sampler/sampler.py:195-208, :436-440).
+//
+// Design (DESIGN.md has the long form):
+//   * one 64-lane wavefront owns one Markov chain for the whole launch; 4 chains
+//     per 256-thread workgroup share the read-only tables staged in LDS;
+//   * the chain's occupancy lives in LDS as one byte per site for the whole launch
+//     (loaded / stored coalesced once per launch); per-site cluster-member index
+//     rows stream coalesced from L2/HBM ([site][member][slot], slot = lane);
+//   * every lane evaluates <= NSLOT clusters of the flipped site, the enthalpy
+//     delta is a DPP wave reduction, the accept decision is wave-uniform;
+//   * feature (trace) deltas are accumulated per lane in LDS and reduced once per
+//     launch; Philox4x32-10 counter RNG generated 16 steps at a time across lanes.
+// MFMA is not used: the work is sparse integer gathers + table lookups.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/smolmc.h"
+#include "philox.h"
+
+// ----------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------
+extern thread_local std::string smolmc_g_err;
+static int fail(const std::string &m) {
+    smolmc_g_err = m;
+    return 1;
+}
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess)                                                             \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+static const double SMOLMC_KB = 8.617333262145e-5; // smol/constants.py:4
+
+// ----------------------------------------------------------------------------
+// device-side parameter block
+// ----------------------------------------------------------------------------
+// device-side sample recording (Sampler.sample + SampleContainer.save_sampled_trace,
+// sampler/sampler.py:195-210, container.py:384-397): every `every` steps one row per walker
+struct SampleBufs {
+    long long every;   // 0 = off
+    double *H;         // [nsamples][R]
+    double *feat;      // [nsamples][R][F]
+    uint8_t *acc;      // [nsamples][R]
+    uint8_t *occ;      // [nsamples][R][Npad] or null
+};
+
+struct KParams {
+    // model geometry
+    int N, Npad, Fce, F, nclasses, Cpad, Mmax, nsub, step_type;
+    int has_ewald, has_mu, ew_W, ew_M, mu_W, corr_mode;
+    // optimised MC tables
+    const void *idx;              // IdxT [N][Mmax][Cpad]
+    const uint8_t *site_class;    // [N] (255 = no clusters)
+    const uint4 *descA;           // [nclasses][Cpad]  {xoff, u16 strides[6]}
+    const uint4 *descB;           // [nclasses][Cpad]  {foff, tlen, feat|K<<16, 0}
+    const double *slot_fs;        // [nclasses][Cpad]  feature scale size/(ratio*J)
+    const int *cls_niter;         // [nclasses]
+    const double *xt;             // decision tensors (per class), xt_len doubles
+    const double *ft;             // feature tensors, ft_len doubles
+    int xt_len, ft_len;
+    // ewald / mu
+    const int *ew_inds;           // [N][ew_W]
+    const double *ew_Mt;          // [M][M] transposed ewald matrix
+    double ew_coef;
+    // compact Ewald (when the matrix factorises as q_a q_b G[site_a][site_b]):
+    int ew_compact, ew_nact;      // ew_nact = number of sites whose species can change
+    int ew_act_base;              // first such site when they are contiguous, else -1
+    const int *ew_act;            // [ew_nact] those sites
+    const double *ew_frozen;      // [N] sum over single-species sites k of q_k G[s][k]
+    const double *ew_G;           // [N][ew_nact] site kernel restricted to changeable sites
+    const double *ew_qs;          // [N][ew_W] charge of (site, code), 0 for vacancies
+    const double *ew_dg;          // [N][ew_W] diagonal entry M[a][a] of (site, code)
+    const double *mu;             // [N][mu_W]
+    // sublattices
+    const int *sub_ptr;           // [nsub+1]
+    const int *sub_sites;         // concatenated active sites
+    const int *sub_base;          // [nsub] first site if contiguous else -1
+    const int *sub_code_ptr;      // [nsub+1]
+    const int *sub_codes;
+    const double *sub_cum;        // [nsub] cumulative probabilities
+    // walker state
+    int R;
+    uint8_t *occ;                 // [R][Npad]
+    double *enthalpy;             // [R]
+    double *features;             // [R][F]
+    const double *beta;           // [R]
+    const uint64_t *seeds;        // [R]
+    uint64_t *nsteps, *nacc;      // [R]
+    uint8_t *last_acc;            // [R]
+    long long steps_to_run;
+    // replay
+    const int *rp_steps;          // [R][nsteps][4]
+    const double *rp_u;           // [R][nsteps]
+    uint8_t *rp_acc;              // [R][nsteps]
+    double *rp_H;                 // [R][nsteps]
+    // Wang-Landau
+    int L;
+    double wl_min, wl_max, wl_bin, wl_flat, wl_div;
+    long long wl_check, wl_update;
+    double *wl_entropy;           // [R][L]
+    long long *wl_hist;           // [R][L]
+    long long *wl_occur;          // [R][L]
+    double *wl_meanf;             // [R][L][F]
+    double *wl_m;                 // [R]
+    long long *wl_counter;        // [R]
+    // lds layout (bytes)
+    int lds_tables, lds_per_wave;
+    SampleBufs smp;
+};
+
+// ----------------------------------------------------------------------------
+// wave helpers
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    // inclusive DPP scan inside each 16-lane row, then row broadcasts; lane 63 holds
+    // the total, returned wave-uniform.
+#define SMOLMC_DPP_STEP(ctrl, rmask)                                                       \
+    {                                                                                      \
+        int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false); \
+        int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
+        v += __hiloint2double(hi_, lo_);                                                   \
+    }
+    SMOLMC_DPP_STEP(0x111, 0xf) // row_shr:1
+    SMOLMC_DPP_STEP(0x112, 0xf) // row_shr:2
+    SMOLMC_DPP_STEP(0x114, 0xf) // row_shr:4
+    SMOLMC_DPP_STEP(0x118, 0xf) // row_shr:8
+    SMOLMC_DPP_STEP(0x142, 0xa) // row_bcast:15 -> rows 1,3
+    SMOLMC_DPP_STEP(0x143, 0xc) // row_bcast:31 -> rows 2,3
+#undef SMOLMC_DPP_STEP
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ double uni_d(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// exact floor(x / y), y > 0 : Python's float // (wanglandau.py:180)
+__device__ __forceinline__ double floordiv_exact(double x, double y) {
+    double q = floor(x / y);
+    double r = fma(-q, y, x);
+    if (r < 0) q -= 1.0;
+    else if (r >= y) q += 1.0;
+    return q;
+}
+
+
+// ----------------------------------------------------------------------------
+// lean Metropolis kernel (parameter blocks; the kernel itself is in mc_lean.h): one site class, one contiguous active sublattice with the
+// default encoding, cluster-interaction features, no Ewald term, engine RNG.
+// This is the shape of BASELINE configs 1/2/4; everything else takes mc_kernel.
+//   * member index rows are lane-packed: idx[site][lane][NSLOT][MM] (u16), one vector
+//     load per flip;
+//   * per-(orbit, self position) DELTA tables dt[(old*S+new)][base] = T[.. new ..] - T[.. old ..]
+//     live in LDS: one 8-byte LDS read per cluster instead of two reads + a subtract
+//     (the subtraction is done once on the host in float64: identical value);
+//   * slot constants and feature accumulators stay in registers for the whole launch.
+// ----------------------------------------------------------------------------
+struct WlParams { // Wang-Landau state of the walkers (kernel/wanglandau.py:107-122)
+    int L;
+    double vmin, vmax, bin, flat, div;
+    long long check, update;
+    double *entropy;     // [R][L]
+    long long *hist;     // [R][L]
+    long long *occur;    // [R][L]
+    double *meanf;       // [R][L][F]
+    double *m;           // [R]
+    long long *counter;  // [R]
+};
+
+struct LeanSlot {
+    uint32_t doff8;      // byte offset of the slot's delta table
+    uint32_t stride8[3]; // 8 * stride of the other members
+    uint32_t feat;       // feature index (orbit id)
+    uint32_t live;       // 0 for padded slots
+    double w;            // natural parameter * size / (ratio * J)
+    double fs;           // size / (ratio * J)
+};
+
+struct LeanParams {
+    const uint16_t *idx;   // [N][64][NSLOT][MM]
+    const double *dt;      // delta tables, all padded to a common [S*S][NTP] shape
+    const LeanSlot *slots; // [NSLOT][64]
+    const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
+    uint8_t *occ;
+    double *enthalpy, *features;
+    const double *beta;
+    const uint64_t *seeds;
+    uint64_t *nsteps, *nacc;
+    uint8_t *last_acc;
+    int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
+    uint32_t nt8, snt8;    // 8*NTP and 8*NTP*S: (old, new) -> byte offset old*snt8 + new*nt8
+    // LDS address of site s = s ^ (((s >> swz_a) & swz_m) << swz_b): a bank swizzle chosen on
+    // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
+    int swz_a, swz_m, swz_b, Nlds;
+    long long steps;
+    SampleBufs smp;
+    // compact Ewald term (see build_compact_ewald); feature index Fce, coefficient ew_coef
+    int ew_W, ew_nact, ew_act_base;
+    const int *ew_act;
+    const double *ew_G, *ew_qs, *ew_dg, *ew_frozen;
+    double ew_coef;
+    WlParams wl;
+    // TableFlip (mcusher.py:397-711) for the single active sublattice
+    int tf_n;               // number of flip vectors
+    const int *tf_table;    // [tf_n][ncodes]
+    const double *tf_w;     // [2 tf_n]
+    double tf_sw;           // swap_weight
+};
+
+__device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
+
+
+struct RefTables { // device copies of the smolmc_tables arrays
+    int N, Npad, P, num_orbits, num_corr, n_orb, Fce, F, corr_mode;
+    const int *orb_id, *orb_bit_id, *orb_nsites, *orb_nfunc, *orb_tensor_len, *orb_stride_off,
+        *tensor_indices;
+    const long long *orb_ctensor_off, *orb_itensor_off, *full_off, *site_ptr, *loc_off;
+    const double *corr_tensors, *interaction_tensors, *loc_ratio;
+    const int *full_idx, *loc_orbit, *loc_nrows, *loc_idx;
+    double offset;
+    int has_ewald, ew_W, ew_M, has_mu, mu_W;
+    const int *ew_inds;
+    const double *ew_M_rowmajor; // original matrix (for the full feature)
+    const double *ew_Mt;
+    const double *mu;
+};
+
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct smolmc_handle {
+    smolmc_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<void *> allocs;
+    KParams kp;
+    RefTables rt;
+    int R = 0, N = 0, Npad = 0, F = 0, Fce = 0, L = 0;
+    std::vector<double> natural;
+    // dispatch
+    int nslot = 0, mm = 0;
+    bool generic = false, idx16 = false;
+    size_t lds_bytes = 0;
+    int waves_per_block = 4;
+    // lean kernel (single class / single contiguous sublattice / interactions / no ewald)
+    bool lean_tables = false, lean = false;
+    int lean_nslot = 0, lean_mm = 0;
+    size_t lean_lds = 0;
+    LeanParams lp;
+    // device-side samples of the last smolmc_run_sampled
+    SampleBufs smp;
+    long long smp_n = 0;
+    bool smp_has_occ = false;
+    // scratch
+    uint8_t *d_eval_occ = nullptr;
+    size_t eval_occ_cap = 0;
+    double *d_natural = nullptr;
+    double *d_beta = nullptr;
+};
+
+static void free_samples(smolmc_handle *h);
+
+template <typename T>
+static int dev_upload(smolmc_handle *h, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIPCHK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (n) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)p;
+    return 0;
+}
+template <typename T> static int dev_alloc(smolmc_handle *h, size_t n, T **dst, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIPCHK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (zero) HIPCHK(hipMemset(p, 0, bytes));
+    *dst = (T *)p;
+    return 0;
+}
+#define TRY(x)                                                                            \
+    do {                                                                                  \
+        if (int rc_ = (x)) return rc_;                                                    \
+    } while (0)
+
+
+// launchers defined in the per-NSLOT translation units
+int smolmc_launch_general_2(smolmc_handle *h, const KParams &kp, int replay);
+int smolmc_launch_general_4(smolmc_handle *h, const KParams &kp, int replay);
+int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
+int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
+int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);

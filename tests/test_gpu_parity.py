@@ -292,3 +292,62 @@ def test_compact_ewald_matches_dense_rows_and_oracle(step, monkeypatch):
         np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(a["features"], x["features"], rtol=RTOL, atol=1e-8)
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
+@pytest.mark.parametrize("cutoffs,step", [
+    ({2: 6.0, 3: 5.0, 4: 4.2}, capi.STEP_SWAP),   # 183 clusters/site, quadruplets: NSLOT=4, MM=3
+    ({2: 7.5, 3: 5.8}, capi.STEP_FLIP),            # 717 clusters/site: NSLOT=16 (general kernel)
+])
+def test_large_cluster_sets_match_oracle(cutoffs, step, general, monkeypatch):
+    """Models with many clusters per site (more lanes-slots per wave, 4-body clusters)."""
+    from oracle import oracle as orc
+    from smol_amd import synth
+
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    model = synth.build_cluster_model(synth.fcc_prim(), cutoffs)
+    sc = synth.build_supercell(model, [6, 6, 6])
+    mu = None
+    if step == capi.STEP_FLIP:
+        mu = np.tile(np.array([0.05, -0.1]), (sc.num_sites, 1))
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=9, scale=0.005), mu_table=mu)
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(31)
+    occ0 = (rng.random((R, sc.num_sites)) < 0.5).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(77)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ0, seeds, 1800.0)
+    ora.set_state(occ0, seeds, 1800.0)
+    np.testing.assert_allclose(eng.get_state()["features"], ora.get_state()["features"], rtol=RTOL, atol=1e-8)
+    eng.run(300)
+    ora.run(300)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"])
+    assert np.array_equal(a["n_accepted"], b["n_accepted"])
+    np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+
+
+def test_model_loaded_from_npz_runs_identically(tmp_path):
+    """A model that went through the wire format (smol_amd.io) drives the engine to the same
+    trajectory as the in-memory tables."""
+    from smol_amd import io
+
+    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=T["C_mu"])
+    path = str(tmp_path / "m.npz")
+    io.save_tables(path, tab)
+    tab2 = io.load_tables(path)
+    cfg = capi.make_config(3, capi.KERNEL_METROPOLIS, capi.STEP_FLIP)
+    a, b = _engine(tab, cfg), _engine(tab2, cfg)
+    occ0 = np.tile(T["C_occ0"], (3, 1))
+    for e in (a, b):
+        e.set_state(occ0, [1, 2, 3], 2000.0)
+        e.run(250)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["occupancy"], sb["occupancy"])
+    np.testing.assert_array_equal(sa["enthalpy"], sb["enthalpy"])

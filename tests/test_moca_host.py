@@ -73,6 +73,8 @@ def test_sampler_from_ensemble_defaults_and_errors(ensemble):
     finally:
         ensemble.chemical_potentials = None
     with pytest.raises(ValueError):
+        moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="multi-step")
+    with pytest.raises(NotImplementedError):  # TableFlip needs an explicit flip table here
         moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="table-flip")
     with pytest.raises(NotImplementedError):
         moca.Sampler.from_ensemble(ensemble, temperature=500, kernel_type="UniformlyRandom")
