@@ -428,7 +428,7 @@ class TableSet:
             for s in range(sc.num_sites):
                 for code in range(prim.nspecies[sc.site_b[s]]):
                     if inds[s, code] >= 0:
-                        q[inds[s, code]] = prim.charges[sc.site_b[s]][code]
+                        q[inds[s, code]] = prim.charges[sc.site_b[s]][code]  # vacancies have no index
             return q
         return ewald_charges
 

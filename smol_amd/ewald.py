@@ -131,7 +131,12 @@ def supercell_ewald(sc, eta=None, acc=12.0):
     prim = sc.model.prim
     P, N = sc.size, sc.num_sites
     nsp = np.array([prim.nspecies[b] for b in sc.site_b])
-    inds, M = ewald_indices(nsp)
+    vac = {}
+    for s in range(N):
+        v = {c for c, q in enumerate(prim.charges[sc.site_b[s]]) if q is None}
+        if v:
+            vac[s] = v
+    inds, M = ewald_indices(nsp, vac)
     # supercell lattice and site fractional coords (in supercell basis)
     sc_lat = sc.scmatrix.astype(float) @ prim.lattice
     inv = np.linalg.inv(sc.scmatrix.astype(float))

@@ -98,7 +98,8 @@ class PrimCell:
             self.charges = [[0.0] * s for s in self.nspecies]
         if self.labels is None:
             self.labels = [
-                (self.nspecies[b], tuple(self.charges[b])) for b in range(self.nb)
+                (self.nspecies[b], tuple(-1e9 if q is None else q for q in self.charges[b]))
+                for b in range(self.nb)
             ]
 
     @property
@@ -583,16 +584,22 @@ def fcc_conventional_prim(a=4.09, nspecies=2):
     return PrimCell(lat, fc, [nspecies] * 4)
 
 
-def rocksalt_prim(a=4.2, cation_charges=(1.0, 3.0, 4.0), anion_charge=-2.0):
-    """Rocksalt primitive cell: cation site (len(cation_charges) species) + fixed anion."""
+def rocksalt_prim(a=4.2, cation_charges=(1.0, 3.0, 4.0), anion_charge=-2.0, anion_charges=None):
+    """Rocksalt primitive cell: cation site (len(cation_charges) species) + anion site.
+
+    A charge of ``None`` marks a Vacancy (last in the site space like the reference,
+    smol/cofe/space/domain.py:157-161; it gets no Ewald index).  ``anion_charges`` with more
+    than one entry makes the anion sublattice active too (e.g. (-2, -1) for O2-/F-)."""
     lat = 0.5 * a * np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=float)
     names = ["Li+", "Mn3+", "Ti4+", "Nb5+", "Zr4+"]
+    an = list(anion_charges) if anion_charges is not None else [anion_charge]
+    cat_names = [("Vacancy" if q is None else names[i]) for i, q in enumerate(cation_charges)]
     return PrimCell(
         lat,
         [[0, 0, 0], [0.5, 0.5, 0.5]],
-        [len(cation_charges), 1],
-        charges=[list(cation_charges), [anion_charge]],
-        species=[names[: len(cation_charges)], ["O2-"]],
+        [len(cation_charges), len(an)],
+        charges=[list(cation_charges), an],
+        species=[cat_names, ["O2-", "F-", "S2-"][: len(an)]],
     )
 
 

@@ -19,6 +19,12 @@ CASES = {
     "fcc3_indicator_skew": dict(prim=lambda: synth.fcc_prim(nspecies=3), cutoffs={2: 5.0, 3: 3.0},
                                 sc=[[3, 0, 0], [1, 4, 0], [0, 1, 5]], basis="indicator",
                                 ewald=False, seed=4),
+    "rocksalt333_vacancy_ewald": dict(prim=lambda: synth.rocksalt_prim(cation_charges=(1.0, 3.0, None)),
+                                      cutoffs={2: 6.0, 3: 4.5}, sc=[3, 3, 3], basis="sinusoid",
+                                      ewald=True, seed=6),
+    "rocksalt333_two_sublattices": dict(prim=lambda: synth.rocksalt_prim(anion_charges=(-2.0, -1.0)),
+                                        cutoffs={2: 4.5, 3: 3.2}, sc=[3, 3, 3], basis="sinusoid",
+                                        ewald=True, seed=7),
     "fcc_prim222_aliased": dict(prim=lambda: synth.fcc_prim(), cutoffs={2: 6.0, 3: 5.0},
                                 sc=[2, 2, 2], basis="sinusoid", ewald=False, seed=5),
 }

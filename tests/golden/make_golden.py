@@ -484,6 +484,16 @@ def main():
     mE = golden_case(core, "fcc_prim222_aliased", synth.fcc_prim(), {2: 6.0, 3: 5.0},
                      [2, 2, 2], nflips=40, seed=5)
 
+    # case F: vacancies on the cation site (Ewald index -1 paths of ewald.pyx:46-57)
+    mF = golden_case(core, "rocksalt333_vacancy_ewald",
+                     synth.rocksalt_prim(cation_charges=(1.0, 3.0, None)), {2: 6.0, 3: 4.5},
+                     [3, 3, 3], with_ewald=True, seed=6)
+    # case G: two ACTIVE sublattices (cations Li/Mn/Ti + anions O/F): mixed site spaces in
+    # one orbit, two site classes, sublattice choice in the ushers
+    mG = golden_case(core, "rocksalt333_two_sublattices",
+                     synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 4.5, 3: 3.2},
+                     [3, 3, 3], with_ewald=True, seed=7)
+
     # trajectories (replay mode)
     from smol_amd import ewald as ewmod
 
@@ -527,6 +537,20 @@ def main():
     r = run_metropolis(proc, "int", subs, "swap", 1500.0, occ0, 1500, seed=98)
     traj.update({f"C_swap_int_{k}": v for k, v in r.items()})
     traj["C_occ0"], traj["C_mu"], traj["C_T"] = occ0, mu, np.array([1500.0])
+    # two active sublattices (case G): swap and semigrand flip
+    model, sc, coefs, proc, active = mG
+    nsp = np.array([model.prim.nspecies[b] for b in sc.site_b])
+    subs = [Sub(np.flatnonzero(sc.site_b == 0), 3), Sub(np.flatnonzero(sc.site_b == 1), 2)]
+    occ0 = rand_occ(np.random.default_rng(19), sc)
+    mu = np.zeros((sc.num_sites, 3))
+    mu[sc.site_b == 0] = [0.2, -0.1, 0.05]
+    mu[sc.site_b == 1, :2] = [-0.3, 0.15]
+    r = run_metropolis(proc, "int", subs, "swap", 2500.0, occ0, 1500, seed=71)
+    traj.update({f"G_swap_int_{k}": v for k, v in r.items()})
+    proc.mu_table = mu
+    r = run_metropolis(proc, "corr", subs, "flip", 2500.0, occ0, 1500, seed=72)
+    traj.update({f"G_flip_corr_{k}": v for k, v in r.items()})
+    traj["G_occ0"], traj["G_mu"], traj["G_T"] = occ0, mu, np.array([2500.0])
     np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **traj)
     print("trajectories written")
 

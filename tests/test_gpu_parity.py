@@ -79,6 +79,39 @@ def test_replay_semigrand_flip_ewald_mu(mode):
     _check_replay(eng, f"C_flip_{mode}", 2)
 
 
+def test_replay_two_sublattices():
+    tab = tables_for("rocksalt333_two_sublattices", MODES["int"])
+    eng = _engine(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    eng.set_state(np.tile(T["G_occ0"], (2, 1)), temperature=T["G_T"][0])
+    _check_replay(eng, "G_swap_int", 2)
+    tab = tables_for("rocksalt333_two_sublattices", MODES["corr"], mu_table=T["G_mu"])
+    eng = _engine(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    eng.set_state(np.tile(T["G_occ0"], (2, 1)), temperature=T["G_T"][0])
+    _check_replay(eng, "G_flip_corr", 2)
+
+
+def test_empty_swap_steps_on_gpu():
+    """No site of another species: empty, 'accepted' steps that change nothing
+    (mcusher.py:197-199); with one solute the partner search falls back to the long
+    candidate stream."""
+    from oracle import oracle as orc
+
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    cfg = capi.make_config(3, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    occ = np.zeros((3, tab.num_sites), dtype=np.int32)
+    occ[1, 0] = 1
+    occ[2, :3] = 1
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ, [3, 4, 5], 800.0)
+    ora.set_state(occ, [3, 4, 5], 800.0)
+    eng.run(400)
+    ora.run(400)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"])
+    assert np.array_equal(a["n_accepted"], b["n_accepted"])
+    assert np.array_equal(a["occupancy"][0], occ[0]) and a["n_accepted"][0] == 400
+
+
 def test_replay_swap_ewald():
     tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=T["C_mu"])
     eng = _engine(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
@@ -117,12 +150,19 @@ CONFIGS = [
     ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None),
     ("fcc3_indicator_skew", "corr", capi.STEP_SWAP, None),
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2"),
+    ("rocksalt333_vacancy_ewald", "int", capi.STEP_FLIP, "mu3"),
+    ("rocksalt333_vacancy_ewald", "corr", capi.STEP_SWAP, None),
+    ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None),
+    ("rocksalt333_two_sublattices", "corr", capi.STEP_FLIP, "muG"),
+    ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG"),
 ]
 
 
 def _mu(kind, c):
     if kind is None:
         return None
+    if kind == "muG":
+        return T["G_mu"]
     nsp = 2 if kind == "mu2" else 3
     mu = np.zeros((c["sc"].num_sites, nsp))
     act = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b]) > 1
@@ -351,3 +391,27 @@ def test_model_loaded_from_npz_runs_identically(tmp_path):
     sa, sb = a.get_state(), b.get_state()
     assert np.array_equal(sa["occupancy"], sb["occupancy"])
     np.testing.assert_array_equal(sa["enthalpy"], sb["enthalpy"])
+
+
+def test_more_than_65535_sites_uses_32bit_rows():
+    """N > 65535: index rows no longer fit 16 bits (general kernel with int32 rows)."""
+    from oracle import oracle as orc
+    from smol_amd import synth
+
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [41, 41, 41])  # 68921 sites
+    assert sc.num_sites > 65535
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=2))
+    R = 3
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    rng = np.random.default_rng(3)
+    occ0 = (rng.random((R, sc.num_sites)) < 0.5).astype(np.int32)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ0, [7, 8, 9], 1500.0)
+    ora.set_state(occ0, [7, 8, 9], 1500.0)
+    np.testing.assert_allclose(eng.get_state()["features"], ora.get_state()["features"], rtol=RTOL)
+    eng.run(500)
+    ora.run(500)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"])
+    np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)

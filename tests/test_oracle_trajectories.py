@@ -53,6 +53,18 @@ def test_metropolis_swap_ewald_replay():
     _check(mc, "C_swap_int")
 
 
+def test_two_sublattice_replays():
+    """Two active sublattices: sublattice choice in the ushers, mixed site spaces."""
+    tab = tables_for("rocksalt333_two_sublattices", MODES["int"])
+    mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    mc.set_state(T["G_occ0"][None], [0], T["G_T"])
+    _check(mc, "G_swap_int")
+    tab = tables_for("rocksalt333_two_sublattices", MODES["corr"], mu_table=T["G_mu"])
+    mc = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    mc.set_state(T["G_occ0"][None], [0], T["G_T"])
+    _check(mc, "G_flip_corr")
+
+
 @pytest.mark.parametrize("tag", ["B_wl", "B_wlflat"])
 def test_wang_landau_replay(tag):
     tab = tables_for("fcc_prim666_triplets", MODES["int"])
@@ -128,3 +140,19 @@ def test_usher_statistics():
         assert counts[nact:].sum() == 0  # anions are never proposed
         p = counts[:nact] / n
         assert abs(p - 1 / nact).max() < 5 * np.sqrt(1 / nact / n)
+
+
+def test_empty_swap_steps_when_no_partner_exists():
+    """Swap on a single-species occupancy: swap_options is empty, the step is [] and is
+    'accepted' without changing anything (mcusher.py:197-199, metropolis.py:46)."""
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    mc = orc.OracleMC(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    occ = np.zeros((2, tab.num_sites), dtype=np.int32)
+    occ[1, 0] = 1  # one solute: swaps are possible but partners are rare
+    mc.set_state(occ, [3, 4], 800.0)
+    s0 = mc.get_state()
+    mc.run(300)
+    st = mc.get_state()
+    assert np.array_equal(st["occupancy"][0], occ[0])
+    assert st["n_accepted"][0] == 300 and st["enthalpy"][0] == s0["enthalpy"][0]
+    assert st["occupancy"][1].sum() == 1  # the solute only moved
