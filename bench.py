@@ -72,19 +72,13 @@ def usable_cores():
 MEASURED_TRAFFIC_BYTES = {(4096, 10000): 5.08e7}
 
 
-def cpu_baseline(tab, sc, seconds=12.0):
-    """The CPU oracle (port of the reference's compiled core + kernel logic) timed on the
-    host cores of this box with OpenMP over walkers, on a bounded sample of the workload."""
-    cores = usable_cores()
-    # before the oracle library is loaded; bound, passive-wait threads are ~2.3x faster than
-    # libgomp's defaults under this box's cgroup quota (tools/cpu_baseline_probe.py)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+def cpu_baseline_child(seconds=12.0):
+    """Runs inside a fresh interpreter (see cpu_baseline): the CPU oracle timed on the host."""
+    cores = int(os.environ["OMP_NUM_THREADS"])
     from oracle import oracle as orc
     from smol_amd import capi
 
+    model, sc, tab = build_workload()
     R = max(cores, 1) * 4
     cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
     mc = orc.OracleMC(tab, cfg)
@@ -96,14 +90,32 @@ def cpu_baseline(tab, sc, seconds=12.0):
         mc.run(chunk)
         done += chunk
     dt = time.perf_counter() - t0
-    return {
+    print(json.dumps({
         "value": 2.0 * R * done / dt,
         "unit": "attempted flips/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{R} walkers x {done} swap steps of the same 4096-site workload, "
-                  f"OpenMP over walkers ({cores} threads), {dt:.1f} s",
-    }
+                  f"OpenMP over walkers ({cores} bound threads), {dt:.1f} s",
+    }))
+
+
+def cpu_baseline():
+    """The CPU oracle (port of the reference's compiled core + kernel logic) timed on the
+    host cores of this box with OpenMP over walkers, on a bounded sample of the workload.
+    It runs in a fresh interpreter: libgomp reads its environment once, when first loaded,
+    and torch has already loaded it in this process (bound, passive-wait threads are ~2.3x
+    faster than the defaults under this box's cgroup quota, tools/cpu_baseline_probe.py)."""
+    import subprocess
+
+    cores = usable_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores",
+               OMP_WAIT_POLICY="passive")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -114,7 +126,11 @@ def main():
     ap.add_argument("--replicas", type=int, default=N_REPLICAS)
     ap.add_argument("--mc-per-step", type=int, default=MC_PER_STEP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child()
+        return
 
     import torch
     import torch.distributed as dist
@@ -225,7 +241,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tab, sc)
+            out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -475,6 +475,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         std::map<std::pair<int, int>, uint32_t> doff_of;
         const std::vector<Slot> &sl = slots[class_rep[0]];
         bool ok = true;
+        double sum_abs = 0.0;
         for (size_t q = 0; q < sl.size() && ok; ++q) {
             const Slot &k = sl[q];
             const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
@@ -505,7 +506,17 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.w = t->ce_coefs[t->orb_id[o]] * scale;
             L.fs = scale;
             if (dt.size() > 5500) ok = false; // keep the LDS tables within budget
+            double dmax = 0.0;
+            {
+                const double *D = dt.data() + doff_of[key];
+                for (size_t z = 0; z < tlen; ++z) dmax = std::max(dmax, std::fabs(D[z]));
+            }
+            sum_abs += std::fabs(L.w) * dmax;
         }
+        // float32 pre-test of the accept decision: a step sums at most two flips' worth of
+        // |w * d| over the slots, a float32 conversion + 6-level tree adds at most
+        // 7 * 2^-24 of that; 2^-19 leaves a 4.5x margin.
+        h->lp.fast_eps = 2.0 * sum_abs * ldexp(1.0, -19);
         h->lp.nt8 = (uint32_t)NTP * 8u;
         h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
@@ -840,6 +851,12 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         if (lean) {
             LeanParams &lp = h->lp;
             if (t->has_mu && dev_upload(h, mu_row.data(), mu_row.size(), &lp.mu_row)) return bail(1);
+            if (t->has_mu) { // the mu delta of a step joins the float32 sum (<= 2 flips * 2 |mu|)
+                double mmax = 0.0;
+                for (double v : mu_row) mmax = std::max(mmax, std::fabs(v));
+                lp.fast_eps += 4.0 * mmax * ldexp(1.0, -19);
+            }
+            if (getenv("SMOLMC_NO_FAST_ACCEPT")) lp.fast_eps = 0.0; // A/B switch
             lp.occ = kp.occ;
             lp.enthalpy = kp.enthalpy;
             lp.features = kp.features;

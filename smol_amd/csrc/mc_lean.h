@@ -29,6 +29,32 @@ __device__ __forceinline__ double wave_sum_all(double v) {
     return v;
 }
 
+// float32 sum over the wave for the accept pre-test, returned wave-uniform: 4 fused
+// v_add_f32_dpp inside the 16-lane rows, then row_bcast:15 / row_bcast:31 in place (rows
+// outside the row mask keep their value; only lane 63 needs the total) and v_readlane 63.
+// The compiler does not fuse the partial-row-mask forms, hence the asm; the s_nops are the
+// gfx9 DPP / readlane-SGPR wait states the hazard recogniser cannot see inside asm.
+template <int CTRL> __device__ __forceinline__ float dpp_add_f32(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_f32_uniform(float v) {
+    v = dpp_add_f32<0xB1>(v);
+    v = dpp_add_f32<0x4E>(v);
+    v = dpp_add_f32<0x141>(v);
+    v = dpp_add_f32<0x140>(v);
+    float total;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_readlane_b32 %0, %1, 63\n\t"
+                 "s_nop 1"
+                 : "=s"(total), "+v"(v));
+    return total;
+}
+
 // The same sum on the matrix pipe: two v_mfma_f64_16x16x4_f64 with B = ones
 // (D[i][j] = sum_k A[i][k], lane l holds A[l & 15][l >> 4]; C/D: col = lane & 15,
 // row = (lane >> 4) + 4 * reg) and three VALU adds in between.  Frees ~19 VALU issue
@@ -139,6 +165,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
     double acc_mu = 0.0, acc_ew = 0.0;
+    // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
+    // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
+    // only the rare undecided step pays for the float64 reduction, so decisions are exactly
+    // those of the float64 rule.  The enthalpy then accumulates per lane (acc_e) and is
+    // reduced when it is read (sample rows, end of launch).
+    constexpr bool FAST = !WL && !HAS_EW;
+    double acc_e = 0.0;
+    float thr_lo = 0.0f, thr_hi = 0.0f;
     int last_acc = 1;
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
     double *featp = P.features + (size_t)r * P.F;
@@ -178,6 +212,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // metropolis.py:46-48 compares the exponent with log(rng.random()): take the
             // float64 log of all 16 uniforms of the batch at once (lane-parallel)
             logu = log(philox_u53(o.w[2], o.w[3]));
+            if (FAST) {
+                // accept <=> -beta dH > log u <=> dH < log(u) / -beta =: thr  (dH <= 0 always
+                // passes since thr >= 0); certain on either side of thr -+ eps
+                const double thr = logu / nbeta;
+                const double eps = P.fast_eps + 1e-6 * fabs(thr);
+                thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
+                thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+            }
             if (STEP == SMOLMC_STEP_SWAP) {
                 cand[0] = sbase + (int)__umulhi(o.w[0], nact);
                 cand[1] = sbase + (int)__umulhi(o.w[1], nact);
@@ -302,38 +344,50 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                           (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
             }
         }
-        double dH = LEAN_WAVE_SUM(e);
-        double dEw = 0.0;
-        if (HAS_EW) {
-            dEw = LEAN_WAVE_SUM(ew_part) + ew_uni;
-            dH += P.ew_coef * dEw;
-        }
         double dMu = 0.0;
         if (HAS_MU && nfl >= 1) {
             dMu = s_mu[n1] - s_mu[o1];
             if (nfl == 2) dMu += s_mu[n2] - s_mu[o2];
-            dH -= dMu;
         }
-
-        // -------- accept / update (metropolis.py:31-49, kernel/base.py:327-343) --------
-        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
-                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        double dH = 0.0, dEw = 0.0;
         bool accepted;
-        if (!WL) {
-            const double exponent = nbeta * dH + 0.0;
-            accepted = (exponent >= 0.0) || (exponent > lu);
-        } else {
-            // WangLandau._accept_step (wanglandau.py:186-202)
-            const double new_h = H + dH;
-            if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
-                accepted = false;
-            } else {
-                const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
-                const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
-                const double exponent = wl_S[b] - wl_S[nb] + 0.0;
+        bool decided = false;
+        if (FAST) {
+            const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
+            const float S = wave_sum_f32_uniform(ef);
+            const unsigned long long bit = 1ull << l4;
+            const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
+            const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
+            decided = ca | cr;
+            accepted = ca;
+        }
+        if (!decided) {
+            dH = LEAN_WAVE_SUM(e);
+            if (HAS_EW) {
+                dEw = LEAN_WAVE_SUM(ew_part) + ew_uni;
+                dH += P.ew_coef * dEw;
+            }
+            if (HAS_MU) dH -= dMu;
+            // -------- accept (metropolis.py:31-49) --------
+            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                               (int)rdlane((uint32_t)__double2loint(logu), l4));
+            if (!WL) {
+                const double exponent = nbeta * dH + 0.0;
                 accepted = (exponent >= 0.0) || (exponent > lu);
+            } else {
+                // WangLandau._accept_step (wanglandau.py:186-202)
+                const double new_h = H + dH;
+                if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
+                    accepted = false;
+                } else {
+                    const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
+                    const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                    const double exponent = wl_S[b] - wl_S[nb] + 0.0;
+                    accepted = (exponent >= 0.0) || (exponent > lu);
+                }
             }
         }
+        // -------- update (kernel/base.py:327-343) --------
         if (accepted) {
             if (!WL) {
 #pragma unroll
@@ -357,7 +411,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             acc_mu += dMu;
             acc_ew += dEw;
-            H += dH;
+            if (FAST) acc_e += e; else H += dH;
             nacc++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
             if (lane == 0) occ[a1] = (uint8_t)o1; // undo the tentative first flip
@@ -425,8 +479,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (!WL && HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
             if (!WL && HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0))
                 P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            const double Hnow = FAST ? H + (wave_sum_all(acc_e) - acc_mu) : H;
             if (lane == 0) {
-                P.smp.H[row] = H;
+                P.smp.H[row] = Hnow;
                 P.smp.acc[row] = (uint8_t)last_acc;
             }
             if (P.smp.occ) {
@@ -461,6 +516,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     }
+    if (FAST) H += wave_sum_all(acc_e) - acc_mu;
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
         if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;

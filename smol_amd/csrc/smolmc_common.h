@@ -225,6 +225,9 @@ struct LeanParams {
     // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
     int swz_a, swz_m, swz_b, Nlds;
     long long steps;
+    // bound on |float32 tree sum - exact sum| of the per-lane enthalpy partials of one step
+    // (see the fast accept decision in mc_lean_kernel); 0 disables the float32 pre-test
+    double fast_eps;
     SampleBufs smp;
     // compact Ewald term (see build_compact_ewald); feature index Fce, coefficient ew_coef
     int ew_W, ew_nact, ew_act_base;
