@@ -857,6 +857,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.fast_eps += 4.0 * mmax * ldexp(1.0, -19);
             }
             if (getenv("SMOLMC_NO_FAST_ACCEPT")) lp.fast_eps = 0.0; // A/B switch
+            // test hook: widen the undecided band so that both decision paths interleave
+            if (const char *sc = getenv("SMOLMC_FAST_EPS_SCALE")) lp.fast_eps *= atof(sc);
             lp.occ = kp.occ;
             lp.enthalpy = kp.enthalpy;
             lp.features = kp.features;

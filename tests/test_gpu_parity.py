@@ -215,6 +215,39 @@ def test_native_stream_matches_oracle(name, mode, step, mukind, general, monkeyp
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
 
 
+@pytest.mark.parametrize("scale", ["1", "3e3", "1e9"], ids=["default-band", "wide-band", "always-exact"])
+@pytest.mark.parametrize("step,mukind", [(capi.STEP_SWAP, None), (capi.STEP_FLIP, "mu2")])
+def test_fast_accept_pretest_never_changes_a_decision(step, mukind, scale, monkeypatch):
+    """The lean kernel decides most steps on a float32 wave sum and falls back to the exact
+    float64 rule inside an error band.  Widening the band (test hook) makes the two decision
+    paths interleave at different rates; the trajectory must not depend on it and must equal
+    the oracle's (metropolis.py:46-48 evaluated in float64) over many steps and temperatures."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    monkeypatch.setenv("SMOLMC_FAST_EPS_SCALE", scale)
+    name = "fcc_prim666_triplets"
+    c = load_case(name)
+    tab = tables_for(name, MODES["int"], mu_table=_mu(mukind, c))
+    R = 64
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(17)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(104729)
+    temps = np.geomspace(30.0, 30000.0, R)  # from almost-always-reject to almost-always-accept
+    eng = _engine(tab, cfg)
+    ora = orc.OracleMC(tab, cfg)
+    eng.set_state(occ0, seeds, temps)
+    ora.set_state(occ0, seeds, temps)
+    eng.run(4000)
+    ora.run(4000)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"])
+    assert np.array_equal(a["n_accepted"], b["n_accepted"])
+    np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+
+
 @pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 def test_native_wang_landau_matches_oracle(general, monkeypatch):
     from oracle import oracle as orc
