@@ -66,10 +66,13 @@ def usable_cores():
     return max(1, n)
 
 
-# HBM bytes per launch of the default configuration from the PMC passes committed under
-# profiles/ (FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 correction + WRITE_SIZE): the
-# occupancies in and out; everything else is cache-resident.
-MEASURED_TRAFFIC_BYTES = {(4096, 10000): 5.08e7}
+# HBM bytes per launch of the default configuration from the two separate PMC passes committed
+# under profiles/ (r01_final_pmc.txt): FETCH_SIZE 17.36 MB + WRITE_SIZE 17.39 MB (KiB counters,
+# summed over 4 dispatches / 4).  MI355X_MICROARCH.md's x2 FETCH_SIZE correction is for 16 B/lane
+# streams; this kernel streams the occupancy with 4 B/lane loads and the undoubled counter already
+# equals the known byte count (16.78 MB of occupancy + the index rows), so it is used as read.
+# The occupancies go in and out once per launch; everything else is LDS/L2 resident.
+MEASURED_TRAFFIC_BYTES = {(4096, 10000): 3.475e7}
 
 
 def cpu_baseline_child(seconds=12.0):
