@@ -34,7 +34,11 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 1
+#define SMOLMC_ABI_VERSION 2
+
+#define SMOLMC_BIAS_NONE 0
+#define SMOLMC_BIAS_FUGACITY 1
+#define SMOLMC_BIAS_SQUARE_CHARGE 2
 #define SMOLMC_MAX_CLUSTER_SITES 6 /* largest cluster (sites per cluster) supported */
 
 /* feature_mode */
@@ -130,6 +134,19 @@ typedef struct smolmc_tables {
     const int32_t *flip_table;   /* [n_flip_vectors x sum(codes of active sublattices)] */
     const double *flip_weights;  /* [2 x n_flip_vectors] (mcusher.py:519-538) */
     double swap_weight;          /* probability of a canonical Swap instead (mcusher.py:540) */
+
+    /* MCBias (smol/moca/kernel/bias.py): an extra term delta_bias added to the Metropolis
+     * exponent (metropolis.py:43-44) and traced as `bias` (kernel/base.py:307-311,362-363).
+     * bias_table is [num_sites x bias_width], indexed [site][species code]:
+     *   SMOLMC_BIAS_FUGACITY       FugacityBias._fu_table (bias.py:208-226): fugacity fractions,
+     *                              1 where unused; bias = sum_sites log(table[site][occ])
+     *   SMOLMC_BIAS_SQUARE_CHARGE  SquareChargeBias._c_table (bias.py:256-262): oxidation states,
+     *                              0 where unused; bias = -bias_penalty * (sum_sites table)^2
+     * Not allowed with Wang-Landau (wanglandau.py:127-128). */
+    int32_t bias_type;           /* SMOLMC_BIAS_* */
+    int32_t bias_width;
+    const double *bias_table;
+    double bias_penalty;         /* SquareChargeBias.penalty (> 0) */
 } smolmc_tables;
 
 typedef struct smolmc_config {
@@ -177,6 +194,9 @@ int smolmc_get_state(smolmc_handle *h, int32_t *occ /*RxN*/, double *features /*
                      double *enthalpy /*R*/, uint64_t *n_accepted /*R*/,
                      uint64_t *n_steps /*R*/, uint8_t *last_accepted /*R*/);
 /* WangLandau trace extras (wanglandau.py:247-251,268-288); NULLs allowed */
+/* trace.bias of every walker (kernel/base.py:362-363 + accumulated delta_trace.bias);
+ * error when the model has no bias term */
+int smolmc_get_bias(smolmc_handle *h, double *bias /*R*/);
 int smolmc_get_wl(smolmc_handle *h, double *entropy /*RxL*/, int64_t *histogram /*RxL*/,
                   int64_t *occurrences /*RxL*/, double *mean_features /*RxLxF*/,
                   double *mod_factor /*R*/);

@@ -56,6 +56,11 @@ def lib():
         L.orc_mc_set_temperature.argtypes = [C.c_void_p, f64p]
         L.orc_mc_get_state.argtypes = [C.c_void_p, i32p, f64p, f64p, u64p, u64p, u8p]
         L.orc_mc_get_wl.argtypes = [C.c_void_p, f64p, i64p, i64p, f64p, f64p]
+        L.orc_mc_get_bias.argtypes = [C.c_void_p, f64p]
+        L.orc_compute_bias.restype = C.c_double
+        L.orc_compute_bias.argtypes = [tp, i32p]
+        L.orc_compute_bias_change.restype = C.c_double
+        L.orc_compute_bias_change.argtypes = [tp, i32p, i32p, C.c_int]
         L.orc_mc_run.argtypes = [C.c_void_p, C.c_int64]
         L.orc_mc_replay.argtypes = [C.c_void_p, C.c_int64, i32p, f64p, u8p, f64p]
         L.orc_mc_propose.argtypes = [C.c_void_p, C.c_int, C.c_uint64, i32p, f64p]
@@ -124,6 +129,15 @@ class OracleEvaluator:
             _p(wf, C.c_int32), _p(wi, C.c_int32), _p(out, C.c_double),
         )
         return out
+
+    def bias(self, occ):
+        """MCBias.compute_bias (bias.py:174-186, :264-277)."""
+        return lib().orc_compute_bias(self.t, _p(self._occ(occ), C.c_int32))
+
+    def bias_change(self, occ, flips):
+        """MCBias.compute_bias_change (bias.py:75-93, :188-206)."""
+        fl = np.ascontiguousarray(np.asarray(flips, dtype=np.int32).reshape(-1, 2))
+        return lib().orc_compute_bias_change(self.t, _p(self._occ(occ), C.c_int32), _p(fl, C.c_int32), len(fl))
 
     def natural_parameters(self):
         out = np.zeros(self.F)
@@ -204,6 +218,12 @@ class OracleMC:
             _p(mf, C.c_double), _p(m, C.c_double),
         )
         return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
+
+    def get_bias(self):
+        b = np.zeros(self.R)
+        if lib().orc_mc_get_bias(self.h, _p(b, C.c_double)):
+            raise RuntimeError("model has no bias term")
+        return b
 
     def propose(self, r, step, with_priori=False):
         fl = np.zeros(16, dtype=np.int32)

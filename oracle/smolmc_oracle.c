@@ -310,11 +310,63 @@ typedef struct orc_mc {
     /* Wang-Landau aux state (wanglandau.py:107-122) */
     double *wl_entropy, *wl_meanf, *wl_m, *wl_cur_h, *wl_cur_f;
     int64_t *wl_hist, *wl_occur, *wl_counter;
+    double *bias;      /* R: trace.bias (kernel/base.py:362-363) */
 } orc_mc;
+
+/* MCBias.compute_bias (smol/moca/kernel/bias.py:174-186 Fugacity, :264-277 SquareCharge) */
+double orc_compute_bias(const smolmc_tables *t, const int32_t *occ) {
+    int N = t->num_sites, W = t->bias_width;
+    if (t->bias_type == SMOLMC_BIAS_FUGACITY) {
+        double b = 0;
+        for (int s = 0; s < N; ++s) b += log(t->bias_table[(size_t)s * W + occ[s]]);
+        return b;
+    }
+    if (t->bias_type == SMOLMC_BIAS_SQUARE_CHARGE) {
+        double c = 0;
+        for (int s = 0; s < N; ++s) c += t->bias_table[(size_t)s * W + occ[s]];
+        return -t->bias_penalty * (c * c);
+    }
+    return 0.0;
+}
+
+/* compute_bias_change: FugacityBias overrides it with the log-ratio of the last flip per
+ * site (bias.py:188-206); SquareChargeBias inherits the recompute-and-subtract default
+ * (bias.py:75-93), restated on the running total charge */
+double orc_compute_bias_change(const smolmc_tables *t, const int32_t *occ, const int32_t *flips,
+                               int nflips) {
+    int W = t->bias_width;
+    if (t->bias_type == SMOLMC_BIAS_FUGACITY) {
+        double d = 0;
+        for (int f = 0; f < nflips; ++f) {
+            int site = flips[2 * f], last = 1;
+            for (int g = f + 1; g < nflips; ++g) last &= flips[2 * g] != site; /* dict keeps the last */
+            if (!last) continue;
+            d += log(t->bias_table[(size_t)site * W + flips[2 * f + 1]] /
+                     t->bias_table[(size_t)site * W + occ[site]]);
+        }
+        return d;
+    }
+    if (t->bias_type == SMOLMC_BIAS_SQUARE_CHARGE) {
+        double c = 0;
+        for (int s = 0; s < t->num_sites; ++s) c += t->bias_table[(size_t)s * W + occ[s]];
+        double cn = c;
+        for (int f = 0; f < nflips; ++f) {
+            int site = flips[2 * f], last = 1;
+            for (int g = f + 1; g < nflips; ++g) last &= flips[2 * g] != site;
+            if (!last) continue;
+            cn += t->bias_table[(size_t)site * W + flips[2 * f + 1]] -
+                  t->bias_table[(size_t)site * W + occ[site]];
+        }
+        return -t->bias_penalty * (cn * cn) - (-t->bias_penalty * (c * c));
+    }
+    return 0.0;
+}
 
 static const double ORC_KB = 8.617333262145e-5; /* smol/constants.py:4 */
 
 int orc_mc_create(const smolmc_tables *t, const smolmc_config *cfg, orc_mc **out) {
+    if (t->bias_type && cfg->kernel_type == SMOLMC_KERNEL_WANGLANDAU)
+        return 2; /* "Cannot apply bias to Wang-Landau simulation!" (wanglandau.py:127-128) */
     orc_mc *h = (orc_mc *)calloc(1, sizeof(orc_mc));
     if (!h) return 1;
     h->t = t;
@@ -334,6 +386,7 @@ int orc_mc_create(const smolmc_tables *t, const smolmc_config *cfg, orc_mc **out
     h->naccepted = (uint64_t *)calloc(h->R, 8);
     h->last_accepted = (uint8_t *)calloc(h->R, 1);
     h->natural = (double *)calloc(h->F, 8);
+    h->bias = (double *)calloc(h->R, 8);
     orc_natural_parameters(t, h->natural);
     if (cfg->kernel_type == SMOLMC_KERNEL_WANGLANDAU) {
         /* len(np.arange(min, max, bin)) (wanglandau.py:107) */
@@ -359,7 +412,7 @@ void orc_mc_destroy(orc_mc *h) {
     free(h->temperature); free(h->seeds); free(h->nsteps); free(h->naccepted);
     free(h->last_accepted); free(h->natural); free(h->wl_entropy); free(h->wl_hist);
     free(h->wl_occur); free(h->wl_meanf); free(h->wl_m); free(h->wl_cur_h); free(h->wl_cur_f);
-    free(h->wl_counter);
+    free(h->wl_counter); free(h->bias);
     free(h);
 }
 
@@ -391,6 +444,7 @@ int orc_mc_set_state(orc_mc *h, const int32_t *occ, const uint64_t *seeds,
         double *f = h->features + (size_t)r * h->F;
         orc_feature_vector(h->t, h->occ + (size_t)r * h->N, f);
         h->enthalpy[r] = dotp(h->natural, f, h->F);
+        h->bias[r] = orc_compute_bias(h->t, h->occ + (size_t)r * h->N);
         if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU) {
             memcpy(h->wl_cur_f + (size_t)r * h->F, f, sizeof(double) * h->F);
             h->wl_cur_h[r] = h->enthalpy[r];
@@ -421,6 +475,12 @@ int orc_mc_get_state(orc_mc *h, int32_t *occ, double *features, double *enthalpy
     if (n_accepted) memcpy(n_accepted, h->naccepted, (size_t)h->R * 8);
     if (n_steps) memcpy(n_steps, h->nsteps, (size_t)h->R * 8);
     if (last_accepted) memcpy(last_accepted, h->last_accepted, (size_t)h->R);
+    return 0;
+}
+
+int orc_mc_get_bias(orc_mc *h, double *bias) {
+    if (!h->t->bias_type) return 1;
+    memcpy(bias, h->bias, (size_t)h->R * 8);
     return 0;
 }
 
@@ -690,10 +750,12 @@ static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u,
     orc_feature_vector_change(t, occ, flips, nflips, h->work_f + (size_t)r * h->N,
                               h->work_i + (size_t)r * h->N, dfeat);
     double dH = dotp(h->natural, dfeat, F); /* base.py:303-306 */
+    double dB = t->bias_type ? orc_compute_bias_change(t, occ, flips, nflips) : 0.0; /* :307-311 */
     int accepted;
     if (h->cfg.kernel_type == SMOLMC_KERNEL_METROPOLIS) {
         double beta = 1.0 / (ORC_KB * h->temperature[r]); /* base.py:398 */
         double exponent = -beta * dH + log_priori;         /* metropolis.py:41-42 */
+        if (t->bias_type) exponent += dB;                  /* :43-44 */
         accepted = exponent >= 0 ? 1 : (exponent > log(u)); /* :46-48 */
     } else {
         double emin = h->cfg.wl_min_enthalpy, emax = h->cfg.wl_max_enthalpy, bsz = h->cfg.wl_bin_size;
@@ -719,6 +781,7 @@ static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u,
         double *feat = h->features + (size_t)r * F;
         for (int i = 0; i < F; ++i) feat[i] += dfeat[i]; /* sampler.py:204-207 */
         h->enthalpy[r] += dH;
+        h->bias[r] += dB;
         h->naccepted[r]++;
         if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU) { /* wanglandau.py:216-218 */
             double *cf = h->wl_cur_f + (size_t)r * F;

@@ -22,6 +22,7 @@ KERNEL_WANGLANDAU = 1
 STEP_FLIP = 0
 STEP_SWAP = 1
 STEP_TABLE_FLIP = 2
+BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE = 0, 1, 2
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -78,6 +79,10 @@ class smolmc_tables(C.Structure):
         ("flip_table", _i32p),
         ("flip_weights", _f64p),
         ("swap_weight", C.c_double),
+        ("bias_type", C.c_int32),
+        ("bias_width", C.c_int32),
+        ("bias_table", _f64p),
+        ("bias_penalty", C.c_double),
     ]
 
 
@@ -350,6 +355,30 @@ class TableSet:
         if self.struct.has_mu:
             p.append(-1.0)
         return np.array(p)
+
+    def set_bias(self, bias_type, table=None, penalty=0.0):
+        """Attach (or clear) an MCBias term (smol/moca/kernel/bias.py): ``table`` is the
+        reference's per-(site, species code) table -- fugacity fractions (BIAS_FUGACITY,
+        bias.py:208-226) or oxidation states (BIAS_SQUARE_CHARGE, bias.py:256-262)."""
+        t = self.struct
+        if bias_type == BIAS_NONE:
+            t.bias_type, t.bias_width, t.bias_penalty = 0, 0, 0.0
+            t.bias_table = _f64p()
+            self._keep.pop("bias_table", None)
+            return self
+        if bias_type not in (BIAS_FUGACITY, BIAS_SQUARE_CHARGE):
+            raise ValueError(f"unknown bias type {bias_type}")
+        tb = _arr(table, np.float64, "bias_table")
+        if tb.ndim != 2 or tb.shape[0] != t.num_sites or tb.shape[1] < t.max_species:
+            raise ValueError("bias table must be [num_sites x >= max species per site]")
+        if bias_type == BIAS_FUGACITY and not np.all(tb > 0):
+            raise ValueError("fugacity fractions must be positive")
+        if bias_type == BIAS_SQUARE_CHARGE and not penalty > 0:
+            raise ValueError("Penalty factor should be > 0!")  # bias.py:250-251
+        self._keep["bias_table"] = tb
+        t.bias_type, t.bias_width, t.bias_penalty = int(bias_type), tb.shape[1], float(penalty)
+        t.bias_table = _ptr(tb, C.c_double)
+        return self
 
     @classmethod
     def from_synth(

@@ -739,6 +739,28 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     kp.ew_Mt = h->rt.ew_Mt;
     kp.ew_coef = t->ewald_coef;
     kp.mu = h->rt.mu;
+    // MCBias (smol/moca/kernel/bias.py)
+    if (t->bias_type) {
+        if (t->bias_type != SMOLMC_BIAS_FUGACITY && t->bias_type != SMOLMC_BIAS_SQUARE_CHARGE)
+            return bail(fail("unknown bias_type"));
+        if (wl) return bail(fail("Cannot apply bias to Wang-Landau simulation!")); // wanglandau.py:127-128
+        if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP)
+            return bail(fail("bias terms are implemented for Flip / Swap steps"));
+        if (!t->bias_table || t->bias_width < t->max_species)
+            return bail(fail("bias_table must be [num_sites x >= max_species]"));
+        if (t->bias_type == SMOLMC_BIAS_SQUARE_CHARGE && !(t->bias_penalty > 0.0))
+            return bail(fail("Penalty factor should be > 0!")); // bias.py:250-251
+        h->bias_host.assign(t->bias_table, t->bias_table + (size_t)t->num_sites * t->bias_width);
+        if (t->bias_type == SMOLMC_BIAS_FUGACITY)
+            for (double v : h->bias_host)
+                if (!(v > 0.0)) return bail(fail("fugacity fractions must be positive"));
+        kp.bias_type = t->bias_type;
+        kp.bias_W = t->bias_width;
+        kp.bias_pen = t->bias_penalty;
+        if (dev_upload(h, h->bias_host.data(), h->bias_host.size(), &kp.bias_tab)) return bail(1);
+        if (dev_alloc(h, (size_t)cfg->n_replicas, &kp.bias) || dev_alloc(h, (size_t)cfg->n_replicas, &kp.charge))
+            return bail(1);
+    }
     if (t->has_ewald && t->ewald_charges && getenv("SMOLMC_DENSE_EWALD") == nullptr)
         if (int rc = build_compact_ewald(h, t)) return bail(rc);
     // sublattices
@@ -826,7 +848,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
-        bool lean = h->lean_tables && h->F <= 64 && (!wl || (!t->has_ewald && !t->has_mu)) &&
+        bool lean = h->lean_tables && h->F <= 64 && !t->bias_type && (!wl || (!t->has_ewald && !t->has_mu)) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
                     getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
@@ -1004,6 +1026,26 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
         HIPCHK(hipMemsetAsync(kp.nacc, 0, R * 8, h->stream));
     }
     HIPCHK(hipMemsetAsync(kp.last_acc, 1, R, h->stream));
+    if (kp.bias_type) {
+        // MCBias.compute_bias of every initial occupancy (kernel/base.py:362-363), on the host:
+        // the occupancies are host arrays here and this runs once per set_state
+        std::vector<double> b0(R), q0(R, 0.0);
+        const int N = h->N, W = kp.bias_W;
+        for (size_t r = 0; r < R; ++r) {
+            const int32_t *o = occ + r * (size_t)N;
+            double acc = 0.0;
+            if (kp.bias_type == SMOLMC_BIAS_FUGACITY) {
+                for (int s = 0; s < N; ++s) acc += log(h->bias_host[(size_t)s * W + o[s]]); // bias.py:174-186
+                b0[r] = acc;
+            } else {
+                for (int s = 0; s < N; ++s) acc += h->bias_host[(size_t)s * W + o[s]];
+                q0[r] = acc;
+                b0[r] = -kp.bias_pen * (acc * acc); // bias.py:264-277
+            }
+        }
+        HIPCHK(hipMemcpy(kp.bias, b0.data(), R * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(kp.charge, q0.data(), R * 8, hipMemcpyHostToDevice));
+    }
     TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));
     hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,
                        kp.features, h->d_natural, kp.enthalpy, (int)R, h->F);
@@ -1037,6 +1079,15 @@ extern "C" int smolmc_sync(smolmc_handle *h) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_get_bias(smolmc_handle *h, double *bias) {
+    if (!h || !bias) return fail("null argument");
+    if (!h->kp.bias_type) return fail("the model has no bias term");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(bias, h->kp.bias, (size_t)h->R * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

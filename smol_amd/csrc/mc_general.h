@@ -204,6 +204,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
     unsigned long long nacc = P.nacc[r];
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
     double acc_ew = 0.0, acc_mu = 0.0; // Ewald / chemical-work feature deltas (uniform)
+    double bias = P.bias_type ? P.bias[r] : 0.0;     // trace.bias (kernel/base.py:362-363)
+    double charge = P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[r] : 0.0;
     int last_acc = 1;
     double wl_m = 0.0;
     long long wl_counter = 0;
@@ -397,12 +399,32 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         double dH = wave_sum(e);
         if (P.has_ewald) dH += P.ew_coef * dEw;
         if (P.has_mu) dH -= dMu;
+        // MCBias.compute_bias_change against the ORIGINAL occupancy (kernel/base.py:307-311):
+        // FugacityBias log-ratio per flipped site (bias.py:188-206); SquareChargeBias the
+        // difference of -penalty * charge^2 (bias.py:75-93, :264-277) on the running charge
+        double dB = 0.0, dQ = 0.0;
+        if (!WL && P.bias_type && nfl >= 1) {
+            const double *b1 = P.bias_tab + (size_t)s1 * P.bias_W;
+            const int orig2 = nfl == 2 ? uni((int)L.occ[s2]) : 0;
+            const double *b2 = P.bias_tab + (size_t)s2 * P.bias_W;
+            if (P.bias_type == SMOLMC_BIAS_FUGACITY) {
+                dB = log(b1[n1] / b1[o1]);
+                if (nfl == 2) dB += log(b2[n2] / b2[orig2]);
+            } else {
+                dQ = b1[n1] - b1[o1];
+                if (nfl == 2) dQ += b2[n2] - b2[orig2];
+                const double cn = charge + dQ;
+                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+            }
+            dB = uni_d(dB);
+            dQ = uni_d(dQ);
+        }
 
         // ================= accept ==============================================
         bool accepted;
         if (!WL) {
             // MetropolisAcceptMixin._accept_step (metropolis.py:31-49)
-            const double exponent = -beta * dH + 0.0;
+            const double exponent = -beta * dH + 0.0 + dB;
             accepted = exponent >= 0.0 ? true : (exponent > log(u));
         } else {
             // WangLandau._accept_step (wanglandau.py:186-202)
@@ -442,6 +464,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             acc_ew += dEw;
             acc_mu += dMu;
             H += dH;
+            bias += dB;
+            charge += dQ;
             nacc++;
         }
         last_acc = accepted ? 1 : 0;
@@ -556,6 +580,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
         P.last_acc[r] = (uint8_t)last_acc;
+        if (P.bias_type) P.bias[r] = bias;
+        if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[r] = charge;
     }
 }
 

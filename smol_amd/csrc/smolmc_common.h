@@ -95,6 +95,11 @@ struct KParams {
     const double *ew_qs;          // [N][ew_W] charge of (site, code), 0 for vacancies
     const double *ew_dg;          // [N][ew_W] diagonal entry M[a][a] of (site, code)
     const double *mu;             // [N][mu_W]
+    // MCBias (smol/moca/kernel/bias.py): table [N][bias_W], running bias / net charge [R]
+    int bias_type, bias_W;
+    const double *bias_tab;
+    double bias_pen;
+    double *bias, *charge;
     // sublattices
     const int *sub_ptr;           // [nsub+1]
     const int *sub_sites;         // concatenated active sites
@@ -297,6 +302,7 @@ struct smolmc_handle {
     size_t eval_occ_cap = 0;
     double *d_natural = nullptr;
     double *d_beta = nullptr;
+    std::vector<double> bias_host; // host copy of the MCBias table (initial bias in set_state)
 };
 
 static void free_samples(smolmc_handle *h);

@@ -35,6 +35,7 @@ SYMBOLS = {
     "smolmc_set_temperature": (C.c_int, [_HP, _f64p]),
     "smolmc_get_state": (C.c_int, [_HP, _i32p, _f64p, _f64p, _u64p, _u64p, _u8p]),
     "smolmc_get_wl": (C.c_int, [_HP, _f64p, _i64p, _i64p, _f64p, _f64p]),
+    "smolmc_get_bias": (C.c_int, [_HP, _f64p]),
     "smolmc_run": (C.c_int, [_HP, C.c_int64]),
     "smolmc_sync": (C.c_int, [_HP]),
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
@@ -64,7 +65,7 @@ def load_library(path=None):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.smolmc_abi_version() != 1:
+    if lib.smolmc_abi_version() != 2:
         raise RuntimeError("smolmc ABI version mismatch")
     if path is None:
         _LIB = lib
@@ -184,6 +185,12 @@ class Engine:
             )
         )
         return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
+
+    def get_bias(self):
+        """trace.bias of every walker (models created with an MCBias term)."""
+        b = np.zeros(self.R)
+        self._chk(self._lib.smolmc_get_bias(self._h, _p(b, C.c_double)))
+        return b
 
     # ---- hot path -------------------------------------------------------------
     def run(self, nsteps, sync=False):

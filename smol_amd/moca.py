@@ -68,8 +68,10 @@ class Trace(SimpleNamespace):
 class Sublattice:
     """Sites sharing one site space (smol/moca/sublattice.py:23-107)."""
 
-    def __init__(self, species, sites):
+    def __init__(self, species, sites, charges=None):
         self.species = tuple(species)
+        # oxidation state of every species (0 for a vacancy); used by CompositionSpace
+        self.charges = tuple(0 if q is None else q for q in (charges or [0] * len(self.species)))
         self.sites = np.unique(np.asarray(sites, dtype=np.int64))
         self.active_sites = self.sites.copy()
         if len(self.species) <= 1:
@@ -223,8 +225,8 @@ class Processor:
             if key in groups:
                 groups[key][1].append(sites)
             else:
-                groups[key] = (names[b], [sites])
-        return [Sublattice(sp, np.concatenate(st)) for sp, st in groups.values()]
+                groups[key] = (names[b], [sites], prim.charges[b])
+        return [Sublattice(sp, np.concatenate(st), q) for sp, st, q in groups.values()]
 
     def encode_occupancy(self, occupancy):
         return np.array(occupancy, dtype=np.int32)
@@ -462,6 +464,19 @@ class Ensemble:
         for s in self._sublattices:
             s.reset_restricted_sites()
 
+    def composition_space(self, charge_balanced=True, other_constraints=None, optimize_basis=False,
+                          table_ergodic=False):
+        """CompositionSpace over ALL sublattices of this ensemble, sizes reduced by their gcd,
+        as TableFlip builds it (mcusher.py:489-518)."""
+        from .composition import CompositionSpace
+
+        sizes = np.array([len(s.sites) for s in self._sublattices], dtype=np.int64)
+        sizes = sizes // np.gcd.reduce(sizes)
+        spaces = [list(zip(s.species, s.charges)) for s in self._sublattices]
+        return CompositionSpace(spaces, sizes, charge_neutral=charge_balanced,
+                                other_constraints=other_constraints, optimize_basis=optimize_basis,
+                                table_ergodic=table_ergodic)
+
     # -- tables for the engine -----------------------------------------------------
     def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1):
         tab = self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
@@ -532,13 +547,112 @@ STEP_TYPES = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP, "table-flip": capi
               "tableflip": capi.STEP_TABLE_FLIP}
 
 
+# --------------------------------------------------------------------------- #
+# bias terms (smol/moca/kernel/bias.py)
+# --------------------------------------------------------------------------- #
+class MCBias:
+    """Host record of a bias term: builds the per-(site, species code) table the engine
+    consumes (smol/moca/kernel/bias.py:24-93)."""
+
+    bias_type = capi.BIAS_NONE
+    penalty = 0.0
+
+    def __init__(self, sublattices):
+        self.sublattices = list(sublattices)
+        self.active_sublattices = [s for s in self.sublattices if s.is_active]
+        self.spec = dict(type=self.__class__.__name__)
+
+    def _shape(self):
+        return (sum(len(s.sites) for s in self.sublattices),
+                max(int(max(s.encoding)) for s in self.sublattices) + 1)
+
+
+class FugacityBias(MCBias):
+    """Fugacity-fraction bias (bias.py:96-226): bias = sum_sites log f(site, species)."""
+
+    bias_type = capi.BIAS_FUGACITY
+
+    def __init__(self, sublattices, fugacity_fractions=None):
+        super().__init__(sublattices)
+        self._species = [set(s.species) for s in self.active_sublattices]
+        if fugacity_fractions is None:
+            # the reference takes the prim's site compositions (bias.py:139-141); the synthetic
+            # prims carry none, so the default is the uniform composition
+            fugacity_fractions = [{sp: 1.0 / len(s.species) for sp in s.species}
+                                  for s in self.active_sublattices]
+        self.fugacity_fractions = fugacity_fractions
+
+    @property
+    def fugacity_fractions(self):
+        return self._fus
+
+    @fugacity_fractions.setter
+    def fugacity_fractions(self, value):
+        value = [dict(v) for v in value]
+        if not all(sum(fus.values()) == 1 for fus in value):
+            raise ValueError("Fugacity ratios must add to one.")  # bias.py:161-162
+        if len(value) != len(self._species):
+            raise ValueError("one fugacity-fraction dictionary per active sublattice is required")
+        for spec, vals in zip(self._species, value):
+            if spec != set(vals.keys()):
+                raise ValueError(
+                    "Fugacity fractions given are missing or not valid species.\n"
+                    f"Values must be given for each  of the following: {self._species}"
+                )  # bias.py:163-170
+        self._fus = value
+        table = np.ones(self._shape())  # _build_fu_table (bias.py:208-226)
+        for fus, s in zip(value, self.active_sublattices):
+            table[s.sites[:, None], s.encoding] = np.array([fus[sp] for sp in s.species])[None, :]
+        self._table = table
+        self.spec["fugacity_fractions"] = value
+
+    def compute_bias(self, occupancy):
+        return float(sum(np.log(self._table[i, c]) for i, c in enumerate(occupancy)))
+
+
+class SquareChargeBias(MCBias):
+    """Square-charge bias (bias.py:229-277): bias = -penalty * (net charge)^2."""
+
+    bias_type = capi.BIAS_SQUARE_CHARGE
+
+    def __init__(self, sublattices, penalty=0.5):
+        super().__init__(sublattices)
+        if penalty <= 0:
+            raise ValueError("Penalty factor should be > 0!")
+        self.penalty = float(penalty)
+        table = np.zeros(self._shape())
+        for s in self.sublattices:
+            table[s.sites[:, None], s.encoding] = np.array(s.charges, dtype=float)[None, :]
+        self._table = table
+        self.spec["penalty"] = self.penalty
+
+    def compute_bias(self, occupancy):
+        c = self._table[np.arange(len(occupancy)), occupancy].sum()
+        return float(-self.penalty * c**2)
+
+
+BIAS_TYPES = {"fugacity": FugacityBias, "fugacity-bias": FugacityBias, "fugacitybias": FugacityBias,
+              "square-charge": SquareChargeBias, "square-charge-bias": SquareChargeBias,
+              "squarechargebias": SquareChargeBias}
+
+
+def mcbias_factory(bias_type, sublattices, **kwargs):
+    """bias.py mcbias_factory: class from its (hyphenated / camel-case) name."""
+    key = str(bias_type).lower().replace("_", "-")
+    if key not in BIAS_TYPES:
+        raise NotImplementedError(f"{bias_type} is not implemented on the MI355X engine "
+                                  f"(available: FugacityBias, SquareChargeBias).")
+    return BIAS_TYPES[key](sublattices, **kwargs)
+
+
 class MCKernel:
     """Per-walker kernel record (smol/moca/kernel/base.py:169-343).  Holds the parameters
     the reference keeps per kernel object; the stepping itself happens on the GPU."""
 
     kernel_type = None
+    valid_bias = ("FugacityBias", "SquareChargeBias")
 
-    def __init__(self, ensemble, step_type, *args, seed=None, **kwargs):
+    def __init__(self, ensemble, step_type, *args, seed=None, bias_type=None, bias_kwargs=None, **kwargs):
         if step_type not in STEP_TYPES:
             raise ValueError(
                 f"{step_type} is not a valid MCUsher for this kernel (supported: {sorted(STEP_TYPES)})."
@@ -549,13 +663,33 @@ class MCKernel:
         # MCUsher arguments (TableFlip: flip_table, flip_weights, swap_weight; mcusher.py:414-426)
         self.usher_kwargs = {k: kwargs[k] for k in ("flip_table", "flip_weights", "swap_weight")
                              if k in kwargs}
-        if STEP_TYPES[step_type] == capi.STEP_TABLE_FLIP and "flip_table" not in self.usher_kwargs:
-            raise NotImplementedError(
-                "TableFlip needs an explicit flip_table: CompositionSpace (automatic flip-table "
-                "generation, smol/moca/composition/space.py) is not part of this engine yet"
-            )
+        if STEP_TYPES[step_type] == capi.STEP_TABLE_FLIP and self.usher_kwargs.get("flip_table") is None:
+            # TableFlip.__init__ (mcusher.py:489-518): no table given -> build it from the
+            # sublattices' species / charges with a CompositionSpace
+            self.usher_kwargs["flip_table"] = ensemble.composition_space(
+                charge_balanced=kwargs.get("charge_balanced", True),
+                other_constraints=kwargs.get("other_constraints"),
+                optimize_basis=kwargs.get("optimize_basis", False),
+                table_ergodic=kwargs.get("table_ergodic", False),
+            ).flip_table
         self._seed = seed if seed is not None else np.random.SeedSequence().entropy
         self.spec = dict(kernel=self.__class__.__name__, seed=self._seed, step=step_type)
+        self._bias = None
+        if bias_type is not None:  # kernel/base.py:229-235
+            self.bias = mcbias_factory(bias_type, ensemble.sublattices, **(bias_kwargs or {}))
+
+    @property
+    def bias(self):
+        return self._bias
+
+    @bias.setter
+    def bias(self, bias):
+        if self.valid_bias is None:
+            raise ValueError("Cannot apply bias to Wang-Landau simulation!")  # wanglandau.py:127-128
+        if bias.__class__.__name__ not in self.valid_bias:
+            raise ValueError(f"{type(bias)} is not a valid MCBias for this kernel.")  # base.py:281-282
+        self._bias = bias
+        self.spec["bias"] = bias.spec
 
     @property
     def ensemble(self):
@@ -594,6 +728,7 @@ class WangLandau(MCKernel):
     """Wang-Landau kernel (smol/moca/kernel/wanglandau.py:17-300)."""
 
     kernel_type = capi.KERNEL_WANGLANDAU
+    valid_bias = None  # "Wang-Landau does not need bias" (wanglandau.py:24)
 
     def __init__(self, ensemble, step_type, min_enthalpy, max_enthalpy, bin_size, *args,
                  flatness=0.8, mod_factor=1.0, check_period=1000, update_period=1,
@@ -828,6 +963,8 @@ class Sampler:
         if isinstance(k0, Metropolis):
             fields["temperature"] = np.empty((0, nwalkers, 1), dtype=np.float64)
         fields["accepted"] = np.empty((0, nwalkers, 1), dtype=bool)
+        if k0.bias is not None:  # trace.bias (kernel/base.py:362-363)
+            fields["bias"] = np.empty((0, nwalkers, 1), dtype=np.float64)
         if isinstance(k0, WangLandau):
             L = len(k0._levels)
             fields.update(
@@ -867,9 +1004,11 @@ class Sampler:
     def _get_engine(self, device=0):
         k0 = self._kernels[0]
         ens = k0.ensemble
-        key = (id(ens._mu_table), tuple(len(s.active_sites) for s in ens.sublattices), device)
+        key = (id(ens._mu_table), tuple(len(s.active_sites) for s in ens.sublattices), device, id(k0.bias))
         if self._engine is None or self._engine_key != key:
             tables = ens.make_tables(**k0.usher_kwargs)
+            if k0.bias is not None:
+                tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty)
             if isinstance(k0, WangLandau):
                 cfg = capi.make_config(
                     len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], device,
@@ -923,6 +1062,8 @@ class Sampler:
         if isinstance(self._kernels[0], Metropolis):
             tr.temperature = self._temperatures().reshape(nw, 1)
         tr.accepted = st["accepted"].reshape(nw, 1)
+        if self._kernels[0].bias is not None:
+            tr.bias = eng.get_bias().reshape(nw, 1)
         if isinstance(self._kernels[0], WangLandau):
             wl = eng.get_wl()
             tr.histogram = wl["histogram"]
@@ -943,8 +1084,9 @@ class Sampler:
         self.setup_sample(initial_occupancies)
         eng = self._get_engine()
         nsamples = nsteps // thin_by
-        if isinstance(self._kernels[0], WangLandau):
-            # WL traces carry per-walker L x F arrays: fetched per sample
+        if isinstance(self._kernels[0], WangLandau) or self._kernels[0].bias is not None:
+            # WL traces carry per-walker L x F arrays, biased kernels the running bias:
+            # fetched per sample
             for _ in range(nsamples):
                 eng.run(thin_by)
                 yield self._current_trace(eng)

@@ -80,8 +80,8 @@ def test_table_flip_through_sampler():
     ens = moca.Ensemble.from_cluster_expansion(
         sc, synth.random_coefs(model, seed=5, scale=0.05),
         chemical_potentials={"Li+": 0.1, "Mn3+": -0.2, "Ti4+": 0.05})
-    with pytest.raises(NotImplementedError):
-        moca.Sampler.from_ensemble(ens, temperature=2000, step_type="table-flip")
+    auto = moca.Sampler.from_ensemble(ens, temperature=2000, step_type="table-flip")
+    assert np.abs(auto.mckernels[0].usher_kwargs["flip_table"]).tolist() == [[1, 3, 2, 0]]  # CompositionSpace
     # reference-style table: columns for ALL sublattices (cations, then the inactive anions)
     sampler = moca.Sampler.from_ensemble(ens, temperature=2000, step_type="table-flip", nwalkers=3,
                                          seeds=[1, 2, 3], flip_table=[[1, -3, 2, 0]], swap_weight=0.2)

@@ -74,8 +74,9 @@ def test_sampler_from_ensemble_defaults_and_errors(ensemble):
         ensemble.chemical_potentials = None
     with pytest.raises(ValueError):
         moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="multi-step")
-    with pytest.raises(NotImplementedError):  # TableFlip needs an explicit flip table here
-        moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="table-flip")
+    # TableFlip without a table builds it from a CompositionSpace (mcusher.py:489-518)
+    s3 = moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="table-flip")
+    assert np.abs(s3.mckernels[0].usher_kwargs["flip_table"]).tolist() == [[1, 1]]
     with pytest.raises(NotImplementedError):
         moca.Sampler.from_ensemble(ensemble, temperature=500, kernel_type="UniformlyRandom")
 

@@ -1,8 +1,8 @@
 """TableFlip (charge-neutral semigrand steps, smol/moca/kernel/mcusher.py:397-711).
 
 The reference's own checks are (i) known a-priori factors for a flip table produced by
-CompositionSpace (tests/test_moca/test_mcushers.py:199-234 -- CompositionSpace is not part of
-this engine, so those table-dependent numbers cannot be reproduced) and (ii) a detailed-
+CompositionSpace (tests/test_moca/test_mcushers.py:199-234 -- reproduced on the host in
+tests/test_composition.py, which also ties the oracle's factor to that host formula) and (ii) a detailed-
 balance histogram over compositions (test_mcushers.py:237-319).  (ii) is restated here for
 the oracle on CPU and, in tests/test_gpu_table_flip.py, for the engine; the a-priori
 formula is additionally checked against hand-computed values."""
