@@ -888,6 +888,52 @@ class SampleContainer:
                 out[sp] = out.get(sp, 0) + (sub == code).sum(axis=-1)
         return out
 
+    def get_sublattice_species_counts(self, sublattice, discard=0, thin_by=1, flat=True):
+        """Counts of each species of one sublattice, last axis ordered like its site space
+        (container.py:349-382)."""
+        if not any(sublattice is s for s in self.sublattices):
+            raise ValueError(
+                "Sublattice provided is not recognized.\n Provide one included in the sublattices "
+                "attribute of this SampleContainer."
+            )
+        occ = self.get_occupancies(discard, thin_by, flat=False)[..., sublattice.sites]
+        counts = np.stack([(occ == code).sum(axis=-1) for code in sublattice.encoding], axis=-1).astype(float)
+        return self._flatten(counts) if flat else counts
+
+    def get_sublattice_compositions(self, sublattice, discard=0, thin_by=1, flat=True):
+        return self.get_sublattice_species_counts(sublattice, discard, thin_by, flat) / len(sublattice.sites)
+
+    def get_compositions(self, discard=0, thin_by=1, flat=True):
+        """Fraction of ALL sites held by each species (container.py:240-243)."""
+        return {sp: c / self.shape[1] for sp, c in self.get_species_counts(discard, thin_by, flat).items()}
+
+    def mean_composition(self, discard=0, thin_by=1, flat=True):
+        return {sp: c.mean(axis=0) for sp, c in self.get_compositions(discard, thin_by, flat).items()}
+
+    def composition_variance(self, discard=0, thin_by=1, flat=True):
+        return {sp: c.var(axis=0) for sp, c in self.get_compositions(discard, thin_by, flat).items()}
+
+    def mean_sublattice_composition(self, sublattice, discard=0, thin_by=1, flat=True):
+        return self.get_sublattice_compositions(sublattice, discard, thin_by, flat).mean(axis=0)
+
+    def sublattice_composition_variance(self, sublattice, discard=0, thin_by=1, flat=True):
+        return self.get_sublattice_compositions(sublattice, discard, thin_by, flat).var(axis=0)
+
+    def get_minimum_energy(self, discard=0, thin_by=1, flat=True):
+        return self.get_energies(discard, thin_by, flat).min(axis=0)
+
+    def get_minimum_energy_occupancy(self, discard=0, thin_by=1, flat=True):
+        inds = self.get_energies(discard, thin_by, flat).argmin(axis=0)
+        occ = self.get_occupancies(discard, thin_by, flat)
+        return occ[inds] if flat else occ[inds, np.arange(self.shape[0])][0]
+
+    def get_orbit_factors(self, function_orbit_ids, discard=0, thin_by=1, flat=True):
+        """Sum of natural_parameter * feature over the functions of each orbit id
+        (container.py:269-280)."""
+        vals = self.natural_parameters * self.get_feature_vectors(discard=discard, thin_by=thin_by, flat=flat)
+        ids = np.asarray(function_orbit_ids)
+        return np.array([np.sum(vals[..., ids == i]) for i in range(len(self.natural_parameters))])
+
     def save_sampled_trace(self, trace, thinned_by):
         for name, value in trace.items():
             getattr(self._trace, name)[self._nsamples] = value

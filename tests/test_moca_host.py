@@ -119,6 +119,30 @@ def test_sample_container_bookkeeping(ensemble):
     assert np.isclose(c.sampling_efficiency(), 0.8)
     assert np.isclose(c.mean_enthalpy(), 2.0)
     np.testing.assert_allclose(c.get_energies(), c.get_enthalpies())  # no mu -> same
+    # composition getters (container.py:235-243,282-304,336-382; tests/test_moca/test_container.py)
+    sub = ensemble.sublattices[0]
+    counts = c.get_sublattice_species_counts(sub, flat=False)
+    occs = c.get_occupancies(flat=False)
+    assert counts.shape == (5, nw, 2)
+    np.testing.assert_array_equal(counts[..., 1], occs[..., sub.sites].sum(axis=-1))
+    np.testing.assert_array_equal(counts.sum(axis=-1), len(sub.sites))
+    np.testing.assert_allclose(c.get_sublattice_compositions(sub).sum(axis=-1), 1.0)
+    comps = c.get_compositions()
+    assert set(comps) == set(sub.species) and comps[sub.species[0]].shape == (10,)
+    np.testing.assert_allclose(sum(c.mean_composition().values()), 1.0)
+    np.testing.assert_allclose(c.mean_sublattice_composition(sub),
+                               c.get_sublattice_compositions(sub).mean(axis=0))
+    assert c.sublattice_composition_variance(sub).shape == (2,)
+    assert all(v >= 0 for v in c.composition_variance().values())
+    with pytest.raises(ValueError, match="not recognized"):
+        c.get_sublattice_species_counts(moca.Sublattice(sub.species, sub.sites))
+    assert c.get_minimum_energy() == c.get_minimum_enthalpy() == 0.0
+    np.testing.assert_array_equal(c.get_minimum_energy_occupancy(), c.get_minimum_enthalpy_occupancy())
+    np.testing.assert_array_equal(c.get_minimum_enthalpy_occupancy(flat=False), occs[0])
+    ids = np.arange(F) % 3
+    of = c.get_orbit_factors(ids)
+    vals = c.natural_parameters * c.get_feature_vectors()
+    np.testing.assert_allclose(of[:3], [vals[:, ids == i].sum() for i in range(3)])
     c.vacuum()
     assert c._trace.occupancy.shape[0] == 5
     c.clear()
