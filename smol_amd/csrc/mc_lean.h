@@ -297,7 +297,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // rare empty step, the loaded row is then unused)
         uint16_t row2[ROW];
         if (STEP == SMOLMC_STEP_SWAP) {
+#ifdef SMOLMC_EXP_ROW2 // timing experiment only: row of an early-known site (wrong results)
+            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
+#else
             const uint16_t *p = idx_lane + (size_t)s2 * (64 * ROW);
+#endif
 #pragma unroll
             for (int q = 0; q < ROW; ++q) row2[q] = p[q];
         }
@@ -326,7 +330,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
+#ifndef SMOLMC_EXP_NOTENT // timing experiment only when defined (wrong results)
             if (lane == 0) occ[a1] = (uint8_t)n1;
+#endif
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
@@ -371,9 +377,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // -------- accept (metropolis.py:31-49) --------
             const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
                                                (int)rdlane((uint32_t)__double2loint(logu), l4));
+            // (the ballots make the wave-uniform decision visibly uniform to the compiler:
+            // scalar branch, uniform counters in SGPRs)
             if (!WL) {
                 const double exponent = nbeta * dH + 0.0;
-                accepted = (exponent >= 0.0) || (exponent > lu);
+                accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
             } else {
                 // WangLandau._accept_step (wanglandau.py:186-202)
                 const double new_h = H + dH;
@@ -383,7 +391,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
                     const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
                     const double exponent = wl_S[b] - wl_S[nb] + 0.0;
-                    accepted = (exponent >= 0.0) || (exponent > lu);
+                    accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
                 }
             }
         }
@@ -407,6 +415,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             if (lane == 0) {
                 if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+#ifdef SMOLMC_EXP_NOTENT
+                if (STEP == SMOLMC_STEP_SWAP) occ[a1] = (uint8_t)n1;
+#endif
                 if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             }
             acc_mu += dMu;
@@ -414,7 +425,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (FAST) acc_e += e; else H += dH;
             nacc++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
+#ifndef SMOLMC_EXP_NOTENT
             if (lane == 0) occ[a1] = (uint8_t)o1; // undo the tentative first flip
+#endif
         }
         last_acc = accepted ? 1 : 0;
         s1 = s1n;

@@ -55,7 +55,7 @@ def load_library(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = path or LIB_PATH
+    p = path or os.environ.get("SMOLMC_LIB") or LIB_PATH  # SMOLMC_LIB: A/B builds of the kernels
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; "
