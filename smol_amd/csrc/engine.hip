@@ -1162,9 +1162,29 @@ static void free_samples(smolmc_handle *h) {
 
 static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
     if (h->lean) {
-        LeanParams lp = h->lp;
-        lp.smp = smp;
-        return launch_lean(h, lp, nsteps);
+        // the lean kernels count steps in 32 bits: launches are split at 2^30 steps (on a
+        // sample boundary when samples are being recorded)
+        int64_t chunk = (int64_t)1 << 30;
+        if (smp.every) {
+            if (smp.every > chunk) return fail("thin_by must be <= 2^30 steps");
+            chunk -= chunk % smp.every;
+        }
+        int64_t done = 0;
+        while (done < nsteps) {
+            const int64_t n = std::min(chunk, nsteps - done);
+            LeanParams lp = h->lp;
+            lp.smp = smp;
+            if (smp.every) {
+                const size_t rows = (size_t)(done / smp.every) * h->R;
+                lp.smp.H += rows;
+                lp.smp.feat += rows * h->F;
+                lp.smp.acc += rows;
+                if (lp.smp.occ) lp.smp.occ += rows * h->Npad;
+            }
+            if (int rc = launch_lean(h, lp, n)) return rc;
+            done += n;
+        }
+        return 0;
     }
     KParams kp = h->kp;
     kp.steps_to_run = nsteps;

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double wl_m = WL ? P.wl.m[r] : 0.0;
     long long wl_counter = WL ? P.wl.counter[r] : 0;
     unsigned long long step = P.nsteps[r];
-    unsigned long long nacc = P.nacc[r];
+    uint32_t nacc_add = 0; // accepted steps of this launch (32-bit counter; < 2^31 steps per launch)
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    long long smp_countdown = P.smp.every, smp_index = 0;
+    uint32_t smp_countdown = (uint32_t)P.smp.every;
+    long long smp_index = 0;
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
     uint32_t W0 = 0, W1 = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
@@ -200,7 +201,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         for (int q = 0; q < ROW; ++q) row1[q] = p[q];
     }
 
-    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+    const uint32_t nsteps32 = (uint32_t)P.steps; // the host splits launches at 2^30 steps
+    for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
         // -------- random words of this step (generated 16 steps at a time) --------
         const unsigned long long base = step & ~15ull;
         if (base != batch_base) {
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
 #ifndef SMOLMC_EXP_NOTENT // timing experiment only when defined (wrong results)
-            if (lane == 0) occ[a1] = (uint8_t)n1;
+            occ[a1] = (uint8_t)n1; // every lane stores the same byte: no exec juggling
 #endif
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
@@ -413,20 +415,18 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
-            if (lane == 0) {
-                if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+            if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
 #ifdef SMOLMC_EXP_NOTENT
-                if (STEP == SMOLMC_STEP_SWAP) occ[a1] = (uint8_t)n1;
+            if (STEP == SMOLMC_STEP_SWAP) occ[a1] = (uint8_t)n1;
 #endif
-                if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
-            }
+            if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             acc_mu += dMu;
             acc_ew += dEw;
             if (FAST) acc_e += e; else H += dH;
-            nacc++;
+            nacc_add++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
 #ifndef SMOLMC_EXP_NOTENT
-            if (lane == 0) occ[a1] = (uint8_t)o1; // undo the tentative first flip
+            occ[a1] = (uint8_t)o1; // undo the tentative first flip
 #endif
         }
         last_acc = accepted ? 1 : 0;
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
 
         if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
-            smp_countdown = P.smp.every;
+            smp_countdown = (uint32_t)P.smp.every;
             const size_t row = (size_t)smp_index * P.R + r;
             smp_index++;
             if (WL) {
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
-        P.nacc[r] = nacc;
+        P.nacc[r] += nacc_add;
         P.last_acc[r] = (uint8_t)last_acc;
     }
 }
