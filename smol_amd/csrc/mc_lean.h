@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     constexpr bool FAST = !WL && !HAS_EW;
     double acc_e = 0.0;
     float thr_lo = 0.0f, thr_hi = 0.0f;
-    int last_acc = 1;
+    uint32_t nacc_before = 0; // accept counter before the current step: last_acc is read lazily
+    int nsite = 0, naddr = 0;
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
@@ -189,13 +190,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 
     // software pipeline: the site of step k comes from W(k-1, 0, 1), so the index row of
     // the NEXT step is always known one step ahead and is fetched while this step runs.
-    int s1;
+    int s1, a1;
     uint16_t row1[ROW];
     {
         const unsigned long long sp = step - 1ull;
         const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
                                                             key0, key1).w[1]);
         s1 = sbase + (int)__umulhi(w, nact);
+        a1 = lean_swz(s1, swa, swm, swb);
         const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
 #pragma unroll
         for (int q = 0; q < ROW; ++q) row1[q] = p[q];
@@ -211,6 +213,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
                                                0u, key0, key1);
             W0 = o.w[0]; W1 = o.w[1];
+            // site of the step AFTER the lane's step and its swizzled LDS address, lane-parallel
+            // (one v_readlane each per step instead of the scalar mulhi + swizzle chain)
+            nsite = sbase + (int)__umulhi(o.w[1], nact);
+            naddr = lean_swz(nsite, swa, swm, swb);
             // metropolis.py:46-48 compares the exponent with log(rng.random()): take the
             // float64 log of all 16 uniforms of the batch at once (lane-parallel)
             logu = log(philox_u53(o.w[2], o.w[3]));
@@ -233,14 +239,14 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         const int l4 = (int)(step & 15ull) * 4;
         // prefetch the index row of the next step's site (depends only on random words)
-        const int s1n = sbase + (int)__umulhi(rdlane(W1, l4), nact);
+        const int s1n = (int)rdlane((uint32_t)nsite, l4);
+        const int a1n = (int)rdlane((uint32_t)naddr, l4);
         uint16_t rown[ROW];
         {
             const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
 #pragma unroll
             for (int q = 0; q < ROW; ++q) rown[q] = p[q];
         }
-        const int a1 = lean_swz(s1, swa, swm, swb);
         const int o1 = uni((int)occ[a1]);
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         if (STEP == SMOLMC_STEP_FLIP) {
@@ -398,6 +404,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
         // -------- update (kernel/base.py:327-343) --------
+        nacc_before = nacc_add;
         if (accepted) {
             if (!WL) {
 #pragma unroll
@@ -429,8 +436,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             occ[a1] = (uint8_t)o1; // undo the tentative first flip
 #endif
         }
-        last_acc = accepted ? 1 : 0;
         s1 = s1n;
+        a1 = a1n;
 #pragma unroll
         for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
 
@@ -495,7 +502,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const double Hnow = FAST ? H + (wave_sum_all(acc_e) - acc_mu) : H;
             if (lane == 0) {
                 P.smp.H[row] = Hnow;
-                P.smp.acc[row] = (uint8_t)last_acc;
+                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
             }
             if (P.smp.occ) {
                 uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
@@ -536,7 +543,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
-        P.last_acc[r] = (uint8_t)last_acc;
+        if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
     }
 }
 
