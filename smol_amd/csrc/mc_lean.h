@@ -105,6 +105,34 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
     return out;
 }
 
+// Index row of one site: ROW u16 entries per lane, fetched with raw buffer loads
+// (resource descriptor + SGPR site offset + constant per-lane VGPR offset: no 64-bit VALU
+// address arithmetic per step).  Words hold two u16 entries each.
+template <int NW> struct RowWords { uint32_t w[NW]; };
+template <int NW>
+__device__ __forceinline__ RowWords<NW> load_row(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    RowWords<NW> r;
+    if constexpr (NW == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        r.w[0] = v[0]; r.w[1] = v[1];
+    } else if constexpr (NW == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0);
+        r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2];
+    } else if constexpr (NW == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3];
+    } else {
+        static_assert(NW == 6, "row width");
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        const auto u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 16u, soff, 0);
+        r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3]; r.w[4] = u[0]; r.w[5] = u[1];
+    }
+    return r;
+}
+template <int NW> __device__ __forceinline__ uint32_t row_entry(const RowWords<NW> &r, int q) {
+    return (r.w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+}
+
 template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -186,21 +214,23 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
-    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+    constexpr int NW = ROW / 2;                       // dwords per lane per site
+    constexpr uint32_t SITE_BYTES = 64u * ROW * 2u;
+    const __amdgpu_buffer_rsrc_t idx_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
 
     // software pipeline: the site of step k comes from W(k-1, 0, 1), so the index row of
     // the NEXT step is always known one step ahead and is fetched while this step runs.
     int s1, a1;
-    uint16_t row1[ROW];
+    RowWords<NW> row1;
     {
         const unsigned long long sp = step - 1ull;
         const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
                                                             key0, key1).w[1]);
         s1 = sbase + (int)__umulhi(w, nact);
         a1 = lean_swz(s1, swa, swm, swb);
-        const uint16_t *p = idx_lane + (size_t)s1 * (64 * ROW);
-#pragma unroll
-        for (int q = 0; q < ROW; ++q) row1[q] = p[q];
+        row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
     }
 
     const uint32_t nsteps32 = (uint32_t)P.steps; // the host splits launches at 2^30 steps
@@ -241,12 +271,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // prefetch the index row of the next step's site (depends only on random words)
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
-        uint16_t rown[ROW];
-        {
-            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
-#pragma unroll
-            for (int q = 0; q < ROW; ++q) rown[q] = p[q];
-        }
+        const RowWords<NW> rown = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
         const int o1 = uni((int)occ[a1]);
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         if (STEP == SMOLMC_STEP_FLIP) {
@@ -303,15 +328,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 
         // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
         // rare empty step, the loaded row is then unused)
-        uint16_t row2[ROW];
+        RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) {
 #ifdef SMOLMC_EXP_ROW2 // timing experiment only: row of an early-known site (wrong results)
-            const uint16_t *p = idx_lane + (size_t)s1n * (64 * ROW);
+            row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
 #else
-            const uint16_t *p = idx_lane + (size_t)s2 * (64 * ROW);
+            row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
 #endif
-#pragma unroll
-            for (int q = 0; q < ROW; ++q) row2[q] = p[q];
         }
 
         // -------- enthalpy delta ---------------------------------------------------
@@ -322,7 +345,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row1[it * MM + m]]);
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
                 d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
                 e = fma(wgt[it], d1[it], e);
             }
@@ -346,7 +369,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row2[it * MM + m]]);
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
                 d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
                 e = fma(wgt[it], d2[it], e);
             }
@@ -438,8 +461,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         s1 = s1n;
         a1 = a1n;
-#pragma unroll
-        for (int q = 0; q < ROW; ++q) row1[q] = rown[q];
+        row1 = rown;
 
         if (WL) {
             // WangLandau._do_post_step (wanglandau.py:222-266)
