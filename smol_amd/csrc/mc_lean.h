@@ -196,10 +196,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
     // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
     // only the rare undecided step pays for the float64 reduction, so decisions are exactly
-    // those of the float64 rule.  The enthalpy then accumulates per lane (acc_e) and is
+    // those of the float64 rule.  The enthalpy is then rebuilt from the per-slot feature
+    // accumulators (sum_slots w * acc, the same sum in another order) and is
     // reduced when it is read (sample rows, end of launch).
     constexpr bool FAST = !WL && !HAS_EW;
-    double acc_e = 0.0;
     float thr_lo = 0.0f, thr_hi = 0.0f;
     uint32_t nacc_before = 0; // accept counter before the current step: last_acc is read lazily
     int nsite = 0, naddr = 0;
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             acc_mu += dMu;
             acc_ew += dEw;
-            if (FAST) acc_e += e; else H += dH;
+            if (!FAST) H += dH;
             nacc_add++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
 #ifndef SMOLMC_EXP_NOTENT
@@ -521,7 +521,12 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (!WL && HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
             if (!WL && HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0))
                 P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
-            const double Hnow = FAST ? H + (wave_sum_all(acc_e) - acc_mu) : H;
+            double lane_e = 0.0;
+            if (FAST) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) lane_e = fma(wgt[it], acc[it], lane_e);
+            }
+            const double Hnow = FAST ? H + (wave_sum_all(lane_e) - acc_mu) : H;
             if (lane == 0) {
                 P.smp.H[row] = Hnow;
                 P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
@@ -558,7 +563,12 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     }
-    if (FAST) H += wave_sum_all(acc_e) - acc_mu;
+    if (FAST) {
+        double lane_e = 0.0;
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) lane_e = fma(wgt[it], acc[it], lane_e);
+        H += wave_sum_all(lane_e) - acc_mu;
+    }
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
         if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
