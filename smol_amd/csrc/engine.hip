@@ -160,6 +160,29 @@ __global__ void unpack_occ_kernel(const uint8_t *occ8, int *occ32, int N, int Np
     const int s = (int)(i % N);
     occ32[i] = (int)occ8[rr * Npad + s];
 }
+// Ewald potential field of every walker from scratch (set_state): one block per walker, the
+// charges q(k, occ_k) of the changeable sites staged in LDS, each wave sums rows
+// phi[j] = sum_{k != j} q_k G[site_j][k].
+__global__ void __launch_bounds__(256) ewald_field_init_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    double *q = (double *)fsm;
+    const int r = blockIdx.x, na = P.ew_nact, W = P.ew_W;
+    const uint8_t *occ = P.occ + (size_t)r * P.Npad;
+    for (int k = threadIdx.x; k < na; k += blockDim.x) {
+        const int site = P.sbase + k;
+        q[k] = P.ew_qs[(size_t)site * W + occ[site]];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wave; j < na; j += nw) {
+        const double *g = P.ew_G + (size_t)(P.sbase + j) * na;
+        double acc = 0.0;
+        for (int k = lane; k < na; k += 64) acc = fma(k != j ? q[k] : 0.0, g[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) P.ew_phi[(size_t)r * na + j] = acc;
+    }
+}
+
 __global__ void dot_features_kernel(const double *features, const double *natural, double *enthalpy,
                                     int R, int F) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -926,8 +949,26 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             h->lean_lds = ((size_t)lp.dt_len + 8) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
+            // Ewald potential field in LDS when the changeable sites are the active
+            // sublattice and it fits beside the occupancies
+            lp.ew_field = 0;
+            if (lean && t->has_ewald && kp.ew_act_base == sbase && kp.ew_nact == nact &&
+                getenv("SMOLMC_NO_EWALD_FIELD") == nullptr) {
+                const size_t with_field = h->lean_lds + (size_t)4 * nact * 8;
+                if (with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
+                    if (dev_alloc(h, (size_t)h->R * nact, &lp.ew_phi)) return bail(1);
+                    lp.ew_field = 1;
+                    h->lean_lds = with_field;
+                }
+            }
         }
         h->lean = lean;
+        if (getenv("SMOLMC_DEBUG"))
+            fprintf(stderr, "[smolmc] lean=%d tables=%d nslot=%d mm=%d lds=%zu ew=%d compact=%d field=%d nact=%d "
+                            "ew_nact=%d ew_act_base=%d sbase=%d general: nslot=%d mm=%d lds=%zu\n",
+                    (int)lean, (int)h->lean_tables, h->lean_nslot, h->lean_mm, h->lean_lds, t->has_ewald,
+                    kp.ew_compact, h->lp.ew_field, nact, kp.ew_nact, kp.ew_act_base, sbase, h->nslot, h->mm,
+                    h->lds_bytes);
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
                 return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
@@ -1045,6 +1086,11 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
         }
         HIPCHK(hipMemcpy(kp.bias, b0.data(), R * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(kp.charge, q0.data(), R * 8, hipMemcpyHostToDevice));
+    }
+    if (h->lean && h->lp.ew_field) {
+        hipLaunchKernelGGL(ewald_field_init_kernel, dim3((unsigned)R), dim3(256), (size_t)h->lp.ew_nact * 8,
+                           h->stream, h->lp);
+        HIPCHK(hipGetLastError());
     }
     TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));
     hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,

@@ -105,6 +105,24 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
     return out;
 }
 
+// potential-field update after an accepted flip of site s by charge dq: every other
+// changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous).  Four loads in
+// flight per lane; j == own index is skipped (phi excludes the self term).
+__device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int js = s - P.sbase, na = P.ew_nact;
+    for (int j0 = lane; j0 < na; j0 += 256) {
+        double gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = g[min(j0 + 64 * u, na - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < na && j != js) phi[j] = fma(dq, gv[u], phi[j]);
+        }
+    }
+}
+
 // Index row of one site: ROW u16 entries per lane, fetched with raw buffer loads
 // (resource descriptor + SGPR site offset + constant per-lane VGPR offset: no 64-bit VALU
 // address arithmetic per step).  Words hold two u16 entries each.
@@ -142,7 +160,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int r = uni(blockIdx.x * nwaves + wave);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len;               // 8 doubles
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0);
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0) +
+                            ((HAS_EW && P.ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
     unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
     // Metropolis: scratch for the feature reduction; Wang-Landau: the CURRENT features
@@ -150,6 +169,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double *s_feat = (double *)(wbase + P.Nlds);
     double *wl_S = s_feat + 64;                   // WL: entropy [L]
     long long *wl_Hh = (long long *)(wl_S + (WL ? P.wl.L : 0)); // WL: histogram [L]
+    double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64);     // Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
@@ -160,6 +180,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         for (int i = lane; i < P.Npad / 4; i += 64)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = (WL && lane < P.F) ? P.features[(size_t)r * P.F + lane] : 0.0;
+        if (HAS_EW && P.ew_field)
+            for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
         if (WL)
             for (int i = lane; i < P.wl.L; i += 64) {
                 wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
@@ -351,12 +373,17 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
         double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
+        double dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
             const int W = P.ew_W;
-            const double dq = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
-            ew_part = 2.0 * dq * lean_ewald_partial(P, occ, lane, s1, swa, swm, swb);
-            ew_uni = 2.0 * dq * P.ew_frozen[s1] +
-                     (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+            dq1 = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
+            if (P.ew_field)
+                ew_uni = 2.0 * dq1 * (phi[s1 - sbase] + P.ew_frozen[s1]);
+            else {
+                ew_part = 2.0 * dq1 * lean_ewald_partial(P, occ, lane, s1, swa, swm, swb);
+                ew_uni = 2.0 * dq1 * P.ew_frozen[s1];
+            }
+            ew_uni += P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1];
         }
         if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
@@ -375,10 +402,15 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             if (HAS_EW) {
                 const int W = P.ew_W;
-                const double dq = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
-                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s2, swa, swm, swb);
-                ew_uni += 2.0 * dq * P.ew_frozen[s2] +
-                          (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+                dq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
+                if (P.ew_field) // the second flip sees the first through the cross term
+                    ew_uni += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)] +
+                                           P.ew_frozen[s2]);
+                else {
+                    ew_part += 2.0 * dq2 * lean_ewald_partial(P, occ, lane, s2, swa, swm, swb);
+                    ew_uni += 2.0 * dq2 * P.ew_frozen[s2];
+                }
+                ew_uni += P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2];
             }
         }
         double dMu = 0.0;
@@ -401,7 +433,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (!decided) {
             dH = LEAN_WAVE_SUM(e);
             if (HAS_EW) {
-                dEw = LEAN_WAVE_SUM(ew_part) + ew_uni;
+                dEw = (P.ew_field ? 0.0 : LEAN_WAVE_SUM(ew_part)) + ew_uni;
                 dH += P.ew_coef * dEw;
             }
             if (HAS_MU) dH -= dMu;
@@ -450,6 +482,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (STEP == SMOLMC_STEP_SWAP) occ[a1] = (uint8_t)n1;
 #endif
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
+            if (HAS_EW && P.ew_field) {
+                if (dq1 != 0.0) field_apply(P, phi, lane, s1, dq1);
+                if (STEP == SMOLMC_STEP_SWAP && dq2 != 0.0) field_apply(P, phi, lane, s2, dq2);
+            }
             acc_mu += dMu;
             acc_ew += dEw;
             if (!FAST) H += dH;
@@ -540,6 +576,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
 
     // ---- write back ---------------------------------------------------------------
+    if (HAS_EW && P.ew_field)
+        for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
         uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
         for (int i = lane; i < P.Npad / 4; i += 64)
@@ -601,11 +639,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const int r = uni(blockIdx.x * nwaves + wave);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64;
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (P.ew_field ? (size_t)P.ew_nact * 8 : 0);
     unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     double *s_feat = (double *)(wbase + P.Nlds);
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
+    double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64); // Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     const bool has_mu = P.mu_row != nullptr, has_ew = P.ew_G != nullptr;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -617,6 +656,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = 0.0;
         if (lane < 16) s_cnt[lane] = 0;
+        if (P.ew_field)
+            for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
     }
     __syncthreads();
     if (!live) return;
@@ -856,6 +897,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
+        double vdq = 0.0; // lane f holds the charge change of flip f (potential-field mode)
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
         for (int f = 0; f < nfl; ++f) {
@@ -878,8 +920,22 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             if (has_ew) {
                 const int W = P.ew_W;
                 const double dq = P.ew_qs[(size_t)s * W + nw] - P.ew_qs[(size_t)s * W + od];
-                ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s, swa, swm, swb);
-                ew_uni += 2.0 * dq * P.ew_frozen[s] + (P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od]);
+                if (P.ew_field) {
+                    // flip f sees the earlier flips of the step through the cross terms
+                    double pot = phi[s - sbase] + P.ew_frozen[s];
+                    for (int m = 0; m < f; ++m) {
+                        const int sm = (int)rdlane((uint32_t)vsite, m);
+                        const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
+                                                            (int)rdlane((uint32_t)__double2loint(vdq), m));
+                        pot = fma(dqm, P.ew_G[(size_t)s * P.ew_nact + (sm - sbase)], pot);
+                    }
+                    ew_uni += 2.0 * dq * pot;
+                    if (lane == f) vdq = dq;
+                } else {
+                    ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s, swa, swm, swb);
+                    ew_uni += 2.0 * dq * P.ew_frozen[s];
+                }
+                ew_uni += P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od];
             }
             if (has_mu) dMu += s_mu[nw] - s_mu[od];
             if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative
@@ -887,7 +943,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         double dH = wave_sum_all(e);
         double dEw = 0.0;
         if (has_ew) {
-            dEw = wave_sum_all(ew_part) + ew_uni;
+            dEw = (P.ew_field ? 0.0 : wave_sum_all(ew_part)) + ew_uni;
             dH += P.ew_coef * dEw;
         }
         if (has_mu) dH -= dMu;
@@ -902,6 +958,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 const int *urow = P.tf_table + (dir >> 1) * nc;
                 s_cnt[lane] += ((dir & 1) ? -1 : 1) * urow[lane];
             }
+            if (P.ew_field)
+                for (int f = 0; f < nfl; ++f) {
+                    const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
+                                                        (int)rdlane((uint32_t)__double2loint(vdq), f));
+                    if (dqf != 0.0) field_apply(P, phi, lane, (int)rdlane((uint32_t)vsite, f), dqf);
+                }
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;
@@ -938,6 +1000,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
     }
 
+    if (P.ew_field)
+        for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
         uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
         for (int i = lane; i < P.Npad / 4; i += 64)

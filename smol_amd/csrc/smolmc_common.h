@@ -239,6 +239,11 @@ struct LeanParams {
     const int *ew_act;
     const double *ew_G, *ew_qs, *ew_dg, *ew_frozen;
     double ew_coef;
+    // potential-field mode: phi[r][j] = sum over changeable sites k != j of q(k, occ_k) G[j][k]
+    // lives in LDS for the launch (HBM copy between launches): a proposal costs O(1), an
+    // accepted flip one row update
+    int ew_field;
+    double *ew_phi;          // [R][ew_nact]
     WlParams wl;
     // TableFlip (mcusher.py:397-711) for the single active sublattice
     int tf_n;               // number of flip vectors

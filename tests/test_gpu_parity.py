@@ -367,6 +367,48 @@ def test_compact_ewald_matches_dense_rows_and_oracle(step, monkeypatch):
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
 
 
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP])
+def test_ewald_potential_field_matches_row_sums_and_oracle(step, monkeypatch):
+    """The lean kernel keeps the Ewald potential phi[j] = sum_k q_k G[j][k] of every walker in
+    LDS (O(1) per proposal, one row update per accepted flip; HBM copy between launches).
+    Over many launches of uneven length its trajectory must equal the per-step row sums
+    (SMOLMC_NO_EWALD_FIELD) and the CPU oracle, and the Ewald feature must not drift from a
+    from-scratch evaluation (ewald.pyx:38-58 applied to the final occupancy)."""
+    from oracle import oracle as orc
+
+    c = load_case("rocksalt444_ewald")
+    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=_mu("mu3", c))
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(33)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(77)
+    temps = np.linspace(800.0, 6000.0, R)
+    field = _engine(tab, cfg)
+    monkeypatch.setenv("SMOLMC_NO_EWALD_FIELD", "1")
+    rows = _engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_EWALD_FIELD")
+    ora = orc.OracleMC(tab, cfg)
+    for e in (field, rows, ora):
+        e.set_state(occ0, seeds, temps)
+    for chunk in (1, 2, 37, 500, 3, 2000):
+        for e in (field, rows, ora):
+            e.run(chunk)
+        a, b, o = field.get_state(), rows.get_state(), ora.get_state()
+        for x in (b, o):
+            assert np.array_equal(a["occupancy"], x["occupancy"])
+            assert np.array_equal(a["n_accepted"], x["n_accepted"])
+            np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(a["features"], field.eval_full(a["occupancy"]), rtol=RTOL, atol=1e-8)
+    # a continued set_state (new occupancies, same streams) rebuilds the field
+    field.set_state(a["occupancy"][::-1].copy(), seeds, temps, reset_aux=False)
+    ora.set_state(a["occupancy"][::-1].copy(), seeds, temps, reset_aux=False)
+    field.run(300)
+    ora.run(300)
+    assert np.array_equal(field.get_state()["occupancy"], ora.get_state()["occupancy"])
+
+
 @pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 @pytest.mark.parametrize("cutoffs,step", [
     ({2: 6.0, 3: 5.0, 4: 4.2}, capi.STEP_SWAP),   # 183 clusters/site, quadruplets: NSLOT=4, MM=3

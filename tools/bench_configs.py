@@ -60,7 +60,7 @@ def main():
         mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
         tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1,
                                        mu_table=mu)
-        R, mc = a.replicas or 2048, a.mc or 200
+        R, mc = a.replicas or 2048, a.mc or 2000
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP)
         occ, T, flips_per_step = rand_occ(sc, R, 3), 3000.0, 1
         name = f"config3: ternary rocksalt {d}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip"
