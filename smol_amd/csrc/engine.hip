@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) ewald_field_init_kernel(const LeanParams 
         double acc = 0.0;
         for (int k = lane; k < na; k += 64) acc = fma(k != j ? q[k] : 0.0, g[k], acc);
         acc = wave_sum(acc);
-        if (lane == 0) P.ew_phi[(size_t)r * na + j] = acc;
+        if (lane == 0) P.ew_phi[(size_t)r * na + j] = acc + P.ew_frozen[P.sbase + j];
     }
 }
 
@@ -695,6 +695,8 @@ static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
     TRY(dev_upload(h, G.data(), G.size(), &h->kp.ew_G));
     TRY(dev_upload(h, qs.data(), qs.size(), &h->kp.ew_qs));
     TRY(dev_upload(h, dg.data(), dg.size(), &h->kp.ew_dg));
+    h->ew_qs_host = qs;
+    h->ew_dg_host = dg;
     h->kp.ew_compact = 1;
     return 0;
 }
@@ -946,7 +948,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
             }
-            h->lean_lds = ((size_t)lp.dt_len + 8) * 8 +
+            h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
             // Ewald potential field in LDS when the changeable sites are the active
@@ -955,7 +957,20 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             if (lean && t->has_ewald && kp.ew_act_base == sbase && kp.ew_nact == nact &&
                 getenv("SMOLMC_NO_EWALD_FIELD") == nullptr) {
                 const size_t with_field = h->lean_lds + (size_t)4 * nact * 8;
-                if (with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
+                // charge / diagonal term per species code must not depend on the site
+                bool uniform = kp.ew_W <= 8;
+                std::vector<double> qrow(8, 0.0), dgrow(8, 0.0);
+                for (int c = 0; uniform && c < kp.ew_W; ++c) {
+                    qrow[c] = h->ew_qs_host[(size_t)sbase * kp.ew_W + c];
+                    dgrow[c] = h->ew_dg_host[(size_t)sbase * kp.ew_W + c];
+                    for (int i = 0; i < nact; ++i)
+                        if (h->ew_qs_host[(size_t)(sbase + i) * kp.ew_W + c] != qrow[c] ||
+                            h->ew_dg_host[(size_t)(sbase + i) * kp.ew_W + c] != dgrow[c])
+                            uniform = false;
+                }
+                if (uniform && with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
+                    if (dev_upload(h, qrow.data(), 8, &lp.ew_qrow) || dev_upload(h, dgrow.data(), 8, &lp.ew_dgrow))
+                        return bail(1);
                     if (dev_alloc(h, (size_t)h->R * nact, &lp.ew_phi)) return bail(1);
                     lp.ew_field = 1;
                     h->lean_lds = with_field;

@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double *s_mu = s_dt + P.dt_len;               // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0) +
                             ((HAS_EW && P.ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
-    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
+    double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
+    unsigned char *wbase = (unsigned char *)(s_mu + 24) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
     // Metropolis: scratch for the feature reduction; Wang-Landau: the CURRENT features
     // (wanglandau.py:216-218 needs them every step for the per-bin running mean)
@@ -173,6 +174,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
+    if (HAS_EW && P.ew_field && threadIdx.x < 8) {
+        s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
+        s_dg[threadIdx.x] = P.ew_dgrow[threadIdx.x];
+    }
     const bool live = r < P.R;
     if (live) {
         // the swizzle only touches address bits >= 2: move whole dwords
@@ -375,15 +380,16 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
         double dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
-            const int W = P.ew_W;
-            dq1 = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
-            if (P.ew_field)
-                ew_uni = 2.0 * dq1 * (phi[s1 - sbase] + P.ew_frozen[s1]);
-            else {
+            if (P.ew_field) { // no global loads: charges / diagonal terms per code from LDS
+                dq1 = s_q[n1] - s_q[o1];
+                ew_uni = 2.0 * dq1 * phi[s1 - sbase] + (s_dg[n1] - s_dg[o1]);
+            } else {
+                const int W = P.ew_W;
+                dq1 = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
                 ew_part = 2.0 * dq1 * lean_ewald_partial(P, occ, lane, s1, swa, swm, swb);
-                ew_uni = 2.0 * dq1 * P.ew_frozen[s1];
+                ew_uni = 2.0 * dq1 * P.ew_frozen[s1] +
+                         (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
             }
-            ew_uni += P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1];
         }
         if (STEP == SMOLMC_STEP_SWAP) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
@@ -401,16 +407,17 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 e = fma(wgt[it], d2[it], e);
             }
             if (HAS_EW) {
-                const int W = P.ew_W;
-                dq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
-                if (P.ew_field) // the second flip sees the first through the cross term
-                    ew_uni += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)] +
-                                           P.ew_frozen[s2]);
-                else {
+                if (P.ew_field) { // the second flip sees the first through the cross term
+                    dq2 = s_q[n2] - s_q[o2];
+                    ew_uni += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)]) +
+                              (s_dg[n2] - s_dg[o2]);
+                } else {
+                    const int W = P.ew_W;
+                    dq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
                     ew_part += 2.0 * dq2 * lean_ewald_partial(P, occ, lane, s2, swa, swm, swb);
-                    ew_uni += 2.0 * dq2 * P.ew_frozen[s2];
+                    ew_uni += 2.0 * dq2 * P.ew_frozen[s2] +
+                              (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
                 }
-                ew_uni += P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2];
             }
         }
         double dMu = 0.0;
@@ -640,7 +647,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (P.ew_field ? (size_t)P.ew_nact * 8 : 0);
-    unsigned char *wbase = (unsigned char *)(s_mu + 8) + (size_t)wave * per_wave;
+    double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
+    unsigned char *wbase = (unsigned char *)(s_mu + 24) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     double *s_feat = (double *)(wbase + P.Nlds);
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
@@ -649,6 +657,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const bool has_mu = P.mu_row != nullptr, has_ew = P.ew_G != nullptr;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (threadIdx.x < 8) s_mu[threadIdx.x] = (has_mu && threadIdx.x < P.ncodes) ? P.mu_row[threadIdx.x] : 0.0;
+    if (P.ew_field && threadIdx.x < 8) {
+        s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
+        s_dg[threadIdx.x] = P.ew_dgrow[threadIdx.x];
+    }
     const bool live = r < P.R;
     if (live) {
         const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
@@ -918,24 +930,25 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 pend[it] += d;
             }
             if (has_ew) {
-                const int W = P.ew_W;
-                const double dq = P.ew_qs[(size_t)s * W + nw] - P.ew_qs[(size_t)s * W + od];
                 if (P.ew_field) {
                     // flip f sees the earlier flips of the step through the cross terms
-                    double pot = phi[s - sbase] + P.ew_frozen[s];
+                    const double dq = s_q[nw] - s_q[od];
+                    double pot = phi[s - sbase];
                     for (int m = 0; m < f; ++m) {
                         const int sm = (int)rdlane((uint32_t)vsite, m);
                         const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
                                                             (int)rdlane((uint32_t)__double2loint(vdq), m));
                         pot = fma(dqm, P.ew_G[(size_t)s * P.ew_nact + (sm - sbase)], pot);
                     }
-                    ew_uni += 2.0 * dq * pot;
+                    ew_uni += 2.0 * dq * pot + (s_dg[nw] - s_dg[od]);
                     if (lane == f) vdq = dq;
                 } else {
+                    const int W = P.ew_W;
+                    const double dq = P.ew_qs[(size_t)s * W + nw] - P.ew_qs[(size_t)s * W + od];
                     ew_part += 2.0 * dq * lean_ewald_partial(P, occ, lane, s, swa, swm, swb);
-                    ew_uni += 2.0 * dq * P.ew_frozen[s];
+                    ew_uni += 2.0 * dq * P.ew_frozen[s] +
+                              (P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od]);
                 }
-                ew_uni += P.ew_dg[(size_t)s * W + nw] - P.ew_dg[(size_t)s * W + od];
             }
             if (has_mu) dMu += s_mu[nw] - s_mu[od];
             if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative

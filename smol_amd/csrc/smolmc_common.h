@@ -243,7 +243,9 @@ struct LeanParams {
     // lives in LDS for the launch (HBM copy between launches): a proposal costs O(1), an
     // accepted flip one row update
     int ew_field;
-    double *ew_phi;          // [R][ew_nact]
+    double *ew_phi;          // [R][ew_nact]  (includes the frozen-site sums)
+    const double *ew_qrow, *ew_dgrow; // [8] charge / diagonal term per species code (field mode:
+                                      // identical for every active site, checked at create)
     WlParams wl;
     // TableFlip (mcusher.py:397-711) for the single active sublattice
     int tf_n;               // number of flip vectors
@@ -308,6 +310,7 @@ struct smolmc_handle {
     double *d_natural = nullptr;
     double *d_beta = nullptr;
     std::vector<double> bias_host; // host copy of the MCBias table (initial bias in set_state)
+    std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
 };
 
 static void free_samples(smolmc_handle *h);
