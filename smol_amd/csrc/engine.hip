@@ -939,6 +939,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     return bail(1);
                 lp.tf_n = t->n_flip_vectors;
                 lp.tf_sw = t->swap_weight;
+                if (t->n_flip_vectors > 8) return bail(fail("at most 8 flip vectors are supported"));
             }
             if (wl) {
                 lp.wl.L = h->L;
@@ -974,6 +975,19 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     if (dev_alloc(h, (size_t)h->R * nact, &lp.ew_phi)) return bail(1);
                     lp.ew_field = 1;
                     h->lean_lds = with_field;
+                }
+            }
+            if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
+                // block-shared flip table / weights (48 doubles) and, when it fits, ln(k) for
+                // k <= n_active from the host libm (the oracle's log-factorial sums use the same)
+                h->lean_lds += 48 * 8;
+                lp.tf_ln_len = 0;
+                if (h->lean_lds + (size_t)(nact + 1) * 8 <= 150 * 1024) {
+                    std::vector<double> ln((size_t)nact + 1, 0.0);
+                    for (int k = 1; k <= nact; ++k) ln[k] = std::log((double)k);
+                    if (dev_upload(h, ln.data(), ln.size(), &lp.tf_ln)) return bail(1);
+                    lp.tf_ln_len = nact + 1;
+                    h->lean_lds += (size_t)(nact + 1) * 8;
                 }
             }
         }

@@ -648,7 +648,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     double *s_mu = s_dt + P.dt_len; // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (P.ew_field ? (size_t)P.ew_nact * 8 : 0);
     double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
-    unsigned char *wbase = (unsigned char *)(s_mu + 24) + (size_t)wave * per_wave;
+    // block-shared copies of the flip table (<= 8 vectors x 8 codes), its weights and ln(k)
+    double *s_tfw = s_mu + 24;
+    int *s_tf = (int *)(s_tfw + 16);
+    double *s_ln = s_tfw + 16 + 32;
+    unsigned char *wbase = (unsigned char *)(s_ln + P.tf_ln_len) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     double *s_feat = (double *)(wbase + P.Nlds);
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
@@ -661,6 +665,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
         s_dg[threadIdx.x] = P.ew_dgrow[threadIdx.x];
     }
+    for (int i = threadIdx.x; i < 2 * P.tf_n; i += blockDim.x) s_tfw[i] = P.tf_w[i];
+    for (int i = threadIdx.x; i < P.tf_n * P.ncodes; i += blockDim.x) s_tf[i] = P.tf_table[i];
+    for (int i = threadIdx.x; i < P.tf_ln_len; i += blockDim.x) s_ln[i] = P.tf_ln[i];
     const bool live = r < P.R;
     if (live) {
         const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
@@ -737,14 +744,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         double sumw = 0.0;
         if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
             for (int idx = 0; idx < nf2; ++idx) {
-                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int *row = s_tf + (idx >> 1) * nc;
                 const int sg = (idx & 1) ? -1 : 1;
                 bool ok = true;
                 for (int c = 0; c < nc; ++c) {
                     const int v = s_cnt[c] + sg * row[c];
                     ok = ok && v >= 0 && v <= (int)nact;
                 }
-                sumw += ok ? P.tf_w[idx] : 0.0;
+                sumw += ok ? s_tfw[idx] : 0.0;
             }
             sumw = uni_d(sumw);
             if (!(sumw > 0.0)) do_swap = true;
@@ -806,7 +813,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             double cum = 0.0;
             int last = -1;
             for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
-                const int *row = P.tf_table + (idx >> 1) * nc;
+                const int *row = s_tf + (idx >> 1) * nc;
                 const int sg = (idx & 1) ? -1 : 1;
                 bool ok = true;
                 for (int c = 0; c < nc; ++c) {
@@ -815,33 +822,33 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 }
                 if (!ok) continue;
                 last = idx;
-                cum += P.tf_w[idx];
+                cum += s_tfw[idx];
                 if (target < cum) dir = idx;
             }
             if (dir < 0) dir = last;
             dir = uni(dir);
-            const int *urow = P.tf_table + (dir >> 1) * nc;
+            const int *urow = s_tf + (dir >> 1) * nc;
             const int usg = (dir & 1) ? -1 : 1;
             // compute_log_priori_factor (mcusher.py:656-711)
             {
                 double sum_next = 0.0;
                 for (int idx = 0; idx < nf2; ++idx) {
-                    const int *row = P.tf_table + (idx >> 1) * nc;
+                    const int *row = s_tf + (idx >> 1) * nc;
                     const int sg = (idx & 1) ? -1 : 1;
                     bool ok = true;
                     for (int c = 0; c < nc; ++c) {
                         const int v = s_cnt[c] + usg * urow[c] + sg * row[c];
                         ok = ok && v >= 0 && v <= (int)nact;
                     }
-                    sum_next += ok ? P.tf_w[idx] : 0.0;
+                    sum_next += ok ? s_tfw[idx] : 0.0;
                 }
-                const double p_now = (1.0 - P.tf_sw) * P.tf_w[dir] / sumw;
-                const double p_next = (1.0 - P.tf_sw) * P.tf_w[dir ^ 1] / sum_next;
+                const double p_now = (1.0 - P.tf_sw) * s_tfw[dir] / sumw;
+                const double p_next = (1.0 - P.tf_sw) * s_tfw[dir ^ 1] / sum_next;
                 double lf = log(p_next / p_now);
                 for (int c = 0; c < nc; ++c) {
                     const int u = usg * urow[c], n0 = s_cnt[c];
-                    for (int k = 1; k <= u; ++k) lf -= log((double)(n0 + k));
-                    for (int k = 0; k < -u; ++k) lf += log((double)(n0 - k));
+                    for (int k = 1; k <= u; ++k) lf -= (n0 + k) < P.tf_ln_len ? s_ln[n0 + k] : log((double)(n0 + k));
+                    for (int k = 0; k < -u; ++k) lf += (n0 - k) < P.tf_ln_len ? s_ln[n0 - k] : log((double)(n0 - k));
                 }
                 log_priori = uni_d(lf);
             }
@@ -910,6 +917,15 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
         double vdq = 0.0; // lane f holds the charge change of flip f (potential-field mode)
+        // cross terms G[s_i][s_j] of all flip pairs of the step in ONE gather (lane 8 i + j holds
+        // pair j < i), issued before the flips are evaluated so that its latency (the site
+        // kernel lives in L2 / Infinity Cache) overlaps with the cluster-expansion part
+        double vG = 0.0;
+        if (has_ew && P.ew_field && nfl > 1) {
+            const int pi = lane >> 3, pj = lane & 7;
+            const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
+            if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - sbase)];
+        }
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
         for (int f = 0; f < nfl; ++f) {
@@ -935,10 +951,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     const double dq = s_q[nw] - s_q[od];
                     double pot = phi[s - sbase];
                     for (int m = 0; m < f; ++m) {
-                        const int sm = (int)rdlane((uint32_t)vsite, m);
                         const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
                                                             (int)rdlane((uint32_t)__double2loint(vdq), m));
-                        pot = fma(dqm, P.ew_G[(size_t)s * P.ew_nact + (sm - sbase)], pot);
+                        const double gfm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vG), 8 * f + m),
+                                                            (int)rdlane((uint32_t)__double2loint(vG), 8 * f + m));
+                        pot = fma(dqm, gfm, pot);
                     }
                     ew_uni += 2.0 * dq * pot + (s_dg[nw] - s_dg[od]);
                     if (lane == f) vdq = dq;
@@ -951,7 +968,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 }
             }
             if (has_mu) dMu += s_mu[nw] - s_mu[od];
-            if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative
+            occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative (every lane, same byte)
         }
         double dH = wave_sum_all(e);
         double dEw = 0.0;
@@ -963,12 +980,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
         const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
                                            (int)rdlane((uint32_t)__double2loint(logu), l4));
-        const bool accepted = (exponent >= 0.0) || (exponent > lu);
+        const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         if (accepted) {
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             if (dir >= 0 && lane < nc) {
-                const int *urow = P.tf_table + (dir >> 1) * nc;
+                const int *urow = s_tf + (dir >> 1) * nc;
                 s_cnt[lane] += ((dir & 1) ? -1 : 1) * urow[lane];
             }
             if (P.ew_field)
@@ -984,7 +1001,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         } else {
             for (int f = nfl - 1; f >= 0; --f) { // undo the tentative flips
                 const int s = (int)rdlane((uint32_t)vsite, f), od = (int)rdlane((uint32_t)vold, f);
-                if (lane == 0) occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
+                occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
             }
         }
         last_acc = accepted ? 1 : 0;

@@ -252,6 +252,8 @@ struct LeanParams {
     const int *tf_table;    // [tf_n][ncodes]
     const double *tf_w;     // [2 tf_n]
     double tf_sw;           // swap_weight
+    const double *tf_ln;    // [tf_ln_len] ln(k), host libm (LDS copy; 0 = compute on the device)
+    int tf_ln_len;
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
