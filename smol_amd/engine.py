@@ -186,6 +186,18 @@ class Engine:
         )
         return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
 
+    def audit_drift(self):
+        """Drift of the running trace against a from-scratch evaluation of the current
+        occupancies (the batched full-vector kernel, evaluator.pyx:121-209): returns
+        (max |features - recomputed|, max |enthalpy - natural_parameters . recomputed|).
+        The reference bounds the analogous per-flip drift in tests/test_moca/test_processor.py
+        :170-172; here it is the accumulated value after any number of steps."""
+        st = self.get_state()
+        full = self.eval_full(st["occupancy"])
+        df = float(np.max(np.abs(st["features"] - full)))
+        dh = float(np.max(np.abs(st["enthalpy"] - full @ self.natural_parameters)))
+        return df, dh
+
     def get_bias(self):
         """trace.bias of every walker (models created with an MCBias term)."""
         b = np.zeros(self.R)

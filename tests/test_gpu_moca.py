@@ -217,3 +217,21 @@ def test_replica_exchange_on_engine(fcc):
     np.testing.assert_allclose(st["features"], eng.eval_full(st["occupancy"]), rtol=1e-10, atol=1e-8)
     H_by_rung = st["enthalpy"][np.argsort(rex.rung_of)]
     assert H_by_rung[:4].mean() < H_by_rung[-4:].mean()  # cold rungs sit lower
+
+
+def test_accumulated_drift_stays_at_rounding_level(fcc):
+    """SURVEY 8f rank 3 (drift audit): after 2e5 swap steps per walker the running features /
+    enthalpy differ from a from-scratch evaluation by ~1e-11 absolute (extensive values ~1e2)."""
+    from smol_amd.engine import Engine
+
+    model, sc, coefs = fcc
+    tab = moca.Ensemble.from_cluster_expansion(sc, coefs).make_tables()
+    R = 32
+    eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    rng = np.random.default_rng(1)
+    occ = np.vstack([_rand_occ(rng, sc)[0] for _ in range(R)])
+    eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(5), 2000.0)
+    assert max(eng.audit_drift()) < 1e-9
+    eng.run(200_000)
+    df, dh = eng.audit_drift()
+    assert df < 1e-8 and dh < 1e-8
