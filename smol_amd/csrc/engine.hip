@@ -483,13 +483,15 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         }
         h->lp.swz_a = best_a; h->lp.swz_m = best_m; h->lp.swz_b = best_b; h->lp.Nlds = Nlds;
 
-        // delta tables, one per (orbit, self position), all padded to [S*S][NTP]
-        int NTP = 1, SMAX = t->max_species;
-        for (int o = 0; o < t->n_orb; ++o) NTP = std::max(NTP, (int)t->orb_tensor_len[o]);
-        // one table = S*S*NTP doubles; the stride between tables is padded so that it is
-        // not a multiple of the 64-dword LDS bank period (lanes of one wave read the same
-        // (pair, base) entry of DIFFERENT tables: an unpadded power-of-two stride makes
-        // them all collide on one bank pair)
+        // delta tables, one per (orbit, self position): D[(old, new)][b] with the COMPACT base
+        // index b = sum_m S^m * species(member m) over the other members of the cluster (S =
+        // max species per site), padded to a common [S*S][NTP], NTP = S^MML.  Symmetric
+        // clusters give bitwise-equal tables for several self positions: those are shared.
+        const int SMAX = t->max_species;
+        int NTP = 1;
+        for (int m = 0; m < MML; ++m) NTP *= SMAX;
+        // the stride between tables is padded so that it is not a multiple of the 64-dword LDS
+        // bank period (lanes of one wave read the same (pair, base) entry of DIFFERENT tables)
         size_t tlen = (size_t)SMAX * SMAX * NTP;
         if ((tlen & 1) == 0) tlen += 1;
         std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
@@ -508,22 +510,44 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
             const auto key = std::make_pair(o, k.p);
             if (!doff_of.count(key)) {
-                doff_of[key] = (uint32_t)dt.size();
-                dt.resize(dt.size() + tlen, 0.0);
-                double *D = dt.data() + doff_of[key];
-                for (int oldc = 0; oldc < Sself; ++oldc)
-                    for (int newc = 0; newc < Sself; ++newc)
-                        for (int b = 0; b < Nt; ++b) {
-                            const int fi = b + ss * newc, ii = b + ss * oldc;
-                            if (fi < Nt && ii < Nt) D[((size_t)oldc * SMAX + newc) * NTP + b] = T[fi] - T[ii];
-                        }
+                std::vector<double> D(tlen, 0.0);
+                int nb = 1;
+                for (int a = 0; a < I - 1; ++a) nb *= SMAX;
+                for (int b = 0; b < nb; ++b) {
+                    // decode b into the species of the other members -> tensor base index
+                    long base = 0;
+                    int rem = b;
+                    bool valid = true;
+                    for (int a = 0; a < I; ++a) {
+                        if (a == k.p) continue;
+                        const int v = rem % SMAX;
+                        rem /= SMAX;
+                        const int Sa = a == 0 ? Nt / st[0] : st[a - 1] / st[a];
+                        if (v >= Sa) valid = false;
+                        base += (long)st[a] * v;
+                    }
+                    if (!valid) continue;
+                    for (int oldc = 0; oldc < Sself; ++oldc)
+                        for (int newc = 0; newc < Sself; ++newc)
+                            D[((size_t)oldc * SMAX + newc) * NTP + b] =
+                                T[base + (long)ss * newc] - T[base + (long)ss * oldc];
+                }
+                uint32_t at = 0;
+                for (size_t off = tlen; off + tlen <= dt.size() && !at; off += tlen)
+                    if (memcmp(dt.data() + off, D.data(), tlen * sizeof(double)) == 0) at = (uint32_t)off;
+                if (!at) {
+                    at = (uint32_t)dt.size();
+                    dt.insert(dt.end(), D.begin(), D.end());
+                }
+                doff_of[key] = at;
             }
             const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
             LeanSlot &L = ls[(q / 64) * 64 + (q % 64)];
             L.doff8 = doff_of[key] * 8u;
-            int m = 0;
-            for (int a = 0; a < I; ++a)
-                if (a != k.p) L.stride8[m++] = (uint32_t)st[a] * 8u;
+            {
+                uint32_t cs = 8u;
+                for (int m = 0; m < I - 1; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
+            }
             L.feat = (uint32_t)t->orb_id[o];
             L.live = 1;
             L.w = t->ce_coefs[t->orb_id[o]] * scale;
