@@ -106,17 +106,18 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
 }
 
 // potential-field update after an accepted flip of site s by charge dq: every other
-// changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous).  Four loads in
+// changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous).  Eight loads in
 // flight per lane; j == own index is skipped (phi excludes the self term).
 __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
     const double *g = P.ew_G + (size_t)s * P.ew_nact;
     const int js = s - P.sbase, na = P.ew_nact;
-    for (int j0 = lane; j0 < na; j0 += 256) {
-        double gv[4];
+    constexpr int U = 8; // loads in flight per lane: the row comes from L2 / Infinity Cache
+    for (int j0 = lane; j0 < na; j0 += 64 * U) {
+        double gv[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gv[u] = g[min(j0 + 64 * u, na - 1)];
+        for (int u = 0; u < U; ++u) gv[u] = g[min(j0 + 64 * u, na - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int j = j0 + 64 * u;
             if (j < na && j != js) phi[j] = fma(dq, gv[u], phi[j]);
         }
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
     uint32_t W0 = 0, W1 = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
+    double vGc = 0.0; // Ewald field mode: prefetched cross terms of the first-round candidates
     double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
@@ -292,6 +294,15 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 cand[3] = sbase + (int)__umulhi(o.w[3], nact);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
+                if (HAS_EW && P.ew_field) {
+                    // cross term G[candidate][site of the lane's step] of the first-round
+                    // candidates of all 16 steps in one gather, issued a batch ahead (the site
+                    // kernel lives in L2 / Infinity Cache; a dependent load per step would sit on
+                    // the critical path).  The site of step k comes from the block of step k-1.
+                    const int prev = __shfl(nsite, (lane & ~3) - 4);
+                    const int site_l = lane < 4 ? s1 : prev;
+                    vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (site_l - sbase)];
+                }
             }
         }
         const int l4 = (int)(step & 15ull) * 4;
@@ -301,6 +312,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         const RowWords<NW> rown = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
         const int o1 = uni((int)occ[a1]);
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
+        int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
         if (STEP == SMOLMC_STEP_FLIP) {
             // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
@@ -319,6 +331,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                         found = (int)rdlane((uint32_t)cand[j], b);
                         fa = (int)rdlane((uint32_t)canda[j], b);
                         fo = (int)rdlane((uint32_t)v, b);
+                        if (j == 0) fb = b;
                     }
                 }
             }
@@ -409,8 +422,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (HAS_EW) {
                 if (P.ew_field) { // the second flip sees the first through the cross term
                     dq2 = s_q[n2] - s_q[o2];
-                    ew_uni += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)]) +
-                              (s_dg[n2] - s_dg[o2]);
+                    const double cross =
+                        fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
+                                                   (int)rdlane((uint32_t)__double2loint(vGc), fb))
+                                : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)];
+                    ew_uni += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * cross) + (s_dg[n2] - s_dg[o2]);
                 } else {
                     const int W = P.ew_W;
                     dq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];

@@ -64,6 +64,18 @@ def main():
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP)
         occ, T, flips_per_step = rand_occ(sc, R, 3), 3000.0, 1
         name = f"config3: ternary rocksalt {d}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip"
+    elif a.config == 6:
+        # (not in BASELINE.json) config-3 lattice, canonical swap with the Ewald term: the common
+        # production case for ionic systems at fixed composition
+        d = a.dim or 12
+        model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 6.0, 3: 5.0})
+        sc = synth.build_supercell(model, [d] * 3)
+        ew = ewald.supercell_ewald(sc)
+        tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1)
+        R, mc = a.replicas or 2048, a.mc or 2000
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+        occ, T, flips_per_step = rand_occ(sc, R, 3), 3000.0, 2
+        name = f"config6: ternary rocksalt {d}^3 ({sc.num_sites} sites), triplet CE + Ewald, canonical swap"
     elif a.config == 4:
         # config-2 Hamiltonian, Wang-Landau, 1024 walkers
         model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.0, 3: 5.0})
@@ -126,7 +138,7 @@ def main():
         )))
         return
     else:
-        raise SystemExit("config must be 1, 3, 4 or 5")
+        raise SystemExit("config must be 1, 3, 4, 5 or 6")
     setup_s = time.time() - t0
     eng = Engine(tab, cfg)
     eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(777), T)
