@@ -146,6 +146,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the engine has no CPU fallback)")
+    # one process per GPU; if the launcher masks devices per rank only device 0 is visible
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -244,8 +246,12 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            except Exception as exc:  # the GPU measurement must not be lost with it
+                out["cpu_baseline"] = {"value": None, "unit": "attempted flips/s", "cores": usable_cores(),
+                                       "kind": "port", "sample": f"failed: {exc}"[:300]}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
