@@ -812,6 +812,14 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     }
     if (t->has_ewald && t->ewald_charges && getenv("SMOLMC_DENSE_EWALD") == nullptr)
         if (int rc = build_compact_ewald(h, t)) return bail(rc);
+    // potential field of every walker in HBM: needs the compact form and
+    // contiguous changeable sites; the lean kernels stage the same buffer through LDS
+    kp.ew_field = 0;
+    if (kp.ew_compact && kp.ew_act_base >= 0 && (size_t)kp.ew_nact * 8 <= 150 * 1024 &&
+        getenv("SMOLMC_NO_EWALD_FIELD") == nullptr) {
+        if (dev_alloc(h, (size_t)cfg->n_replicas * kp.ew_nact, &kp.ew_phi)) return bail(1);
+        kp.ew_field = 1;
+    }
     // sublattices
     {
         const int ns = t->n_sublattices;
@@ -993,10 +1001,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                             h->ew_dg_host[(size_t)(sbase + i) * kp.ew_W + c] != dgrow[c])
                             uniform = false;
                 }
-                if (uniform && with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
+                if (uniform && kp.ew_field && with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
                     if (dev_upload(h, qrow.data(), 8, &lp.ew_qrow) || dev_upload(h, dgrow.data(), 8, &lp.ew_dgrow))
                         return bail(1);
-                    if (dev_alloc(h, (size_t)h->R * nact, &lp.ew_phi)) return bail(1);
+                    lp.ew_phi = kp.ew_phi;
                     lp.ew_field = 1;
                     h->lean_lds = with_field;
                 }
@@ -1140,9 +1148,17 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
         HIPCHK(hipMemcpy(kp.bias, b0.data(), R * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(kp.charge, q0.data(), R * 8, hipMemcpyHostToDevice));
     }
-    if (h->lean && h->lp.ew_field) {
-        hipLaunchKernelGGL(ewald_field_init_kernel, dim3((unsigned)R), dim3(256), (size_t)h->lp.ew_nact * 8,
-                           h->stream, h->lp);
+    if (kp.ew_field) {
+        LeanParams fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.occ = kp.occ; fp.Npad = h->Npad; fp.sbase = kp.ew_act_base; fp.ew_nact = kp.ew_nact;
+        fp.ew_W = kp.ew_W; fp.ew_qs = kp.ew_qs; fp.ew_G = kp.ew_G; fp.ew_frozen = kp.ew_frozen;
+        fp.ew_phi = kp.ew_phi;
+        const size_t shm = (size_t)kp.ew_nact * 8;
+        if (shm > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)ewald_field_init_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(ewald_field_init_kernel, dim3((unsigned)R), dim3(256), shm, h->stream, fp);
         HIPCHK(hipGetLastError());
     }
     TRY(launch_eval_full(h, kp.occ, (int)R, kp.features));

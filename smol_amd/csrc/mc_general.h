@@ -132,6 +132,29 @@ __device__ __forceinline__ double ewald_compact_partial(const KParams &P, const 
     return out;
 }
 
+// potential-field update in HBM after an accepted flip of site s by charge dq (general
+// kernel): phi[j] += dq * G[s][j] for every other changeable site j; lane-strided, so each
+// address is always touched by the same lane (program order keeps later updates coherent).
+__device__ __forceinline__ void field_apply_global(const KParams &P, double *phi, int lane, int s, double dq) {
+    const double *g = P.ew_G + (size_t)s * P.ew_nact;
+    const int js = s - P.ew_act_base, na = P.ew_nact;
+    constexpr int U = 8; // loads in flight per lane (the row streams from Infinity Cache / HBM)
+    for (int j0 = lane; j0 < na; j0 += 64 * U) {
+        double gv[U], pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + 64 * u, na - 1);
+            gv[u] = g[j];
+            pv[u] = phi[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < na && j != js) phi[j] = fma(dq, gv[u], pv[u]);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // the Monte-Carlo kernel
 // ----------------------------------------------------------------------------
@@ -369,7 +392,24 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             }
         }
         double dEw = 0.0, dMu = 0.0;
-        if (P.has_ewald && nfl >= 1) {
+        double fdq1 = 0.0, fdq2 = 0.0; // potential-field mode: charge changes of the flips
+        if (P.has_ewald && nfl >= 1 && P.ew_field) {
+            // O(1) proposal from the walker's potential field (HBM copy, read past the L1 so
+            // that the row updates of earlier accepted steps are seen)
+            double *phi = P.ew_phi + (size_t)r * P.ew_nact;
+            const int W = P.ew_W, ab = P.ew_act_base;
+            fdq1 = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
+            const double p1 = __hip_atomic_load(&phi[s1 - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dEw = 2.0 * fdq1 * p1 + (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+            if (nfl == 2) {
+                fdq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
+                const double p2 = __hip_atomic_load(&phi[s2 - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double cross = s2 != s1 ? P.ew_G[(size_t)s2 * P.ew_nact + (s1 - ab)] : 0.0;
+                dEw += 2.0 * fdq2 * (p2 + fdq1 * cross) +
+                       (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+            }
+            dEw = uni_d(dEw);
+        } else if (P.has_ewald && nfl >= 1) {
             if (P.ew_compact) {
                 const int W = P.ew_W;
                 const double s1sum = P.ew_frozen[s1] + wave_sum(ewald_compact_partial<false>(P, L, lane, s1, 0, 0));
@@ -460,6 +500,11 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                     if (P.has_ewald) L.wl_cf[P.Fce] += dEw;
                     if (P.has_mu) L.wl_cf[P.Fce + P.has_ewald] += dMu;
                 }
+            }
+            if (P.has_ewald && P.ew_field) {
+                double *phi = P.ew_phi + (size_t)r * P.ew_nact;
+                if (fdq1 != 0.0) field_apply_global(P, phi, lane, s1, fdq1);
+                if (nfl == 2 && fdq2 != 0.0) field_apply_global(P, phi, lane, s2, fdq2);
             }
             acc_ew += dEw;
             acc_mu += dMu;

@@ -94,6 +94,10 @@ struct KParams {
     const double *ew_G;           // [N][ew_nact] site kernel restricted to changeable sites
     const double *ew_qs;          // [N][ew_W] charge of (site, code), 0 for vacancies
     const double *ew_dg;          // [N][ew_W] diagonal entry M[a][a] of (site, code)
+    // potential field in HBM (general kernel): phi[r][j] = frozen[j] + sum_{k != j} q_k G[j][k]
+    // over the changeable sites (contiguous, ew_act_base >= 0); see DESIGN 4.4
+    int ew_field;
+    double *ew_phi;               // [R][ew_nact]
     const double *mu;             // [N][mu_W]
     // MCBias (smol/moca/kernel/bias.py): table [N][bias_W], running bias / net charge [R]
     int bias_type, bias_W;

@@ -76,6 +76,19 @@ def main():
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
         occ, T, flips_per_step = rand_occ(sc, R, 3), 3000.0, 2
         name = f"config6: ternary rocksalt {d}^3 ({sc.num_sites} sites), triplet CE + Ewald, canonical swap"
+    elif a.config == 7:
+        # (not in BASELINE.json) two ACTIVE sublattices: Li+/Mn3+/Ti4+ cations and O2-/F- anions
+        # on rocksalt (the disordered-rocksalt oxyfluoride shape), CE (+ Ewald), canonical swap
+        d = a.dim or 12
+        model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 6.0, 3: 4.5})
+        sc = synth.build_supercell(model, [d] * 3)
+        ew = ewald.supercell_ewald(sc) if not os.environ.get("CONFIG7_NO_EWALD") else None
+        tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1)
+        R, mc = a.replicas or 2048, a.mc or 1000
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+        occ, T, flips_per_step = rand_occ(sc, R, 3), 3000.0, 2
+        name = (f"config7: rocksalt {d}^3 ({sc.num_sites} sites), ternary cations + binary anions, CE"
+                f"{' + Ewald' if ew is not None else ''}, canonical swap")
     elif a.config == 4:
         # config-2 Hamiltonian, Wang-Landau, 1024 walkers
         model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.0, 3: 5.0})
@@ -138,7 +151,7 @@ def main():
         )))
         return
     else:
-        raise SystemExit("config must be 1, 3, 4, 5 or 6")
+        raise SystemExit("config must be 1, 3, 4, 5, 6 or 7")
     setup_s = time.time() - t0
     eng = Engine(tab, cfg)
     eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(777), T)
