@@ -893,8 +893,12 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     size_t pw = (size_t)h->Npad;
     if (wl)
         pw += (size_t)h->L * 16 + (size_t)h->F * 8;
-    else
-        pw += (size_t)h->Fce * 64 * 8;
+    else {
+        const size_t by_feat = (size_t)h->Fce * 64 * 8;
+        const size_t by_slot = ((size_t)kp.nclasses * kp.Cpad + h->Fce) * 8;
+        kp.acc_by_slot = (!kp.corr_mode && by_slot < by_feat) ? 1 : 0;
+        pw += kp.acc_by_slot ? by_slot : by_feat;
+    }
     pw = (pw + 15) / 16 * 16;
     kp.lds_tables = (int)tb;
     kp.lds_per_wave = (int)pw;

@@ -77,7 +77,7 @@ __device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int c
             __hip_atomic_fetch_add(&L.wl_cf[feat + k], fs * d, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
         } else {
-            double *cell = L.acc + (size_t)(feat + k) * 64 + lane;
+            double *cell = P.acc_by_slot ? L.acc + (size_t)cls * P.Cpad + c : L.acc + (size_t)(feat + k) * 64 + lane;
             *cell = fma(fs, d, *cell);
         }
     }
@@ -158,6 +158,32 @@ __device__ __forceinline__ void field_apply_global(const KParams &P, double *phi
 // ----------------------------------------------------------------------------
 // the Monte-Carlo kernel
 // ----------------------------------------------------------------------------
+// Metropolis feature deltas accumulated since launch start, reduced over the wave:
+// calls emit(f, value) on lane 0 for every cluster-expansion feature f.
+template <typename F>
+__device__ __forceinline__ void reduce_feature_acc(const KParams &P, const Lds &L, int lane, F emit) {
+    if (P.acc_by_slot) {
+        double *out = L.acc + (size_t)P.nclasses * P.Cpad; // [Fce] scratch
+        for (int f = lane; f < P.Fce; f += 64) out[f] = 0.0;
+        for (int cls = 0; cls < P.nclasses; ++cls)
+            for (int c = lane; c < P.Cpad; c += 64) {
+                const uint4 b = L.descB[cls * P.Cpad + c];
+                const double v = L.acc[(size_t)cls * P.Cpad + c];
+                if (v != 0.0)
+                    __hip_atomic_fetch_add(&out[b.z & 0xffffu], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        for (int f = 0; f < P.Fce; ++f) {
+            const double sm = out[f];
+            if (lane == 0) emit(f, sm);
+        }
+    } else {
+        for (int f = 0; f < P.Fce; ++f) {
+            const double sm = wave_sum(L.acc[(size_t)f * 64 + lane]);
+            if (lane == 0) emit(f, sm);
+        }
+    }
+}
+
 template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
 __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int replay) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -214,7 +240,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             }
             for (int i = lane; i < P.F; i += 64) L.wl_cf[i] = P.features[(size_t)r * P.F + i];
         } else {
-            for (int i = lane; i < P.Fce * 64; i += 64) L.acc[i] = 0.0;
+            const int ncell = P.acc_by_slot ? P.nclasses * P.Cpad + P.Fce : P.Fce * 64;
+            for (int i = lane; i < ncell; i += 64) L.acc[i] = 0.0;
         }
     }
     __syncthreads();
@@ -572,10 +599,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             if (WL) {
                 for (int i = lane; i < P.F; i += 64) dstf[i] = L.wl_cf[i];
             } else {
-                for (int f = 0; f < P.Fce; ++f) {
-                    const double sm = wave_sum(L.acc[(size_t)f * 64 + lane]);
-                    if (lane == 0) dstf[f] = base[f] + sm;
-                }
+                reduce_feature_acc(P, L, lane, [&](int f, double sm) { dstf[f] = base[f] + sm; });
                 if (lane == 0) {
                     if (P.has_ewald) dstf[P.Fce] = base[P.Fce] + acc_ew;
                     if (P.has_mu) dstf[P.Fce + P.has_ewald] = base[P.Fce + P.has_ewald] + acc_mu;
@@ -611,10 +635,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
             P.wl_counter[r] = wl_counter;
         }
     } else {
-        for (int f = 0; f < P.Fce; ++f) {
-            const double s = wave_sum(L.acc[(size_t)f * 64 + lane]);
-            if (lane == 0) feat[f] += s;
-        }
+        reduce_feature_acc(P, L, lane, [&](int f, double sm) { feat[f] += sm; });
         if (lane == 0) {
             if (P.has_ewald) feat[P.Fce] += acc_ew;
             if (P.has_mu) feat[P.Fce + P.has_ewald] += acc_mu;

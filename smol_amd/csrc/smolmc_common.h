@@ -136,6 +136,10 @@ struct KParams {
     double *wl_meanf;             // [R][L][F]
     double *wl_m;                 // [R]
     long long *wl_counter;        // [R]
+    // Metropolis feature accumulators in LDS: acc_by_slot = 0 -> [Fce][64] cells (feature, lane);
+    // 1 -> [nclasses][Cpad] cells (class, slot) + [Fce] scratch, used in interaction mode when
+    // that is smaller (models with many orbits)
+    int acc_by_slot;
     // lds layout (bytes)
     int lds_tables, lds_per_wave;
     SampleBufs smp;
