@@ -185,7 +185,7 @@ __device__ __forceinline__ void reduce_feature_acc(const KParams &P, const Lds &
 }
 
 template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>
-__global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int replay) {
+__global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KParams P, const int replay) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -265,13 +265,15 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
     }
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0; // RNG batch: lane l = block (l&3) of step base+(l>>2)
     uint32_t w_site_carry = 0;
+    double logu_b = 0.0; // native mode: log(u) of the lane's step, computed per batch
     unsigned long long batch_base = ~0ull - 64ull;
     long long smp_countdown = P.smp.every, smp_index = 0;
 
     for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
         // ================= proposal =========================================
         int nfl = 0, s1 = 0, n1 = 0, o1 = 0, s2 = 0, n2 = 0, o2 = 0;
-        double u = 0.0;
+        double u = 0.0, lu = 0.0;
+        bool have_lu = false; // native mode supplies log(u) from the batch; replay takes it per step
         if (replay) {
             const int *st = P.rp_steps + ((size_t)r * P.steps_to_run + it_step) * 4;
             int a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3];
@@ -297,11 +299,16 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                 philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
                                              0u, key0, key1);
                 W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+                // log of the acceptance uniform of all 16 steps at once (block-0 lanes)
+                logu_b = log(philox_u53(o.w[2], o.w[3]));
             }
             const int l4 = (int)(step & 15ull) * 4;
             const uint32_t w_sub = rdlane(W0, l4);
             const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
             u = philox_u53(rdlane(W2, l4), rdlane(W3, l4));
+            lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu_b), l4),
+                                  (int)rdlane((uint32_t)__double2loint(logu_b), l4));
+            have_lu = true;
             // sublattice: MCUsher.get_random_sublattice (mcusher.py:146-148)
             int sl = 0;
             if (P.nsub > 1) {
@@ -492,7 +499,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
         if (!WL) {
             // MetropolisAcceptMixin._accept_step (metropolis.py:31-49)
             const double exponent = -beta * dH + 0.0 + dB;
-            accepted = exponent >= 0.0 ? true : (exponent > log(u));
+            accepted = __ballot(exponent >= 0.0 ? true : (exponent > (have_lu ? lu : log(u)))) != 0ull;
         } else {
             // WangLandau._accept_step (wanglandau.py:186-202)
             const double new_h = H + dH;
@@ -502,7 +509,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                 const int b = (int)floordiv_exact(H - P.wl_min, P.wl_bin);
                 const int nb = (int)floordiv_exact(new_h - P.wl_min, P.wl_bin);
                 const double exponent = L.wl_S[b] - L.wl_S[nb] + 0.0;
-                accepted = exponent >= 0.0 ? true : (exponent > log(u));
+                accepted = __ballot(exponent >= 0.0 ? true : (exponent > (have_lu ? lu : log(u)))) != 0ull;
             }
         }
 
@@ -520,9 +527,9 @@ __global__ void __launch_bounds__(256) mc_kernel(const KParams P, const int repl
                 for (int it = 0; it < NSLOT; ++it)
                     if (it < nit2) accum_slot<WL>(P, L, cls2, lane + 64 * it, lane, ii2[it], jf2[it]);
             }
+            if (nfl >= 1) L.occ[s1] = (uint8_t)n1; // every lane stores the same byte
+            if (nfl == 2) L.occ[s2] = (uint8_t)n2;
             if (lane == 0) {
-                if (nfl >= 1) L.occ[s1] = (uint8_t)n1;
-                if (nfl == 2) L.occ[s2] = (uint8_t)n2;
                 if (WL) {
                     if (P.has_ewald) L.wl_cf[P.Fce] += dEw;
                     if (P.has_mu) L.wl_cf[P.Fce + P.has_ewald] += dMu;
