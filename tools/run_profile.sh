@@ -12,5 +12,5 @@ done
 cd $R
 python tools/rocpd_summary.py gpurun_out/prof_final gpurun_out/pmc_final_* > gpurun_out/final_summary.txt 2>&1
 tail -5 gpurun_out/bench_r01_final.json
-for c in 1 3 4 5; do python tools/bench_configs.py --config $c > gpurun_out/config${c}_final.json 2> gpurun_out/config${c}_final.err; done
+for c in 1 3 4 5 6 7; do python tools/bench_configs.py --config $c > gpurun_out/config${c}_final.json 2> gpurun_out/config${c}_final.err; done
 cat gpurun_out/config*_final.json
