@@ -183,6 +183,14 @@ __global__ void __launch_bounds__(256) ewald_field_init_kernel(const LeanParams 
     }
 }
 
+// Wang-Landau per-bin feature statistics: running means <-> running sums (sum = mean * occurrences)
+__global__ void wl_meanf_convert_kernel(double *meanf, const long long *occur, size_t cells, int F, int to_mean) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells * (size_t)F) return;
+    const long long n = occur[i / F];
+    if (n > 0) meanf[i] = to_mean ? meanf[i] / (double)n : meanf[i] * (double)n;
+}
+
 __global__ void dot_features_kernel(const double *features, const double *natural, double *enthalpy,
                                     int R, int F) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -984,6 +992,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
                 lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
+                lp.wl.sum_mode = (kp.wl_update == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
             }
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
@@ -1175,6 +1184,7 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
         HIPCHK(hipMemsetAsync(kp.wl_hist, 0, RL * 8, h->stream));
         HIPCHK(hipMemsetAsync(kp.wl_occur, 0, RL * 8, h->stream));
         HIPCHK(hipMemsetAsync(kp.wl_meanf, 0, RL * h->F * 8, h->stream));
+        h->wl_sums = false; // all zero: either representation
         HIPCHK(hipMemsetAsync(kp.wl_counter, 0, R * 8, h->stream));
         std::vector<double> m0(R, h->cfg.wl_mod_factor);
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1237,6 +1247,17 @@ extern "C" int smolmc_get_state(smolmc_handle *h, int32_t *occ, double *features
     return 0;
 }
 
+// bring kp.wl_meanf into the representation the next consumer expects (see WlParams::sum_mode)
+static int wl_set_representation(smolmc_handle *h, bool sums) {
+    if (h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU || h->wl_sums == sums) return 0;
+    const size_t cells = (size_t)h->R * h->L, n = cells * h->F;
+    hipLaunchKernelGGL(wl_meanf_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                       h->kp.wl_meanf, h->kp.wl_occur, cells, h->F, sums ? 0 : 1);
+    HIPCHK(hipGetLastError());
+    h->wl_sums = sums;
+    return 0;
+}
+
 extern "C" int smolmc_get_wl(smolmc_handle *h, double *entropy, int64_t *histogram,
                              int64_t *occurrences, double *mean_features, double *mod_factor) {
     if (!h) return fail("null handle");
@@ -1245,6 +1266,8 @@ extern "C" int smolmc_get_wl(smolmc_handle *h, double *entropy, int64_t *histogr
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t RL = (size_t)h->R * h->L;
     KParams &kp = h->kp;
+    TRY(wl_set_representation(h, false));
+    HIPCHK(hipStreamSynchronize(h->stream));
     if (entropy) HIPCHK(hipMemcpy(entropy, kp.wl_entropy, RL * 8, hipMemcpyDeviceToHost));
     if (histogram) HIPCHK(hipMemcpy(histogram, kp.wl_hist, RL * 8, hipMemcpyDeviceToHost));
     if (occurrences) HIPCHK(hipMemcpy(occurrences, kp.wl_occur, RL * 8, hipMemcpyDeviceToHost));
@@ -1280,6 +1303,7 @@ static void free_samples(smolmc_handle *h) {
 }
 
 static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
+    TRY(wl_set_representation(h, h->lean && h->lp.wl.sum_mode));
     if (h->lean) {
         // the lean kernels count steps in 32 bits: launches are split at 2^30 steps (on a
         // sample boundary when samples are being recorded)
@@ -1389,13 +1413,14 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     if (e == hipSuccess) e = hipMemcpy(d_u, uniforms, n * 8, hipMemcpyHostToDevice);
     int rc = 0;
     if (e == hipSuccess) {
+        rc = wl_set_representation(h, false);
         KParams kp = h->kp;
         kp.steps_to_run = nsteps;
         kp.rp_steps = d_steps;
         kp.rp_u = d_u;
         kp.rp_acc = d_acc;
         kp.rp_H = d_H;
-        rc = launch_mc(h, kp, 1);
+        if (!rc) rc = launch_mc(h, kp, 1);
         if (!rc) e = hipStreamSynchronize(h->stream);
         if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
         if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);

@@ -214,6 +214,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double H = P.enthalpy[r];
     const double nbeta = WL ? 0.0 : -P.beta[r];
     double wl_m = WL ? P.wl.m[r] : 0.0;
+    // bin coordinate of the current enthalpy, carried from the post-step of the previous step
+    double wl_bq = WL ? floordiv_exact(H - P.wl.vmin, P.wl.bin) : 0.0;
     long long wl_counter = WL ? P.wl.counter[r] : 0;
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0; // accepted steps of this launch (32-bit counter; < 2^31 steps per launch)
@@ -442,6 +444,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (nfl == 2) dMu += s_mu[n2] - s_mu[o2];
         }
         double dH = 0.0, dEw = 0.0;
+        double wl_nbq = 0.0; // WL: bin coordinate of the proposed enthalpy
         bool accepted;
         bool decided = false;
         if (FAST) {
@@ -474,8 +477,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
                     accepted = false;
                 } else {
-                    const int b = (int)floordiv_exact(H - P.wl.vmin, P.wl.bin);
-                    const int nb = (int)floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                    const int b = (int)wl_bq;
+                    wl_nbq = floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                    const int nb = (int)wl_nbq;
                     const double exponent = wl_S[b] - wl_S[nb] + 0.0;
                     accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
                 }
@@ -524,8 +528,24 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 
         if (WL) {
             // WangLandau._do_post_step (wanglandau.py:222-266)
-            const double bq = floordiv_exact(H - P.wl.vmin, P.wl.bin);
-            if (bq >= 0.0 && bq < (double)P.wl.L) {
+            // the bin only moves on accepted steps, to the one computed by the accept test
+            const double bq = accepted ? wl_nbq : wl_bq;
+            wl_bq = bq;
+            if (P.wl.sum_mode) {
+                // update_period == 1: occurrences and feature SUMS by fire-and-forget atomics (the
+                // running mean of wanglandau.py:235-239 is sum / occurrences, formed when read)
+                if (bq >= 0.0 && bq < (double)P.wl.L) {
+                    const int b = (int)bq;
+                    wl_counter++;
+                    const size_t cell = (size_t)r * P.wl.L + b;
+                    if (lane < P.F) unsafeAtomicAdd(P.wl.meanf + cell * P.F + lane, s_feat[lane]);
+                    if (lane == 0) {
+                        wl_S[b] += wl_m;
+                        wl_Hh[b] += 1;
+                        atomicAdd((unsigned long long *)(P.wl.occur + cell), 1ull);
+                    }
+                }
+            } else if (bq >= 0.0 && bq < (double)P.wl.L) {
                 const int b = (int)bq;
                 wl_counter++;
                 const size_t cell = (size_t)r * P.wl.L + b;

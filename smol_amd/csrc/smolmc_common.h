@@ -207,7 +207,9 @@ struct WlParams { // Wang-Landau state of the walkers (kernel/wanglandau.py:107-
     double *entropy;     // [R][L]
     long long *hist;     // [R][L]
     long long *occur;    // [R][L]
-    double *meanf;       // [R][L][F]
+    double *meanf;       // [R][L][F]  running means -- or, while sum_mode is set, running SUMS
+    int sum_mode;        // lean kernel with update_period == 1: mean = sum / occurrences (no
+                         // read-modify-write round trip per step; converted when read)
     double *m;           // [R]
     long long *counter;  // [R]
 };
@@ -319,6 +321,7 @@ struct smolmc_handle {
     size_t eval_occ_cap = 0;
     double *d_natural = nullptr;
     double *d_beta = nullptr;
+    bool wl_sums = false; // kp.wl_meanf currently holds sums (lean Wang-Landau) instead of means
     std::vector<double> bias_host; // host copy of the MCBias table (initial bias in set_state)
     std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
 };
