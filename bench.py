@@ -108,7 +108,7 @@ def cpu_baseline():
     host cores of this box with OpenMP over walkers, on a bounded sample of the workload.
     It runs in a fresh interpreter: libgomp reads its environment once, when first loaded,
     and torch has already loaded it in this process (bound, passive-wait threads are ~2.3x
-    faster than the defaults under this box's cgroup quota, tools/cpu_baseline_probe.py)."""
+    faster than the defaults under this box's cgroup quota)."""
     import subprocess
 
     cores = usable_cores()
