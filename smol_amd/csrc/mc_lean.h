@@ -720,6 +720,30 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     for (int a = lane; a < (int)nact; a += 64)
         atomicAdd(&s_cnt[(int)occ[lean_swz(sbase + a, swa, swm, swb)]], 1);
+    // lane-indexed working copies: lane c (< ncodes) holds the count of species c and column c
+    // of every flip vector; feasibility of a direction is then one compare + one ballot
+    int vcnt = lane < P.ncodes ? s_cnt[lane] : 0;
+    int vtf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vtf[i] = (i < P.tf_n && lane < P.ncodes) ? s_tf[i * P.ncodes + lane] : 0;
+    // bit idx of the result: direction idx (2 i = +vector i, 2 i + 1 = -vector i) keeps every
+    // count inside [0, n_active] when applied to the counts vc (flip_weights_mask, math.py:832-867)
+    auto feasible = [&](const int vc) -> unsigned {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < P.tf_n) {
+                const int vp = vc + vtf[i], vm = vc - vtf[i];
+                if (__ballot(vp < 0 || vp > P.nact) == 0ull) m |= 1u << (2 * i);
+                if (__ballot(vm < 0 || vm > P.nact) == 0ull) m |= 2u << (2 * i);
+            }
+        return m;
+    };
+    auto masked_sum = [&](const unsigned m) -> double { // sum of the weights of the set directions
+        double sw = 0.0;
+        for (int idx = 0; idx < 2 * P.tf_n; ++idx) sw += ((m >> idx) & 1u) ? s_tfw[idx] : 0.0;
+        return sw;
+    };
 
     uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
     double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
@@ -749,7 +773,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     unsigned long long batch_base = ~0ull;
     uint32_t w_site_carry = 0;
     constexpr int ROW = NSLOT * MM;
-    const uint16_t *idx_lane = P.idx + (size_t)lane * ROW;
+    constexpr int NW = ROW / 2;
+    constexpr uint32_t SITE_BYTES = 64u * ROW * 2u;
+    const __amdgpu_buffer_rsrc_t idx_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
     const int nf2 = 2 * P.tf_n;
 
     for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
@@ -775,21 +803,17 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // flips of this step live lane-indexed: lane f holds flip f
         int vsite = 0, vnew = 0, vold = 0;
         int nfl = 0, dir = -1;
+        int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
+#ifdef SMOLMC_EXP_TF_SWAPONLY
+        do_swap = true;
+#endif
         double sumw = 0.0;
+        unsigned feas_now = 0;
         if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
-            for (int idx = 0; idx < nf2; ++idx) {
-                const int *row = s_tf + (idx >> 1) * nc;
-                const int sg = (idx & 1) ? -1 : 1;
-                bool ok = true;
-                for (int c = 0; c < nc; ++c) {
-                    const int v = s_cnt[c] + sg * row[c];
-                    ok = ok && v >= 0 && v <= (int)nact;
-                }
-                sumw += ok ? s_tfw[idx] : 0.0;
-            }
-            sumw = uni_d(sumw);
+            feas_now = feasible(vcnt);
+            sumw = masked_sum(feas_now);
             if (!(sumw > 0.0)) do_swap = true;
         }
         if (do_swap) {
@@ -849,40 +873,30 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             double cum = 0.0;
             int last = -1;
             for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
-                const int *row = s_tf + (idx >> 1) * nc;
-                const int sg = (idx & 1) ? -1 : 1;
-                bool ok = true;
-                for (int c = 0; c < nc; ++c) {
-                    const int v = s_cnt[c] + sg * row[c];
-                    ok = ok && v >= 0 && v <= (int)nact;
-                }
-                if (!ok) continue;
+                if (!((feas_now >> idx) & 1u)) continue;
                 last = idx;
                 cum += s_tfw[idx];
                 if (target < cum) dir = idx;
             }
             if (dir < 0) dir = last;
-            dir = uni(dir);
-            const int *urow = s_tf + (dir >> 1) * nc;
             const int usg = (dir & 1) ? -1 : 1;
+            // column values of the chosen vector, lane-indexed (register array -> select chain)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
+            vu *= usg; // lane c: change of the count of species c
             // compute_log_priori_factor (mcusher.py:656-711)
             {
-                double sum_next = 0.0;
-                for (int idx = 0; idx < nf2; ++idx) {
-                    const int *row = s_tf + (idx >> 1) * nc;
-                    const int sg = (idx & 1) ? -1 : 1;
-                    bool ok = true;
-                    for (int c = 0; c < nc; ++c) {
-                        const int v = s_cnt[c] + usg * urow[c] + sg * row[c];
-                        ok = ok && v >= 0 && v <= (int)nact;
-                    }
-                    sum_next += ok ? s_tfw[idx] : 0.0;
+                const double sum_next = masked_sum(feasible(vcnt + vu));
+                double lf = 0.0;
+                // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
+                // case away from the composition limits), no division / log needed
+                if (!(s_tfw[dir] == s_tfw[dir ^ 1] && sum_next == sumw)) {
+                    const double p_now = (1.0 - P.tf_sw) * s_tfw[dir] / sumw;
+                    const double p_next = (1.0 - P.tf_sw) * s_tfw[dir ^ 1] / sum_next;
+                    lf = log(p_next / p_now);
                 }
-                const double p_now = (1.0 - P.tf_sw) * s_tfw[dir] / sumw;
-                const double p_next = (1.0 - P.tf_sw) * s_tfw[dir ^ 1] / sum_next;
-                double lf = log(p_next / p_now);
                 for (int c = 0; c < nc; ++c) {
-                    const int u = usg * urow[c], n0 = s_cnt[c];
+                    const int u = (int)rdlane((uint32_t)vu, c), n0 = (int)rdlane((uint32_t)vcnt, c);
                     for (int k = 1; k <= u; ++k) lf -= (n0 + k) < P.tf_ln_len ? s_ln[n0 + k] : log((double)(n0 + k));
                     for (int k = 0; k < -u; ++k) lf += (n0 - k) < P.tf_ln_len ? s_ln[n0 - k] : log((double)(n0 - k));
                 }
@@ -896,7 +910,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
             bool have_round = false;
             for (int c = 0; c < nc; ++c) {
-                int need = -(usg * urow[c]);
+                int need = -(int)rdlane((uint32_t)vu, c);
                 while (need > 0) {
                     if (!have_round) {
                         const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
@@ -932,7 +946,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             // random assignment of the collected sites to the enriched species (:627-631)
             int qdraw = 0;
             for (int c = 0; c < nc; ++c) {
-                const int u = usg * urow[c];
+                const int u = (int)rdlane((uint32_t)vu, c);
                 for (int k = 0; k < u; ++k) {
                     const int wl = l4 + 2 + (qdraw >> 2);
                     const int wj = qdraw & 3;
@@ -964,19 +978,21 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
-        for (int f = 0; f < nfl; ++f) {
+        // the index rows of the first four flips are fetched together (their sites are known),
+        // so that only one memory latency is exposed per step
+        RowWords<NW> rows[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (f < nfl) rows[f] = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES);
+        auto eval_flip = [&](const int f, const RowWords<NW> &row) {
             const int s = (int)rdlane((uint32_t)vsite, f), nw = (int)rdlane((uint32_t)vnew, f);
             const int od = (int)rdlane((uint32_t)vold, f);
-            const uint16_t *p = idx_lane + (size_t)s * (64 * ROW);
-            uint16_t row[ROW];
-#pragma unroll
-            for (int q = 0; q < ROW; ++q) row[q] = p[q];
             const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row[it * MM + m]]);
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row, it * MM + m)]);
                 const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
                 e = fma(wgt[it], d, e);
                 pend[it] += d;
@@ -1005,7 +1021,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
             if (has_mu) dMu += s_mu[nw] - s_mu[od];
             occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative (every lane, same byte)
-        }
+        };
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (f < nfl) eval_flip(f, rows[f]);
+        for (int f = 4; f < nfl; ++f)
+            eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
         double dH = wave_sum_all(e);
         double dEw = 0.0;
         if (has_ew) {
@@ -1020,10 +1041,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         if (accepted) {
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
-            if (dir >= 0 && lane < nc) {
-                const int *urow = s_tf + (dir >> 1) * nc;
-                s_cnt[lane] += ((dir & 1) ? -1 : 1) * urow[lane];
-            }
+            vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
             if (P.ew_field)
                 for (int f = 0; f < nfl; ++f) {
                     const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
