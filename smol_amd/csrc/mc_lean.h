@@ -739,9 +739,15 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
         return m;
     };
+    const double vw = lane < 2 * P.tf_n ? s_tfw[lane] : 0.0; // lane idx: weight of direction idx
+    auto weight_of = [&](const int idx) -> double {
+        return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vw), idx),
+                                (int)rdlane((uint32_t)__double2loint(vw), idx));
+    };
     auto masked_sum = [&](const unsigned m) -> double { // sum of the weights of the set directions
         double sw = 0.0;
-        for (int idx = 0; idx < 2 * P.tf_n; ++idx) sw += ((m >> idx) & 1u) ? s_tfw[idx] : 0.0;
+        for (int idx = 0; idx < 2 * P.tf_n; ++idx)
+            if ((m >> idx) & 1u) sw += weight_of(idx);
         return sw;
     };
 
@@ -875,7 +881,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
                 if (!((feas_now >> idx) & 1u)) continue;
                 last = idx;
-                cum += s_tfw[idx];
+                cum += weight_of(idx);
                 if (target < cum) dir = idx;
             }
             if (dir < 0) dir = last;
@@ -890,9 +896,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 double lf = 0.0;
                 // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
                 // case away from the composition limits), no division / log needed
-                if (!(s_tfw[dir] == s_tfw[dir ^ 1] && sum_next == sumw)) {
-                    const double p_now = (1.0 - P.tf_sw) * s_tfw[dir] / sumw;
-                    const double p_next = (1.0 - P.tf_sw) * s_tfw[dir ^ 1] / sum_next;
+                const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
+                if (!(w_now == w_back && sum_next == sumw)) {
+                    const double p_now = (1.0 - P.tf_sw) * w_now / sumw;
+                    const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
                     lf = log(p_next / p_now);
                 }
                 for (int c = 0; c < nc; ++c) {
@@ -903,14 +910,18 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 log_priori = uni_d(lf);
             }
             // pick the sites of the depleted species from the candidate stream
-            // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round
-            int vcol = 0, ncol = 0; // collected sites, lane-indexed
-            long long tlast = -1;
+            // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round, lane l holds
+            // t = 256 round + 4 l + j.  The scan is scalar: per species four ballots (one per j),
+            // each pick = first set bit at or after the running stream position.
+            int vcol = 0, ncol = 0;   // collected sites, lane-indexed
+            uint32_t tpos = 0;        // next stream position inside the current round
             uint32_t round = 0;
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
             bool have_round = false;
             for (int c = 0; c < nc; ++c) {
                 int need = -(int)rdlane((uint32_t)vu, c);
+                unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
+                bool have_masks = false;
                 while (need > 0) {
                     if (!have_round) {
                         const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
@@ -921,23 +932,28 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                             cv[j] = (int)occ[lean_swz(cs[j], swa, swm, swb)];
                         }
                         have_round = true;
+                        have_masks = false;
+                        tpos = 0;
                     }
-                    // smallest stream position t > tlast in this lane that holds species c and
-                    // was not collected yet
-                    long long mint = -1;
+                    if (!have_masks) {
 #pragma unroll
-                    for (int j = 3; j >= 0; --j) {
-                        const long long t = (long long)round * 256 + 4 * lane + j;
-                        bool ok = cv[j] == c && t > tlast;
-                        for (int z = 0; z < ncol; ++z) ok = ok && cs[j] != (int)rdlane((uint32_t)vcol, z);
-                        if (ok) mint = t;
+                        for (int j = 0; j < 4; ++j) B[j] = __ballot(cv[j] == c);
+                        have_masks = true;
                     }
-                    const unsigned long long m = __ballot(mint >= 0);
-                    if (!m) { round++; have_round = false; continue; }
-                    const int b = __ffsll((long long)m) - 1;
-                    const int tj = (int)(((unsigned)rdlane((uint32_t)(int)(mint & 0xffffffffll), b)) & 3u);
-                    tlast = (long long)round * 256 + 4 * b + tj;
-                    const int picked = (int)rdlane((uint32_t)(tj == 0 ? cs[0] : tj == 1 ? cs[1] : tj == 2 ? cs[2] : cs[3]), b);
+                    // first candidate of species c at stream position >= tpos
+                    uint32_t best = 0xffffffffu;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t l0 = tpos > (uint32_t)j ? (tpos - (uint32_t)j + 3u) >> 2 : 0u; // first lane with 4 l + j >= tpos
+                        const unsigned long long m = l0 < 64u ? (B[j] >> l0) << l0 : 0ull;
+                        if (m) best = min(best, 4u * (uint32_t)(__ffsll((long long)m) - 1) + (uint32_t)j);
+                    }
+                    if (best == 0xffffffffu) { round++; have_round = false; continue; }
+                    tpos = best + 1u;
+                    const int bl = (int)(best >> 2), bj = (int)(best & 3u);
+                    const int picked = (int)rdlane((uint32_t)(bj == 0 ? cs[0] : bj == 1 ? cs[1] : bj == 2 ? cs[2] : cs[3]), bl);
+                    // a site already collected in this step is skipped (choice without replacement)
+                    if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
                     if (lane == ncol) vcol = picked;
                     ncol++;
                     need--;
