@@ -1027,10 +1027,12 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 // k <= n_active from the host libm (the oracle's log-factorial sums use the same)
                 h->lean_lds += 48 * 8;
                 lp.tf_ln_len = 0;
-                if (h->lean_lds + (size_t)(nact + 1) * 8 <= 150 * 1024) {
-                    std::vector<double> ln((size_t)nact + 1, 0.0);
-                    for (int k = 1; k <= nact; ++k) ln[k] = std::log((double)k);
-                    if (dev_upload(h, ln.data(), ln.size(), &lp.tf_ln)) return bail(1);
+                // ... unless it would cost the second resident workgroup per CU (160 KiB / 2)
+                const size_t half = 80 * 1024, with_ln = h->lean_lds + (size_t)(nact + 1) * 8;
+                std::vector<double> ln((size_t)nact + 1, 0.0);
+                for (int k = 1; k <= nact; ++k) ln[k] = std::log((double)k);
+                if (dev_upload(h, ln.data(), ln.size(), &lp.tf_ln)) return bail(1);
+                if (with_ln <= 150 * 1024 && (with_ln <= half || h->lean_lds > half)) {
                     lp.tf_ln_len = nact + 1;
                     h->lean_lds += (size_t)(nact + 1) * 8;
                 }

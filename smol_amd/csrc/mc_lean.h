@@ -904,8 +904,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 }
                 for (int c = 0; c < nc; ++c) {
                     const int u = (int)rdlane((uint32_t)vu, c), n0 = (int)rdlane((uint32_t)vcnt, c);
-                    for (int k = 1; k <= u; ++k) lf -= (n0 + k) < P.tf_ln_len ? s_ln[n0 + k] : log((double)(n0 + k));
-                    for (int k = 0; k < -u; ++k) lf += (n0 - k) < P.tf_ln_len ? s_ln[n0 - k] : log((double)(n0 - k));
+                    // ln(k) from the host-libm table (LDS copy when it fits, else HBM / scalar cache)
+                    const double *lnt = P.tf_ln_len ? s_ln : P.tf_ln;
+                    for (int k = 1; k <= u; ++k) lf -= lnt[n0 + k];
+                    for (int k = 0; k < -u; ++k) lf += lnt[n0 - k];
                 }
                 log_priori = uni_d(lf);
             }
