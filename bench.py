@@ -93,8 +93,18 @@ def cpu_baseline_child(seconds=12.0):
         mc.run(chunk)
         done += chunk
     dt = time.perf_counter() - t0
+    # (i) of SURVEY 8d: one walker on one thread, a few seconds
+    one = orc.OracleMC(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    one.set_state(initial_occupancies(sc, 0, 1), np.array([12345], dtype=np.uint64), TEMPERATURE)
+    one.run(2000)
+    n1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 3.0:
+        one.run(20000)
+        n1 += 20000
+    single = 2.0 * n1 / (time.perf_counter() - t1)
     print(json.dumps({
         "value": 2.0 * R * done / dt,
+        "single_thread_value": single,
         "unit": "attempted flips/s",
         "cores": cores,
         "kind": "port",
