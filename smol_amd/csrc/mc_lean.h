@@ -217,6 +217,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // bin coordinate of the current enthalpy, carried from the post-step of the previous step
     double wl_bq = WL ? floordiv_exact(H - P.wl.vmin, P.wl.bin) : 0.0;
     long long wl_counter = WL ? P.wl.counter[r] : 0;
+    // counter modulo the check / update periods, carried instead of recomputed (a 64-bit
+    // modulo by a runtime divisor every step costs more than the step's arithmetic)
+    long long wl_rem_check = WL ? wl_counter % P.wl.check : 0;
+    long long wl_rem_update = WL ? wl_counter % P.wl.update : 0;
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0; // accepted steps of this launch (32-bit counter; < 2^31 steps per launch)
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
@@ -537,6 +541,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (bq >= 0.0 && bq < (double)P.wl.L) {
                     const int b = (int)bq;
                     wl_counter++;
+                    if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
+                    if (++wl_rem_update == P.wl.update) wl_rem_update = 0;
                     const size_t cell = (size_t)r * P.wl.L + b;
                     if (lane < P.F) unsafeAtomicAdd(P.wl.meanf + cell * P.F + lane, s_feat[lane]);
                     if (lane == 0) {
@@ -548,6 +554,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             } else if (bq >= 0.0 && bq < (double)P.wl.L) {
                 const int b = (int)bq;
                 wl_counter++;
+                    if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
+                    if (++wl_rem_update == P.wl.update) wl_rem_update = 0;
                 const size_t cell = (size_t)r * P.wl.L + b;
                 long long total = 0;
                 if (lane == 0) total = P.wl.occur[cell];
@@ -558,13 +566,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     const double inv = 1.0 / (double)(total + 1);
                     *mf = inv * (s_feat[lane] + (double)total * (*mf));
                 }
-                if (wl_counter % P.wl.update == 0 && lane == 0) {
+                if (wl_rem_update == 0 && lane == 0) {
                     wl_S[b] += wl_m;
                     wl_Hh[b] += 1;
                     P.wl.occur[cell] = total + 1;
                 }
             }
-            if (wl_counter % P.wl.check == 0) {
+            if (wl_rem_check == 0) {
                 long cnt = 0;
                 double sum = 0;
                 for (int i = lane; i < P.wl.L; i += 64)
