@@ -917,7 +917,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
-        bool lean = h->lean_tables && h->F <= 64 && !t->bias_type && (!wl || (!t->has_ewald && !t->has_mu)) &&
+        // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
+        bool lean = h->lean_tables && h->F <= 64 && !t->bias_type &&
+                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 &&
+                             getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
                     getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
@@ -992,7 +995,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
                 lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
-                lp.wl.sum_mode = (kp.wl_update == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
+                lp.wl.sum_mode = 1;
             }
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));

@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double wl_m = WL ? P.wl.m[r] : 0.0;
     // bin coordinate of the current enthalpy, carried from the post-step of the previous step
     double wl_bq = WL ? floordiv_exact(H - P.wl.vmin, P.wl.bin) : 0.0;
+    const double wl_inv_bin = WL ? 1.0 / P.wl.bin : 0.0;
     long long wl_counter = WL ? P.wl.counter[r] : 0;
-    // counter modulo the check / update periods, carried instead of recomputed (a 64-bit
+    // counter modulo the check period, carried instead of recomputed (a 64-bit
     // modulo by a runtime divisor every step costs more than the step's arithmetic)
     long long wl_rem_check = WL ? wl_counter % P.wl.check : 0;
-    long long wl_rem_update = WL ? wl_counter % P.wl.update : 0;
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0; // accepted steps of this launch (32-bit counter; < 2^31 steps per launch)
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     accepted = false;
                 } else {
                     const int b = (int)wl_bq;
-                    wl_nbq = floordiv_exact(new_h - P.wl.vmin, P.wl.bin);
+                    wl_nbq = floordiv_exact_inv(new_h - P.wl.vmin, P.wl.bin, wl_inv_bin);
                     const int nb = (int)wl_nbq;
                     const double exponent = wl_S[b] - wl_S[nb] + 0.0;
                     accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
@@ -535,41 +535,19 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // the bin only moves on accepted steps, to the one computed by the accept test
             const double bq = accepted ? wl_nbq : wl_bq;
             wl_bq = bq;
-            if (P.wl.sum_mode) {
-                // update_period == 1: occurrences and feature SUMS by fire-and-forget atomics (the
-                // running mean of wanglandau.py:235-239 is sum / occurrences, formed when read)
-                if (bq >= 0.0 && bq < (double)P.wl.L) {
-                    const int b = (int)bq;
-                    wl_counter++;
-                    if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
-                    if (++wl_rem_update == P.wl.update) wl_rem_update = 0;
-                    const size_t cell = (size_t)r * P.wl.L + b;
-                    if (lane < P.F) unsafeAtomicAdd(P.wl.meanf + cell * P.F + lane, s_feat[lane]);
-                    if (lane == 0) {
-                        wl_S[b] += wl_m;
-                        wl_Hh[b] += 1;
-                        atomicAdd((unsigned long long *)(P.wl.occur + cell), 1ull);
-                    }
-                }
-            } else if (bq >= 0.0 && bq < (double)P.wl.L) {
+            // the lean kernel is only dispatched for update_period == 1 (everything else takes
+            // mc_kernel): occurrences and per-bin feature SUMS by fire-and-forget atomics -- the
+            // running mean of wanglandau.py:235-239 is sum / occurrences, formed when read
+            if (bq >= 0.0 && bq < (double)P.wl.L) {
                 const int b = (int)bq;
                 wl_counter++;
-                    if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
-                    if (++wl_rem_update == P.wl.update) wl_rem_update = 0;
-                const size_t cell = (size_t)r * P.wl.L + b;
-                long long total = 0;
-                if (lane == 0) total = P.wl.occur[cell];
-                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
-                        (unsigned)uni((int)(total & 0xffffffffll));
-                if (lane < P.F) {
-                    double *mf = P.wl.meanf + cell * P.F + lane;
-                    const double inv = 1.0 / (double)(total + 1);
-                    *mf = inv * (s_feat[lane] + (double)total * (*mf));
-                }
-                if (wl_rem_update == 0 && lane == 0) {
+                if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
+                double *cellf = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
+                if (lane < P.F) unsafeAtomicAdd(cellf + lane, s_feat[lane]);
+                if (lane == 0) {
                     wl_S[b] += wl_m;
                     wl_Hh[b] += 1;
-                    P.wl.occur[cell] = total + 1;
+                    atomicAdd((unsigned long long *)(P.wl.occur + (size_t)r * P.wl.L + b), 1ull);
                 }
             }
             if (wl_rem_check == 0) {

@@ -189,6 +189,16 @@ __device__ __forceinline__ double floordiv_exact(double x, double y) {
 }
 
 
+// the same with a precomputed 1 / y: the estimate floor(x * inv_y) is within one of the exact
+// quotient floor and the remainder test moves it there (no float64 division per step)
+__device__ __forceinline__ double floordiv_exact_inv(double x, double y, double inv_y) {
+    double q = floor(x * inv_y);
+    double r = fma(-q, y, x);
+    if (r < 0) q -= 1.0;
+    else if (r >= y) q += 1.0;
+    return q;
+}
+
 // ----------------------------------------------------------------------------
 // lean Metropolis kernel (parameter blocks; the kernel itself is in mc_lean.h): one site class, one contiguous active sublattice with the
 // default encoding, cluster-interaction features, no Ewald term, engine RNG.
