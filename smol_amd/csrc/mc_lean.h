@@ -798,9 +798,6 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
-#ifdef SMOLMC_EXP_TF_SWAPONLY
-        do_swap = true;
-#endif
         double sumw = 0.0;
         unsigned feas_now = 0;
         if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
