@@ -171,6 +171,11 @@ int smolmc_destroy(smolmc_handle *h);
 const char *smolmc_last_error(void);
 int smolmc_abi_version(void);
 
+/* Which kernel family this handle dispatches to, as a short text ("lean nslot=2 mm=2 field=1" /
+ * "general nslot=8 mm=2 field=1"): lets callers and tests assert that the intended path runs
+ * (no reference counterpart). Writes at most n bytes including the terminator. */
+int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n);
+
 /* ---- sizes -------------------------------------------------------------- */
 int smolmc_num_features(const smolmc_handle *h); /* len(ensemble.natural_parameters) */
 int smolmc_wl_num_levels(const smolmc_handle *h); /* len(np.arange(min,max,bin)) wanglandau.py:107 */

@@ -918,7 +918,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
-        bool lean = h->lean_tables && h->F <= 64 && !t->bias_type &&
+        bool lean = h->lean_tables && h->F <= 64 &&
                     (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 &&
                              getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
@@ -942,9 +942,30 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 for (int c = 0; c < nc; ++c)
                     if (t->mu_table[(size_t)(sbase + i) * t->mu_width + c] != mu_row[c]) lean = false;
         }
+        std::vector<double> bias_pair(64, 0.0);
+        if (lean && t->bias_type) {
+            // the bias row must be the same on every active site (it is defined per sublattice)
+            const int W = t->bias_width;
+            for (int i = 0; lean && i < nact; ++i)
+                for (int c = 0; c < nc; ++c)
+                    if (h->bias_host[(size_t)(sbase + i) * W + c] != h->bias_host[(size_t)sbase * W + c]) lean = false;
+            if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) lean = false;
+            for (int o = 0; lean && o < nc; ++o)
+                for (int n = 0; n < nc; ++n) {
+                    const double a = h->bias_host[(size_t)sbase * W + n], b = h->bias_host[(size_t)sbase * W + o];
+                    bias_pair[o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
+                }
+        }
         if (lean) {
             LeanParams &lp = h->lp;
             if (t->has_mu && dev_upload(h, mu_row.data(), mu_row.size(), &lp.mu_row)) return bail(1);
+            if (t->bias_type) {
+                if (dev_upload(h, bias_pair.data(), bias_pair.size(), &lp.bias_pair)) return bail(1);
+                lp.bias_type = t->bias_type;
+                lp.bias_pen = t->bias_penalty;
+                lp.bias = kp.bias;
+                lp.charge = kp.charge;
+            }
             if (t->has_mu) { // the mu delta of a step joins the float32 sum (<= 2 flips * 2 |mu|)
                 double mmax = 0.0;
                 for (double v : mu_row) mmax = std::max(mmax, std::fabs(v));
@@ -1213,6 +1234,17 @@ extern "C" int smolmc_sync(smolmc_handle *h) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
+    if (!h || !buf || n <= 0) return fail("null argument");
+    if (h->lean)
+        snprintf(buf, (size_t)n, "lean nslot=%d mm=%d field=%d lds=%zu", h->lean_nslot, h->lean_mm,
+                 h->lp.ew_field, h->lean_lds);
+    else
+        snprintf(buf, (size_t)n, "general nslot=%d mm=%d field=%d lds=%zu", h->nslot, h->mm, h->kp.ew_field,
+                 h->lds_bytes);
     return 0;
 }
 

@@ -227,6 +227,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
     double acc_mu = 0.0, acc_ew = 0.0;
+    // MCBias (runtime, Metropolis only): biased walkers always take the exact decision path
+    const int btype = WL ? 0 : P.bias_type;
+    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[r] : 0.0;
     // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
     // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
     // only the rare undecided step pays for the float64 reduction, so decisions are exactly
@@ -449,9 +452,22 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         double dH = 0.0, dEw = 0.0;
         double wl_nbq = 0.0; // WL: bin coordinate of the proposed enthalpy
+        // compute_bias_change against the original occupancy (kernel/base.py:307-311; bias.py)
+        double dB = 0.0, dQ = 0.0;
+        if (btype && nfl >= 1) {
+            double x = P.bias_pair[o1 * 8 + n1];
+            if (nfl == 2) x += P.bias_pair[o2 * 8 + n2];
+            if (btype == SMOLMC_BIAS_FUGACITY) {
+                dB = x;
+            } else {
+                dQ = x;
+                const double cn = charge + dQ;
+                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+            }
+        }
         bool accepted;
         bool decided = false;
-        if (FAST) {
+        if (FAST && !btype) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
             const unsigned long long bit = 1ull << l4;
@@ -473,7 +489,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // (the ballots make the wave-uniform decision visibly uniform to the compiler:
             // scalar branch, uniform counters in SGPRs)
             if (!WL) {
-                const double exponent = nbeta * dH + 0.0;
+                const double exponent = nbeta * dH + 0.0 + dB; // metropolis.py:41-44
                 accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
             } else {
                 // WangLandau._accept_step (wanglandau.py:186-202)
@@ -519,6 +535,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             acc_mu += dMu;
             acc_ew += dEw;
+            bias_acc += dB;
+            charge += dQ;
             if (!FAST) H += dH;
             nacc_add++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
@@ -635,6 +653,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) lane_e = fma(wgt[it], acc[it], lane_e);
         H += wave_sum_all(lane_e) - acc_mu;
+    }
+    if (btype && lane == 0) {
+        P.bias[r] += bias_acc;
+        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[r] = charge;
     }
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;

@@ -238,6 +238,12 @@ struct LeanParams {
     const double *dt;      // delta tables, all padded to a common [S*S][NTP] shape
     const LeanSlot *slots; // [NSLOT][64]
     const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
+    // MCBias on the single active sublattice: bias_pair[old * 8 + new] = log(f_new / f_old)
+    // (FugacityBias) or q_new - q_old (SquareChargeBias); running bias / net charge per walker
+    int bias_type;
+    const double *bias_pair;
+    double bias_pen;
+    double *bias, *charge;
     uint8_t *occ;
     double *enthalpy, *features;
     const double *beta;

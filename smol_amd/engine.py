@@ -36,6 +36,7 @@ SYMBOLS = {
     "smolmc_get_state": (C.c_int, [_HP, _i32p, _f64p, _f64p, _u64p, _u64p, _u8p]),
     "smolmc_get_wl": (C.c_int, [_HP, _f64p, _i64p, _i64p, _f64p, _f64p]),
     "smolmc_get_bias": (C.c_int, [_HP, _f64p]),
+    "smolmc_kernel_info": (C.c_int, [_HP, C.c_char_p, C.c_int]),
     "smolmc_run": (C.c_int, [_HP, C.c_int64]),
     "smolmc_sync": (C.c_int, [_HP]),
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
@@ -197,6 +198,12 @@ class Engine:
         df = float(np.max(np.abs(st["features"] - full)))
         dh = float(np.max(np.abs(st["enthalpy"] - full @ self.natural_parameters)))
         return df, dh
+
+    def kernel_info(self):
+        """Kernel family this handle dispatches to, e.g. 'lean nslot=2 mm=2 field=0 lds=19968'."""
+        buf = C.create_string_buffer(128)
+        self._chk(self._lib.smolmc_kernel_info(self._h, buf, 128))
+        return buf.value.decode()
 
     def get_bias(self):
         """trace.bias of every walker (models created with an MCBias term)."""

@@ -26,11 +26,17 @@ def _occ(sc, rng, R):
     return occ
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 @pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
 @pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
 @pytest.mark.parametrize("kind", ["fugacity", "square-charge"])
-def test_biased_trajectories_match_oracle(rocksalt, kind, step, ewald):
+def test_biased_trajectories_match_oracle(rocksalt, kind, step, ewald, general, monkeypatch):
     from oracle import oracle as orc
+
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
 
     model, sc, coefs = rocksalt
     ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.2 if ewald else None)
@@ -45,6 +51,7 @@ def test_biased_trajectories_match_oracle(rocksalt, kind, step, ewald):
     seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(6151)
     temps = np.linspace(600.0, 5000.0, R)
     eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("general" if general else "lean")  # both paths are pinned
     eng.set_state(occ0, seeds, temps)
     ora.set_state(occ0, seeds, temps)
     np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
