@@ -490,3 +490,31 @@ def test_more_than_65535_sites_uses_32bit_rows():
     a, b = eng.get_state(), ora.get_state()
     assert np.array_equal(a["occupancy"], b["occupancy"])
     np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("name,mode,step,mukind,kernel,expected", [
+    ("fcc_conv444_pairs", "int", capi.STEP_SWAP, None, "metropolis", "lean"),
+    ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None, "metropolis", "lean"),
+    ("fcc_prim666_triplets", "int", capi.STEP_FLIP, "mu2", "metropolis", "lean"),
+    ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None, "wang-landau", "lean"),
+    ("rocksalt444_ewald", "int", capi.STEP_FLIP, "mu3", "metropolis", "lean"),        # compact Ewald + field
+    ("rocksalt333_vacancy_ewald", "int", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
+    ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "metropolis", "general"),  # correlation features
+    ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
+    ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "general"),
+    ("rocksalt444_ewald", "int", capi.STEP_SWAP, None, "wang-landau", "general"),     # WL + Ewald
+])
+def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, expected, monkeypatch):
+    """DESIGN.md section 4 dispatch rules, asserted through smolmc_kernel_info: the parity tests
+    above must not silently run everything on the general kernel."""
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    c = load_case(name)
+    tab = tables_for(name, MODES[mode], mu_table=_mu(mukind, c))
+    if kernel == "metropolis":
+        cfg = capi.make_config(3, capi.KERNEL_METROPOLIS, step)
+    else:
+        cfg = capi.make_config(3, capi.KERNEL_WANGLANDAU, step, min_enthalpy=-50.0, max_enthalpy=50.0, bin_size=0.5)
+    info = _engine(tab, cfg).kernel_info()
+    assert info.startswith(expected), info
+    if name == "rocksalt444_ewald":
+        assert "field=1" in info
