@@ -518,3 +518,45 @@ def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, e
     assert info.startswith(expected), info
     if name == "rocksalt444_ewald":
         assert "field=1" in info
+
+
+@pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])
+def test_split_launches_equal_one_launch(kernel, monkeypatch):
+    """The lean kernels count steps in 32 bits, so the host splits long runs into several
+    launches (on sample boundaries).  With the split forced to tiny chunks the samples and the
+    final state must equal those of a single launch."""
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    c = load_case("fcc_prim666_triplets")
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    R = 5
+    if kernel == "metropolis":
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    else:
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=-40.3, max_enthalpy=40.7,
+                               bin_size=0.5, check_period=40)
+    rng = np.random.default_rng(5)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(500)
+    one = _engine(tab, cfg)
+    one.set_state(occ0, seeds, 1500.0)
+    ref = one.run_sampled(12, 25, occupancy=True)
+    ref_state = one.get_state()
+    monkeypatch.setenv("SMOLMC_LAUNCH_CHUNK", "60")  # -> chunks of 50 steps = 2 samples
+    many = _engine(tab, cfg)
+    assert many.kernel_info().startswith("lean")
+    many.set_state(occ0, seeds, 1500.0)
+    got = many.run_sampled(12, 25, occupancy=True)
+    st = many.get_state()
+    assert np.array_equal(got["occupancy"], ref["occupancy"])
+    assert np.array_equal(got["accepted"], ref["accepted"])
+    np.testing.assert_allclose(got["enthalpy"], ref["enthalpy"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got["features"], ref["features"], rtol=RTOL, atol=1e-8)
+    assert np.array_equal(st["occupancy"], ref_state["occupancy"])
+    assert np.array_equal(st["n_steps"], ref_state["n_steps"])
+    many.run(130)  # unsampled run, split at 60 steps
+    one.run(130)
+    assert np.array_equal(many.get_state()["occupancy"], one.get_state()["occupancy"])
+    if kernel == "wang-landau":
+        wa, wb = many.get_wl(), one.get_wl()
+        assert np.array_equal(wa["histogram"], wb["histogram"]) and np.array_equal(wa["occurrences"], wb["occurrences"])
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
