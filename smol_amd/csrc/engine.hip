@@ -417,9 +417,12 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
 
     // ---- lean tables (see mc_lean_kernel) ------------------------------------------
     memset(&h->lp, 0, sizeof(LeanParams));
-    if (class_rep.size() == 1 && !aliased && !corr && N <= 65535 && niter_max <= 4 && need_mm <= 3 &&
-        num_ce_features(t) <= 64) {
-        const int NSL = niter_max <= 2 ? 2 : 4;
+    // one site class: mc_lean_kernel (NSLOT <= 4); up to four classes or up to 512 clusters per
+    // site: mc_lean_multi_kernel (per-class slot records in LDS)
+    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && !corr && N <= 65535 && niter_max <= 8 &&
+        need_mm <= 3 && num_ce_features(t) <= 64) {
+        const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
+        const int NCLS = (int)class_rep.size();
         const int MML = need_mm <= 2 ? 2 : 3;
         const int ROW = NSL * MML;
         std::vector<uint16_t> lidx((size_t)N * 64 * ROW);
@@ -503,11 +506,13 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         size_t tlen = (size_t)SMAX * SMAX * NTP;
         if ((tlen & 1) == 0) tlen += 1;
         std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
-        std::vector<LeanSlot> ls((size_t)NSL * 64);
+        std::vector<LeanSlot> ls((size_t)NCLS * NSL * 64);
         memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
         std::map<std::pair<int, int>, uint32_t> doff_of;
-        const std::vector<Slot> &sl = slots[class_rep[0]];
         bool ok = true;
+        double sum_abs_max = 0.0;
+        for (int cls = 0; cls < NCLS && ok; ++cls) {
+        const std::vector<Slot> &sl = slots[class_rep[cls]];
         double sum_abs = 0.0;
         for (size_t q = 0; q < sl.size() && ok; ++q) {
             const Slot &k = sl[q];
@@ -550,7 +555,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 doff_of[key] = at;
             }
             const double scale = (double)t->size / t->loc_ratio[k.rec] / (double)t->loc_nrows[k.rec];
-            LeanSlot &L = ls[(q / 64) * 64 + (q % 64)];
+            LeanSlot &L = ls[((size_t)cls * NSL + q / 64) * 64 + (q % 64)];
             L.doff8 = doff_of[key] * 8u;
             {
                 uint32_t cs = 8u;
@@ -560,7 +565,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.live = 1;
             L.w = t->ce_coefs[t->orb_id[o]] * scale;
             L.fs = scale;
-            if (dt.size() > 5500) ok = false; // keep the LDS tables within budget
+            if (dt.size() > 8000) ok = false; // keep the LDS tables within budget
             double dmax = 0.0;
             {
                 const double *D = dt.data() + doff_of[key];
@@ -568,10 +573,12 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             }
             sum_abs += std::fabs(L.w) * dmax;
         }
+        sum_abs_max = std::max(sum_abs_max, sum_abs);
+        }
         // float32 pre-test of the accept decision: a step sums at most two flips' worth of
         // |w * d| over the slots, a float32 conversion + 6-level tree adds at most
         // 7 * 2^-24 of that; 2^-19 leaves a 4.5x margin.
-        h->lp.fast_eps = 2.0 * sum_abs * ldexp(1.0, -19);
+        h->lp.fast_eps = 2.0 * sum_abs_max * ldexp(1.0, -19);
         h->lp.nt8 = (uint32_t)NTP * 8u;
         h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
@@ -582,6 +589,8 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             h->lean_tables = true;
             h->lean_nslot = NSL;
             h->lean_mm = MML;
+            h->lean_ncls = NCLS;
+            h->site_class_host = site_class;
         }
     }
     return 0;
@@ -921,8 +930,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         bool lean = h->lean_tables && h->F <= 64 &&
                     (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 &&
                              getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
-                    (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 &&
-                    getenv("SMOLMC_FORCE_GENERAL") == nullptr;
+                    (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
+                    h->lean_nslot <= 4 && getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
         std::vector<double> mu_row;
         if (lean) {
@@ -1063,6 +1072,97 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             }
         }
         h->lean = lean;
+        // ---- several classes / sublattices (or > 256 clusters per site): mc_lean_multi_kernel
+        if (!lean && h->lean_tables && !wl && !t->bias_type && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
+            h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+            getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
+            LeanParams &lp = h->lp;
+            const int ns = t->n_sublattices;
+            bool ok = true;
+            std::vector<double> mu_rows(32, 0.0), q_rows(32, 0.0), dg_rows(32, 0.0);
+            double cum = 0.0, mmax = 0.0;
+            for (int k = 0; k < ns && ok; ++k) {
+                const int64_t a0 = t->sub_site_ptr[k], a1 = t->sub_site_ptr[k + 1];
+                const int na = (int)(a1 - a0), ncod = (int)(t->sub_code_ptr[k + 1] - t->sub_code_ptr[k]);
+                const int sb = t->sub_active_sites[a0];
+                if (na <= 0 || ncod < 2 || ncod > 8) ok = false;
+                for (int i = 0; ok && i < na; ++i)
+                    if (t->sub_active_sites[a0 + i] != sb + i) ok = false;
+                for (int c = 0; ok && c < ncod; ++c)
+                    if (t->sub_codes[t->sub_code_ptr[k] + c] != c) ok = false;
+                const int cls = ok ? h->site_class_host[sb] : 255;
+                if (cls == 255) ok = false;
+                for (int i = 0; ok && i < na; ++i)
+                    if (h->site_class_host[sb + i] != cls) ok = false; // classes == sublattices
+                if (!ok) break;
+                lp.m_sbase[k] = sb; lp.m_nact[k] = na; lp.m_ncodes[k] = ncod; lp.m_cls[k] = cls;
+                cum += t->sub_probs[k];
+                lp.m_cum[k] = cum;
+                if (t->has_mu) {
+                    if (t->mu_width < ncod) ok = false;
+                    for (int c = 0; ok && c < ncod; ++c) {
+                        const double v = t->mu_table[(size_t)sb * t->mu_width + c];
+                        mu_rows[k * 8 + c] = v;
+                        mmax = std::max(mmax, std::fabs(v));
+                        for (int i = 0; i < na; ++i)
+                            if (t->mu_table[(size_t)(sb + i) * t->mu_width + c] != v) ok = false;
+                    }
+                }
+                if (t->has_ewald) {
+                    if (kp.ew_W > 8 || sb < kp.ew_act_base || sb + na > kp.ew_act_base + kp.ew_nact) ok = false;
+                    for (int c = 0; ok && c < kp.ew_W; ++c) {
+                        q_rows[k * 8 + c] = h->ew_qs_host[(size_t)sb * kp.ew_W + c];
+                        dg_rows[k * 8 + c] = h->ew_dg_host[(size_t)sb * kp.ew_W + c];
+                        for (int i = 0; i < na; ++i)
+                            if (h->ew_qs_host[(size_t)(sb + i) * kp.ew_W + c] != q_rows[k * 8 + c] ||
+                                h->ew_dg_host[(size_t)(sb + i) * kp.ew_W + c] != dg_rows[k * 8 + c])
+                                ok = false;
+                    }
+                }
+            }
+            // LDS: shared tables + slot records, per wave occupancy + scratch + accumulators (+ field)
+            const size_t nrec = (size_t)h->lean_ncls * h->lean_nslot * 64;
+            const size_t shared = ((size_t)lp.dt_len + 96) * 8 + nrec * 24;
+            // the potential field goes to LDS only while it stays small beside the rest of the
+            // wave's state (else the HBM copy is used in place: ew_field 2)
+            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * 8;
+            const bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
+            const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
+            // waves per workgroup: the shared tables are paid once per workgroup, so pick the size
+            // that keeps the most waves resident per CU (160 KiB of LDS)
+            int wpb = 0, best_waves = 0;
+            for (int w : {8, 4, 2, 1}) {
+                const size_t need = shared + per_wave * w;
+                if (need > 160 * 1024 - 512) continue;
+                const int waves = (int)((160 * 1024) / need) * w;
+                if (waves > best_waves) { best_waves = waves; wpb = w; }
+            }
+            if (wpb == 0) ok = false;
+            if (ok) {
+                if (t->has_mu && dev_upload(h, mu_rows.data(), 32, &lp.m_mu)) return bail(1);
+                if (t->has_ewald &&
+                    (dev_upload(h, q_rows.data(), 32, &lp.m_q) || dev_upload(h, dg_rows.data(), 32, &lp.m_dg)))
+                    return bail(1);
+                if (t->has_mu) lp.fast_eps += 4.0 * mmax * ldexp(1.0, -19);
+                if (getenv("SMOLMC_NO_FAST_ACCEPT")) lp.fast_eps = 0.0;
+                if (const char *sc = getenv("SMOLMC_FAST_EPS_SCALE")) lp.fast_eps *= atof(sc);
+                lp.m_ncls = h->lean_ncls; lp.m_nsub = ns;
+                lp.occ = kp.occ; lp.enthalpy = kp.enthalpy; lp.features = kp.features; lp.beta = kp.beta;
+                lp.seeds = kp.seeds; lp.nsteps = kp.nsteps; lp.nacc = kp.nacc; lp.last_acc = kp.last_acc;
+                lp.R = h->R; lp.N = h->N; lp.Npad = h->Npad; lp.F = h->F; lp.Fce = h->Fce;
+                lp.ew_field = 0;
+                if (t->has_ewald) {
+                    lp.ew_W = kp.ew_W; lp.ew_nact = kp.ew_nact; lp.ew_act_base = kp.ew_act_base;
+                    lp.ew_G = kp.ew_G; lp.ew_coef = kp.ew_coef; lp.ew_phi = kp.ew_phi;
+                    lp.ew_field = phi_lds ? 1 : 2;
+                    lp.sbase = kp.ew_act_base; // field_apply indexes phi relative to it
+                }
+                h->lean_lds = shared + per_wave * wpb;
+                h->waves_per_block_lean = wpb;
+                h->lean = true;
+                h->lean_multi = true;
+            }
+        }
         if (getenv("SMOLMC_DEBUG"))
             fprintf(stderr, "[smolmc] lean=%d tables=%d nslot=%d mm=%d lds=%zu ew=%d compact=%d field=%d nact=%d "
                             "ew_nact=%d ew_act_base=%d sbase=%d general: nslot=%d mm=%d lds=%zu\n",
@@ -1240,8 +1340,8 @@ extern "C" int smolmc_sync(smolmc_handle *h) {
 extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     if (!h || !buf || n <= 0) return fail("null argument");
     if (h->lean)
-        snprintf(buf, (size_t)n, "lean nslot=%d mm=%d field=%d lds=%zu", h->lean_nslot, h->lean_mm,
-                 h->lp.ew_field, h->lean_lds);
+        snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu", h->lean_multi ? "lean-multi" : "lean",
+                 h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds);
     else
         snprintf(buf, (size_t)n, "general nslot=%d mm=%d field=%d lds=%zu", h->nslot, h->mm, h->kp.ew_field,
                  h->lds_bytes);
@@ -1326,6 +1426,9 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
 
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
+    if (h->lean_multi)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_4(h, lp) : smolmc_launch_multi_8(h, lp));
     return h->lean_nslot == 2 ? smolmc_launch_lean_2(h, lp) : smolmc_launch_lean_4(h, lp);
 }
 

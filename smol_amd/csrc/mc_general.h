@@ -158,6 +158,33 @@ __device__ __forceinline__ void field_apply_global(const KParams &P, double *phi
 // ----------------------------------------------------------------------------
 // the Monte-Carlo kernel
 // ----------------------------------------------------------------------------
+__device__ __forceinline__ void field_apply_global2(const KParams &P, double *phi, int lane, int s1, double dq1,
+                                                    int s2, double dq2) {
+    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
+    const int j1 = s1 - P.ew_act_base, j2 = s2 - P.ew_act_base, na = P.ew_nact;
+    constexpr int U = 4;
+    for (int j0 = lane; j0 < na; j0 += 64 * U) {
+        double ga[U], gb[U], pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + 64 * u, na - 1);
+            ga[u] = g1[j];
+            gb[u] = g2[j];
+            pv[u] = phi[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < na) {
+                double v = pv[u];
+                if (j != j1) v = fma(dq1, ga[u], v);
+                if (j != j2) v = fma(dq2, gb[u], v);
+                phi[j] = v;
+            }
+        }
+    }
+}
+
 // Metropolis feature deltas accumulated since launch start, reduced over the wave:
 // calls emit(f, value) on lane 0 for every cluster-expansion feature f.
 template <typename F>
@@ -537,8 +564,14 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             }
             if (P.has_ewald && P.ew_field) {
                 double *phi = P.ew_phi + (size_t)r * P.ew_nact;
-                if (fdq1 != 0.0) field_apply_global(P, phi, lane, s1, fdq1);
-                if (nfl == 2 && fdq2 != 0.0) field_apply_global(P, phi, lane, s2, fdq2);
+                // two flips: one pass over phi (the update is bound by HBM / Infinity-Cache traffic);
+                // a replayed step may flip the same site twice -> two passes keep the self-exclusion
+                if (nfl == 2 && s2 != s1) {
+                    if (fdq1 != 0.0 || fdq2 != 0.0) field_apply_global2(P, phi, lane, s1, fdq1, s2, fdq2);
+                } else {
+                    if (fdq1 != 0.0) field_apply_global(P, phi, lane, s1, fdq1);
+                    if (nfl == 2 && fdq2 != 0.0) field_apply_global(P, phi, lane, s2, fdq2);
+                }
             }
             acc_ew += dEw;
             acc_mu += dMu;

@@ -124,6 +124,33 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
     }
 }
 
+// both flips of a swap in one pass over phi (one read-modify-write per entry instead of two)
+__device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, int lane, int s1, double dq1,
+                                             int s2, double dq2) {
+    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
+    const int j1 = s1 - P.sbase, j2 = s2 - P.sbase, na = P.ew_nact;
+    constexpr int U = 4;
+    for (int j0 = lane; j0 < na; j0 += 64 * U) {
+        double ga[U], gb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + 64 * u, na - 1);
+            ga[u] = g1[j];
+            gb[u] = g2[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < na) {
+                double v = phi[j];
+                if (j != j1) v = fma(dq1, ga[u], v);
+                if (j != j2) v = fma(dq2, gb[u], v);
+                phi[j] = v;
+            }
+        }
+    }
+}
+
 // Index row of one site: ROW u16 entries per lane, fetched with raw buffer loads
 // (resource descriptor + SGPR site offset + constant per-lane VGPR offset: no 64-bit VALU
 // address arithmetic per step).  Words hold two u16 entries each.
@@ -140,11 +167,17 @@ __device__ __forceinline__ RowWords<NW> load_row(__amdgpu_buffer_rsrc_t rs, uint
     } else if constexpr (NW == 4) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
         r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3];
-    } else {
-        static_assert(NW == 6, "row width");
+    } else if constexpr (NW == 6) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
         const auto u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 16u, soff, 0);
         r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3]; r.w[4] = u[0]; r.w[5] = u[1];
+    } else {
+        static_assert(NW % 4 == 0, "row width");
+#pragma unroll
+        for (int b = 0; b < NW / 4; ++b) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u * b, soff, 0);
+            r.w[4 * b] = v[0]; r.w[4 * b + 1] = v[1]; r.w[4 * b + 2] = v[2]; r.w[4 * b + 3] = v[3];
+        }
     }
     return r;
 }
@@ -530,8 +563,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #endif
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
             if (HAS_EW && P.ew_field) {
-                if (dq1 != 0.0) field_apply(P, phi, lane, s1, dq1);
-                if (STEP == SMOLMC_STEP_SWAP && dq2 != 0.0) field_apply(P, phi, lane, s2, dq2);
+                if (STEP == SMOLMC_STEP_SWAP) {
+                    if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
+                } else if (dq1 != 0.0) {
+                    field_apply(P, phi, lane, s1, dq1);
+                }
             }
             acc_mu += dMu;
             acc_ew += dEw;

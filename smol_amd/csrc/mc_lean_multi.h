@@ -1,0 +1,445 @@
+// mc_lean_multi.h -- lean Metropolis kernel for models with several site classes / several
+// active sublattices (disordered cation AND anion sublattices, symmetry-distinct sites) and
+// for up to 512 clusters per site.  Same design as mc_lean_kernel (one wavefront per walker,
+// occupancy + delta tables in LDS, lane-packed index rows, float32 accept pre-test, Ewald
+// potential field), with the per-class state moved from registers to LDS:
+//   * slot records {table offset, strides, weight} per (class, slot, lane), read per flip;
+//   * feature accumulators per (class, slot, lane) as LDS cells (ds_add_f64 on accept);
+//   * per-sublattice site range / species count / mu / charge rows.
+// Proposal stream identical to the oracle's: sublattice from W(step, 0, 0) and the cumulative
+// sublattice probabilities (mcusher.py:146-148), site word W(step - 1, 0, 1), swap candidates
+// inside the chosen sublattice.  The sites of a batch of 16 steps are formed at batch time, so
+// the next step's row is prefetched except across a batch boundary (one exposed fetch per 16).
+#pragma once
+#include "mc_lean.h"
+
+// element k (< 4) of a kernel-argument array without dynamic indexing (which would go through scratch)
+__device__ __forceinline__ int sel4(const int (&a)[4], int k) {
+    return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3]));
+}
+
+// potential field kept in HBM (ew_field == 2: it would cost too much LDS): same update as
+// field_apply, lane-strided read-modify-write; both flips of a swap in ONE pass over phi (the
+// update is bound by HBM / Infinity-Cache traffic: 2 G rows + one read-modify-write of phi)
+__device__ __forceinline__ void field_apply_hbm(const LeanParams &P, double *phi, int lane, int s1, double dq1,
+                                                int s2, double dq2) {
+    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
+    const int j1 = s1 - P.sbase, j2 = s2 - P.sbase, na = P.ew_nact;
+    constexpr int U = 4;
+    for (int j0 = lane; j0 < na; j0 += 64 * U) {
+        double ga[U], gb[U], pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + 64 * u, na - 1);
+            ga[u] = g1[j];
+            gb[u] = g2[j];
+            pv[u] = phi[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < na) {
+                double v = pv[u];
+                if (j != j1) v = fma(dq1, ga[u], v);
+                if (j != j2) v = fma(dq2, gb[u], v);
+                phi[j] = v;
+            }
+        }
+    }
+}
+
+struct MultiRec { // slot record, 24 bytes
+    uint32_t doff8;
+    uint32_t st8[3];
+    double w;
+};
+
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW>
+__global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    const int NC = P.m_ncls, NS = P.m_nsub;
+    // block-shared: delta tables | mu rows [4][8] | q rows [4][8] | dg rows [4][8] | slot records
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len;
+    double *s_q = s_mu + 32, *s_dg = s_mu + 64;
+    MultiRec *s_rec = (MultiRec *)(s_mu + 96);
+    const int nrec = NC * NSLOT * 64;
+    // per wave: occupancy [Nlds] | zero pad 64 | feature scratch [64] | acc cells [NC][NSLOT][64] | phi
+    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 8 +
+                            ((HAS_EW && P.ew_field == 1) ? (size_t)P.ew_nact * 8 : 0);
+    unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
+    uint8_t *occ = wbase;
+    double *s_feat = (double *)(wbase + P.Nlds + 64);
+    double *s_acc = s_feat + 64;
+    // Ewald potential field: LDS copy (ew_field 1) or the walker's HBM array itself (ew_field 2)
+    const bool phi_lds = HAS_EW && P.ew_field == 1;
+    double *phi = phi_lds ? s_acc + nrec : P.ew_phi + (size_t)r * P.ew_nact;
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (threadIdx.x < 32) {
+        s_mu[threadIdx.x] = HAS_MU ? P.m_mu[threadIdx.x] : 0.0;
+        s_q[threadIdx.x] = HAS_EW ? P.m_q[threadIdx.x] : 0.0;
+        s_dg[threadIdx.x] = HAS_EW ? P.m_dg[threadIdx.x] : 0.0;
+    }
+    for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
+        const LeanSlot sl = P.slots[i];
+        MultiRec rec;
+        rec.doff8 = sl.doff8;
+        rec.st8[0] = sl.stride8[0]; rec.st8[1] = sl.stride8[1]; rec.st8[2] = sl.stride8[2];
+        rec.w = sl.w;
+        s_rec[i] = rec;
+    }
+    const bool live = r < P.R;
+    if (live) {
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
+        s_feat[lane] = 0.0;
+        for (int i = lane; i < nrec; i += 64) s_acc[i] = 0.0;
+        if (phi_lds)
+            for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
+    }
+    __syncthreads();
+    if (!live) return;
+
+    double H = P.enthalpy[r];
+    const double nbeta = -P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    uint32_t nacc_add = 0, nacc_before = 0;
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    const uint32_t nt8 = P.nt8, snt8 = P.snt8;
+    const int abase = P.ew_act_base;
+    double acc_mu = 0.0, acc_ew = 0.0;
+    constexpr bool FAST = !HAS_EW; // float32 accept pre-test (Ewald variants take the exact path)
+    float thr_lo = 0.0f, thr_hi = 0.0f;
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    uint32_t smp_countdown = (uint32_t)P.smp.every;
+    long long smp_index = 0;
+    constexpr int ROW = NSLOT * MM;
+    constexpr int NW = ROW / 2;
+    constexpr uint32_t SITE_BYTES = 64u * ROW * 2u;
+    const __amdgpu_buffer_rsrc_t idx_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
+
+    // per-step values of the current batch, lane-indexed (lane 4 k holds step base + k)
+    uint32_t W0 = 0, W1 = 0;
+    double logu = 0.0;
+    int vsite = 0, vaddr = 0, vsub = 0;
+    int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0};
+    double vGc = 0.0;
+    unsigned long long batch_base = ~0ull;
+    RowWords<NW> row1;
+    bool have_row1 = false;
+
+    auto sub_of = [&](uint32_t w0) -> int { // MCUsher.get_random_sublattice (mcusher.py:146-148)
+        if (NS == 1) return 0;
+        const double x = (double)w0 * (1.0 / 4294967296.0);
+        int sl = NS - 1;
+        for (int k = NS - 2; k >= 0; --k)
+            if (x < P.m_cum[k]) sl = k;
+        return sl;
+    };
+
+    const uint32_t nsteps32 = (uint32_t)P.steps;
+    for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            // site word of the batch's first step: W(base - 1, 0, 1)
+            uint32_t carry;
+            if (batch_base == base - 16) {
+                carry = rdlane(W1, 60);
+            } else {
+                const unsigned long long sp = base - 1ull;
+                carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u, key0, key1).w[1]);
+            }
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), 0u,
+                                               key0, key1);
+            W0 = o.w[0]; W1 = o.w[1];
+            logu = log(philox_u53(o.w[2], o.w[3]));
+            if (FAST) {
+                const double thr = logu / nbeta;
+                const double eps = P.fast_eps + 1e-6 * fabs(thr);
+                thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
+                thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+            }
+            // sublattice / site / candidates of the lane's step
+            const uint32_t w0_blk0 = (uint32_t)__shfl((int)W0, lane & ~3);
+            const uint32_t w1_prev = (uint32_t)__shfl((int)W1, (lane & ~3) - 4);
+            const uint32_t w_site = lane < 4 ? carry : w1_prev;
+            vsub = sub_of(w0_blk0);
+            const int sb = sel4(P.m_sbase, vsub);
+            const uint32_t na = (uint32_t)sel4(P.m_nact, vsub);
+            vsite = sb + (int)__umulhi(w_site, na);
+            vaddr = lean_swz(vsite, swa, swm, swb);
+            if (STEP == SMOLMC_STEP_SWAP) {
+                cand[0] = sb + (int)__umulhi(o.w[0], na);
+                cand[1] = sb + (int)__umulhi(o.w[1], na);
+                cand[2] = sb + (int)__umulhi(o.w[2], na);
+                cand[3] = sb + (int)__umulhi(o.w[3], na);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
+                if (HAS_EW && P.ew_field) vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (vsite - abase)];
+            }
+            have_row1 = false;
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        const int s1 = (int)rdlane((uint32_t)vsite, l4), a1 = (int)rdlane((uint32_t)vaddr, l4);
+        const int sub1 = (int)rdlane((uint32_t)vsub, l4);
+        const int cls1 = sel4(P.m_cls, sub1);
+        if (!have_row1) row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
+        // prefetch the next step's row while this one runs (not across a batch boundary)
+        RowWords<NW> rown = row1;
+        have_row1 = l4 < 60;
+        if (have_row1) rown = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
+
+        const int o1 = uni((int)occ[a1]);
+        int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0, fb = -1;
+        if (STEP == SMOLMC_STEP_FLIP) {
+            const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(sel4(P.m_ncodes, sub1) - 1));
+            n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
+            nfl = 1;
+        } else {
+            int found = -1, fo = 0, fa = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int v = (int)occ[canda[j]];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cand[j], b);
+                        fa = (int)rdlane((uint32_t)canda[j], b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                        if (j == 0) fb = b;
+                    }
+                }
+            }
+            if (found < 0) {
+                const int sb = sel4(P.m_sbase, sub1);
+                const uint32_t na = (uint32_t)sel4(P.m_nact, sub1);
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sb + (int)__umulhi(o.w[j], na);
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fa = lean_swz(found, swa, swm, swb);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
+                        int any = 0;
+                        for (uint32_t a = lane; a < na; a += 64)
+                            any |= ((int)occ[lean_swz(sb + (int)a, swa, swm, swb)] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) { s2 = found; a2 = fa; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
+            else { nfl = 0; n1 = o1; s2 = s1; a2 = a1; o2 = o1; n2 = o1; }
+        }
+        RowWords<NW> row2 = row1;
+        if (STEP == SMOLMC_STEP_SWAP) row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
+
+        // -------- enthalpy delta: slot records of the site's class from LDS ------------------
+        const MultiRec *rec1 = s_rec + ((size_t)cls1 * NSLOT) * 64 + lane;
+        double e = 0.0, d1[NSLOT], d2[NSLOT];
+        {
+            const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const MultiRec rc = rec1[it * 64];
+                uint32_t a = rc.doff8;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
+                d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
+                e = fma(rc.w, d1[it], e);
+            }
+        }
+        double ew_uni = 0.0, dq1 = 0.0, dq2 = 0.0;
+        if (HAS_EW) {
+            dq1 = s_q[sub1 * 8 + n1] - s_q[sub1 * 8 + o1];
+            const double p1 = phi_lds ? phi[s1 - abase]
+                                      : __hip_atomic_load(&phi[s1 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ew_uni = 2.0 * dq1 * p1 + (s_dg[sub1 * 8 + n1] - s_dg[sub1 * 8 + o1]);
+        }
+        if (STEP == SMOLMC_STEP_SWAP) {
+            occ[a1] = (uint8_t)n1; // tentative: the second flip sees the first (expansion.py:217-229)
+            const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const MultiRec rc = rec1[it * 64]; // both sites of a swap share the sublattice / class
+                uint32_t a = rc.doff8;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
+                d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
+                e = fma(rc.w, d2[it], e);
+            }
+            if (HAS_EW) {
+                dq2 = s_q[sub1 * 8 + n2] - s_q[sub1 * 8 + o2];
+                const double cross =
+                    fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
+                                               (int)rdlane((uint32_t)__double2loint(vGc), fb))
+                            : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - abase)];
+                const double p2 = phi_lds ? phi[s2 - abase]
+                                          : __hip_atomic_load(&phi[s2 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ew_uni += 2.0 * dq2 * (p2 + dq1 * cross) + (s_dg[sub1 * 8 + n2] - s_dg[sub1 * 8 + o2]);
+            }
+        }
+        double dMu = 0.0;
+        if (HAS_MU && nfl >= 1) {
+            dMu = s_mu[sub1 * 8 + n1] - s_mu[sub1 * 8 + o1];
+            if (nfl == 2) dMu += s_mu[sub1 * 8 + n2] - s_mu[sub1 * 8 + o2];
+        }
+        double dH = 0.0, dEw = HAS_EW ? ew_uni : 0.0;
+        bool accepted = false, decided = false;
+        if (!HAS_EW) { // float32 pre-test (see mc_lean_kernel)
+            const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
+            const float S = wave_sum_f32_uniform(ef);
+            const unsigned long long bit = 1ull << l4;
+            const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
+            const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
+            decided = ca | cr;
+            accepted = ca;
+        }
+        if (!decided) {
+            dH = wave_sum_all(e);
+            if (HAS_EW) dH += P.ew_coef * dEw;
+            if (HAS_MU) dH -= dMu;
+            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                               (int)rdlane((uint32_t)__double2loint(logu), l4));
+            const double exponent = nbeta * dH + 0.0;
+            accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        }
+        nacc_before = nacc_add;
+        if (accepted) {
+            double *cell = s_acc + ((size_t)cls1 * NSLOT) * 64 + lane;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it)
+                cell[it * 64] += STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+            if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+            if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
+            if (HAS_EW) {
+                if (phi_lds) {
+                    if (STEP == SMOLMC_STEP_SWAP) {
+                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
+                    } else if (dq1 != 0.0) {
+                        field_apply(P, phi, lane, s1, dq1);
+                    }
+                } else {
+                    if (dq1 != 0.0 || dq2 != 0.0) field_apply_hbm(P, phi, lane, s1, dq1, s2, dq2);
+                }
+            }
+            acc_mu += dMu;
+            acc_ew += dEw;
+            nacc_add++;
+        } else if (STEP == SMOLMC_STEP_SWAP) {
+            occ[a1] = (uint8_t)o1;
+        }
+        row1 = rown;
+
+        if (P.smp.every && --smp_countdown == 0) {
+            smp_countdown = (uint32_t)P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            s_feat[lane] = 0.0;
+            double lane_e = 0.0;
+            for (int i = lane; i < nrec; i += 64) {
+                const LeanSlot sl = P.slots[i];
+                const double v = s_acc[i];
+                lane_e = fma(sl.w, v, lane_e);
+                if (sl.live && v != 0.0)
+                    __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
+            if (HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
+            if (HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0));
+            if (lane == 0) {
+                P.smp.H[row] = Hnow;
+                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
+    }
+
+    // ---- write back ---------------------------------------------------------------
+    if (phi_lds)
+        for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
+    {
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+    }
+    s_feat[lane] = 0.0;
+    double lane_e = 0.0;
+    for (int i = lane; i < nrec; i += 64) {
+        const LeanSlot sl = P.slots[i];
+        const double v = s_acc[i];
+        lane_e = fma(sl.w, v, lane_e);
+        if (sl.live && v != 0.0)
+            __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    H += wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0);
+    if (lane == 0) {
+        if (HAS_EW) featp[P.Fce] += acc_ew;
+        if (HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] += nacc_add;
+        if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
+    }
+}
+
+template <int NSLOT, int MM, int STEP, bool MU, bool EW>
+static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned wpb = (unsigned)h->waves_per_block_lean;
+    const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
+    auto kern = mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), h->lean_lds, h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+template <int NSLOT, int MM> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.m_mu != nullptr, ew = lp.ew_field != 0;
+    if (h->cfg.step_type == SMOLMC_STEP_SWAP) {
+        if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, true>(h, lp)
+                          : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, true>(h, lp);
+        return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, false>(h, lp)
+                  : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, false>(h, lp);
+    }
+    if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, true>(h, lp)
+                      : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, true>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, false>(h, lp)
+              : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, false>(h, lp);
+}
+template <int NSLOT> static int launch_multi_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2>(h, lp) : launch_multi_nm<NSLOT, 3>(h, lp);
+}

@@ -273,6 +273,11 @@ struct LeanParams {
     const double *ew_qrow, *ew_dgrow; // [8] charge / diagonal term per species code (field mode:
                                       // identical for every active site, checked at create)
     WlParams wl;
+    // mc_lean_multi_kernel: several site classes / active sublattices (classes == sublattices)
+    int m_ncls, m_nsub;
+    int m_sbase[4], m_nact[4], m_ncodes[4], m_cls[4];
+    double m_cum[4];                     // cumulative sublattice probabilities
+    const double *m_mu, *m_q, *m_dg;     // [4][8] per-sublattice mu / charge / diagonal rows (or null)
     // TableFlip (mcusher.py:397-711) for the single active sublattice
     int tf_n;               // number of flip vectors
     const int *tf_table;    // [tf_n][ncodes]
@@ -323,9 +328,12 @@ struct smolmc_handle {
     bool generic = false, idx16 = false;
     size_t lds_bytes = 0;
     int waves_per_block = 4;
+    int waves_per_block_lean = 4; // mc_lean_multi_kernel (LDS-sized)
     // lean kernel (single class / single contiguous sublattice / interactions / no ewald)
     bool lean_tables = false, lean = false;
-    int lean_nslot = 0, lean_mm = 0;
+    int lean_nslot = 0, lean_mm = 0, lean_ncls = 0;
+    bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
+    std::vector<int> site_class_host;   // site -> class (255 = no clusters)
     size_t lean_lds = 0;
     LeanParams lp;
     // device-side samples of the last smolmc_run_sampled
@@ -376,3 +384,6 @@ int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_8(smolmc_handle *h, const LeanParams &lp);

@@ -501,7 +501,8 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("rocksalt333_vacancy_ewald", "int", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
     ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "metropolis", "general"),  # correlation features
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
-    ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "general"),
+    ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
+    ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
     ("rocksalt444_ewald", "int", capi.STEP_SWAP, None, "wang-landau", "general"),     # WL + Ewald
 ])
 def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, expected, monkeypatch):
