@@ -1126,7 +1126,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             // the potential field goes to LDS only while it stays small beside the rest of the
             // wave's state (else the HBM copy is used in place: ew_field 2)
             const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * 8;
-            const bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
+            const bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2 &&
+                                 getenv("SMOLMC_MULTI_PHI_HBM") == nullptr; // (test hook: force the HBM field)
             const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
             // waves per workgroup: the shared tables are paid once per workgroup, so pick the size
             // that keeps the most waves resident per CU (160 KiB of LDS)

@@ -561,3 +561,88 @@ def test_split_launches_equal_one_launch(kernel, monkeypatch):
         wa, wb = many.get_wl(), one.get_wl()
         assert np.array_equal(wa["histogram"], wb["histogram"]) and np.array_equal(wa["occurrences"], wb["occurrences"])
         np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant", ["lds-field", "hbm-field", "no-ewald"])
+@pytest.mark.parametrize("step,mukind", [(capi.STEP_SWAP, None), (capi.STEP_FLIP, "muG")], ids=["swap", "flip+mu"])
+def test_lean_multi_kernel_two_sublattices(step, mukind, variant, monkeypatch):
+    """mc_lean_multi_kernel (several active sublattices): trajectories equal the oracle's and the
+    general kernel's, with the Ewald potential field in LDS, forced into HBM, and without the
+    Ewald term; thinned device-side samples equal step-wise runs."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    if variant == "hbm-field":
+        monkeypatch.setenv("SMOLMC_MULTI_PHI_HBM", "1")
+    name = "rocksalt333_two_sublattices"
+    c = load_case(name)
+    if variant == "no-ewald":
+        tab = capi.TableSet.from_synth(c["sc"], c["coefs"], feature_mode=MODES["int"], mu_table=_mu(mukind, c))
+    else:
+        tab = tables_for(name, MODES["int"], mu_table=_mu(mukind, c))
+    R = 11
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(41)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) * np.uint64(977) + np.uint64(3)
+    temps = np.linspace(700.0, 5000.0, R)
+    eng = _engine(tab, cfg)
+    info = eng.kernel_info()
+    assert info.startswith("lean-multi")
+    assert ("field=1" in info) == (variant == "lds-field") and ("field=2" in info) == (variant == "hbm-field")
+    monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    gen = _engine(tab, cfg)
+    assert gen.kernel_info().startswith("general")
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL")
+    ora = orc.OracleMC(tab, cfg)
+    for e in (eng, gen, ora):
+        e.set_state(occ0, seeds, temps)
+    for chunk in (1, 15, 16, 17, 400):
+        for e in (eng, gen, ora):
+            e.run(chunk)
+        a, g, o = eng.get_state(), gen.get_state(), ora.get_state()
+        for x in (g, o):
+            assert np.array_equal(a["occupancy"], x["occupancy"])
+            assert np.array_equal(a["n_accepted"], x["n_accepted"])
+            assert np.array_equal(a["accepted"], x["accepted"])
+            np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(a["features"], x["features"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    smp = eng.run_sampled(4, 30, occupancy=True)
+    for i in range(4):
+        ora.run(30)
+        so = ora.get_state()
+        assert np.array_equal(smp["occupancy"][i], so["occupancy"])
+        np.testing.assert_allclose(smp["enthalpy"][i], so["enthalpy"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(smp["features"][i], so["features"], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("step", [capi.STEP_SWAP, capi.STEP_FLIP])
+def test_lean_multi_kernel_many_clusters(step):
+    """257-512 clusters per site (one class) take mc_lean_multi_kernel with NSLOT = 8."""
+    from oracle import oracle as orc
+    from smol_amd import synth
+
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.5, 3: 5.2})  # 451 clusters / site
+    sc = synth.build_supercell(model, [6, 6, 6])
+    mu = None
+    if step == capi.STEP_FLIP:
+        mu = np.tile(np.array([0.0, 0.15]), (sc.num_sites, 1))
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=9), mu_table=mu)
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean-multi nslot=8")
+    rng = np.random.default_rng(2)
+    occ0 = (rng.random((R, sc.num_sites)) < 0.5).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(60)
+    for e in (eng, ora):
+        e.set_state(occ0, seeds, 3000.0)
+        e.run(37)
+        e.run(300)
+    a, o = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], o["occupancy"])
+    np.testing.assert_allclose(a["enthalpy"], o["enthalpy"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(a["features"], o["features"], rtol=RTOL, atol=1e-8)
