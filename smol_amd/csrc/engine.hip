@@ -1430,6 +1430,8 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     if (h->lean_multi)
         return h->lean_nslot == 2 ? smolmc_launch_multi_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_4(h, lp) : smolmc_launch_multi_8(h, lp));
+    if (lp.bias_type && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP)
+        return h->lean_nslot == 2 ? smolmc_launch_lean_bias_2(h, lp) : smolmc_launch_lean_bias_4(h, lp);
     return h->lean_nslot == 2 ? smolmc_launch_lean_2(h, lp) : smolmc_launch_lean_4(h, lp);
 }
 

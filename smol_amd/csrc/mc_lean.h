@@ -185,7 +185,7 @@ template <int NW> __device__ __forceinline__ uint32_t row_entry(const RowWords<N
     return (r.w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
 }
 
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL>
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -260,8 +260,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const uint32_t nact = (uint32_t)P.nact, nt8 = P.nt8, snt8 = P.snt8;
     const int sbase = P.sbase;
     double acc_mu = 0.0, acc_ew = 0.0;
-    // MCBias (runtime, Metropolis only): biased walkers always take the exact decision path
-    const int btype = WL ? 0 : P.bias_type;
+    // MCBias (separate instantiations, lean_bias_n*.hip: even a never-taken runtime branch costs
+    // the unbiased kernel 10 %): biased walkers always take the exact decision path
+    const int btype = BIAS ? P.bias_type : 0;
     double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[r] : 0.0;
     // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
     // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         bool accepted;
         bool decided = false;
-        if (FAST && !btype) {
+        if (FAST && !BIAS) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
             const unsigned long long bit = 1ull << l4;
@@ -1167,10 +1168,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 }
 
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
-    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL>;
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1212,6 +1213,25 @@ static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
     return 0;
 }
 
+
+// biased Metropolis variants (instantiated in lean_bias_n*.hip only)
+template <int NSLOT, int MM, int STEP>
+static int launch_lean_bias_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (ew)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false, true>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, true>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, false, false, true>(h, lp);
+}
+template <int NSLOT> static int launch_lean_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_lean_bias_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp)
+                    : launch_lean_bias_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
+    return swap ? launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp)
+                : launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
+}
 
 template <int NSLOT> static int launch_lean_nslot(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)

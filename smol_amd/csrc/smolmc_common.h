@@ -384,6 +384,8 @@ int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_bias_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_8(smolmc_handle *h, const LeanParams &lp);
