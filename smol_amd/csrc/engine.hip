@@ -1073,8 +1073,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         }
         h->lean = lean;
         // ---- several classes / sublattices (or > 256 clusters per site): mc_lean_multi_kernel
-        if (!lean && h->lean_tables && !wl && !t->bias_type && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
-            h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
+        if (!lean && h->lean_tables && !wl && !t->bias_type && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
@@ -1120,12 +1120,18 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     }
                 }
             }
+            int ndims = 0, max_nact = 0;
+            for (int k = 0; k < ns && ok; ++k) { ndims += lp.m_ncodes[k]; max_nact = std::max(max_nact, lp.m_nact[k]); }
+            if (table && ok) {
+                if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights) ok = false;
+                else if (t->n_flip_vectors > 8 || ndims > 16) ok = false;
+            }
             // LDS: shared tables + slot records, per wave occupancy + scratch + accumulators (+ field)
             const size_t nrec = (size_t)h->lean_ncls * h->lean_nslot * 64;
-            const size_t shared = ((size_t)lp.dt_len + 96) * 8 + nrec * 24;
+            const size_t shared = ((size_t)lp.dt_len + 96 + (table ? 80 : 0)) * 8 + nrec * 24;
             // the potential field goes to LDS only while it stays small beside the rest of the
             // wave's state (else the HBM copy is used in place: ew_field 2)
-            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * 8;
+            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * (table ? 16 : 8);
             const bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2 &&
                                  getenv("SMOLMC_MULTI_PHI_HBM") == nullptr; // (test hook: force the HBM field)
             const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
@@ -1147,7 +1153,18 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 if (t->has_mu) lp.fast_eps += 4.0 * mmax * ldexp(1.0, -19);
                 if (getenv("SMOLMC_NO_FAST_ACCEPT")) lp.fast_eps = 0.0;
                 if (const char *sc = getenv("SMOLMC_FAST_EPS_SCALE")) lp.fast_eps *= atof(sc);
-                lp.m_ncls = h->lean_ncls; lp.m_nsub = ns;
+                lp.m_ncls = h->lean_ncls; lp.m_nsub = ns; lp.m_ndims = ndims;
+                if (table) {
+                    std::vector<double> ln((size_t)max_nact + 1, 0.0);
+                    for (int k = 1; k <= max_nact; ++k) ln[k] = std::log((double)k);
+                    if (dev_upload(h, t->flip_table, (size_t)t->n_flip_vectors * ndims, &lp.tf_table) ||
+                        dev_upload(h, t->flip_weights, (size_t)2 * t->n_flip_vectors, &lp.tf_w) ||
+                        dev_upload(h, ln.data(), ln.size(), &lp.tf_ln))
+                        return bail(1);
+                    lp.tf_n = t->n_flip_vectors;
+                    lp.tf_sw = t->swap_weight;
+                    lp.tf_ln_len = 0;
+                }
                 lp.occ = kp.occ; lp.enthalpy = kp.enthalpy; lp.features = kp.features; lp.beta = kp.beta;
                 lp.seeds = kp.seeds; lp.nsteps = kp.nsteps; lp.nacc = kp.nacc; lp.last_acc = kp.last_acc;
                 lp.R = h->R; lp.N = h->N; lp.Npad = h->Npad; lp.F = h->F; lp.Fce = h->Fce;
@@ -1174,9 +1191,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
                 return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
                                  "smol/moca/composition/space.py:404-429)"));
-            if (!lean || wl)
-                return bail(fail("TableFlip is implemented for single-class, single-sublattice "
-                                 "Metropolis models (the lean path) only"));
+            if (!h->lean || wl)
+                return bail(fail("TableFlip is implemented for Metropolis models on the lean paths only "
+                                 "(interaction features, contiguous sublattices = site classes, <= 512 "
+                                 "clusters per site, uniform mu rows, factorising Ewald matrix)"));
             if (!(t->swap_weight >= 0.0 && t->swap_weight < 1.0))
                 return bail(fail("swap_weight must be in [0, 1)"));
         }

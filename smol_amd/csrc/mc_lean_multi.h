@@ -440,6 +440,518 @@ template <int NSLOT, int MM> static int launch_multi_nm(smolmc_handle *h, const 
     return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, false>(h, lp)
               : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, false>(h, lp);
 }
+
+
+// ----------------------------------------------------------------------------
+// TableFlip for several active sublattices (mcusher.py:397-711): flip vectors span the
+// species of ALL active sublattices ("counts" dimensions d = sum of their species, <= 16),
+// e.g. Li+ + F- <-> Mn3+ + O2- style charge-neutral exchanges between the cation and anion
+// sublattices.  Same algorithm as mc_table_kernel (feasibility by compare + ballot on
+// lane-indexed counts, scalar ballot scan of the candidate stream, a-priori factor, sequential
+// evaluation with tentative LDS writes) on the multi-class state layout of
+// mc_lean_multi_kernel; sites of the depleted species are drawn sublattice by sublattice from
+// ONE candidate stream, exactly as the oracle does.
+// ----------------------------------------------------------------------------
+template <int NSLOT, int MM>
+__global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r = uni(blockIdx.x * nwaves + wave);
+    const int NC = P.m_ncls, NS = P.m_nsub;
+    const bool has_mu = P.m_mu != nullptr, has_ew = P.ew_field != 0;
+    // block-shared: dt | mu [4][8] | q [4][8] | dg [4][8] | weights [16] | flip table [8][16] ints | records
+    double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len;
+    double *s_q = s_mu + 32, *s_dg = s_mu + 64;
+    double *s_tfw = s_mu + 96;
+    int *s_tf = (int *)(s_tfw + 16);
+    MultiRec *s_rec = (MultiRec *)(s_tfw + 16 + 64);
+    const int nrec = NC * NSLOT * 64;
+    // per wave: occupancy | 64 B (species counts) | feature scratch [64] | acc cells | pending cells | phi
+    const bool phi_lds = has_ew && P.ew_field == 1;
+    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 16 + (phi_lds ? (size_t)P.ew_nact * 8 : 0);
+    unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
+    uint8_t *occ = wbase;
+    int *s_cnt = (int *)(wbase + P.Nlds);
+    double *s_feat = (double *)(wbase + P.Nlds + 64);
+    double *s_acc = s_feat + 64;
+    double *s_pend = s_acc + nrec;
+    double *phi = phi_lds ? s_pend + nrec : P.ew_phi + (size_t)r * P.ew_nact;
+    const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
+    const int D = P.m_ndims;
+    for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (threadIdx.x < 32) {
+        s_mu[threadIdx.x] = has_mu ? P.m_mu[threadIdx.x] : 0.0;
+        s_q[threadIdx.x] = has_ew ? P.m_q[threadIdx.x] : 0.0;
+        s_dg[threadIdx.x] = has_ew ? P.m_dg[threadIdx.x] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 2 * P.tf_n; i += blockDim.x) s_tfw[i] = P.tf_w[i];
+    for (int i = threadIdx.x; i < P.tf_n * D; i += blockDim.x) s_tf[i] = P.tf_table[i];
+    for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
+        const LeanSlot sl = P.slots[i];
+        MultiRec rec;
+        rec.doff8 = sl.doff8;
+        rec.st8[0] = sl.stride8[0]; rec.st8[1] = sl.stride8[1]; rec.st8[2] = sl.stride8[2];
+        rec.w = sl.w;
+        s_rec[i] = rec;
+    }
+    const bool live = r < P.R;
+    if (live) {
+        const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
+        s_feat[lane] = 0.0;
+        if (lane < 16) s_cnt[lane] = 0;
+        for (int i = lane; i < 2 * nrec; i += 64) s_acc[i] = 0.0; // acc + pending cells
+        if (phi_lds)
+            for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint32_t nt8 = P.nt8, snt8 = P.snt8;
+    const int abase = P.ew_act_base;
+    // "counts" dimension of this lane: sublattice, species code, first dimension of the sublattice
+    int dim_sub = 0, dim_base = 0;
+    {
+        int b = 0;
+        for (int k = 0; k < NS; ++k) {
+            const int nck = sel4(P.m_ncodes, k);
+            if (lane >= b && lane < b + nck) { dim_sub = k; dim_base = b; }
+            b += nck;
+        }
+    }
+    const int dim_max = lane < D ? sel4(P.m_nact, dim_sub) : 0;
+    for (int k = 0; k < NS; ++k) {
+        const int sb = sel4(P.m_sbase, k), na = sel4(P.m_nact, k);
+        int b = 0;
+        for (int q = 0; q < k; ++q) b += sel4(P.m_ncodes, q);
+        for (int a = lane; a < na; a += 64) atomicAdd(&s_cnt[b + (int)occ[lean_swz(sb + a, swa, swm, swb)]], 1);
+    }
+    int vcnt = lane < D ? s_cnt[lane] : 0;
+    int vtf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vtf[i] = (i < P.tf_n && lane < D) ? s_tf[i * D + lane] : 0;
+    auto feasible = [&](const int vc) -> unsigned { // flip_weights_mask (math.py:832-867)
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < P.tf_n) {
+                const int vp = vc + vtf[i], vm = vc - vtf[i];
+                if (__ballot(vp < 0 || vp > dim_max) == 0ull) m |= 1u << (2 * i);
+                if (__ballot(vm < 0 || vm > dim_max) == 0ull) m |= 2u << (2 * i);
+            }
+        return m;
+    };
+    const double vw = lane < 2 * P.tf_n ? s_tfw[lane] : 0.0;
+    auto weight_of = [&](const int idx) -> double {
+        return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vw), idx),
+                                (int)rdlane((uint32_t)__double2loint(vw), idx));
+    };
+    auto masked_sum = [&](const unsigned m) -> double {
+        double sw = 0.0;
+        for (int idx = 0; idx < 2 * P.tf_n; ++idx)
+            if ((m >> idx) & 1u) sw += weight_of(idx);
+        return sw;
+    };
+    auto sub_of = [&](uint32_t w0) -> int {
+        if (NS == 1) return 0;
+        const double x = (double)w0 * (1.0 / 4294967296.0);
+        int sl = NS - 1;
+        for (int k = NS - 2; k >= 0; --k)
+            if (x < P.m_cum[k]) sl = k;
+        return sl;
+    };
+
+    double H = P.enthalpy[r];
+    const double nbeta = -P.beta[r];
+    unsigned long long step = P.nsteps[r];
+    uint32_t nacc_add = 0, nacc_before = 0;
+    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    double acc_mu = 0.0, acc_ew = 0.0;
+    double *featp = P.features + (size_t)r * P.F;
+    const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    uint32_t smp_countdown = (uint32_t)P.smp.every;
+    long long smp_index = 0;
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+    double logu = 0.0;
+    unsigned long long batch_base = ~0ull;
+    uint32_t w_site_carry = 0;
+    constexpr int ROW = NSLOT * MM;
+    constexpr int NW = ROW / 2;
+    constexpr uint32_t SITE_BYTES = 64u * ROW * 2u;
+    const __amdgpu_buffer_rsrc_t idx_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
+    const int nf2 = 2 * P.tf_n;
+
+    const uint32_t nsteps32 = (uint32_t)P.steps;
+    for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
+        const unsigned long long base = step & ~15ull;
+        if (base != batch_base) {
+            if (batch_base == base - 16) {
+                w_site_carry = rdlane(W1, 60);
+            } else {
+                const unsigned long long sp = base - 1ull;
+                w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                                key0, key1).w[1]);
+            }
+            batch_base = base;
+            const unsigned long long st = base + (unsigned)(lane >> 2);
+            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), 0u,
+                                               key0, key1);
+            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
+            logu = log(philox_u53(o.w[2], o.w[3]));
+        }
+        const int l4 = (int)(step & 15ull) * 4;
+        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
+
+        // flips of this step, lane-indexed: lane f holds flip f (site, new / old code, sublattice)
+        int vsite = 0, vnew = 0, vold = 0, vfsub = 0;
+        int nfl = 0, dir = -1;
+        int vu = 0; // table step: lane d holds the change of count dimension d
+        double log_priori = 0.0;
+        bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
+        double sumw = 0.0;
+        unsigned feas_now = 0;
+        if (!do_swap) {
+            feas_now = feasible(vcnt);
+            sumw = masked_sum(feas_now);
+            if (!(sumw > 0.0)) do_swap = true;
+        }
+        if (do_swap) {
+            // Swap.propose_step inside the sublattice picked by W(step, 1, 1) (mcusher.py:176-200)
+            const int sl = sub_of(rdlane(W1, l4 + 1));
+            const int sb = sel4(P.m_sbase, sl);
+            const uint32_t na = (uint32_t)sel4(P.m_nact, sl);
+            const int s1 = sb + (int)__umulhi(w_site, na);
+            const int o1 = uni((int)occ[lean_swz(s1, swa, swm, swb)]);
+            int found = -1, fo = 0;
+            const uint32_t ws[4] = {W0, W1, W2, W3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (found < 0) {
+                    const int cs = sb + (int)__umulhi(ws[j], na);
+                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)cs, b);
+                        fo = (int)rdlane((uint32_t)v, b);
+                    }
+                }
+            }
+            if (found < 0) {
+                for (uint32_t q = 0;; ++q) {
+                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    int selsite = -1, selv = 0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int cs = sb + (int)__umulhi(o.w[j], na);
+                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                        if (v != o1) { selsite = cs; selv = v; }
+                    }
+                    const unsigned long long m = __ballot(selsite >= 0);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        found = (int)rdlane((uint32_t)selsite, b);
+                        fo = (int)rdlane((uint32_t)selv, b);
+                        break;
+                    }
+                    if ((q & 63u) == 0) {
+                        int any = 0;
+                        for (uint32_t a = lane; a < na; a += 64)
+                            any |= ((int)occ[lean_swz(sb + (int)a, swa, swm, swb)] != o1);
+                        if (__ballot(any) == 0ull) break;
+                    }
+                }
+            }
+            if (found >= 0) {
+                nfl = 2;
+                vsite = lane == 0 ? s1 : found;
+                vnew = lane == 0 ? fo : o1;
+                vold = lane == 0 ? o1 : fo;
+                vfsub = sl;
+            }
+        } else {
+            // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
+            const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
+            double cum = 0.0;
+            int last = -1;
+            for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
+                if (!((feas_now >> idx) & 1u)) continue;
+                last = idx;
+                cum += weight_of(idx);
+                if (target < cum) dir = idx;
+            }
+            if (dir < 0) dir = last;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
+            vu *= (dir & 1) ? -1 : 1;
+            { // compute_log_priori_factor (mcusher.py:656-711)
+                const double sum_next = masked_sum(feasible(vcnt + vu));
+                double lf = 0.0;
+                const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
+                if (!(w_now == w_back && sum_next == sumw)) {
+                    const double p_now = (1.0 - P.tf_sw) * w_now / sumw;
+                    const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
+                    lf = log(p_next / p_now);
+                }
+                for (int c = 0; c < D; ++c) {
+                    const int u = (int)rdlane((uint32_t)vu, c), n0 = (int)rdlane((uint32_t)vcnt, c);
+                    for (int k = 1; k <= u; ++k) lf -= P.tf_ln[n0 + k];
+                    for (int k = 0; k < -u; ++k) lf += P.tf_ln[n0 - k];
+                }
+                log_priori = uni_d(lf);
+            }
+            // sites of the depleted species, sublattice by sublattice, from the candidate stream
+            // c_t = W(step, 4 + t / 4, t % 4) (256 candidates per wave round, position kept across
+            // species AND sublattices); then the random assignment to the enriched species
+            uint32_t tpos = 0, round = 0, ow[4] = {0, 0, 0, 0};
+            bool have_round = false;
+            int qdraw = 0, dbase = 0;
+            for (int sl = 0; sl < NS; ++sl) {
+                const int sb = sel4(P.m_sbase, sl), ncod = sel4(P.m_ncodes, sl);
+                const uint32_t na = (uint32_t)sel4(P.m_nact, sl);
+                int vcol = 0, ncol = 0; // sites collected in this sublattice, lane-indexed
+                int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
+                bool have_sites = false; // cs / cv valid for (round, sl)
+                for (int c = 0; c < ncod; ++c) {
+                    int need = -(int)rdlane((uint32_t)vu, dbase + c);
+                    unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
+                    bool have_masks = false;
+                    while (need > 0) {
+                        if (!have_round) {
+                            const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                               4u + 64u * round + (uint32_t)lane, 0u, key0, key1);
+                            ow[0] = o.w[0]; ow[1] = o.w[1]; ow[2] = o.w[2]; ow[3] = o.w[3];
+                            have_round = true;
+                            have_sites = false;
+                            tpos = 0;
+                        }
+                        if (!have_sites) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                cs[j] = sb + (int)__umulhi(ow[j], na);
+                                cv[j] = (int)occ[lean_swz(cs[j], swa, swm, swb)];
+                            }
+                            have_sites = true;
+                            have_masks = false;
+                        }
+                        if (!have_masks) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) B[j] = __ballot(cv[j] == c);
+                            have_masks = true;
+                        }
+                        uint32_t best = 0xffffffffu;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t l0 = tpos > (uint32_t)j ? (tpos - (uint32_t)j + 3u) >> 2 : 0u;
+                            const unsigned long long m = l0 < 64u ? (B[j] >> l0) << l0 : 0ull;
+                            if (m) best = min(best, 4u * (uint32_t)(__ffsll((long long)m) - 1) + (uint32_t)j);
+                        }
+                        if (best == 0xffffffffu) { round++; have_round = false; continue; }
+                        tpos = best + 1u;
+                        const int bl = (int)(best >> 2), bj = (int)(best & 3u);
+                        const int picked = (int)rdlane((uint32_t)(bj == 0 ? cs[0] : bj == 1 ? cs[1] : bj == 2 ? cs[2] : cs[3]), bl);
+                        if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
+                        if (lane == ncol) vcol = picked;
+                        ncol++;
+                        need--;
+                    }
+                }
+                for (int c = 0; c < ncod; ++c) { // random assignment (:627-631)
+                    const int u = (int)rdlane((uint32_t)vu, dbase + c);
+                    for (int k = 0; k < u; ++k) {
+                        const int wl = l4 + 2 + (qdraw >> 2);
+                        const int wj = qdraw & 3;
+                        const uint32_t word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
+                        qdraw++;
+                        const int rr = (int)__umulhi(word, (uint32_t)ncol);
+                        const int site = (int)rdlane((uint32_t)vcol, rr);
+                        const int od = uni((int)occ[lean_swz(site, swa, swm, swb)]);
+                        if (lane == nfl) { vsite = site; vnew = c; vold = od; vfsub = sl; }
+                        nfl++;
+                        const int nxt = __shfl_down(vcol, 1);
+                        if (lane >= rr) vcol = nxt;
+                        ncol--;
+                    }
+                }
+                dbase += ncod;
+            }
+        }
+
+        // -------- sequential evaluation of the flips of this step -----------------------
+        double e = 0.0, ew_uni = 0.0, dMu = 0.0;
+        double vdq = 0.0;
+        double vG = 0.0;
+        if (has_ew && nfl > 1) {
+            const int pi = lane >> 3, pj = lane & 7;
+            const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
+            if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - abase)];
+        }
+        unsigned cmask = 0; // classes with pending feature deltas
+        RowWords<NW> rows[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (f < nfl) rows[f] = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES);
+        auto eval_flip = [&](const int f, const RowWords<NW> &row) {
+            const int s = (int)rdlane((uint32_t)vsite, f), nw = (int)rdlane((uint32_t)vnew, f);
+            const int od = (int)rdlane((uint32_t)vold, f), sl = (int)rdlane((uint32_t)vfsub, f);
+            const int cls = sel4(P.m_cls, sl);
+            cmask |= 1u << cls;
+            const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
+            const MultiRec *rec = s_rec + ((size_t)cls * NSLOT) * 64 + lane;
+            double *pend = s_pend + ((size_t)cls * NSLOT) * 64 + lane;
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const MultiRec rc = rec[it * 64];
+                uint32_t a = rc.doff8;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row, it * MM + m)]);
+                const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
+                e = fma(rc.w, d, e);
+                pend[it * 64] += d;
+            }
+            if (has_ew) {
+                const double dq = s_q[sl * 8 + nw] - s_q[sl * 8 + od];
+                double pot = phi_lds ? phi[s - abase]
+                                     : __hip_atomic_load(&phi[s - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int m = 0; m < f; ++m) {
+                    const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
+                                                        (int)rdlane((uint32_t)__double2loint(vdq), m));
+                    const double gfm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vG), 8 * f + m),
+                                                        (int)rdlane((uint32_t)__double2loint(vG), 8 * f + m));
+                    pot = fma(dqm, gfm, pot);
+                }
+                ew_uni += 2.0 * dq * pot + (s_dg[sl * 8 + nw] - s_dg[sl * 8 + od]);
+                if (lane == f) vdq = dq;
+            }
+            if (has_mu) dMu += s_mu[sl * 8 + nw] - s_mu[sl * 8 + od];
+            occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative (every lane, same byte)
+        };
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (f < nfl) eval_flip(f, rows[f]);
+        for (int f = 4; f < nfl; ++f)
+            eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
+        double dH = wave_sum_all(e);
+        const double dEw = has_ew ? ew_uni : 0.0;
+        if (has_ew) dH += P.ew_coef * dEw;
+        if (has_mu) dH -= dMu;
+        const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        nacc_before = nacc_add;
+        // pending feature deltas of the touched classes: keep (accept) or drop (reject)
+        for (int cls = 0; cls < NC; ++cls)
+            if ((cmask >> cls) & 1u) {
+                double *pend = s_pend + ((size_t)cls * NSLOT) * 64 + lane;
+                double *cell = s_acc + ((size_t)cls * NSLOT) * 64 + lane;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    if (accepted) cell[it * 64] += pend[it * 64];
+                    pend[it * 64] = 0.0;
+                }
+            }
+        if (accepted) {
+            vcnt += vu;
+            if (has_ew)
+                for (int f = 0; f < nfl; ++f) {
+                    const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
+                                                        (int)rdlane((uint32_t)__double2loint(vdq), f));
+                    if (dqf == 0.0) continue;
+                    const int sf = (int)rdlane((uint32_t)vsite, f);
+                    if (phi_lds) field_apply(P, phi, lane, sf, dqf);
+                    else field_apply_hbm(P, phi, lane, sf, dqf, sf, 0.0);
+                }
+            acc_mu += dMu;
+            acc_ew += dEw;
+            nacc_add++;
+        } else {
+            for (int f = nfl - 1; f >= 0; --f) { // undo the tentative flips
+                const int s = (int)rdlane((uint32_t)vsite, f), od = (int)rdlane((uint32_t)vold, f);
+                occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
+            }
+        }
+
+        if (P.smp.every && --smp_countdown == 0) {
+            smp_countdown = (uint32_t)P.smp.every;
+            const size_t row = (size_t)smp_index * P.R + r;
+            smp_index++;
+            s_feat[lane] = 0.0;
+            double lane_e = 0.0;
+            for (int i = lane; i < nrec; i += 64) {
+                const LeanSlot sl = P.slots[i];
+                const double v = s_acc[i];
+                lane_e = fma(sl.w, v, lane_e);
+                if (sl.live && v != 0.0)
+                    __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
+            if (has_ew && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
+            if (has_mu && lane == P.Fce + (has_ew ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (has_ew ? P.ew_coef * acc_ew : 0.0));
+            if (lane == 0) {
+                P.smp.H[row] = Hnow;
+                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+            }
+            if (P.smp.occ) {
+                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
+                for (int i = lane; i < P.Npad / 4; i += 64)
+                    dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+            }
+        }
+    }
+
+    if (phi_lds)
+        for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
+    {
+        uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
+        for (int i = lane; i < P.Npad / 4; i += 64)
+            dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
+    }
+    s_feat[lane] = 0.0;
+    double lane_e = 0.0;
+    for (int i = lane; i < nrec; i += 64) {
+        const LeanSlot sl = P.slots[i];
+        const double v = s_acc[i];
+        lane_e = fma(sl.w, v, lane_e);
+        if (sl.live && v != 0.0)
+            __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    H += wave_sum_all(lane_e) - acc_mu + (has_ew ? P.ew_coef * acc_ew : 0.0);
+    if (lane == 0) {
+        if (has_ew) featp[P.Fce] += acc_ew;
+        if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
+        P.enthalpy[r] = H;
+        P.nsteps[r] = step;
+        P.nacc[r] += nacc_add;
+        if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
+    }
+}
+
+template <int NSLOT, int MM> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
+    const unsigned wpb = (unsigned)h->waves_per_block_lean;
+    const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
+    auto kern = mc_table_multi_kernel<NSLOT, MM>;
+    if (h->lean_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lean_lds));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), h->lean_lds, h->stream, lp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
 template <int NSLOT> static int launch_multi_nslot(smolmc_handle *h, const LeanParams &lp) {
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+        return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2>(h, lp) : launch_table_multi_inst<NSLOT, 3>(h, lp);
     return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2>(h, lp) : launch_multi_nm<NSLOT, 3>(h, lp);
 }

@@ -274,7 +274,7 @@ struct LeanParams {
                                       // identical for every active site, checked at create)
     WlParams wl;
     // mc_lean_multi_kernel: several site classes / active sublattices (classes == sublattices)
-    int m_ncls, m_nsub;
+    int m_ncls, m_nsub, m_ndims;         // m_ndims = sum of species over the sublattices (TableFlip)
     int m_sbase[4], m_nact[4], m_ncodes[4], m_cls[4];
     double m_cum[4];                     // cumulative sublattice probabilities
     const double *m_mu, *m_q, *m_dg;     // [4][8] per-sublattice mu / charge / diagonal rows (or null)

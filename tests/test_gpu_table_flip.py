@@ -94,3 +94,59 @@ def test_table_flip_through_sampler():
     assert np.all(charge[occs[..., : sc.size]].sum(axis=-1) == 2 * sc.size)  # neutral throughout
     f = ens.compute_feature_vector(occs[-1, 0])
     np.testing.assert_allclose(c.get_feature_vectors(flat=False)[-1, 0], f, rtol=1e-10, atol=1e-8)
+
+
+@pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
+def test_table_flip_across_two_sublattices(ewald):
+    """TableFlip with flip vectors spanning the cation AND the anion sublattice (the shape of the
+    reference's own TableFlip tests, tests/test_moca/test_mcushers.py:199-319): the table comes
+    from CompositionSpace, the engine runs mc_table_multi_kernel, trajectories equal the
+    oracle's, every sample stays charge neutral and the composition moves on both sublattices."""
+    from oracle import oracle as orc
+    from smol_amd import moca, synth
+    from smol_amd.engine import Engine
+
+    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=8, scale=0.02),
+                                               ewald_coefficient=0.05 if ewald else None)
+    cs = ens.composition_space(optimize_basis=True, table_ergodic=True)
+    table = np.asarray(cs.flip_table)
+    assert table.shape[1] == 5 and len(table) >= 2
+    assert np.any(table[:, :3] != 0) and np.any(table[:, 3:] != 0)  # couples both sublattices
+    tab = ens.make_tables(flip_table=table, swap_weight=0.15)
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    P = sc.size
+    rng = np.random.default_rng(13)
+    occ = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # 17 Li+ + 8 Mn3+ + 2 Ti4+ = +49, 22 O2- + 5 F- = -49
+        perm = rng.permutation(P)
+        occ[r, perm[:8]] = 1
+        occ[r, perm[8:10]] = 2
+        occ[r, P + rng.permutation(P)[:5]] = 1
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(900)
+    temps = np.linspace(1500.0, 6000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean-multi")
+    eng.set_state(occ, seeds, temps)
+    ora.set_state(occ, seeds, temps)
+    q = np.zeros((sc.num_sites, 3))
+    q[:P] = [1, 3, 4]
+    q[P:, :2] = [-2, -1]
+    comps = set()
+    for chunk in (1, 9, 40, 300, 700):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+        charge = q[np.arange(sc.num_sites)[None, :], a["occupancy"]].sum(axis=1)
+        assert np.all(charge == 0)
+        for o in a["occupancy"]:
+            comps.add((int((o[:P] == 1).sum()), int((o[:P] == 2).sum()), int((o[P:] == 1).sum())))
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-8)
+    assert len({c[2] for c in comps}) > 1 and len({c[0] for c in comps}) > 1  # F and Mn contents moved
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
