@@ -150,3 +150,54 @@ def test_table_flip_across_two_sublattices(ewald):
     np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-8)
     assert len({c[2] for c in comps}) > 1 and len({c[0] for c in comps}) > 1  # F and Mn contents moved
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+
+
+def test_two_sublattice_table_flip_detailed_balance():
+    """Zero Hamiltonian on cation {Li+, Mn3+, Ti4+} + anion {O2-, F-} sublattices (27 sites each):
+    the chain must visit a charge-neutral composition (n_Mn, n_Ti, n_F) with probability
+    proportional to its number of configurations, 27!/(n_Li! n_Mn! n_Ti!) * C(27, n_F) -- the
+    histogram test of tests/test_moca/test_mcushers.py:237-319 on the engine, with the flip table
+    from CompositionSpace (ergodic completion) and 10 % canonical swaps."""
+    from math import comb
+
+    from smol_amd import moca, synth
+    from smol_amd.engine import Engine
+
+    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 3.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, np.zeros(model.num_corr_functions))
+    table = ens.composition_space(optimize_basis=True, table_ergodic=True).flip_table
+    tab = ens.make_tables(flip_table=table, swap_weight=0.1)
+    R, P = 256, sc.size
+    eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP))
+    assert eng.kernel_info().startswith("lean-multi")
+    rng = np.random.default_rng(21)
+    occ = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # start: 6 Mn3+, 2 Ti4+, 9 F-  (charge 19 + 18 + 8 = 45 = 2*18 + 9)
+        perm = rng.permutation(P)
+        occ[r, perm[:6]] = 1
+        occ[r, perm[6:8]] = 2
+        occ[r, P + rng.permutation(P)[:9]] = 1
+    eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(77), 1000.0)
+    eng.run(4000)
+    counts = {}
+    nsamp = 60
+    for _ in range(nsamp):
+        eng.run(400)
+        o = eng.get_state()["occupancy"]
+        keys = zip((o[:, :P] == 1).sum(axis=1), (o[:, :P] == 2).sum(axis=1), (o[:, P:] == 1).sum(axis=1))
+        for k in keys:
+            k = tuple(int(x) for x in k)
+            counts[k] = counts.get(k, 0) + 1
+    w = {}
+    for n_mn in range(P + 1):
+        for n_ti in range(P + 1 - n_mn):
+            n_f = 54 - ((P - n_mn - n_ti) + 3 * n_mn + 4 * n_ti)
+            if 0 <= n_f <= P:
+                w[(n_mn, n_ti, n_f)] = comb(P, n_mn) * comb(P - n_mn, n_ti) * comb(P, n_f)
+    assert set(counts) <= set(w)  # only charge-neutral compositions are ever visited
+    tot_w, tot_c = sum(w.values()), sum(counts.values())
+    top = sorted(w, key=lambda k: -w[k])[:8]
+    for k in top:
+        p = w[k] / tot_w
+        assert counts.get(k, 0) / tot_c == pytest.approx(p, abs=max(0.012, 5 * np.sqrt(p / tot_c)))
