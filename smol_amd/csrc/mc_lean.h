@@ -185,6 +185,29 @@ template <int NW> __device__ __forceinline__ uint32_t row_entry(const RowWords<N
     return (r.w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
 }
 
+// Wang-Landau flatness check (wanglandau.py:253-264), every check_period steps: kept out of
+// line so that its temporaries do not add to the register pressure of the step loop.
+// Returns the (possibly reduced) modification factor.
+__device__ __noinline__ double wl_flatness_check(const double *wl_S, long long *wl_Hh, int L, double flat,
+                                                 double div, double wl_m, int lane) {
+    long cnt = 0;
+    double sum = 0;
+    for (int i = lane; i < L; i += 64)
+        if (wl_S[i] > 0) { cnt++; sum += (double)wl_Hh[i]; }
+    const double tcnt = wave_sum_all((double)cnt), tsum = wave_sum_all(sum);
+    if (tcnt >= 2.0) {
+        const double thr = flat * (tsum / tcnt);
+        int bad = 0;
+        for (int i = lane; i < L; i += 64)
+            if (wl_S[i] > 0 && !((double)wl_Hh[i] > thr)) bad = 1;
+        if (__ballot(bad) == 0ull) {
+            for (int i = lane; i < L; i += 64) wl_Hh[i] = 0;
+            wl_m = wl_m / div;
+        }
+    }
+    return wl_m;
+}
+
 template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -605,23 +628,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     atomicAdd((unsigned long long *)(P.wl.occur + (size_t)r * P.wl.L + b), 1ull);
                 }
             }
-            if (wl_rem_check == 0) {
-                long cnt = 0;
-                double sum = 0;
-                for (int i = lane; i < P.wl.L; i += 64)
-                    if (wl_S[i] > 0) { cnt++; sum += (double)wl_Hh[i]; }
-                const double tcnt = wave_sum_all((double)cnt), tsum = wave_sum_all(sum);
-                if (tcnt >= 2.0) {
-                    const double thr = P.wl.flat * (tsum / tcnt);
-                    int bad = 0;
-                    for (int i = lane; i < P.wl.L; i += 64)
-                        if (wl_S[i] > 0 && !((double)wl_Hh[i] > thr)) bad = 1;
-                    if (__ballot(bad) == 0ull) {
-                        for (int i = lane; i < P.wl.L; i += 64) wl_Hh[i] = 0;
-                        wl_m = wl_m / P.wl.div;
-                    }
-                }
-            }
+            if (wl_rem_check == 0) wl_m = wl_flatness_check(wl_S, wl_Hh, P.wl.L, P.wl.flat, P.wl.div, wl_m, lane);
         }
 
         if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
