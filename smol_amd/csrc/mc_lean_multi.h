@@ -140,9 +140,10 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     auto sub_of = [&](uint32_t w0) -> int { // MCUsher.get_random_sublattice (mcusher.py:146-148)
         if (NS == 1) return 0;
         const double x = (double)w0 * (1.0 / 4294967296.0);
-        int sl = NS - 1;
-        for (int k = NS - 2; k >= 0; --k)
-            if (x < P.m_cum[k]) sl = k;
+        int sl = NS - 1; // (constant indices: a dynamic index into kernel arguments goes through scratch)
+        if (NS > 3 && x < P.m_cum[2]) sl = 2;
+        if (NS > 2 && x < P.m_cum[1]) sl = 1;
+        if (x < P.m_cum[0]) sl = 0;
         return sl;
     };
 
@@ -558,9 +559,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     auto sub_of = [&](uint32_t w0) -> int {
         if (NS == 1) return 0;
         const double x = (double)w0 * (1.0 / 4294967296.0);
-        int sl = NS - 1;
-        for (int k = NS - 2; k >= 0; --k)
-            if (x < P.m_cum[k]) sl = k;
+        int sl = NS - 1; // (constant indices: a dynamic index into kernel arguments goes through scratch)
+        if (NS > 3 && x < P.m_cum[2]) sl = 2;
+        if (NS > 2 && x < P.m_cum[1]) sl = 1;
+        if (x < P.m_cum[0]) sl = 0;
         return sl;
     };
 
