@@ -109,9 +109,16 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
 // changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous).  Eight loads in
 // flight per lane; j == own index is skipped (phi excludes the self term).
 __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
+#ifdef SMOLMC_EXP_GROW0 // timing experiment only (wrong results): every row read hits the same 14 KB
+    const double *g = P.ew_G + (size_t)(s & 1) * P.ew_nact;
+#else
     const double *g = P.ew_G + (size_t)s * P.ew_nact;
+#endif
     const int js = s - P.sbase, na = P.ew_nact;
-    constexpr int U = 8; // loads in flight per lane: the row comes from L2 / Infinity Cache
+    // loads in flight per lane: the row comes from L2 / Infinity Cache, and every batch exposes one
+    // such latency (14 = two batches for the 1728 cation sites of a 12^3 rocksalt cell; measured
+    // 8: +8 %, 20+: register pressure)
+    constexpr int U = 14;
     for (int j0 = lane; j0 < na; j0 += 64 * U) {
         double gv[U];
 #pragma unroll
@@ -129,7 +136,7 @@ __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, i
                                              int s2, double dq2) {
     const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
     const int j1 = s1 - P.sbase, j2 = s2 - P.sbase, na = P.ew_nact;
-    constexpr int U = 4;
+    constexpr int U = 14; // 2 x 14 loads in flight (see field_apply; 4: +17 % on the swap + Ewald shape)
     for (int j0 = lane; j0 < na; j0 += 64 * U) {
         double ga[U], gb[U];
 #pragma unroll
