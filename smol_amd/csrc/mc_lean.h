@@ -105,56 +105,93 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
     return out;
 }
 
+// One straight-line batch of the potential-field sweep: U groups of 64 entries starting at group
+// g0, entry j gains dq1 * ga[j] (+ dq2 * gb[j]).  All loads of the batch are issued first (one
+// exposed latency per batch), addresses are base + immediate offsets (no per-element address
+// arithmetic: the clamped / masked form of this loop cost ~10 VALU and, worse, compiler-made
+// branches per element).  Groups below gdone were already updated by an earlier batch -- the
+// last batch of a sweep is shifted back so that it ends on the last full group -- and are
+// rewritten unchanged (coefficient 0).
+template <int U, bool TWO>
+__device__ __forceinline__ void field_sweep_batch(double *phi, const double *ga, const double *gb, int lane,
+                                                  int g0, int gdone, double dq1, double dq2) {
+    const int j = g0 * 64 + lane;
+    const double *pa = ga + j, *pb = gb + j;
+    double *pp = phi + j;
+    double va[U], vb[U], pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        va[u] = pa[64 * u];
+        if (TWO) vb[u] = pb[64 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool fresh = g0 + u >= gdone; // wave-uniform
+        double v = fma(fresh ? dq1 : 0.0, va[u], pv[u]);
+        if (TWO) v = fma(fresh ? dq2 : 0.0, vb[u], v);
+        pp[64 * u] = v;
+    }
+}
+
+template <bool TWO>
+__device__ __forceinline__ void field_sweep(double *phi, const double *ga, const double *gb, int lane, int na,
+                                            double dq1, double dq2) {
+    // groups per batch, measured on the 1728 cation sites (27 groups) of a 12^3 rocksalt cell:
+    // one row 9 / 14 / 27 -> 1.52 / 1.63 / 1.56 ms (config 3), two rows 9 / 14 / 27 -> 2.80 / 2.70 /
+    // 2.93 ms (swap + Ewald); the row reads run at several TB/s out of L2 / Infinity Cache, so
+    // the differences are memory-system effects, not instruction counts
+    constexpr int U = TWO ? 14 : 9;
+    const int ngf = na >> 6; // full groups of 64 entries
+    int g = 0;
+    if (ngf >= U) {
+        do {
+            const int g0 = min(g, ngf - U);
+            field_sweep_batch<U, TWO>(phi, ga, gb, lane, g0, g, dq1, dq2);
+            g = g0 + U;
+        } while (g < ngf);
+    }
+    for (; g + 4 <= ngf; g += 4) field_sweep_batch<4, TWO>(phi, ga, gb, lane, g, g, dq1, dq2);
+    for (; g < ngf; ++g) field_sweep_batch<1, TWO>(phi, ga, gb, lane, g, g, dq1, dq2);
+    const int j = ngf * 64 + lane;
+    if (j < na) { // ragged tail
+        double v = fma(dq1, ga[j], phi[j]);
+        if (TWO) v = fma(dq2, gb[j], v);
+        phi[j] = v;
+    }
+}
+
 // potential-field update after an accepted flip of site s by charge dq: every other
-// changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous).  Eight loads in
-// flight per lane; j == own index is skipped (phi excludes the self term).
+// changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous); the own entry
+// is left as it was (phi excludes the self term): it is saved here and put back after the sweep.
 __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
 #ifdef SMOLMC_EXP_GROW0 // timing experiment only (wrong results): every row read hits the same 14 KB
     const double *g = P.ew_G + (size_t)(s & 1) * P.ew_nact;
 #else
     const double *g = P.ew_G + (size_t)s * P.ew_nact;
 #endif
-    const int js = s - P.sbase, na = P.ew_nact;
-    // loads in flight per lane: the row comes from L2 / Infinity Cache, and every batch exposes one
-    // such latency (14 = two batches for the 1728 cation sites of a 12^3 rocksalt cell; measured
-    // 8: +8 %, 20+: register pressure)
-    constexpr int U = 14;
-    for (int j0 = lane; j0 < na; j0 += 64 * U) {
-        double gv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) gv[u] = g[min(j0 + 64 * u, na - 1)];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < na && j != js) phi[j] = fma(dq, gv[u], phi[j]);
-        }
-    }
+    const int js = s - P.sbase;
+    const double keep = phi[js];
+    field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
+    phi[js] = keep; // (every lane stores the same value)
 }
 
 // both flips of a swap in one pass over phi (one read-modify-write per entry instead of two)
 __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, int lane, int s1, double dq1,
                                              int s2, double dq2) {
     const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
-    const int j1 = s1 - P.sbase, j2 = s2 - P.sbase, na = P.ew_nact;
-    constexpr int U = 14; // 2 x 14 loads in flight (see field_apply; 4: +17 % on the swap + Ewald shape)
-    for (int j0 = lane; j0 < na; j0 += 64 * U) {
-        double ga[U], gb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(j0 + 64 * u, na - 1);
-            ga[u] = g1[j];
-            gb[u] = g2[j];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < na) {
-                double v = phi[j];
-                if (j != j1) v = fma(dq1, ga[u], v);
-                if (j != j2) v = fma(dq2, gb[u], v);
-                phi[j] = v;
-            }
-        }
+    const int j1 = s1 - P.sbase, j2 = s2 - P.sbase;
+    // entry j1 must not see its own flip (but does see flip 2) and vice versa: both are patched
+    // after the sweep from the values saved here
+    const double keep1 = phi[j1], keep2 = phi[j2];
+    const double c12 = g2[j1], c21 = g1[j2]; // cross terms G[s2][s1], G[s1][s2]
+    field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
+    if (j1 != j2) {
+        phi[j1] = fma(dq2, c12, keep1);
+        phi[j2] = fma(dq1, c21, keep2);
+    } else {
+        phi[j1] = keep1;
     }
 }
 
@@ -597,7 +634,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (STEP == SMOLMC_STEP_SWAP) {
                     if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
                 } else if (dq1 != 0.0) {
+#ifndef SMOLMC_EXP_NOFIELD // timing experiment only when defined (wrong results)
                     field_apply(P, phi, lane, s1, dq1);
+#endif
                 }
             }
             acc_mu += dMu;

@@ -70,3 +70,42 @@ def test_random_shapes_match_oracle(shape, step, kernel):
         wa, wb = eng.get_wl(), ora.get_wl()
         assert np.array_equal(wa["histogram"], wb["histogram"])
         np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("scm", [[9, 9, 9], [10, 10, 10], [8, 8, 12], [6, 6, 5]],
+                         ids=["729", "1000", "768", "180"])
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+def test_ewald_field_sweep_shapes_match_oracle(scm, step):
+    """Potential-field sweep after accepted flips (mc_lean.h field_sweep): batches of 9 / 14 groups
+    of 64 entries with the last batch shifted back, batches of 4 / 1 for short rows and the ragged
+    tail -- cation counts 729 (11 groups + 25), 1000 (15 + 40), 768 (12, no tail), 180 (2 + 52) -- at
+    a temperature where most steps are accepted, GPU vs oracle on the same streams."""
+    from oracle import oracle as orc
+
+    prim = synth.rocksalt_prim()
+    model = synth.build_cluster_model(prim, {2: 4.5})
+    sc = synth.build_supercell(model, scm)
+    rng = np.random.default_rng(sum(scm))
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=3), ewald=ewald.supercell_ewald(sc),
+                                   ewald_coef=0.2)
+    R = 3
+    nsp = np.array([prim.nspecies[b] for b in sc.site_b])
+    occ0 = (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    seeds = rng.integers(1, 2**62, size=R).astype(np.uint64)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean ") and "field=1" in eng.kernel_info()
+    eng.set_state(occ0, seeds, 2.0e5)
+    ora.set_state(occ0, seeds, 2.0e5)
+    for chunk in (1, 40, 160):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    assert a["n_accepted"].min() > 60
+    # the field itself has not drifted: running Ewald term == from-scratch evaluation
+    full = eng.eval_full(a["occupancy"])
+    np.testing.assert_allclose(a["features"], full, rtol=1e-9, atol=1e-8)

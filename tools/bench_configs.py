@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--mc", type=int, default=0)
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--temperature", type=float, default=0.0, help="override the configuration's temperature")
     a = ap.parse_args()
     t0 = time.time()
     if a.config == 1:
@@ -154,6 +155,8 @@ def main():
         raise SystemExit("config must be 1, 3, 4, 5, 6 or 7")
     setup_s = time.time() - t0
     eng = Engine(tab, cfg)
+    if a.temperature > 0.0:
+        T = a.temperature
     eng.set_state(occ, np.arange(R, dtype=np.uint64) + np.uint64(777), T)
     eng.run(mc, sync=True)
     ms = []
