@@ -134,54 +134,29 @@ __device__ __forceinline__ double ewald_compact_partial(const KParams &P, const 
 
 // potential-field update in HBM after an accepted flip of site s by charge dq (general
 // kernel): phi[j] += dq * G[s][j] for every other changeable site j; lane-strided, so each
-// address is always touched by the same lane (program order keeps later updates coherent).
+// address is always touched by the same lane (program order keeps later updates coherent; the
+// self-term patch after the sweep is one store of the same value from every lane).
 __device__ __forceinline__ void field_apply_global(const KParams &P, double *phi, int lane, int s, double dq) {
     const double *g = P.ew_G + (size_t)s * P.ew_nact;
-    const int js = s - P.ew_act_base, na = P.ew_nact;
-    constexpr int U = 8; // loads in flight per lane (the row streams from Infinity Cache / HBM)
-    for (int j0 = lane; j0 < na; j0 += 64 * U) {
-        double gv[U], pv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(j0 + 64 * u, na - 1);
-            gv[u] = g[j];
-            pv[u] = phi[j];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < na && j != js) phi[j] = fma(dq, gv[u], pv[u]);
-        }
-    }
+    const int js = s - P.ew_act_base;
+    const double keep = phi[js]; // phi excludes the self term: put back after the sweep
+    field_sweep<false, 6>(phi, g, g, lane, P.ew_nact, dq, 0.0);
+    phi[js] = keep;
 }
 
-// ----------------------------------------------------------------------------
-// the Monte-Carlo kernel
-// ----------------------------------------------------------------------------
+// both flips of a swap in one pass over phi
 __device__ __forceinline__ void field_apply_global2(const KParams &P, double *phi, int lane, int s1, double dq1,
                                                     int s2, double dq2) {
     const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
-    const int j1 = s1 - P.ew_act_base, j2 = s2 - P.ew_act_base, na = P.ew_nact;
-    constexpr int U = 4;
-    for (int j0 = lane; j0 < na; j0 += 64 * U) {
-        double ga[U], gb[U], pv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(j0 + 64 * u, na - 1);
-            ga[u] = g1[j];
-            gb[u] = g2[j];
-            pv[u] = phi[j];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < na) {
-                double v = pv[u];
-                if (j != j1) v = fma(dq1, ga[u], v);
-                if (j != j2) v = fma(dq2, gb[u], v);
-                phi[j] = v;
-            }
-        }
+    const int j1 = s1 - P.ew_act_base, j2 = s2 - P.ew_act_base;
+    const double keep1 = phi[j1], keep2 = phi[j2];
+    const double c12 = g2[j1], c21 = g1[j2]; // cross terms: entry j1 sees flip 2 only, j2 flip 1 only
+    field_sweep<true, 4>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
+    if (j1 != j2) {
+        phi[j1] = fma(dq2, c12, keep1);
+        phi[j2] = fma(dq1, c21, keep2);
+    } else {
+        phi[j1] = keep1;
     }
 }
 

@@ -18,36 +18,9 @@ __device__ __forceinline__ int sel4(const int (&a)[4], int k) {
     return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3]));
 }
 
-// potential field kept in HBM (ew_field == 2: it would cost too much LDS): same update as
-// field_apply, lane-strided read-modify-write; both flips of a swap in ONE pass over phi (the
-// update is bound by HBM / Infinity-Cache traffic: 2 G rows + one read-modify-write of phi)
-__device__ __forceinline__ void field_apply_hbm(const LeanParams &P, double *phi, int lane, int s1, double dq1,
-                                                int s2, double dq2) {
-    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
-    const int j1 = s1 - P.sbase, j2 = s2 - P.sbase, na = P.ew_nact;
-    constexpr int U = 4;
-    for (int j0 = lane; j0 < na; j0 += 64 * U) {
-        double ga[U], gb[U], pv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(j0 + 64 * u, na - 1);
-            ga[u] = g1[j];
-            gb[u] = g2[j];
-            pv[u] = phi[j];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < na) {
-                double v = pv[u];
-                if (j != j1) v = fma(dq1, ga[u], v);
-                if (j != j2) v = fma(dq2, gb[u], v);
-                phi[j] = v;
-            }
-        }
-    }
-}
-
+// (potential field kept in HBM, ew_field == 2 -- it would cost too much LDS: field_apply /
+// field_apply2 of mc_lean.h are called with the global pointer; the update is then bound by HBM /
+// Infinity-Cache traffic: the G rows plus one read-modify-write of phi)
 struct MultiRec { // slot record, 24 bytes
     uint32_t doff8;
     uint32_t st8[3];
@@ -344,7 +317,12 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                         field_apply(P, phi, lane, s1, dq1);
                     }
                 } else {
-                    if (dq1 != 0.0 || dq2 != 0.0) field_apply_hbm(P, phi, lane, s1, dq1, s2, dq2);
+                    double *phi_g = P.ew_phi + (size_t)r * P.ew_nact;
+                    if (STEP == SMOLMC_STEP_SWAP) {
+                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi_g, lane, s1, dq1, s2, dq2);
+                    } else if (dq1 != 0.0) {
+                        field_apply(P, phi_g, lane, s1, dq1);
+                    }
                 }
             }
             acc_mu += dMu;
@@ -868,7 +846,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                     if (dqf == 0.0) continue;
                     const int sf = (int)rdlane((uint32_t)vsite, f);
                     if (phi_lds) field_apply(P, phi, lane, sf, dqf);
-                    else field_apply_hbm(P, phi, lane, sf, dqf, sf, 0.0);
+                    else field_apply(P, P.ew_phi + (size_t)r * P.ew_nact, lane, sf, dqf);
                 }
             acc_mu += dMu;
             acc_ew += dEw;

@@ -200,6 +200,68 @@ __device__ __forceinline__ double floordiv_exact_inv(double x, double y, double 
 }
 
 // ----------------------------------------------------------------------------
+// Ewald potential-field sweep (shared by the lean, multi-sublattice and general kernels; phi may
+// live in LDS or in HBM)
+// ----------------------------------------------------------------------------
+// One straight-line batch of the potential-field sweep: U groups of 64 entries starting at group
+// g0, entry j gains dq1 * ga[j] (+ dq2 * gb[j]).  All loads of the batch are issued first (one
+// exposed latency per batch), addresses are base + immediate offsets (no per-element address
+// arithmetic: the clamped / masked form of this loop cost ~10 VALU and, worse, compiler-made
+// branches per element).  Groups below gdone were already updated by an earlier batch -- the
+// last batch of a sweep is shifted back so that it ends on the last full group -- and are
+// rewritten unchanged (coefficient 0).
+template <int U, bool TWO>
+__device__ __forceinline__ void field_sweep_batch(double *phi, const double *ga, const double *gb, int lane,
+                                                  int g0, int gdone, double dq1, double dq2) {
+    const int j = g0 * 64 + lane;
+    const double *pa = ga + j, *pb = gb + j;
+    double *pp = phi + j;
+    double va[U], vb[U], pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        va[u] = pa[64 * u];
+        if (TWO) vb[u] = pb[64 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool fresh = g0 + u >= gdone; // wave-uniform
+        double v = fma(fresh ? dq1 : 0.0, va[u], pv[u]);
+        if (TWO) v = fma(fresh ? dq2 : 0.0, vb[u], v);
+        pp[64 * u] = v;
+    }
+}
+
+template <bool TWO, int UB = 0>
+__device__ __forceinline__ void field_sweep(double *phi, const double *ga, const double *gb, int lane, int na,
+                                            double dq1, double dq2) {
+    // groups per batch, measured on the 1728 cation sites (27 groups) of a 12^3 rocksalt cell:
+    // one row 9 / 14 / 27 -> 1.52 / 1.63 / 1.56 ms (config 3), two rows 9 / 14 / 27 -> 2.80 / 2.70 /
+    // 2.93 ms (swap + Ewald); the row reads run at several TB/s out of L2 / Infinity Cache, so
+    // the differences are memory-system effects, not instruction counts
+    // (UB: the general kernel is held to 128 VGPRs and asks for smaller batches)
+    constexpr int U = UB ? UB : (TWO ? 14 : 9);
+    const int ngf = na >> 6; // full groups of 64 entries
+    int g = 0;
+    if (ngf >= U) {
+        do {
+            const int g0 = min(g, ngf - U);
+            field_sweep_batch<U, TWO>(phi, ga, gb, lane, g0, g, dq1, dq2);
+            g = g0 + U;
+        } while (g < ngf);
+    }
+    for (; g + 4 <= ngf; g += 4) field_sweep_batch<4, TWO>(phi, ga, gb, lane, g, g, dq1, dq2);
+    for (; g < ngf; ++g) field_sweep_batch<1, TWO>(phi, ga, gb, lane, g, g, dq1, dq2);
+    const int j = ngf * 64 + lane;
+    if (j < na) { // ragged tail
+        double v = fma(dq1, ga[j], phi[j]);
+        if (TWO) v = fma(dq2, gb[j], v);
+        phi[j] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // lean Metropolis kernel (parameter blocks; the kernel itself is in mc_lean.h): one site class, one contiguous active sublattice with the
 // default encoding, cluster-interaction features, no Ewald term, engine RNG.
 // This is the shape of BASELINE configs 1/2/4; everything else takes mc_kernel.
