@@ -702,6 +702,31 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 }
 
 
+// sum over species c of ln n_c! - ln (n_c + u_c)!  (mcusher.py:694-709) with lane c holding the
+// count n_c and its change u_c: every lane walks its own |u_c| table entries ln(k) (host libm; LDS
+// copy when it fits, else HBM) with the first four reads in flight together -- a scalar loop over
+// species and k costs one dependent (scalar-cache or LDS) round trip per entry -- and the lane
+// partials are then added in species order.  (Deferring the sum to the point where the exponent
+// is formed, to hide the table latency behind the site selection, measured slower.)
+__device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u, int n0, int nc) {
+    const int au = u < 0 ? -u : u;
+    const int sgn = u < 0 ? -1 : 1;           // entries n0+1 .. n0+u (u > 0) or n0 .. n0+u+1 (u < 0)
+    const int first = u < 0 ? n0 : n0 + 1;
+    double t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = k < au ? lnt[first + sgn * k] : 0.0;
+    double part = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part += t[k];
+    for (int k = 4; k < au; ++k) part += lnt[first + sgn * k];
+    part = u < 0 ? part : -part;
+    double tot = 0.0;
+    for (int c = 0; c < nc; ++c)
+        tot += __hiloint2double((int)rdlane((uint32_t)__double2hiint(part), c),
+                                (int)rdlane((uint32_t)__double2loint(part), c));
+    return tot;
+}
+
 // ----------------------------------------------------------------------------
 // TableFlip kernel (charge-neutral semigrand steps, smol/moca/kernel/mcusher.py:397-711)
 // for lean-eligible models: one site class, one contiguous active sublattice, interaction
@@ -940,20 +965,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
                     lf = log(p_next / p_now);
                 }
-                for (int c = 0; c < nc; ++c) {
-                    const int u = (int)rdlane((uint32_t)vu, c), n0 = (int)rdlane((uint32_t)vcnt, c);
-                    // ln(k) from the host-libm table (LDS copy when it fits, else HBM / scalar cache)
-                    const double *lnt = P.tf_ln_len ? s_ln : P.tf_ln;
-                    for (int k = 1; k <= u; ++k) lf -= lnt[n0 + k];
-                    for (int k = 0; k < -u; ++k) lf += lnt[n0 - k];
-                }
+                lf += table_log_count_ratio(P.tf_ln_len ? s_ln : P.tf_ln, vu, vcnt, nc);
                 log_priori = uni_d(lf);
             }
             // pick the sites of the depleted species from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round, lane l holds
             // t = 256 round + 4 l + j.  The scan is scalar: per species four ballots (one per j),
             // each pick = first set bit at or after the running stream position.
-            int vcol = 0, ncol = 0;   // collected sites, lane-indexed
+            int vcol = 0, vcsp = 0, ncol = 0; // collected sites and their (depleted) species, lane-indexed
             uint32_t tpos = 0;        // next stream position inside the current round
             uint32_t round = 0;
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
@@ -994,7 +1013,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     const int picked = (int)rdlane((uint32_t)(bj == 0 ? cs[0] : bj == 1 ? cs[1] : bj == 2 ? cs[2] : cs[3]), bl);
                     // a site already collected in this step is skipped (choice without replacement)
                     if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
-                    if (lane == ncol) vcol = picked;
+                    if (lane == ncol) { vcol = picked; vcsp = c; }
                     ncol++;
                     need--;
                 }
@@ -1010,11 +1029,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     qdraw++;
                     const int rr = (int)__umulhi(word, (uint32_t)ncol);
                     const int site = (int)rdlane((uint32_t)vcol, rr);
-                    const int od = uni((int)occ[lean_swz(site, swa, swm, swb)]);
+                    const int od = (int)rdlane((uint32_t)vcsp, rr); // (known from the scan: no LDS read)
                     if (lane == nfl) { vsite = site; vnew = c; vold = od; }
                     nfl++;
-                    const int nxt = __shfl_down(vcol, 1);
-                    if (lane >= rr) vcol = nxt; // list.remove keeps the order of the rest
+                    // list.remove keeps the order of the rest: lanes >= rr take their right neighbour
+                    // (DPP wave shift, not a cross-lane LDS permute)
+                    const int nxt = __builtin_amdgcn_update_dpp(0, vcol, 0x130, 0xf, 0xf, false);
+                    const int nxs = __builtin_amdgcn_update_dpp(0, vcsp, 0x130, 0xf, 0xf, false);
+                    if (lane >= rr) { vcol = nxt; vcsp = nxs; }
                     ncol--;
                 }
             }

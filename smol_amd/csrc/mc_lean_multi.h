@@ -679,11 +679,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                     const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
                     lf = log(p_next / p_now);
                 }
-                for (int c = 0; c < D; ++c) {
-                    const int u = (int)rdlane((uint32_t)vu, c), n0 = (int)rdlane((uint32_t)vcnt, c);
-                    for (int k = 1; k <= u; ++k) lf -= P.tf_ln[n0 + k];
-                    for (int k = 0; k < -u; ++k) lf += P.tf_ln[n0 - k];
-                }
+                lf += table_log_count_ratio(P.tf_ln, vu, vcnt, D);
                 log_priori = uni_d(lf);
             }
             // sites of the depleted species, sublattice by sublattice, from the candidate stream
