@@ -995,21 +995,28 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                         tpos = 0;
                     }
                     if (!have_masks) {
+                        // candidates of species c at stream positions >= tpos (the position is
+                        // kept across species); picks then go in stream order, so taking the
+                        // minimum and clearing its bit needs no further position masks
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) B[j] = __ballot(cv[j] == c);
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t l0 = tpos > (uint32_t)j ? (tpos - (uint32_t)j + 3u) >> 2 : 0u; // first lane with 4 l + j >= tpos
+                            const unsigned long long b = __ballot(cv[j] == c);
+                            B[j] = l0 < 64u ? (b >> l0) << l0 : 0ull;
+                        }
                         have_masks = true;
                     }
-                    // first candidate of species c at stream position >= tpos
+                    // first remaining candidate (branch-free: ffs of an empty mask gives 0, i.e.
+                    // position 0xfffffffc + j, larger than any real one)
                     uint32_t best = 0xffffffffu;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t l0 = tpos > (uint32_t)j ? (tpos - (uint32_t)j + 3u) >> 2 : 0u; // first lane with 4 l + j >= tpos
-                        const unsigned long long m = l0 < 64u ? (B[j] >> l0) << l0 : 0ull;
-                        if (m) best = min(best, 4u * (uint32_t)(__ffsll((long long)m) - 1) + (uint32_t)j);
-                    }
-                    if (best == 0xffffffffu) { round++; have_round = false; continue; }
+                    for (int j = 0; j < 4; ++j)
+                        best = min(best, 4u * (uint32_t)(__ffsll((long long)B[j]) - 1) + (uint32_t)j);
+                    if (best >= 0xfffffff0u) { round++; have_round = false; continue; }
                     tpos = best + 1u;
                     const int bl = (int)(best >> 2), bj = (int)(best & 3u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) B[j] &= ~((unsigned long long)(bj == j) << bl);
                     const int picked = (int)rdlane((uint32_t)(bj == 0 ? cs[0] : bj == 1 ? cs[1] : bj == 2 ? cs[2] : cs[3]), bl);
                     // a site already collected in this step is skipped (choice without replacement)
                     if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
@@ -1131,10 +1138,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             H += dH;
             nacc++;
         } else {
-            for (int f = nfl - 1; f >= 0; --f) { // undo the tentative flips
-                const int s = (int)rdlane((uint32_t)vsite, f), od = (int)rdlane((uint32_t)vold, f);
-                occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
-            }
+            // undo the tentative flips: lane f restores the site of flip f (the sites of a step
+            // are distinct, so the order of the stores does not matter)
+            if (lane < nfl) occ[lean_swz(vsite, swa, swm, swb)] = (uint8_t)vold;
         }
         last_acc = accepted ? 1 : 0;
 
