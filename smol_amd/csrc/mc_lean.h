@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    uint32_t smp_countdown = (uint32_t)P.smp.every;
+    // (no sampling: a countdown that cannot reach zero within the < 2^31 steps of a launch)
+    uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu;
     long long smp_index = 0;
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
     uint32_t W0 = 0, W1 = 0;
@@ -617,26 +618,33 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     atomicAdd((unsigned long long *)(P.wl.occur + (size_t)r * P.wl.L + b), 1ull);
                 }
             }
-            if (wl_rem_check == 0) wl_m = wl_flatness_check(wl_S, wl_Hh, P.wl.L, P.wl.flat, P.wl.div, wl_m, lane);
+            if (wl_rem_check == 0) {
+                const LeanParamsKernarg Q = rare_params();
+                wl_m = wl_flatness_check(wl_S, wl_Hh, Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
+            }
         }
 
-        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
-            smp_countdown = (uint32_t)P.smp.every;
-            const size_t row = (size_t)smp_index * P.R + r;
+        if (--smp_countdown == 0) { // record one thinned sample of this walker
+            // (sampling parameters re-read from the kernel arguments: see rare_params)
+            const LeanParamsKernarg Q = rare_params();
+            const int qF = Q->F, qFce = Q->Fce;
+            double *const q_feat = Q->smp.feat;
+            smp_countdown = (uint32_t)Q->smp.every;
+            const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
             if (WL) {
-                if (lane < P.F) P.smp.feat[row * P.F + lane] = s_feat[lane];
+                if (lane < qF) q_feat[row * qF + lane] = s_feat[lane];
             } else {
                 s_feat[lane] = 0.0;
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it)
                     __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
+                if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
             }
-            if (!WL && HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
-            if (!WL && HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0))
-                P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
+            if (!WL && HAS_EW && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
+            if (!WL && HAS_MU && lane == qFce + (HAS_EW ? 1 : 0))
+                q_feat[row * qF + lane] = base_feat + acc_mu;
             double lane_e = 0.0;
             if (FAST) {
 #pragma unroll
@@ -644,12 +652,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             const double Hnow = FAST ? H + (wave_sum_all(lane_e) - acc_mu) : H;
             if (lane == 0) {
-                P.smp.H[row] = Hnow;
-                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+                Q->smp.H[row] = Hnow;
+                Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
             }
-            if (P.smp.occ) {
-                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
-                for (int i = lane; i < P.Npad / 4; i += 64)
+            if (Q->smp.occ) {
+                const int qNpad = Q->Npad;
+                uint32_t *dst = (uint32_t *)(Q->smp.occ + row * qNpad);
+                for (int i = lane; i < qNpad / 4; i += 64)
                     dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
             }
         }
@@ -839,7 +848,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     int last_acc = 1;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    long long smp_countdown = P.smp.every, smp_index = 0;
+    long long smp_countdown = P.smp.every ? P.smp.every : -1, smp_index = 0; // (-1: never reaches zero)
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
     double logu = 0.0;
     unsigned long long batch_base = ~0ull;
@@ -1144,25 +1153,29 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
         last_acc = accepted ? 1 : 0;
 
-        if (P.smp.every && --smp_countdown == 0) {
-            smp_countdown = P.smp.every;
-            const size_t rowi = (size_t)smp_index * P.R + r;
+        if (--smp_countdown == 0) {
+            const LeanParamsKernarg Q = rare_params(); // (sampling parameters: see rare_params)
+            const int qF = Q->F, qFce = Q->Fce;
+            double *const q_feat = Q->smp.feat;
+            smp_countdown = Q->smp.every;
+            const size_t rowi = (size_t)smp_index * Q->R + r;
             smp_index++;
             s_feat[lane] = 0.0;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it)
                 __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (lane < P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + s_feat[lane];
-            if (has_ew && lane == P.Fce) P.smp.feat[rowi * P.F + lane] = base_feat + acc_ew;
-            if (has_mu && lane == P.Fce + (has_ew ? 1 : 0)) P.smp.feat[rowi * P.F + lane] = base_feat + acc_mu;
+            if (lane < qFce) q_feat[rowi * qF + lane] = base_feat + s_feat[lane];
+            if (has_ew && lane == qFce) q_feat[rowi * qF + lane] = base_feat + acc_ew;
+            if (has_mu && lane == qFce + (has_ew ? 1 : 0)) q_feat[rowi * qF + lane] = base_feat + acc_mu;
             if (lane == 0) {
-                P.smp.H[rowi] = H;
-                P.smp.acc[rowi] = (uint8_t)last_acc;
+                Q->smp.H[rowi] = H;
+                Q->smp.acc[rowi] = (uint8_t)last_acc;
             }
-            if (P.smp.occ) {
-                uint32_t *dst = (uint32_t *)(P.smp.occ + rowi * P.Npad);
-                for (int i = lane; i < P.Npad / 4; i += 64)
+            if (Q->smp.occ) {
+                const int qNpad = Q->Npad;
+                uint32_t *dst = (uint32_t *)(Q->smp.occ + rowi * qNpad);
+                for (int i = lane; i < qNpad / 4; i += 64)
                     dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
             }
         }

@@ -440,6 +440,20 @@ template <typename T> static int dev_alloc(smolmc_handle *h, size_t n, T **dst, 
 
 
 // launchers defined in the per-NSLOT translation units
+
+#ifdef __HIPCC__
+// Parameters that only rare paths of a step loop need (sample rows, flatness checks) are re-read
+// from the kernel-argument segment where they are used: held in SGPRs for the whole loop they
+// push the hot path into SGPR spills (v_readlane reloads on every step).  The empty asm makes the
+// pointer opaque, so the scalar loads cannot be hoisted back out of the loop.  Valid in kernels
+// whose first argument is the LeanParams block.
+typedef const LeanParams __attribute__((address_space(4))) *LeanParamsKernarg;
+__device__ __forceinline__ LeanParamsKernarg rare_params() {
+    LeanParamsKernarg p = (LeanParamsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#endif
 int smolmc_launch_general_2(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_4(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
