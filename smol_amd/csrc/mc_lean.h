@@ -613,8 +613,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 double *cellf = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
                 if (lane < P.F) unsafeAtomicAdd(cellf + lane, s_feat[lane]);
                 if (lane == 0) {
-                    wl_S[b] += wl_m;
-                    wl_Hh[b] += 1;
+                    // LDS atomics without return value: a read-modify-write would put one more
+                    // LDS round trip on the step's dependency chain (one wave per SIMD here)
+                    __hip_atomic_fetch_add(&wl_S[b], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&wl_Hh[b], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     atomicAdd((unsigned long long *)(P.wl.occur + (size_t)r * P.wl.L + b), 1ull);
                 }
             }
