@@ -862,6 +862,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
     const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
     const int nf2 = 2 * P.tf_n;
+    // cached between accepted table steps: feasible directions at the current counts, their weight
+    // sum, and (lane dir of vlp, bit dir of lp_valid) the log a-priori factor of direction dir
+    bool head_valid = false;
+    unsigned feas_now = 0, lp_valid = 0;
+    double sumw = 0.0, vlp = 0.0;
 
     for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
@@ -889,11 +894,15 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
-        double sumw = 0.0;
-        unsigned feas_now = 0;
         if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
-            feas_now = feasible(vcnt);
-            sumw = masked_sum(feas_now);
+            // the species counts only change on accepted table steps: the feasibility mask, its
+            // weight sum and the a-priori factor of every direction are kept until then
+            if (!head_valid) {
+                feas_now = feasible(vcnt);
+                sumw = masked_sum(feas_now);
+                head_valid = true;
+                lp_valid = 0u;
+            }
             if (!(sumw > 0.0)) do_swap = true;
         }
         if (do_swap) {
@@ -964,8 +973,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
             vu *= usg; // lane c: change of the count of species c
-            // compute_log_priori_factor (mcusher.py:656-711)
-            {
+            // compute_log_priori_factor (mcusher.py:656-711), cached per direction (lane dir of vlp)
+            if (!((lp_valid >> dir) & 1u)) {
                 const double sum_next = masked_sum(feasible(vcnt + vu));
                 double lf = 0.0;
                 // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
@@ -977,8 +986,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     lf = log(p_next / p_now);
                 }
                 lf += table_log_count_ratio(P.tf_ln_len ? s_ln : P.tf_ln, vu, vcnt, nc);
-                log_priori = uni_d(lf);
+                lf = uni_d(lf);
+                if (lane == dir) vlp = lf;
+                lp_valid |= 1u << dir;
             }
+            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
+                                          (int)rdlane((uint32_t)__double2loint(vlp), dir));
             // pick the sites of the depleted species from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round, lane l holds
             // t = 256 round + 4 l + j.  The scan is scalar: per species four ballots (one per j),
@@ -1138,6 +1151,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
+            if (dir >= 0) head_valid = false;
             if (P.ew_field)
                 for (int f = 0; f < nfl; ++f) {
                     const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),

@@ -565,6 +565,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
     const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
     const int nf2 = 2 * P.tf_n;
+    bool head_valid = false; // feasibility mask / weight sum / a-priori factors cached between count changes
+    unsigned feas_now = 0, lp_valid = 0;
+    double sumw = 0.0, vlp = 0.0;
 
     const uint32_t nsteps32 = (uint32_t)P.steps;
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
@@ -593,11 +596,13 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         int vu = 0; // table step: lane d holds the change of count dimension d
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
-        double sumw = 0.0;
-        unsigned feas_now = 0;
         if (!do_swap) {
-            feas_now = feasible(vcnt);
-            sumw = masked_sum(feas_now);
+            if (!head_valid) { // (cached until the counts change: see mc_table_kernel)
+                feas_now = feasible(vcnt);
+                sumw = masked_sum(feas_now);
+                head_valid = true;
+                lp_valid = 0u;
+            }
             if (!(sumw > 0.0)) do_swap = true;
         }
         if (do_swap) {
@@ -670,7 +675,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 #pragma unroll
             for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
             vu *= (dir & 1) ? -1 : 1;
-            { // compute_log_priori_factor (mcusher.py:656-711)
+            if (!((lp_valid >> dir) & 1u)) { // compute_log_priori_factor (mcusher.py:656-711), cached per direction
                 const double sum_next = masked_sum(feasible(vcnt + vu));
                 double lf = 0.0;
                 const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
@@ -680,8 +685,12 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                     lf = log(p_next / p_now);
                 }
                 lf += table_log_count_ratio(P.tf_ln, vu, vcnt, D);
-                log_priori = uni_d(lf);
+                lf = uni_d(lf);
+                if (lane == dir) vlp = lf;
+                lp_valid |= 1u << dir;
             }
+            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
+                                          (int)rdlane((uint32_t)__double2loint(vlp), dir));
             // sites of the depleted species, sublattice by sublattice, from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4) (256 candidates per wave round, position kept across
             // species AND sublattices); then the random assignment to the enriched species
@@ -835,6 +844,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             }
         if (accepted) {
             vcnt += vu;
+            if (dir >= 0) head_valid = false;
             if (has_ew)
                 for (int f = 0; f < nfl; ++f) {
                     const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
