@@ -173,6 +173,13 @@ class Engine:
         return dict(occupancy=occ, features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
                     accepted=la.astype(bool))
 
+    def get_enthalpy(self):
+        """Current enthalpy of every walker (one device-to-host copy; the replica-exchange loop
+        needs nothing else of the state)."""
+        H = np.zeros(self.R)
+        self._chk(self._lib.smolmc_get_state(self._h, None, None, _p(H, C.c_double), None, None, None))
+        return H
+
     def get_wl(self):
         S = np.zeros((self.R, self.L))
         hist = np.zeros((self.R, self.L), dtype=np.int64)

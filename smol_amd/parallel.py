@@ -102,17 +102,19 @@ class ReplicaExchange:
         pairs = np.arange(parity, self.n - 1, 2)
         u = _philox_uniforms(self.seed, self.calls, max(len(pairs), 1))
         beta = 1.0 / (kB * self.ladder)
-        done = []
-        for j, k in enumerate(pairs):
-            a, b = walker_at[k], walker_at[k + 1]
-            expo = (beta[k] - beta[k + 1]) * (enthalpy[a] - enthalpy[b])
-            self.attempted[k] += 1
-            if expo >= 0 or np.log(u[j]) < expo:
-                self.rung_of[a], self.rung_of[b] = k + 1, k
-                self.accepted[k] += 1
-                done.append((int(k), int(k + 1)))
+        # the pairs of one parity are disjoint: all decisions of an attempt at once
+        enthalpy = np.asarray(enthalpy, dtype=np.float64)
+        a, b = walker_at[pairs], walker_at[pairs + 1]
+        expo = (beta[pairs] - beta[pairs + 1]) * (enthalpy[a] - enthalpy[b])
+        with np.errstate(divide="ignore"):
+            acc = (expo >= 0) | (np.log(u[: len(pairs)]) < expo)
+        self.attempted[pairs] += 1
+        won = pairs[acc]
+        self.rung_of[a[acc]] = won + 1
+        self.rung_of[b[acc]] = won
+        self.accepted[won] += 1
         self.calls += 1
-        return done
+        return [(int(k), int(k + 1)) for k in won]
 
     def exchange(self, local_enthalpy):
         """gather + decide; returns this rank's new temperatures (NumPy, len per_rank)."""
@@ -153,6 +155,6 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None):
             engine.export_enthalpy(buf.data_ptr())
             engine.set_temperature(rex.exchange(buf))
         else:
-            rex.decide(engine.get_state(occupancy=False)["enthalpy"])
+            rex.decide(engine.get_enthalpy())
             engine.set_temperature(rex.local_temperatures())
     return rex

@@ -110,3 +110,30 @@ def test_identical_ladder_leaves_temperatures_unchanged():
 def test_ladder_length_mismatch():
     with pytest.raises(ValueError):
         parallel.ReplicaExchange(np.ones(5), 2, 0, 2)
+
+
+def test_vectorised_exchange_decisions_equal_the_pairwise_loop():
+    """ReplicaExchange.decide takes all disjoint pairs of one parity at once; the pair-by-pair
+    statement of the same rule (exchange of neighbouring rungs with probability
+    min(1, exp((beta_k - beta_k+1) (H_a - H_b))), alternating parity) must give the same rungs."""
+    rng = np.random.default_rng(4)
+    n = 37
+    ladder = parallel.geometric_ladder(300.0, 3000.0, n)
+    rex = parallel.ReplicaExchange(ladder, n, seed=9)
+    rung_of = np.arange(n)
+    beta = 1.0 / (parallel.kB * ladder)
+    for call in range(12):
+        H = rng.normal(0.0, 2.0, n)
+        u = parallel._philox_uniforms(9, call, max(len(range(call & 1, n - 1, 2)), 1))
+        walker_at = np.empty(n, dtype=np.int64)
+        walker_at[rung_of] = np.arange(n)
+        want = []
+        for j, k in enumerate(range(call & 1, n - 1, 2)):
+            a, b = walker_at[k], walker_at[k + 1]
+            expo = (beta[k] - beta[k + 1]) * (H[a] - H[b])
+            if expo >= 0 or np.log(u[j]) < expo:
+                rung_of[a], rung_of[b] = k + 1, k
+                want.append((k, k + 1))
+        assert rex.decide(H) == want
+        assert np.array_equal(rex.rung_of, rung_of)
+    assert rex.attempted.sum() == sum(len(range(c & 1, n - 1, 2)) for c in range(12))
