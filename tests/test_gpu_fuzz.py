@@ -109,3 +109,50 @@ def test_ewald_field_sweep_shapes_match_oracle(scm, step):
     # the field itself has not drifted: running Ewald term == from-scratch evaluation
     full = eng.eval_full(a["occupancy"])
     np.testing.assert_allclose(a["features"], full, rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize("scm,field", [([8, 8, 8], "hbm"), ([5, 5, 5], "hbm"), ([4, 4, 4], "lds"), ([8, 8, 8], "general")],
+                         ids=["1024-hbm", "250-hbm", "128-lds", "1024-general"])
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+def test_ewald_field_sweep_two_sublattices(scm, field, step, monkeypatch):
+    """The same sweep with the potential field of ALL changeable sites (cations + anions) in HBM
+    (multi-sublattice lean kernel, forced or chosen by size), in LDS, and in the general kernel:
+    1024 entries = 16 groups (batches of 14 with the shifted last batch, of 9 for single flips),
+    250 = 3 groups + 58, 128 = 2 groups (the LDS copy is only chosen for small cells)."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    monkeypatch.delenv("SMOLMC_MULTI_PHI_HBM", raising=False)
+    if field == "hbm":
+        monkeypatch.setenv("SMOLMC_MULTI_PHI_HBM", "1")
+    if field == "general":
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    prim = synth.rocksalt_prim(anion_charges=(-2.0, -1.0))
+    model = synth.build_cluster_model(prim, {2: 4.5})
+    sc = synth.build_supercell(model, scm)
+    rng = np.random.default_rng(sum(scm) + 1)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=5), ewald=ewald.supercell_ewald(sc),
+                                   ewald_coef=0.2)
+    R = 3
+    nsp = np.array([prim.nspecies[b] for b in sc.site_b])
+    occ0 = (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    seeds = rng.integers(1, 2**62, size=R).astype(np.uint64)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    info = eng.kernel_info()
+    if field == "general":
+        assert info.startswith("general")
+    else:
+        assert info.startswith("lean-multi") and ("field=2" if field == "hbm" else "field=1") in info
+    eng.set_state(occ0, seeds, 2.0e5)
+    ora.set_state(occ0, seeds, 2.0e5)
+    for chunk in (1, 40, 160):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    assert a["n_accepted"].min() > 60
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-9, atol=1e-8)
