@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // reduced when it is read (sample rows, end of launch).
     constexpr bool FAST = !WL && !HAS_EW;
     float thr_lo = 0.0f, thr_hi = 0.0f;
+    const double inv_nbeta = FAST ? 1.0 / nbeta : 0.0;
     uint32_t nacc_before = 0; // accept counter before the current step: last_acc is read lazily
     int nsite = 0, naddr = 0;
     // trace at launch start; features of a sample = base + sum over lanes of fs * acc
@@ -294,7 +295,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     uint32_t W0 = 0, W1 = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
     double vGc = 0.0; // Ewald field mode: prefetched cross terms of the first-round candidates
-    double logu = 0.0; // log of the acceptance uniform of the lane's step (block-0 lanes)
+    double logu = 0.0; // log of the acceptance uniform of step (step & ~63) + lane
+    unsigned long long batch64_base = ~0ull;
     unsigned long long batch_base = ~0ull;
     constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
     constexpr int NW = ROW / 2;                       // dwords per lane per site
@@ -330,16 +332,24 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // (one v_readlane each per step instead of the scalar mulhi + swizzle chain)
             nsite = sbase + (int)__umulhi(o.w[1], nact);
             naddr = lean_swz(nsite, swa, swm, swb);
-            // metropolis.py:46-48 compares the exponent with log(rng.random()): take the
-            // float64 log of all 16 uniforms of the batch at once (lane-parallel)
-            logu = log(philox_u53(o.w[2], o.w[3]));
-            if (FAST) {
-                // accept <=> -beta dH > log u <=> dH < log(u) / -beta =: thr  (dH <= 0 always
-                // passes since thr >= 0); certain on either side of thr -+ eps
-                const double thr = logu / nbeta;
-                const double eps = P.fast_eps + 1e-6 * fabs(thr);
-                thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
-                thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+            // metropolis.py:46-48 compares the exponent with log(rng.random()): the float64 log
+            // (and the float32 thresholds derived from it) of the acceptance uniforms of SIXTY-FOUR
+            // steps at once, lane l <-> step (step & ~63) + l, from one more Philox block per lane
+            // (block 0 of that step; the 16-step batches recompute the same words for the
+            // proposals) -- a log per 16-step batch would use 16 of its 64 lanes
+            if ((step & ~63ull) != batch64_base) {
+                batch64_base = step & ~63ull;
+                const unsigned long long s64 = batch64_base + (unsigned)lane;
+                const philox_out a = philox4x32_10((uint32_t)s64, (uint32_t)(s64 >> 32), 0u, 0u, key0, key1);
+                logu = log(philox_u53(a.w[2], a.w[3]));
+                if (FAST) {
+                    // accept <=> -beta dH > log u <=> dH < log(u) / -beta =: thr  (dH <= 0 always
+                    // passes since thr >= 0); certain on either side of thr -+ eps
+                    const double thr = logu * inv_nbeta; // (a rounding of the band centre: covered by eps)
+                    const double eps = P.fast_eps + 1e-6 * fabs(thr);
+                    thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
+                    thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+                }
             }
             if (STEP == SMOLMC_STEP_SWAP) {
                 cand[0] = sbase + (int)__umulhi(o.w[0], nact);
@@ -360,6 +370,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
         const int l4 = (int)(step & 15ull) * 4;
+        const int l64 = (int)(step & 63ull); // lane of this step's acceptance uniform / thresholds
         // prefetch the index row of the next step's site (depends only on random words)
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
@@ -515,7 +526,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (FAST && !BIAS) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
-            const unsigned long long bit = 1ull << l4;
+            const unsigned long long bit = 1ull << l64;
             const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
             const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
             decided = ca | cr;
@@ -529,8 +540,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             if (HAS_MU) dH -= dMu;
             // -------- accept (metropolis.py:31-49) --------
-            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
-                                               (int)rdlane((uint32_t)__double2loint(logu), l4));
+            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l64),
+                                               (int)rdlane((uint32_t)__double2loint(logu), l64));
             // (the ballots make the wave-uniform decision visibly uniform to the compiler:
             // scalar branch, uniform counters in SGPRs)
             if (!WL) {
