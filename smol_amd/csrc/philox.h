@@ -18,14 +18,11 @@ struct philox_out {
 
 SMOLMC_HD void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0,
                             uint32_t k1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-#else
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32 on the device: the separate
+    // v_mul_hi_u32 + v_mul_lo_u32 pair costs two quarter-rate instructions)
     uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-#endif
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0;
     c1 = lo1;
