@@ -384,23 +384,32 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
             nfl = 1;
         } else {
-            // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate sequence
-            int found = -1, fo = 0, fa = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (found < 0) {
-                    const int v = (int)occ[canda[j]];
-                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
-                    if (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        found = (int)rdlane((uint32_t)cand[j], b);
-                        fa = (int)rdlane((uint32_t)canda[j], b);
-                        fo = (int)rdlane((uint32_t)v, b);
-                        if (j == 0) fb = b;
-                    }
-                }
-            }
-            if (found < 0) {
+            // Swap.propose_step (mcusher.py:176-200) by rejection over the candidate sequence.
+            // Every exit sets the outputs itself and leaves through one branch (a shared
+            // "found >= 0" epilogue costs the common first-candidate hit four compare-and-branch
+            // pairs and a select chain).
+            nfl = 2;
+            n2 = o1;
+            do {
+#define SMOLMC_TRY_CAND(J)                                                                         \
+    {                                                                                              \
+        const int v = (int)occ[canda[J]];                                                          \
+        const unsigned long long m = __ballot(v != o1) & (0xEull << l4);                           \
+        if (m) {                                                                                   \
+            const int b = __ffsll((long long)m) - 1;                                               \
+            s2 = (int)rdlane((uint32_t)cand[J], b);                                                \
+            a2 = (int)rdlane((uint32_t)canda[J], b);                                               \
+            o2 = (int)rdlane((uint32_t)v, b);                                                      \
+            if (J == 0) fb = b;                                                                    \
+            break;                                                                                 \
+        }                                                                                          \
+    }
+                SMOLMC_TRY_CAND(0)
+                SMOLMC_TRY_CAND(1)
+                SMOLMC_TRY_CAND(2)
+                SMOLMC_TRY_CAND(3)
+#undef SMOLMC_TRY_CAND
+                bool hit = false;
                 for (uint32_t q = 0;; ++q) {
                     const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
                                                        4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
@@ -414,9 +423,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     const unsigned long long m = __ballot(selsite >= 0);
                     if (m) {
                         const int b = __ffsll((long long)m) - 1;
-                        found = (int)rdlane((uint32_t)selsite, b);
-                        fa = lean_swz(found, swa, swm, swb);
-                        fo = (int)rdlane((uint32_t)selv, b);
+                        s2 = (int)rdlane((uint32_t)selsite, b);
+                        a2 = lean_swz(s2, swa, swm, swb);
+                        o2 = (int)rdlane((uint32_t)selv, b);
+                        hit = true;
                         break;
                     }
                     if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
@@ -426,9 +436,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                         if (__ballot(any) == 0ull) break;
                     }
                 }
-            }
-            if (found >= 0) { s2 = found; a2 = fa; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
-            else { nfl = 0; n1 = o1; s2 = s1; a2 = a1; o2 = o1; n2 = o1; } // empty step: no-op 'flips'
+                if (!hit) { nfl = 0; s2 = s1; a2 = a1; o2 = o1; } // empty step: no-op 'flips'
+            } while (false);
+            n1 = o2;
         }
 
         // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
