@@ -583,6 +583,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
             TRY(dev_upload(h, lidx.data(), lidx.size(), &h->lp.idx));
+            h->lean_idx_host = std::move(lidx);
             TRY(dev_upload(h, dt.data(), dt.size(), &h->lp.dt));
             TRY(dev_upload(h, ls.data(), ls.size(), &h->lp.slots));
             h->lp.dt_len = (int)dt.size();
@@ -1055,6 +1056,20 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     h->lean_lds = with_field;
                 }
             }
+            // one wave per workgroup (occupancy at LDS address 0, 32-bit index rows, a private
+            // copy of the tables): Metropolis flips / swaps without Ewald term or bias, when 16
+            // such workgroups still fit a CU
+            if (lean && !wl && !t->has_ewald && !t->bias_type && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
+                getenv("SMOLMC_NO_SOLO") == nullptr) {
+                const size_t pw = ((size_t)lp.Nlds + 64 * 8 + 15) & ~(size_t)15;
+                const size_t solo_lds = pw + ((size_t)lp.dt_len + 24) * 8;
+                if (solo_lds * 16 <= 160 * 1024 - 16 * 256) {
+                    std::vector<uint32_t> wide(h->lean_idx_host.begin(), h->lean_idx_host.end());
+                    if (dev_upload(h, wide.data(), wide.size(), &lp.idx32)) return bail(1);
+                    h->lean_solo = true;
+                    h->lean_lds = solo_lds;
+                }
+            }
             if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
                 // block-shared flip table / weights (48 doubles) and, when it fits, ln(k) for
                 // k <= n_active from the host libm (the oracle's log-factorial sums use the same)
@@ -1359,8 +1374,8 @@ extern "C" int smolmc_sync(smolmc_handle *h) {
 extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     if (!h || !buf || n <= 0) return fail("null argument");
     if (h->lean)
-        snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu", h->lean_multi ? "lean-multi" : "lean",
-                 h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds);
+        snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu%s", h->lean_multi ? "lean-multi" : "lean",
+                 h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds, h->lean_solo ? " solo=1" : "");
     else
         snprintf(buf, (size_t)n, "general nslot=%d mm=%d field=%d lds=%zu", h->nslot, h->mm, h->kp.ew_field,
                  h->lds_bytes);

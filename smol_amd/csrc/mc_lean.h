@@ -171,6 +171,11 @@ __device__ __forceinline__ RowWords<NW> load_row(__amdgpu_buffer_rsrc_t rs, uint
 template <int NW> __device__ __forceinline__ uint32_t row_entry(const RowWords<NW> &r, int q) {
     return (r.w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
 }
+// one-wave-per-workgroup layout: 32-bit entries, used as LDS addresses as they are
+template <bool WIDE, int NW> __device__ __forceinline__ uint32_t row_addr(const RowWords<NW> &r, int q) {
+    if constexpr (WIDE) return r.w[q];
+    else return row_entry<NW>(r, q);
+}
 
 // Wang-Landau flatness check (wanglandau.py:253-264), every check_period steps: kept out of
 // line so that its temporaries do not add to the register pressure of the step loop.
@@ -195,19 +200,38 @@ __device__ __noinline__ double wl_flatness_check(const double *wl_S, long long *
     return wl_m;
 }
 
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false>
+// LDS access by absolute address (SOLO layout: the occupancy starts at LDS address 0; going
+// through the `extern __shared__` symbol would cost one "+ symbol" VALU add per access)
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+template <bool ABS> __device__ __forceinline__ uint8_t occ_ld(const uint8_t *occ, uint32_t a) {
+    if constexpr (ABS) return *(const lds_u8_t *)a;
+    else return occ[a];
+}
+template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_t a, uint8_t v) {
+    if constexpr (ABS) *(lds_u8_t *)a = v;
+    else occ[a] = v;
+}
+
+// SOLO: one wave per workgroup with the walker's occupancy at LDS address 0 and the block-shared
+// tables behind it.  The index rows then hold 32-bit LDS addresses that go into ds_read_u8 as
+// they are -- no per-gather "wave base + unpack u16" instruction (8 VALU per swap step) -- and
+// the site / candidate addresses need no base either.  Costs one copy of the tables per wave,
+// so it is chosen when 16 waves per CU still fit (engine.hip).
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false, bool SOLO = false>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (SOLO && (uint32_t)(uintptr_t)smem != 0u) __builtin_trap(); // (no static LDS in this kernel)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
+    const int wave = SOLO ? 0 : threadIdx.x >> 6;
+    const int nwaves = SOLO ? 1 : blockDim.x >> 6;
     const int r = uni(blockIdx.x * nwaves + wave);
-    double *s_dt = (double *)smem;
-    double *s_mu = s_dt + P.dt_len;               // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0) +
                             ((HAS_EW && P.ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
+    double *s_dt = SOLO ? (double *)(smem + ((per_wave + 15) & ~(size_t)15)) : (double *)smem;
+    const uint32_t dt_off = SOLO ? (uint32_t)((per_wave + 15) & ~(size_t)15) : 0u; // table base, folded into the slot offsets
+    double *s_mu = s_dt + P.dt_len;               // 8 doubles
     double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
-    unsigned char *wbase = (unsigned char *)(s_mu + 24) + (size_t)wave * per_wave;
+    unsigned char *wbase = SOLO ? smem : (unsigned char *)(s_mu + 24) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;                         // indexed by SWIZZLED site address
     // Metropolis: scratch for the feature reduction; Wang-Landau: the CURRENT features
     // (wanglandau.py:216-218 needs them every step for the per-bin running mean)
@@ -246,7 +270,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
-        doff8[it] = sl.doff8;
+        doff8[it] = sl.doff8 + dt_off;
         sfeat[it] = sl.feat;      // only used by the Wang-Landau variant
         sfs[it] = sl.live ? sl.fs : 0.0;
 #pragma unroll
@@ -298,12 +322,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double logu = 0.0; // log of the acceptance uniform of step (step & ~63) + lane
     unsigned long long batch64_base = ~0ull;
     unsigned long long batch_base = ~0ull;
-    constexpr int ROW = NSLOT * MM; // u16 entries per lane per site
-    constexpr int NW = ROW / 2;                       // dwords per lane per site
-    constexpr uint32_t SITE_BYTES = 64u * ROW * 2u;
-    const __amdgpu_buffer_rsrc_t idx_rs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
-    const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
+    constexpr int ROW = NSLOT * MM; // entries per lane per site (u16, SOLO: u32)
+    constexpr int NW = SOLO ? ROW : ROW / 2;          // dwords per lane per site
+    constexpr uint32_t ENT = SOLO ? 4u : 2u;
+    constexpr uint32_t SITE_BYTES = 64u * ROW * ENT;
+    const __amdgpu_buffer_rsrc_t idx_rs = __builtin_amdgcn_make_buffer_rsrc(
+        SOLO ? (void *)P.idx32 : (void *)P.idx, 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_voff = (uint32_t)lane * (ROW * ENT);
 
     // software pipeline: the site of step k comes from W(k-1, 0, 1), so the index row of
     // the NEXT step is always known one step ahead and is fetched while this step runs.
@@ -375,7 +400,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
         const RowWords<NW> rown = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
-        const int o1 = uni((int)occ[a1]);
+        const int o1 = uni((int)occ_ld<SOLO>(occ, (uint32_t)a1));
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
         if (STEP == SMOLMC_STEP_FLIP) {
@@ -393,7 +418,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             do {
 #define SMOLMC_TRY_CAND(J)                                                                         \
     {                                                                                              \
-        const int v = (int)occ[canda[J]];                                                          \
+        const int v = (int)occ_ld<SOLO>(occ, (uint32_t)canda[J]);                                                       \
         const unsigned long long m = __ballot(v != o1) & (0xEull << l4);                           \
         if (m) {                                                                                   \
             const int b = __ffsll((long long)m) - 1;                                               \
@@ -460,8 +485,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
-                d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row1, it * MM + m)));
+                d1[it] = *(const double *)((const unsigned char *)smem + (a + pair1)); // (a includes the table base)
                 e = fma(wgt[it], d1[it], e);
             }
         }
@@ -483,15 +508,15 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
 #ifndef SMOLMC_EXP_NOTENT // timing experiment only when defined (wrong results)
-            occ[a1] = (uint8_t)n1; // every lane stores the same byte: no exec juggling
+            occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1); // every lane stores the same byte: no exec juggling
 #endif
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
-                d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row2, it * MM + m)));
+                d2[it] = *(const double *)((const unsigned char *)smem + (a + pair2));
                 e = fma(wgt[it], d2[it], e);
             }
             if (HAS_EW) {
@@ -590,11 +615,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
-            if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
+            if (STEP == SMOLMC_STEP_FLIP) occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1);
 #ifdef SMOLMC_EXP_NOTENT
-            if (STEP == SMOLMC_STEP_SWAP) occ[a1] = (uint8_t)n1;
+            if (STEP == SMOLMC_STEP_SWAP) occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1);
 #endif
-            if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2; // (n2 == o1 == occ[a1] when empty)
+            if (STEP == SMOLMC_STEP_SWAP) occ_st<SOLO>(occ, (uint32_t)a2, (uint8_t)n2); // (n2 == o1 == occ[a1] when empty)
             if (HAS_EW && P.ew_field) {
                 if (STEP == SMOLMC_STEP_SWAP) {
                     if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
@@ -612,7 +637,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             nacc_add++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
 #ifndef SMOLMC_EXP_NOTENT
-            occ[a1] = (uint8_t)o1; // undo the tentative first flip
+            occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)o1); // undo the tentative first flip
 #endif
         }
         s1 = s1n;
@@ -1242,15 +1267,15 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 }
 
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false, bool SOLO = false>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
-    const unsigned grid = (unsigned)((h->R + 3) / 4);
-    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS>;
+    const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SOLO ? 64 : 256), h->lean_lds, h->stream, lp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -1264,6 +1289,9 @@ static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
     if (ew)
         return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false>(h, lp)
                   : launch_lean_inst<NSLOT, MM, STEP, false, true, false>(h, lp);
+    if (h->lean_solo) // Metropolis without Ewald: one wave per workgroup (see mc_lean_kernel)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, false, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, false, false, false, true>(h, lp);
     return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false>(h, lp)
               : launch_lean_inst<NSLOT, MM, STEP, false, false, false>(h, lp);
 }

@@ -297,6 +297,7 @@ struct LeanSlot {
 
 struct LeanParams {
     const uint16_t *idx;   // [N][64][NSLOT][MM]
+    const uint32_t *idx32; // the same entries as 32-bit words (one-wave-per-workgroup layout)
     const double *dt;      // delta tables, all padded to a common [S*S][NTP] shape
     const LeanSlot *slots; // [NSLOT][64]
     const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
@@ -395,6 +396,8 @@ struct smolmc_handle {
     bool lean_tables = false, lean = false;
     int lean_nslot = 0, lean_mm = 0, lean_ncls = 0;
     bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
+    bool lean_solo = false;             // mc_lean_kernel in its one-wave-per-workgroup layout
+    std::vector<uint16_t> lean_idx_host; // lane-packed index rows (kept for the 32-bit copy)
     std::vector<int> site_class_host;   // site -> class (255 = no clusters)
     size_t lean_lds = 0;
     LeanParams lp;

@@ -521,6 +521,49 @@ def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, e
         assert "field=1" in info
 
 
+@pytest.mark.parametrize("name,step,mukind", [("fcc_prim666_triplets", capi.STEP_SWAP, None),
+                                              ("fcc3_indicator_skew", capi.STEP_FLIP, "mu3"),
+                                              ("fcc_conv444_pairs", capi.STEP_SWAP, None)])
+def test_one_wave_per_workgroup_layout_equals_shared_layout(name, step, mukind, monkeypatch):
+    """mc_lean_kernel in its SOLO layout (occupancy at LDS address 0, 32-bit index rows, private
+    tables; chosen for Metropolis models without Ewald term) against the four-waves-per-workgroup
+    layout (SMOLMC_NO_SOLO) and the oracle: same occupancies, counters, samples."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    monkeypatch.delenv("SMOLMC_NO_SOLO", raising=False)
+    c = load_case(name)
+    tab = tables_for(name, MODES["int"], mu_table=_mu(mukind, c))
+    R = 9  # (not a multiple of the four waves of the shared layout)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(77)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) * np.uint64(31) + np.uint64(9)
+    temps = np.linspace(600.0, 4000.0, R)
+    solo = _engine(tab, cfg)
+    assert "solo=1" in solo.kernel_info(), solo.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_SOLO", "1")
+    shared = _engine(tab, cfg)
+    assert shared.kernel_info().startswith("lean") and "solo" not in shared.kernel_info()
+    ora = orc.OracleMC(tab, cfg)
+    for e in (solo, shared, ora):
+        e.set_state(occ0, seeds, temps)
+    for chunk in (1, 15, 16, 64, 65, 300):
+        for e in (solo, shared, ora):
+            e.run(chunk)
+        a = solo.get_state()
+        for x in (shared.get_state(), ora.get_state()):
+            assert np.array_equal(a["occupancy"], x["occupancy"])
+            assert np.array_equal(a["n_accepted"], x["n_accepted"])
+            assert np.array_equal(a["accepted"], x["accepted"])
+            np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(a["features"], x["features"], rtol=RTOL, atol=1e-8)
+    sa, sb = solo.run_sampled(5, 21, occupancy=True), shared.run_sampled(5, 21, occupancy=True)
+    assert np.array_equal(sa["occupancy"], sb["occupancy"]) and np.array_equal(sa["accepted"], sb["accepted"])
+    np.testing.assert_allclose(sa["enthalpy"], sb["enthalpy"], rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])
 def test_split_launches_equal_one_launch(kernel, monkeypatch):
     """The lean kernels count steps in 32 bits, so the host splits long runs into several
