@@ -203,12 +203,21 @@ __device__ __noinline__ double wl_flatness_check(const double *wl_S, long long *
 // LDS access by absolute address (SOLO layout: the occupancy starts at LDS address 0; going
 // through the `extern __shared__` symbol would cost one "+ symbol" VALU add per access)
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+typedef __attribute__((address_space(3))) double lds_f64_t;
+// (the integer -> LDS pointer casts only exist in the device pass: LDS pointers are 32 bits there)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMOLMC_LDS_U8(a) (*(lds_u8_t *)(a))
+#define SMOLMC_LDS_F64(a) (*(const lds_f64_t *)(a))
+#else
+#define SMOLMC_LDS_U8(a) (*(uint8_t *)(uintptr_t)(a))
+#define SMOLMC_LDS_F64(a) (*(const double *)(uintptr_t)(a))
+#endif
 template <bool ABS> __device__ __forceinline__ uint8_t occ_ld(const uint8_t *occ, uint32_t a) {
-    if constexpr (ABS) return *(const lds_u8_t *)a;
+    if constexpr (ABS) return SMOLMC_LDS_U8(a);
     else return occ[a];
 }
 template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_t a, uint8_t v) {
-    if constexpr (ABS) *(lds_u8_t *)a = v;
+    if constexpr (ABS) SMOLMC_LDS_U8(a) = v;
     else occ[a] = v;
 }
 
@@ -220,7 +229,7 @@ template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_
 template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false, bool SOLO = false>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (SOLO && (uint32_t)(uintptr_t)smem != 0u) __builtin_trap(); // (no static LDS in this kernel)
+    if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap(); // (no static LDS in this kernel: absolute LDS addresses below)
     const int lane = threadIdx.x & 63;
     const int wave = SOLO ? 0 : threadIdx.x >> 6;
     const int nwaves = SOLO ? 1 : blockDim.x >> 6;
@@ -486,7 +495,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 uint32_t a = doff8[it];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row1, it * MM + m)));
-                d1[it] = *(const double *)((const unsigned char *)smem + (a + pair1)); // (a includes the table base)
+                d1[it] = SMOLMC_LDS_F64(a + pair1); // (absolute LDS address: a includes the table base)
                 e = fma(wgt[it], d1[it], e);
             }
         }
@@ -516,7 +525,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 uint32_t a = doff8[it];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row2, it * MM + m)));
-                d2[it] = *(const double *)((const unsigned char *)smem + (a + pair2));
+                d2[it] = SMOLMC_LDS_F64(a + pair2);
                 e = fma(wgt[it], d2[it], e);
             }
             if (HAS_EW) {
