@@ -67,12 +67,14 @@ def usable_cores():
 
 
 # HBM bytes per launch of the default configuration from the two separate PMC passes committed
-# under profiles/ (r01_final_pmc.txt): FETCH_SIZE 17.36 MB + WRITE_SIZE 17.39 MB (KiB counters,
-# summed over 4 dispatches / 4).  MI355X_MICROARCH.md's x2 FETCH_SIZE correction is for 16 B/lane
-# streams; this kernel streams the occupancy with 4 B/lane loads and the undoubled counter already
-# equals the known byte count (16.78 MB of occupancy + the index rows), so it is used as read.
-# The occupancies go in and out once per launch; everything else is LDS/L2 resident.
-MEASURED_TRAFFIC_BYTES = {(4096, 10000): 3.475e7}
+# under profiles/ (r01_final_pmc.txt): FETCH_SIZE 50.4 MB + WRITE_SIZE 17.6 MB (KiB counters,
+# summed over 4 dispatches / 4).  The occupancies go in and out once per launch (16.78 MB each
+# way: the 4 B/lane occupancy stream reads back exactly in the undoubled counter, which is how
+# MI355X_MICROARCH.md's x2 FETCH_SIZE correction for 16 B/lane streams was calibrated away for
+# it); the remaining 33 MB of fetches are L2 misses of the 4 MB table of 32-bit index rows (read
+# with 16 B/lane loads, so that part may be under-counted by up to 2x: <= 1.0e8 bytes in all).
+# Everything else is LDS/L2 resident.
+MEASURED_TRAFFIC_BYTES = {(4096, 10000): 6.81e7}
 
 
 def cpu_baseline_child(seconds=12.0):
