@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu;
     long long smp_index = 0;
     // random batch: lane l holds block (l & 3) of step batch_base + (l >> 2)
-    uint32_t W0 = 0, W1 = 0;
+    uint32_t W0 = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0}; // candidate sites / their LDS addresses
     double vGc = 0.0; // Ewald field mode: prefetched cross terms of the first-round candidates
     double logu = 0.0; // log of the acceptance uniform of step (step & ~63) + lane
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
                                                0u, key0, key1);
-            W0 = o.w[0]; W1 = o.w[1];
+            W0 = o.w[0];
             // site of the step AFTER the lane's step and its swizzled LDS address, lane-parallel
             // (one v_readlane each per step instead of the scalar mulhi + swizzle chain)
             nsite = sbase + (int)__umulhi(o.w[1], nact);
@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
             }
         }
-        bool accepted;
+        bool accepted = false;
         bool decided = false;
         if (FAST && !BIAS) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);

@@ -492,12 +492,12 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     const uint32_t nt8 = P.nt8, snt8 = P.snt8;
     const int abase = P.ew_act_base;
     // "counts" dimension of this lane: sublattice, species code, first dimension of the sublattice
-    int dim_sub = 0, dim_base = 0;
+    int dim_sub = 0;
     {
         int b = 0;
         for (int k = 0; k < NS; ++k) {
             const int nck = sel4(P.m_ncodes, k);
-            if (lane >= b && lane < b + nck) { dim_sub = k; dim_base = b; }
+            if (lane >= b && lane < b + nck) dim_sub = k;
             b += nck;
         }
     }
