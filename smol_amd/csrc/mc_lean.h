@@ -405,10 +405,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         const int l4 = (int)(step & 15ull) * 4;
         const int l64 = (int)(step & 63ull); // lane of this step's acceptance uniform / thresholds
-        // prefetch the index row of the next step's site (depends only on random words)
+        // site of the next step (depends only on random words; its index row is fetched below)
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
-        const RowWords<NW> rown = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
         const int o1 = uni((int)occ_ld<SOLO>(occ, (uint32_t)a1));
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
@@ -499,6 +498,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 e = fma(wgt[it], d1[it], e);
             }
         }
+        // index row of the NEXT step's site, straight into row1: its last use (the gathers above)
+        // has been issued, so no second register set and no copy at the end of the step
+        row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1n * SITE_BYTES);
         double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
         double dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
@@ -651,7 +653,6 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
         s1 = s1n;
         a1 = a1n;
-        row1 = rown;
 
         if (WL) {
             // WangLandau._do_post_step (wanglandau.py:222-266)
