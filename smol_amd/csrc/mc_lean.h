@@ -408,7 +408,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // site of the next step (depends only on random words; its index row is fetched below)
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
-        const int o1 = uni((int)occ_ld<SOLO>(occ, (uint32_t)a1));
+        // LDS address of site 1 as a VGPR, made once per step (the compiler would re-make the
+        // SGPR -> VGPR move in every block that touches the site)
+        uint32_t va1 = (uint32_t)a1;
+        asm volatile("" : "+v"(va1));
+        const int o1 = uni((int)occ_ld<SOLO>(occ, va1));
         int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
         int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
         if (STEP == SMOLMC_STEP_FLIP) {
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // the second flip sees the first (expansion.py:217-229): apply it tentatively in
             // LDS (undone below on rejection) instead of patching every gathered value
 #ifndef SMOLMC_EXP_NOTENT // timing experiment only when defined (wrong results)
-            occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1); // every lane stores the same byte: no exec juggling
+            occ_st<SOLO>(occ, va1, (uint8_t)n1); // every lane stores the same byte: no exec juggling
 #endif
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
@@ -626,7 +630,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
-            if (STEP == SMOLMC_STEP_FLIP) occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1);
+            if (STEP == SMOLMC_STEP_FLIP) occ_st<SOLO>(occ, va1, (uint8_t)n1);
 #ifdef SMOLMC_EXP_NOTENT
             if (STEP == SMOLMC_STEP_SWAP) occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1);
 #endif
@@ -648,7 +652,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             nacc_add++;
         } else if (STEP == SMOLMC_STEP_SWAP) {
 #ifndef SMOLMC_EXP_NOTENT
-            occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)o1); // undo the tentative first flip
+            occ_st<SOLO>(occ, va1, (uint8_t)o1); // undo the tentative first flip
 #endif
         }
         s1 = s1n;
