@@ -352,9 +352,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
     }
 
-    const uint32_t nsteps32 = (uint32_t)P.steps; // the host splits launches at 2^30 steps
-    for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
-        // -------- random words of this step (generated 16 steps at a time) --------
+    // Loop skeleton: the steps run in chunks that end at the next random-batch boundary, the
+    // next sample row or the end of the launch, whichever comes first, so that the step loop
+    // itself carries one down-counter and the two lane indices (a per-step batch test, sample
+    // countdown, 64-bit step increment and launch counter cost ~10 SALU instructions per step).
+    uint32_t steps_left = (uint32_t)P.steps; // the host splits launches at 2^30 steps
+    while (steps_left != 0u) {
+        // -------- random words (generated 16 steps at a time) --------
         const unsigned long long base = step & ~15ull;
         if (base != batch_base) {
             batch_base = base;
@@ -403,8 +407,15 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 }
             }
         }
-        const int l4 = (int)(step & 15ull) * 4;
-        const int l64 = (int)(step & 63ull); // lane of this step's acceptance uniform / thresholds
+        uint32_t chunk = 16u - (uint32_t)(step & 15ull);
+        chunk = min(chunk, steps_left);
+        chunk = min(chunk, smp_countdown);
+        steps_left -= chunk;
+        smp_countdown -= chunk;
+        const unsigned long long chunk_end = step + chunk;
+        int l4 = (int)(step & 15ull) * 4;
+        int l64 = (int)(step & 63ull); // lane of this step's acceptance uniform / thresholds
+        do {
         // site of the next step (depends only on random words; its index row is fetched below)
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
@@ -447,8 +458,9 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 SMOLMC_TRY_CAND(3)
 #undef SMOLMC_TRY_CAND
                 bool hit = false;
+                const unsigned long long cur = chunk_end - chunk; // this step (rare path)
                 for (uint32_t q = 0;; ++q) {
-                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                    const philox_out o = philox4x32_10((uint32_t)cur, (uint32_t)(cur >> 32),
                                                        4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
                     int selsite = -1, selv = 0;
 #pragma unroll
@@ -686,7 +698,12 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
 
-        if (--smp_countdown == 0) { // record one thinned sample of this walker
+        l4 += 4;
+        l64 += 1;
+        } while (--chunk != 0u);
+        step = chunk_end;
+
+        if (smp_countdown == 0) { // record one thinned sample of this walker
             // (sampling parameters re-read from the kernel arguments: see rare_params)
             const LeanParamsKernarg Q = rare_params();
             const int qF = Q->F, qFce = Q->Fce;
@@ -768,7 +785,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
-        if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
+        if (P.steps) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
     }
 }
 
