@@ -424,7 +424,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         uint32_t va1 = (uint32_t)a1;
         asm volatile("" : "+v"(va1));
         const int o1 = uni((int)occ_ld<SOLO>(occ, va1));
-        int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0;
+        int nfl, s2, a2, n1, n2 = 0, o2 = 0; // (swap: s2 / a2 / o2 are set by every proposal outcome)
+        if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
         if (STEP == SMOLMC_STEP_FLIP) {
             // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
@@ -438,55 +439,65 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // pairs and a select chain).
             nfl = 2;
             n2 = o1;
-            do {
-#define SMOLMC_TRY_CAND(J)                                                                         \
+            // candidate J of the first round: lanes l4+1 .. l4+3 test their word J
+#define SMOLMC_CAND_MASK(J)                                                                        \
+    const int v##J = (int)occ_ld<SOLO>(occ, (uint32_t)canda[J]);                                   \
+    const unsigned long long m##J = __ballot(v##J != o1) & (0xEull << l4);
+#define SMOLMC_CAND_TAKE(J)                                                                        \
     {                                                                                              \
-        const int v = (int)occ_ld<SOLO>(occ, (uint32_t)canda[J]);                                                       \
-        const unsigned long long m = __ballot(v != o1) & (0xEull << l4);                           \
-        if (m) {                                                                                   \
-            const int b = __ffsll((long long)m) - 1;                                               \
-            s2 = (int)rdlane((uint32_t)cand[J], b);                                                \
-            a2 = (int)rdlane((uint32_t)canda[J], b);                                               \
-            o2 = (int)rdlane((uint32_t)v, b);                                                      \
-            if (J == 0) fb = b;                                                                    \
-            break;                                                                                 \
-        }                                                                                          \
+        const int b = __ffsll((long long)m##J) - 1;                                                \
+        s2 = (int)rdlane((uint32_t)cand[J], b);                                                    \
+        a2 = (int)rdlane((uint32_t)canda[J], b);                                                   \
+        o2 = (int)rdlane((uint32_t)v##J, b);                                                       \
+        if (J == 0) fb = b;                                                                        \
     }
-                SMOLMC_TRY_CAND(0)
-                SMOLMC_TRY_CAND(1)
-                SMOLMC_TRY_CAND(2)
-                SMOLMC_TRY_CAND(3)
-#undef SMOLMC_TRY_CAND
-                bool hit = false;
-                const unsigned long long cur = chunk_end - chunk; // this step (rare path)
-                for (uint32_t q = 0;; ++q) {
-                    const philox_out o = philox4x32_10((uint32_t)cur, (uint32_t)(cur >> 32),
-                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
-                    int selsite = -1, selv = 0;
+            SMOLMC_CAND_MASK(0)
+            if (m0) SMOLMC_CAND_TAKE(0)
+            else {
+                SMOLMC_CAND_MASK(1)
+                if (m1) SMOLMC_CAND_TAKE(1)
+                else {
+                    SMOLMC_CAND_MASK(2)
+                    if (m2) SMOLMC_CAND_TAKE(2)
+                    else {
+                        SMOLMC_CAND_MASK(3)
+                        if (m3) SMOLMC_CAND_TAKE(3)
+                        else {
+                            bool hit = false;
+                            const unsigned long long cur = chunk_end - chunk; // this step (rare path)
+                            for (uint32_t q = 0;; ++q) {
+                                const philox_out o = philox4x32_10((uint32_t)cur, (uint32_t)(cur >> 32),
+                                                                   4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                                int selsite = -1, selv = 0;
 #pragma unroll
-                    for (int j = 3; j >= 0; --j) {
-                        const int cs = sbase + (int)__umulhi(o.w[j], nact);
-                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
-                        if (v != o1) { selsite = cs; selv = v; }
-                    }
-                    const unsigned long long m = __ballot(selsite >= 0);
-                    if (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        s2 = (int)rdlane((uint32_t)selsite, b);
-                        a2 = lean_swz(s2, swa, swm, swb);
-                        o2 = (int)rdlane((uint32_t)selv, b);
-                        hit = true;
-                        break;
-                    }
-                    if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
-                        int any = 0;
-                        for (uint32_t a = lane; a < nact; a += 64)
-                            any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
-                        if (__ballot(any) == 0ull) break;
+                                for (int j = 3; j >= 0; --j) {
+                                    const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                                    if (v != o1) { selsite = cs; selv = v; }
+                                }
+                                const unsigned long long m = __ballot(selsite >= 0);
+                                if (m) {
+                                    const int b = __ffsll((long long)m) - 1;
+                                    s2 = (int)rdlane((uint32_t)selsite, b);
+                                    a2 = lean_swz(s2, swa, swm, swb);
+                                    o2 = (int)rdlane((uint32_t)selv, b);
+                                    hit = true;
+                                    break;
+                                }
+                                if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
+                                    int any = 0;
+                                    for (uint32_t a = lane; a < nact; a += 64)
+                                        any |= ((int)occ[lean_swz(sbase + (int)a, swa, swm, swb)] != o1);
+                                    if (__ballot(any) == 0ull) break;
+                                }
+                            }
+                            if (!hit) { nfl = 0; s2 = s1; a2 = a1; o2 = o1; } // empty step: no-op 'flips'
+                        }
                     }
                 }
-                if (!hit) { nfl = 0; s2 = s1; a2 = a1; o2 = o1; } // empty step: no-op 'flips'
-            } while (false);
+            }
+#undef SMOLMC_CAND_MASK
+#undef SMOLMC_CAND_TAKE
             n1 = o2;
         }
 
