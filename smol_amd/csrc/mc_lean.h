@@ -594,18 +594,8 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
             }
         }
-        bool accepted = false;
-        bool decided = false;
-        if (FAST && !BIAS) {
-            const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
-            const float S = wave_sum_f32_uniform(ef);
-            const unsigned long long bit = 1ull << l64;
-            const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
-            const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
-            decided = ca | cr;
-            accepted = ca;
-        }
-        if (!decided) {
+        // exact float64 decision (metropolis.py:31-49 / wanglandau.py:186-202)
+        auto exact_decision = [&]() -> bool {
             dH = LEAN_WAVE_SUM(e);
             if (HAS_EW) {
                 dEw = (P.ew_field ? 0.0 : LEAN_WAVE_SUM(ew_part)) + ew_uni;
@@ -619,24 +609,23 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             // scalar branch, uniform counters in SGPRs)
             if (!WL) {
                 const double exponent = nbeta * dH + 0.0 + dB; // metropolis.py:41-44
-                accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+                return __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
             } else {
                 // WangLandau._accept_step (wanglandau.py:186-202)
                 const double new_h = H + dH;
                 if (new_h < P.wl.vmin || new_h >= P.wl.vmax) {
-                    accepted = false;
+                    return false;
                 } else {
                     const int b = (int)wl_bq;
                     wl_nbq = floordiv_exact_inv(new_h - P.wl.vmin, P.wl.bin, wl_inv_bin);
                     const int nb = (int)wl_nbq;
                     const double exponent = wl_S[b] - wl_S[nb] + 0.0;
-                    accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+                    return __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
                 }
             }
-        }
+        };
         // -------- update (kernel/base.py:327-343) --------
-        nacc_before = nacc_add;
-        if (accepted) {
+        auto on_accept = [&]() {
             if (!WL) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
@@ -673,10 +662,32 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             charge += dQ;
             if (!FAST) H += dH;
             nacc_add++;
-        } else if (STEP == SMOLMC_STEP_SWAP) {
+        };
+        auto on_reject = [&]() {
+            if (STEP == SMOLMC_STEP_SWAP) {
 #ifndef SMOLMC_EXP_NOTENT
             occ_st<SOLO>(occ, va1, (uint8_t)o1); // undo the tentative first flip
 #endif
+            }
+        };
+        // Each outcome of the float32 pre-test runs its update directly (a merged
+        // "decided / accepted" pair of flags costs the common path extra compare-and-branch steps).
+        nacc_before = nacc_add;
+        bool accepted = false; // (read after this point by the Wang-Landau post-step only)
+        if (FAST && !BIAS) {
+            const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
+            const float S = wave_sum_f32_uniform(ef);
+            const unsigned long long bit = 1ull << l64;
+            const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
+            const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
+            if (ca) on_accept();
+            else if (cr) on_reject();
+            else if (exact_decision()) on_accept();
+            else on_reject();
+        } else {
+            accepted = exact_decision();
+            if (accepted) on_accept();
+            else on_reject();
         }
         s1 = s1n;
         a1 = a1n;
