@@ -291,6 +291,45 @@ def test_errors_surface_as_exceptions():
         _engine(tab, capi.make_config(1, capi.KERNEL_WANGLANDAU, min_enthalpy=2.0, max_enthalpy=1.0))
 
 
+@pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])
+@pytest.mark.parametrize("offset,thin", [(0, 1), (5, 3), (63, 16), (15, 17), (1, 64), (40, 65)])
+def test_sample_rows_at_any_phase_of_the_random_batches(offset, thin, kernel, monkeypatch):
+    """The lean step loop runs in chunks that end at the next 16-step random batch, the next sample
+    row or the end of the launch: sample rows with periods below, at and above the batch lengths
+    (16 and 64 steps), started at arbitrary stream positions, equal step-wise runs and the oracle."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    c = load_case("fcc_prim666_triplets")
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    R = 3
+    if kernel == "metropolis":
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    else:
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=-40.3, max_enthalpy=40.7,
+                               bin_size=0.5, check_period=37)
+    rng = np.random.default_rng(offset + thin)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(7000 + thin)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean")
+    for e in (eng, ora):
+        e.set_state(occ0, seeds, 1800.0)
+        if offset:
+            e.run(offset)
+    ns = 5
+    smp = eng.run_sampled(ns, thin, occupancy=True)
+    for i in range(ns):
+        ora.run(thin)
+        st = ora.get_state()
+        assert np.array_equal(smp["occupancy"][i], st["occupancy"])
+        assert np.array_equal(smp["accepted"][i], st["accepted"])
+        np.testing.assert_allclose(smp["enthalpy"][i], st["enthalpy"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(smp["features"][i], st["features"], rtol=RTOL, atol=1e-8)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["n_steps"], b["n_steps"]) and np.array_equal(a["n_accepted"], b["n_accepted"])
+
+
 @pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 @pytest.mark.parametrize("name,mode,step,mukind", [
     ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None),
