@@ -27,7 +27,9 @@ struct MultiRec { // slot record, 24 bytes
     double w;
 };
 
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW>
+// ONE: a single site class (the 257..512-clusters-per-site models): the slot records stay in
+// registers for the whole launch instead of being re-read from LDS for every flip.
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool ONE = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -110,6 +112,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     RowWords<NW> row1;
     bool have_row1 = false;
 
+    MultiRec rcs[ONE ? NSLOT : 1];
+    if (ONE) {
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) rcs[it] = s_rec[it * 64 + lane];
+    }
     auto sub_of = [&](uint32_t w0) -> int { // MCUsher.get_random_sublattice (mcusher.py:146-148)
         if (NS == 1) return 0;
         const double x = (double)w0 * (1.0 / 4294967296.0);
@@ -169,64 +176,87 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         const int sub1 = (int)rdlane((uint32_t)vsub, l4);
         const int cls1 = sel4(P.m_cls, sub1);
         if (!have_row1) row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
-        // prefetch the next step's row while this one runs (not across a batch boundary)
+        // prefetch the next step's row while this one runs (not across a batch boundary).  ONE:
+        // issued after the gathers of flip 1, straight into row1 (no second register set, no
+        // copy per step); with several classes the earlier issue is worth more than the copy.
         RowWords<NW> rown = row1;
-        have_row1 = l4 < 60;
-        if (have_row1) rown = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
+        if (!ONE) {
+            have_row1 = l4 < 60;
+            if (have_row1) rown = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
+        }
 
         const int o1 = uni((int)occ[a1]);
-        int nfl, s2 = s1, a2 = a1, n1, n2 = 0, o2 = 0, fb = -1;
+        int nfl, s2, a2, n1, n2 = 0, o2 = 0, fb = -1; // (swap: s2 / a2 / o2 are set by every proposal outcome)
+        if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         if (STEP == SMOLMC_STEP_FLIP) {
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(sel4(P.m_ncodes, sub1) - 1));
             n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
             nfl = 1;
         } else {
-            int found = -1, fo = 0, fa = 0;
+            // (nested if / else: one conditional + one unconditional branch on the common
+            // first-candidate hit; see mc_lean_kernel)
+            nfl = 2;
+            n2 = o1;
+#define SMOLMC_CAND_MASK(J)                                                                        \
+    const int v##J = (int)occ[canda[J]];                                                           \
+    const unsigned long long m##J = __ballot(v##J != o1) & (0xEull << l4);
+#define SMOLMC_CAND_TAKE(J)                                                                        \
+    {                                                                                              \
+        const int b = __ffsll((long long)m##J) - 1;                                                \
+        s2 = (int)rdlane((uint32_t)cand[J], b);                                                    \
+        a2 = (int)rdlane((uint32_t)canda[J], b);                                                   \
+        o2 = (int)rdlane((uint32_t)v##J, b);                                                       \
+        if (J == 0) fb = b;                                                                        \
+    }
+            SMOLMC_CAND_MASK(0)
+            if (m0) SMOLMC_CAND_TAKE(0)
+            else {
+                SMOLMC_CAND_MASK(1)
+                if (m1) SMOLMC_CAND_TAKE(1)
+                else {
+                    SMOLMC_CAND_MASK(2)
+                    if (m2) SMOLMC_CAND_TAKE(2)
+                    else {
+                        SMOLMC_CAND_MASK(3)
+                        if (m3) SMOLMC_CAND_TAKE(3)
+                        else {
+                            bool hit = false;
+                            const int sb = sel4(P.m_sbase, sub1);
+                            const uint32_t na = (uint32_t)sel4(P.m_nact, sub1);
+                            for (uint32_t q = 0;; ++q) {
+                                const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                                                                   4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                                int selsite = -1, selv = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (found < 0) {
-                    const int v = (int)occ[canda[j]];
-                    const unsigned long long m = __ballot(v != o1) & (0xEull << l4);
-                    if (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        found = (int)rdlane((uint32_t)cand[j], b);
-                        fa = (int)rdlane((uint32_t)canda[j], b);
-                        fo = (int)rdlane((uint32_t)v, b);
-                        if (j == 0) fb = b;
+                                for (int j = 3; j >= 0; --j) {
+                                    const int cs = sb + (int)__umulhi(o.w[j], na);
+                                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                                    if (v != o1) { selsite = cs; selv = v; }
+                                }
+                                const unsigned long long m = __ballot(selsite >= 0);
+                                if (m) {
+                                    const int b = __ffsll((long long)m) - 1;
+                                    s2 = (int)rdlane((uint32_t)selsite, b);
+                                    a2 = lean_swz(s2, swa, swm, swb);
+                                    o2 = (int)rdlane((uint32_t)selv, b);
+                                    hit = true;
+                                    break;
+                                }
+                                if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
+                                    int any = 0;
+                                    for (uint32_t a = lane; a < na; a += 64)
+                                        any |= ((int)occ[lean_swz(sb + (int)a, swa, swm, swb)] != o1);
+                                    if (__ballot(any) == 0ull) break;
+                                }
+                            }
+                            if (!hit) { nfl = 0; s2 = s1; a2 = a1; o2 = o1; }
+                        }
                     }
                 }
             }
-            if (found < 0) {
-                const int sb = sel4(P.m_sbase, sub1);
-                const uint32_t na = (uint32_t)sel4(P.m_nact, sub1);
-                for (uint32_t q = 0;; ++q) {
-                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
-                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
-                    int selsite = -1, selv = 0;
-#pragma unroll
-                    for (int j = 3; j >= 0; --j) {
-                        const int cs = sb + (int)__umulhi(o.w[j], na);
-                        const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
-                        if (v != o1) { selsite = cs; selv = v; }
-                    }
-                    const unsigned long long m = __ballot(selsite >= 0);
-                    if (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        found = (int)rdlane((uint32_t)selsite, b);
-                        fa = lean_swz(found, swa, swm, swb);
-                        fo = (int)rdlane((uint32_t)selv, b);
-                        break;
-                    }
-                    if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step
-                        int any = 0;
-                        for (uint32_t a = lane; a < na; a += 64)
-                            any |= ((int)occ[lean_swz(sb + (int)a, swa, swm, swb)] != o1);
-                        if (__ballot(any) == 0ull) break;
-                    }
-                }
-            }
-            if (found >= 0) { s2 = found; a2 = fa; o2 = fo; n1 = o2; n2 = o1; nfl = 2; }
-            else { nfl = 0; n1 = o1; s2 = s1; a2 = a1; o2 = o1; n2 = o1; }
+#undef SMOLMC_CAND_MASK
+#undef SMOLMC_CAND_TAKE
+            n1 = o2;
         }
         RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
@@ -238,13 +268,17 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
-                const MultiRec rc = rec1[it * 64];
+                const MultiRec rc = ONE ? rcs[ONE ? it : 0] : rec1[it * 64];
                 uint32_t a = rc.doff8;
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
                 d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
                 e = fma(rc.w, d1[it], e);
             }
+        }
+        if (ONE) { // (see above: row1's last use, the gathers of flip 1, has been issued)
+            have_row1 = l4 < 60;
+            if (have_row1) row1 = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
         }
         double ew_uni = 0.0, dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
@@ -258,7 +292,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
-                const MultiRec rc = rec1[it * 64]; // both sites of a swap share the sublattice / class
+                const MultiRec rc = ONE ? rcs[ONE ? it : 0] : rec1[it * 64]; // both sites of a swap share the sublattice / class
                 uint32_t a = rc.doff8;
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
@@ -331,7 +365,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         } else if (STEP == SMOLMC_STEP_SWAP) {
             occ[a1] = (uint8_t)o1;
         }
-        row1 = rown;
+        if (!ONE) row1 = rown;
 
         if (P.smp.every && --smp_countdown == 0) {
             smp_countdown = (uint32_t)P.smp.every;
@@ -395,7 +429,9 @@ template <int NSLOT, int MM, int STEP, bool MU, bool EW>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW>;
+    // one site class with more than 256 clusters per site: slot records in registers
+    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8>
+                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));

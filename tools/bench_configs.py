@@ -51,6 +51,16 @@ def main():
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
         occ, T, flips_per_step = rand_occ(sc, R, 1, True), 2500.0, 2
         name = "config1: binary FCC conventional 4x4x4, pairs, canonical swap"
+    elif a.config == 8:
+        # (not in BASELINE.json) a larger expansion on the config-2 lattice: pairs to 6.5 A and
+        # triplets to 5.2 A = 451 clusters per site -> mc_lean_multi_kernel with 8 slots per lane
+        model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.5, 3: 5.2})
+        sc = synth.build_supercell(model, [a.dim or 16] * 3)
+        tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=20260928))
+        R, mc = a.replicas or 4096, a.mc or 2000
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+        occ, T, flips_per_step = rand_occ(sc, R, 1, True), 2500.0, 2
+        name = "config8: binary FCC 16^3 (4096 sites), pairs <= 6.5 A + triplets <= 5.2 A (451 clusters/site), canonical swap"
     elif a.config == 3:
         # ternary rocksalt 12^3 + Ewald, semigrand flip with mu table
         d = a.dim or 12
