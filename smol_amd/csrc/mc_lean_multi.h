@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     float thr_lo = 0.0f, thr_hi = 0.0f;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    uint32_t smp_countdown = (uint32_t)P.smp.every;
+    uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
     long long smp_index = 0;
     constexpr int ROW = NSLOT * MM;
     constexpr int NW = ROW / 2;
@@ -367,30 +367,35 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         }
         if (!ONE) row1 = rown;
 
-        if (P.smp.every && --smp_countdown == 0) {
-            smp_countdown = (uint32_t)P.smp.every;
-            const size_t row = (size_t)smp_index * P.R + r;
+        if (--smp_countdown == 0) {
+            const LeanParamsKernarg Q = rare_params(); // (sampling parameters re-read from the kernel arguments)
+            const int qF = Q->F, qFce = Q->Fce;
+            double *const q_feat = Q->smp.feat;
+            const LeanSlot *const q_slots = Q->slots;
+            smp_countdown = (uint32_t)Q->smp.every;
+            const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
             s_feat[lane] = 0.0;
             double lane_e = 0.0;
             for (int i = lane; i < nrec; i += 64) {
-                const LeanSlot sl = P.slots[i];
+                const LeanSlot sl = q_slots[i];
                 const double v = s_acc[i];
                 lane_e = fma(sl.w, v, lane_e);
                 if (sl.live && v != 0.0)
                     __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
-            if (HAS_EW && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
-            if (HAS_MU && lane == P.Fce + (HAS_EW ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
-            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0));
+            if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
+            if (HAS_EW && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
+            if (HAS_MU && lane == qFce + (HAS_EW ? 1 : 0)) q_feat[row * qF + lane] = base_feat + acc_mu;
+            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? Q->ew_coef * acc_ew : 0.0));
             if (lane == 0) {
-                P.smp.H[row] = Hnow;
-                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+                Q->smp.H[row] = Hnow;
+                Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
             }
-            if (P.smp.occ) {
-                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
-                for (int i = lane; i < P.Npad / 4; i += 64)
+            if (Q->smp.occ) {
+                const int qNpad = Q->Npad;
+                uint32_t *dst = (uint32_t *)(Q->smp.occ + row * qNpad);
+                for (int i = lane; i < qNpad / 4; i += 64)
                     dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
             }
         }
