@@ -16,10 +16,24 @@ from smol_amd.capi import smolmc_config, smolmc_tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_SO_NAME = "libsmolmc_oracle.so"
+
+
+def use_fast_math_build():
+    """Select the second build of the same source with the reference's own flag set
+    (-O3 -ffast-math -fopenmp, setup.py:18-25).  Only the cpu_baseline leg of bench.py calls
+    this, before the library is first used; the tests keep the IEEE build because replayed
+    uniforms carry NaN for "not drawn".  Returns the flags of the build in use."""
+    global _SO_NAME
+    if _LIB is not None:
+        raise RuntimeError("oracle library already loaded")
+    _SO_NAME = "libsmolmc_oracle_fast.so"
+    return "-O3 -ffast-math -fopenmp"
+
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libsmolmc_oracle.so")
+    so = os.path.join(_HERE, _SO_NAME)
     src = os.path.join(_HERE, "smolmc_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "smolmc.h")
     stale = (not os.path.exists(so)) or any(

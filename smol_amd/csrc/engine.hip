@@ -1351,6 +1351,23 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
         HIPCHK(hipMemcpy(kp.wl_m, m0.data(), R * 8, hipMemcpyHostToDevice));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU) {
+        // The bin of the CURRENT enthalpy indexes the entropy / histogram arrays unchecked in the
+        // kernels (only proposed enthalpies are tested against the window, wanglandau.py:190-193).
+        // The reference raises IndexError above the window and wraps to a wrong bin below it
+        // (negative Python index, wanglandau.py:175-180); here both are refused up front.
+        std::vector<double> H0(R);
+        HIPCHK(hipMemcpy(H0.data(), kp.enthalpy, R * 8, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < R; ++r)
+            if (!(H0[r] >= h->cfg.wl_min_enthalpy && H0[r] < h->cfg.wl_max_enthalpy)) {
+                char msg[200];
+                snprintf(msg, sizeof msg,
+                         "initial enthalpy %.6f of walker %zu is outside the Wang-Landau window "
+                         "[min_enthalpy, max_enthalpy) = [%.6f, %.6f)",
+                         H0[r], r, h->cfg.wl_min_enthalpy, h->cfg.wl_max_enthalpy);
+                return fail(msg);
+            }
+    }
     return 0;
 }
 

@@ -15,8 +15,19 @@ from . import capi
 
 FORMAT_VERSION = 1
 _SCALARS = ("num_sites", "size", "num_orbits", "num_corr", "max_species", "n_orb", "feature_mode",
-            "has_ewald", "ewald_dim", "ewald_width", "has_mu", "mu_width", "n_sublattices")
-_FLOATS = ("offset", "ewald_coef")
+            "has_ewald", "ewald_dim", "ewald_width", "has_mu", "mu_width", "n_sublattices",
+            "n_flip_vectors", "bias_type", "bias_width")
+_FLOATS = ("offset", "ewald_coef", "swap_weight", "bias_penalty")
+# every array a TableSet keeps alive; a file holding anything else was written by a newer
+# exporter and must not be loaded as if the extra tables were absent
+_ARRAYS = frozenset((
+    "orb_id", "orb_bit_id", "orb_nsites", "orb_nfunc", "orb_tensor_len", "orb_stride_off",
+    "tensor_indices", "orb_ctensor_off", "corr_tensors", "orb_itensor_off", "interaction_tensors",
+    "full_off", "full_idx", "site_ptr", "loc_orbit", "loc_ratio", "loc_nrows", "loc_off", "loc_idx",
+    "ce_coefs", "ewald_inds", "ewald_matrix", "ewald_charges", "mu_table", "sub_site_ptr",
+    "sub_active_sites", "sub_code_ptr", "sub_codes", "sub_probs", "flip_table", "flip_weights",
+    "bias_table",
+))
 
 
 def save_tables(path, tab: capi.TableSet):
@@ -40,6 +51,9 @@ def load_tables(path) -> capi.TableSet:
     if int(d["format_version"]) != FORMAT_VERSION:
         raise ValueError("unsupported table file version")
     A = {k[4:]: d[k] for k in d.files if k.startswith("arr_")}
+    unknown = sorted(set(A) - _ARRAYS)
+    if unknown:
+        raise ValueError(f"table file holds arrays this loader does not know: {unknown}")
     n_orb = int(d["n_orb"])
     N = int(d["num_sites"])
     orbit_data, full, its = [], [], [float(d["offset"])]
@@ -78,6 +92,11 @@ def load_tables(path) -> capi.TableSet:
         ewald_coef=float(d["ewald_coef"]),
         mu_table=A["mu_table"] if has_mu else None,
         ewald_charges=A.get("ewald_charges"),
+        flip_table=A.get("flip_table"),
+        flip_weights=A.get("flip_weights"),
+        swap_weight=float(d["swap_weight"]) if "swap_weight" in d.files else 0.1,
     )
     tab.struct.max_species = int(d["max_species"])
+    if "bias_table" in A:  # MCBias term (files written before it was persisted have none)
+        tab.set_bias(int(d["bias_type"]), A["bias_table"], float(d["bias_penalty"]))
     return tab

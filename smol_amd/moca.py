@@ -71,7 +71,8 @@ class Sublattice:
     def __init__(self, species, sites, charges=None):
         self.species = tuple(species)
         # oxidation state of every species (0 for a vacancy); used by CompositionSpace
-        self.charges = tuple(0 if q is None else q for q in (charges or [0] * len(self.species)))
+        given = [0] * len(self.species) if charges is None else list(charges)
+        self.charges = tuple(0 if q is None else q for q in given)
         self.sites = np.unique(np.asarray(sites, dtype=np.int64))
         self.active_sites = self.sites.copy()
         if len(self.species) <= 1:
@@ -521,7 +522,10 @@ class Ensemble:
         return tab
 
     def _eval(self):
-        key = (id(self._mu_table), tuple(len(s.active_sites) for s in self._sublattices))
+        # content key: a different restriction of the same size, or a new mu table that reuses
+        # the id() of a freed one, must rebuild the handle
+        key = (None if self._mu_table is None else self._mu_table.tobytes(),
+               tuple(np.asarray(s.active_sites).tobytes() for s in self._sublattices))
         if getattr(self, "_eval_key", None) != key:
             self._eval_tables = self.make_tables()
             self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
@@ -770,61 +774,95 @@ def mckernel_factory(kernel_type, ensemble, step_type, *args, **kwargs):
 
 
 # --------------------------------------------------------------------------- #
+# sample storage
+# --------------------------------------------------------------------------- #
+def _merge_walkers(a):
+    """(samples, walkers, ...) -> (samples * walkers, ...), sample-major, singleton axes dropped
+    (what the reference calls "flat", container.py:514-519)."""
+    return np.squeeze(a.reshape((a.shape[0] * a.shape[1],) + a.shape[2:]))
+
+
 class SampleContainer:
-    """In-memory sample storage (smol/moca/sampler/container.py:25-660, HDF5 parts omitted:
-    h5py is not available; use to_npz / from_npz)."""
+    """Thinned samples of one Sampler (interface of smol/moca/sampler/container.py:25-660).
+
+    Storage follows the engine, not the reference's pre-allocated append-and-slice arrays: the
+    device ring of ``smolmc_run_sampled`` hands over whole *blocks* of samples
+    ``(n, nwalkers, ...)``; the container keeps the blocks as delivered and joins them once,
+    lazily, when a getter first needs them.  ``allocate`` / ``vacuum`` therefore have nothing
+    to do and exist only because callers written for smol invoke them.  The HDF5 backend is
+    replaced by ``to_npz`` / ``from_npz`` (h5py is not available)."""
 
     def __init__(self, ensemble, sample_trace, sampling_metadata=None):
         self._ensemble = ensemble
         self.natural_parameters = ensemble.natural_parameters
         self._num_energy_coefs = ensemble.num_energy_coefs
-        self._trace = sample_trace
         self.metadata = dict(sampling_metadata or {})
-        self._nsamples = 0
+        # name -> (dtype, per-sample shape): the schema of a block
+        self._schema = {k: (v.dtype, tuple(v.shape[1:])) for k, v in sample_trace.items()}
+        self._blocks = [{k: v for k, v in sample_trace.items()}] if len(sample_trace.occupancy) else []
+        self._joined = None
         self._total_steps = 0
-        self._aux_checkpoint = None
+
+    # ---- block store ---------------------------------------------------------------
+    def append_block(self, block, thinned_by):
+        """Append ``n`` consecutive samples: ``block[name]`` has shape (n, nwalkers, ...)."""
+        n = len(block["occupancy"])
+        entry = {}
+        for name, (dtype, shape) in self._schema.items():
+            arr = np.asarray(block[name], dtype=dtype)
+            entry[name] = arr.reshape((n,) + shape)
+        self._blocks.append(entry)
+        self._joined = None
+        self._total_steps += n * int(thinned_by)
+
+    def save_sampled_trace(self, trace, thinned_by):
+        """One sample (container.py:384-397): a block of length one."""
+        self.append_block({k: np.asarray(v)[None] for k, v in trace.items()}, thinned_by)
+
+    def _all(self):
+        if self._joined is None:
+            if len(self._blocks) > 1:
+                self._blocks = [{k: np.concatenate([b[k] for b in self._blocks]) for k in self._schema}]
+            self._joined = self._blocks[0] if self._blocks else {
+                k: np.empty((0,) + shape, dtype=dt) for k, (dt, shape) in self._schema.items()}
+        return self._joined
 
     @property
-    def ensemble(self):
-        return self._ensemble
+    def _trace(self):
+        return Trace(**self._all())
 
-    @property
-    def sublattices(self):
-        return self._ensemble.sublattices
+    def allocate(self, nsamples):
+        """No-op: blocks arrive sized by the device ring (container.py:409-413 pre-allocates)."""
 
-    @property
-    def num_samples(self):
-        return self._nsamples
+    def vacuum(self):
+        """No-op: there is no slack to give back (container.py:415-418)."""
 
-    @property
-    def total_mc_steps(self):
-        return self._total_steps
+    def clear(self):
+        self._blocks, self._joined, self._total_steps = [], None, 0
 
-    @property
-    def shape(self):
-        return self._trace.occupancy.shape[1:]
-
-    @property
-    def traced_values(self):
-        return self._trace.names
+    # ---- bookkeeping -----------------------------------------------------------------
+    ensemble = property(lambda self: self._ensemble)
+    sublattices = property(lambda self: self._ensemble.sublattices)
+    num_samples = property(lambda self: sum(len(b["occupancy"]) for b in self._blocks))
+    total_mc_steps = property(lambda self: self._total_steps)
+    shape = property(lambda self: self._schema["occupancy"][1])
+    traced_values = property(lambda self: tuple(self._schema))
 
     def __len__(self):
-        return self._nsamples
+        return self.num_samples
 
     def sampling_efficiency(self, discard=0, flat=True):
-        total_accepted = self._trace.accepted[discard:self._nsamples].sum(axis=0)
-        efficiency = total_accepted / (self._nsamples - discard)
-        return efficiency.mean() if flat else efficiency
+        """Fraction of recorded samples whose last step was accepted (container.py:131-142)."""
+        acc = self._all()["accepted"][discard:]
+        eff = acc.mean(axis=0)
+        return eff.mean() if flat else eff
 
-    @staticmethod
-    def _flatten(traced_values):
-        shape_l = list(traced_values.shape[1:])
-        shape_l[0] = int(np.prod(traced_values.shape[:2]))
-        return np.squeeze(traced_values.reshape(shape_l))
-
+    # ---- selection + reductions --------------------------------------------------------
     def get_trace_value(self, name, discard=0, thin_by=1, flat=True):
-        value = getattr(self._trace, name)[: self._nsamples][discard + thin_by - 1:: thin_by]
-        return self._flatten(value) if flat else value
+        """Samples discard + thin_by - 1, discard + 2 thin_by - 1, ... of one traced value
+        (the reference's selection rule, container.py:181-199)."""
+        picked = self._all()[name][discard + thin_by - 1:: thin_by]
+        return _merge_walkers(picked) if flat else picked
 
     def mean_trace_value(self, name, discard=0, thin_by=1, flat=True):
         return self.get_trace_value(name, discard, thin_by, flat).mean(axis=0)
@@ -832,62 +870,31 @@ class SampleContainer:
     def trace_value_variance(self, name, discard=0, thin_by=1, flat=True):
         return self.get_trace_value(name, discard, thin_by, flat).var(axis=0)
 
-    def get_occupancies(self, discard=0, thin_by=1, flat=True):
-        return self.get_trace_value("occupancy", discard, thin_by, flat)
-
-    def get_enthalpies(self, discard=0, thin_by=1, flat=True):
-        return self.get_trace_value("enthalpy", discard, thin_by, flat)
-
-    def get_feature_vectors(self, discard=0, thin_by=1, flat=True):
-        return self.get_trace_value("features", discard, thin_by, flat)
-
     def get_temperatures(self, discard=0, thin_by=1):
         return self.get_trace_value("temperature", discard, thin_by)
 
     def get_energies(self, discard=0, thin_by=1, flat=True):
-        if len(self.natural_parameters) == self._num_energy_coefs:
-            return self.get_enthalpies(discard, thin_by, flat)
-        feats = self.get_feature_vectors(discard, thin_by, flat=False)
+        """Energy = natural parameters . features over the energy coefficients only
+        (the chemical work / bias terms are not part of it, container.py:217-233)."""
         n = self._num_energy_coefs
-        energies = np.expand_dims(feats[..., :n] @ self.natural_parameters[:n], axis=-1)
-        return self._flatten(energies) if flat else energies
+        if len(self.natural_parameters) == n:
+            return self.get_trace_value("enthalpy", discard, thin_by, flat)
+        feats = self.get_trace_value("features", discard, thin_by, flat=False)
+        energies = (feats[..., :n] @ self.natural_parameters[:n])[..., None]
+        return _merge_walkers(energies) if flat else energies
 
-    def mean_enthalpy(self, discard=0, thin_by=1, flat=True):
-        return self.get_enthalpies(discard, thin_by, flat).mean(axis=0)
-
-    def enthalpy_variance(self, discard=0, thin_by=1, flat=True):
-        return self.get_enthalpies(discard, thin_by, flat).var(axis=0)
-
-    def mean_energy(self, discard=0, thin_by=1, flat=True):
-        return self.get_energies(discard, thin_by, flat).mean(axis=0)
-
-    def energy_variance(self, discard=0, thin_by=1, flat=True):
-        return self.get_energies(discard, thin_by, flat).var(axis=0)
-
-    def mean_feature_vector(self, discard=0, thin_by=1, flat=True):
-        return self.get_feature_vectors(discard, thin_by, flat).mean(axis=0)
-
-    def feature_vector_variance(self, discard=0, thin_by=1, flat=True):
-        return self.get_feature_vectors(discard, thin_by, flat).var(axis=0)
-
-    def get_minimum_enthalpy(self, discard=0, thin_by=1, flat=True):
-        return self.get_enthalpies(discard, thin_by, flat).min(axis=0)
+    def _argmin_occupancy(self, values, discard, thin_by, flat):
+        where = values.argmin(axis=0)
+        occ = self.get_trace_value("occupancy", discard, thin_by, flat)
+        return occ[where] if flat else occ[where, np.arange(self.shape[0])][0]
 
     def get_minimum_enthalpy_occupancy(self, discard=0, thin_by=1, flat=True):
-        inds = self.get_enthalpies(discard, thin_by, flat).argmin(axis=0)
-        occ = self.get_occupancies(discard, thin_by, flat)
-        return occ[inds] if flat else occ[inds, np.arange(self.shape[0])][0]
+        return self._argmin_occupancy(self.get_enthalpies(discard, thin_by, flat), discard, thin_by, flat)
 
-    def get_species_counts(self, discard=0, thin_by=1, flat=True):
-        """Counts of every species code per sublattice (container.py:336-347)."""
-        occ = self.get_occupancies(discard, thin_by, flat)
-        out = {}
-        for s in self.sublattices:
-            sub = occ[..., s.sites]
-            for code, sp in zip(s.encoding, s.species):
-                out[sp] = out.get(sp, 0) + (sub == code).sum(axis=-1)
-        return out
+    def get_minimum_energy_occupancy(self, discard=0, thin_by=1, flat=True):
+        return self._argmin_occupancy(self.get_energies(discard, thin_by, flat), discard, thin_by, flat)
 
+    # ---- compositions --------------------------------------------------------------------
     def get_sublattice_species_counts(self, sublattice, discard=0, thin_by=1, flat=True):
         """Counts of each species of one sublattice, last axis ordered like its site space
         (container.py:349-382)."""
@@ -896,9 +903,18 @@ class SampleContainer:
                 "Sublattice provided is not recognized.\n Provide one included in the sublattices "
                 "attribute of this SampleContainer."
             )
-        occ = self.get_occupancies(discard, thin_by, flat=False)[..., sublattice.sites]
-        counts = np.stack([(occ == code).sum(axis=-1) for code in sublattice.encoding], axis=-1).astype(float)
-        return self._flatten(counts) if flat else counts
+        occ = self.get_trace_value("occupancy", discard, thin_by, flat=False)[..., sublattice.sites]
+        counts = (occ[..., None] == np.asarray(sublattice.encoding)).sum(axis=-2).astype(float)
+        return _merge_walkers(counts) if flat else counts
+
+    def get_species_counts(self, discard=0, thin_by=1, flat=True):
+        """Counts per species name summed over the sublattices that host it (container.py:336-347)."""
+        out = {}
+        for sub in self.sublattices:
+            counts = self.get_sublattice_species_counts(sub, discard, thin_by, flat)
+            for j, sp in enumerate(sub.species):
+                out[sp] = out.get(sp, 0) + counts[..., j].astype(np.int64)
+        return out
 
     def get_sublattice_compositions(self, sublattice, discard=0, thin_by=1, flat=True):
         return self.get_sublattice_species_counts(sublattice, discard, thin_by, flat) / len(sublattice.sites)
@@ -919,14 +935,6 @@ class SampleContainer:
     def sublattice_composition_variance(self, sublattice, discard=0, thin_by=1, flat=True):
         return self.get_sublattice_compositions(sublattice, discard, thin_by, flat).var(axis=0)
 
-    def get_minimum_energy(self, discard=0, thin_by=1, flat=True):
-        return self.get_energies(discard, thin_by, flat).min(axis=0)
-
-    def get_minimum_energy_occupancy(self, discard=0, thin_by=1, flat=True):
-        inds = self.get_energies(discard, thin_by, flat).argmin(axis=0)
-        occ = self.get_occupancies(discard, thin_by, flat)
-        return occ[inds] if flat else occ[inds, np.arange(self.shape[0])][0]
-
     def get_orbit_factors(self, function_orbit_ids, discard=0, thin_by=1, flat=True):
         """Sum of natural_parameter * feature over the functions of each orbit id
         (container.py:269-280)."""
@@ -934,107 +942,128 @@ class SampleContainer:
         ids = np.asarray(function_orbit_ids)
         return np.array([np.sum(vals[..., ids == i]) for i in range(len(self.natural_parameters))])
 
-    def save_sampled_trace(self, trace, thinned_by):
-        for name, value in trace.items():
-            getattr(self._trace, name)[self._nsamples] = value
-        self._nsamples += 1
-        self._total_steps += thinned_by
-
-    def clear(self):
-        self._total_steps = 0
-        self._nsamples = 0
-        for name, value in self._trace.items():
-            setattr(self._trace, name, np.empty((0, *value.shape[1:]), dtype=value.dtype))
-
-    def allocate(self, nsamples):
-        for name, value in self._trace.items():
-            arr = np.empty((nsamples, *value.shape[1:]), dtype=value.dtype)
-            setattr(self._trace, name, np.append(value[: self._nsamples], arr, axis=0))
-
-    def vacuum(self):
-        for name, value in self._trace.items():
-            setattr(self._trace, name, value[: self._nsamples])
-
+    # ---- persistence -----------------------------------------------------------------------
     def to_npz(self, path):
-        """Checkpoint samples (.npz stand-in for to_hdf5, container.py:615): one array per
-        trace name + nsamples / total_mc_steps, like the HDF5 'trace' group (Appendix D)."""
-        np.savez_compressed(
-            path, nsamples=self._nsamples, total_mc_steps=self._total_steps,
-            **{f"trace/{k}": v[: self._nsamples] for k, v in self._trace.items()},
-        )
+        """Checkpoint (.npz stand-in for to_hdf5, container.py:615): one array per trace name +
+        nsamples / total_mc_steps, like the HDF5 'trace' group."""
+        np.savez_compressed(path, nsamples=self.num_samples, total_mc_steps=self._total_steps,
+                            **{f"trace/{k}": v for k, v in self._all().items()})
 
     @classmethod
     def from_npz(cls, path, ensemble):
         d = np.load(path)
-        trace = Trace(**{k[6:]: d[k] for k in d.files if k.startswith("trace/")})
-        c = cls(ensemble, trace)
-        c._nsamples, c._total_steps = int(d["nsamples"]), int(d["total_mc_steps"])
+        n = int(d["nsamples"])
+        arrays = {k[6:]: d[k][:n] for k in d.files if k.startswith("trace/")}
+        c = cls(ensemble, Trace(**{k: v[:0] for k, v in arrays.items()}))
+        c.append_block(arrays, 0)
+        c._total_steps = int(d["total_mc_steps"])
         return c
+
+
+def _install_reductions():
+    """get_X / mean_X / X_variance / get_minimum_X for the scalar-like traced values: the
+    reference writes these ~20 methods out one by one (container.py:201-333); they all are one
+    selection followed by one NumPy reduction."""
+    plural = {"occupancy": "occupancies", "enthalpy": "enthalpies", "features": "feature_vectors"}
+    singular = {"enthalpy": "enthalpy", "features": "feature_vector", "energy": "energy"}
+
+    def selector(field):
+        def get(self, discard=0, thin_by=1, flat=True):
+            return self.get_trace_value(field, discard, thin_by, flat)
+        return get
+
+    for field, name in plural.items():
+        fn = selector(field)
+        fn.__name__ = f"get_{name}"
+        setattr(SampleContainer, fn.__name__, fn)
+
+    def reducer(getter_name, how):
+        def red(self, discard=0, thin_by=1, flat=True):
+            return getattr(getattr(self, getter_name)(discard, thin_by, flat), how)(axis=0)
+        return red
+
+    for field, name in singular.items():
+        getter = "get_energies" if field == "energy" else f"get_{plural[field]}"
+        for pattern, how in ((f"mean_{name}", "mean"), (f"{name}_variance", "var")):
+            fn = reducer(getter, how)
+            fn.__name__ = pattern
+            setattr(SampleContainer, pattern, fn)
+        if field != "features":
+            fn = reducer(getter, "min")
+            fn.__name__ = f"get_minimum_{name}"
+            setattr(SampleContainer, fn.__name__, fn)
+
+
+_install_reductions()
 
 
 # --------------------------------------------------------------------------- #
 class Sampler:
-    """MCMC driver (smol/moca/sampler/sampler.py:22-445) on the batched GPU engine."""
+    """MCMC driver (smol/moca/sampler/sampler.py:22-445) on the batched GPU engine.
 
-    def __init__(self, kernels, container, engine=None):
+    Multi-GPU: walkers are independent (sampler.py:111-116,436-440), so a Sampler built with
+    ``rank`` / ``world_size`` (default: taken from an initialised torch.distributed process
+    group, else a single rank) owns only its contiguous block ``walker_range`` of the
+    ``nwalkers`` global walkers on the device of its rank.  Seeds and initial occupancies are
+    indexed by GLOBAL walker, so walker g runs the same chain whatever the world size;
+    ``global_statistics`` all-reduces the running sums over ranks (RCCL), the only collective."""
+
+    def __init__(self, kernels, container, engine=None, walker_range=None, device=0, world_size=1):
         self._kernels = kernels
         self._container = container
         self._container.metadata["kernels"] = [k.spec for k in kernels]
         self._engine = engine
         self._engine_key = None
+        self._walker_range = walker_range or (0, len(kernels))
+        self._device, self._world = int(device), int(world_size)
 
     @classmethod
     def from_ensemble(cls, ensemble, *args, step_type=None, kernel_type=None, seeds=None,
-                      nwalkers=1, **kwargs):
+                      nwalkers=1, rank=None, world_size=None, device=None, **kwargs):
         """sampler.py:52-139: default step 'flip' when chemical potentials are set else
         'swap'; default kernel Metropolis; one kernel (seed) per walker."""
+        from . import parallel
+
         if step_type is None:
             step_type = "flip" if ensemble.chemical_potentials is not None else "swap"
         if kernel_type is None:
             kernel_type = "Metropolis"
-        if seeds is not None:
-            if len(seeds) != nwalkers:
-                raise ValueError("Number of seeds does not match number of kernels!")
-        else:
-            seeds = [None for _ in range(nwalkers)]
+        if seeds is not None and len(seeds) != nwalkers:
+            raise ValueError("Number of seeds does not match number of kernels!")
+        if rank is None or world_size is None:
+            rank, world_size = parallel.rank_and_world()
+        first, count = parallel.shard(nwalkers, rank, world_size)
+        if count == 0:
+            raise ValueError(f"rank {rank} of {world_size} would own no walker: nwalkers={nwalkers}")
+        local_seeds = [None] * count if seeds is None else list(seeds[first:first + count])
         kernels = [mckernel_factory(kernel_type, ensemble, step_type, *args, seed=s, **kwargs)
-                   for s in seeds]
+                   for s in local_seeds]
         k0 = kernels[0]
         F = len(ensemble.natural_parameters)
-        fields = dict(
-            occupancy=np.empty((0, nwalkers, ensemble.num_sites), dtype=np.int32),
-            features=np.empty((0, nwalkers, F), dtype=np.float64),
-            enthalpy=np.empty((0, nwalkers, 1), dtype=np.float64),
-        )
+        per_walker = dict(occupancy=((ensemble.num_sites,), np.int32), features=((F,), np.float64),
+                          enthalpy=((1,), np.float64))
         if isinstance(k0, Metropolis):
-            fields["temperature"] = np.empty((0, nwalkers, 1), dtype=np.float64)
-        fields["accepted"] = np.empty((0, nwalkers, 1), dtype=bool)
+            per_walker["temperature"] = ((1,), np.float64)
+        per_walker["accepted"] = ((1,), bool)
         if k0.bias is not None:  # trace.bias (kernel/base.py:362-363)
-            fields["bias"] = np.empty((0, nwalkers, 1), dtype=np.float64)
-        if isinstance(k0, WangLandau):
+            per_walker["bias"] = ((1,), np.float64)
+        if isinstance(k0, WangLandau):  # wanglandau.py:268-288
             L = len(k0._levels)
-            fields.update(
-                histogram=np.empty((0, nwalkers, L), dtype=np.int64),
-                occurrences=np.empty((0, nwalkers, L), dtype=np.int64),
-                entropy=np.empty((0, nwalkers, L), dtype=np.float64),
-                cumulative_mean_features=np.empty((0, nwalkers, L, F), dtype=np.float64),
-                mod_factor=np.empty((0, nwalkers, 1), dtype=np.float64),
-            )
-        container = SampleContainer(ensemble, Trace(**fields), ensemble.thermo_boundaries)
-        return cls(kernels, container)
+            per_walker.update(histogram=((L,), np.int64), occurrences=((L,), np.int64),
+                              entropy=((L,), np.float64), cumulative_mean_features=((L, F), np.float64),
+                              mod_factor=((1,), np.float64))
+        schema = Trace(**{k: np.empty((0, count) + shp, dtype=dt) for k, (shp, dt) in per_walker.items()})
+        container = SampleContainer(ensemble, schema, ensemble.thermo_boundaries)
+        container.metadata["walker_range"] = (first, count, nwalkers)
+        if device is None:
+            device = parallel.local_device(rank)
+        return cls(kernels, container, walker_range=(first, count), device=device, world_size=world_size)
 
     # -- accessors -----------------------------------------------------------------
-    @property
-    def mckernels(self):
-        return self._kernels
-
-    @property
-    def seeds(self):
-        return [k.seed for k in self._kernels]
-
-    @property
-    def samples(self):
-        return self._container
+    mckernels = property(lambda self: self._kernels)
+    seeds = property(lambda self: [k.seed for k in self._kernels])
+    samples = property(lambda self: self._container)
+    walker_range = property(lambda self: self._walker_range)
 
     @property
     def engine(self):
@@ -1046,25 +1075,64 @@ class Sampler:
     def clear_samples(self):
         self.samples.clear()
 
+    def global_statistics(self, discard=0):
+        """Sums over ALL walkers of ALL ranks of the recorded samples: walkers, samples, mean
+        enthalpy, enthalpy variance, acceptance.  One all-reduce of five float64 (identity
+        without a process group)."""
+        import torch
+
+        from . import parallel
+
+        H = self.samples.get_enthalpies(discard=discard, flat=False).astype(np.float64)
+        acc = self.samples.get_trace_value("accepted", discard=discard, flat=False)
+        local = torch.tensor([float(H.shape[1]), float(H.size), float(H.sum()), float((H * H).sum()),
+                              float(acc.sum())], dtype=torch.float64)
+        if parallel.collective_device() == "cuda":
+            local = local.cuda(self._device)
+        w, n, s1, s2, a = parallel.global_sums(local).cpu().numpy()
+        mean = s1 / max(n, 1.0)
+        return dict(walkers=int(w), samples=int(n), mean_enthalpy=mean,
+                    enthalpy_variance=s2 / max(n, 1.0) - mean * mean, acceptance=a / max(n, 1.0))
+
     # -- engine plumbing -------------------------------------------------------------
-    def _get_engine(self, device=0):
+    def _model_key(self):
+        """Content key of everything baked into the engine handle: the chemical-potential table,
+        the active sites of every sublattice and the bias table (an id()/count key would miss a
+        different restriction of the same size or a recycled id)."""
+        import hashlib
+
         k0 = self._kernels[0]
         ens = k0.ensemble
-        key = (id(ens._mu_table), tuple(len(s.active_sites) for s in ens.sublattices), device, id(k0.bias))
+        h = hashlib.blake2b(digest_size=16)
+        mu = ens._mu_table
+        h.update(b"mu" if mu is None else np.ascontiguousarray(mu).tobytes())
+        for sub in ens.sublattices:
+            h.update(np.ascontiguousarray(sub.active_sites, dtype=np.int64).tobytes() + b"|")
+        if k0.bias is not None:
+            h.update(np.ascontiguousarray(k0.bias._table).tobytes())
+            h.update(repr((k0.bias.bias_type, k0.bias.penalty)).encode())
+        return h.hexdigest(), self._device
+
+    def _get_engine(self, device=None):
+        if device is not None:
+            self._device = int(device)
+        k0 = self._kernels[0]
+        ens = k0.ensemble
+        key = self._model_key()
         if self._engine is None or self._engine_key != key:
             tables = ens.make_tables(**k0.usher_kwargs)
             if k0.bias is not None:
                 tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty)
             if isinstance(k0, WangLandau):
                 cfg = capi.make_config(
-                    len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], device,
+                    len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], self._device,
                     min_enthalpy=k0._window[0], max_enthalpy=k0._window[1], bin_size=k0._window[2],
                     flatness=k0.flatness, mod_factor=k0._m0, mod_update=k0._mod_divisor,
                     check_period=k0.check_period, update_period=k0.update_period,
                 )
             else:
                 cfg = capi.make_config(len(self._kernels), capi.KERNEL_METROPOLIS,
-                                       STEP_TYPES[k0.step_type], device)
+                                       STEP_TYPES[k0.step_type], self._device)
             self._engine = Engine(tables, cfg)
             self._engine_key = key
             self._state_loaded = False
@@ -1073,21 +1141,29 @@ class Sampler:
     def _temperatures(self):
         return np.array([getattr(k, "temperature", 0.0) for k in self._kernels], dtype=np.float64)
 
-    def _reshape_occu(self, occupancies):
-        """sampler.py:442-end: allow a 1-D occupancy for a single walker."""
-        if occupancies.ndim == 1 and self.samples.shape[0] == 1:
-            return occupancies.reshape(1, -1)
-        raise AttributeError(
-            "The given initial occupancies have incompompatible dimensions. Shape should be "
-            f"{self.samples.shape}."
-        )
+    def _local_occupancies(self, occupancies):
+        """Accepts this rank's walkers (count, N), all walkers (nwalkers, N) -- the rank takes
+        its block -- or a 1-D occupancy for a single walker (sampler.py:442-end)."""
+        occ = np.array(occupancies)
+        first, count = self._walker_range
+        nglobal = self.samples.metadata.get("walker_range", (0, count, count))[2]
+        N = self.samples.shape[1]
+        if occ.shape == (count, N):
+            pass
+        elif occ.shape == (nglobal, N):
+            occ = occ[first:first + count]
+        elif occ.ndim == 1 and count == 1 and occ.shape[0] == N:
+            occ = occ.reshape(1, N)
+        else:
+            raise AttributeError(
+                "The given initial occupancies have incompompatible dimensions. Shape should be "
+                f"{self.samples.shape}."
+            )
+        return occ.astype(np.int32)
 
     def setup_sample(self, initial_occupancies):
         """sampler.py:386-434: copy / reshape occupancies, set aux states, initial trace."""
-        occupancies = np.array(initial_occupancies).copy()
-        if occupancies.shape != self.samples.shape:
-            occupancies = self._reshape_occu(occupancies)
-        occupancies = occupancies.astype(np.int32)
+        occupancies = self._local_occupancies(initial_occupancies)
         eng = self._get_engine()
         seeds = np.array([k.seed64 for k in self._kernels], dtype=np.uint64)
         # a kernel's Generator, accept counters and WL aux arrays persist across run()
@@ -1100,27 +1176,26 @@ class Sampler:
     def _current_trace(self, eng):
         st = eng.get_state()
         nw = len(self._kernels)
-        tr = Trace(
-            occupancy=st["occupancy"],
-            features=st["features"],
-            enthalpy=st["enthalpy"].reshape(nw, 1),
-        )
-        if isinstance(self._kernels[0], Metropolis):
+        tr = Trace(occupancy=st["occupancy"], features=st["features"],
+                   enthalpy=st["enthalpy"].reshape(nw, 1))
+        k0 = self._kernels[0]
+        if isinstance(k0, Metropolis):
             tr.temperature = self._temperatures().reshape(nw, 1)
         tr.accepted = st["accepted"].reshape(nw, 1)
-        if self._kernels[0].bias is not None:
+        if k0.bias is not None:
             tr.bias = eng.get_bias().reshape(nw, 1)
-        if isinstance(self._kernels[0], WangLandau):
+        if isinstance(k0, WangLandau):
             wl = eng.get_wl()
-            tr.histogram = wl["histogram"]
-            tr.occurrences = wl["occurrences"]
-            tr.entropy = wl["entropy"]
+            tr.histogram, tr.occurrences, tr.entropy = wl["histogram"], wl["occurrences"], wl["entropy"]
             tr.cumulative_mean_features = wl["mean_features"]
             tr.mod_factor = wl["mod_factor"].reshape(nw, 1)
         return tr
 
-    def sample(self, nsteps, initial_occupancies, thin_by=1, progress=False):
-        """Generator over thinned traces (sampler.py:164-210); one launch per yield."""
+    def _sample_blocks(self, nsteps, initial_occupancies, thin_by):
+        """Generator over blocks of thinned samples, dict name -> (n, nwalkers, ...): the unit
+        the device ring delivers.  Metropolis without bias: ``smolmc_run_sampled`` records n
+        samples inside one launch; Wang-Landau and biased kernels (per-walker L x F arrays /
+        running bias in the trace) come back one sample per launch."""
         if nsteps % thin_by != 0:
             warnings.warn(
                 f"The number of steps {nsteps} is not a multiple of thin_by  {thin_by}. The last "
@@ -1130,41 +1205,38 @@ class Sampler:
         self.setup_sample(initial_occupancies)
         eng = self._get_engine()
         nsamples = nsteps // thin_by
-        if isinstance(self._kernels[0], WangLandau) or self._kernels[0].bias is not None:
-            # WL traces carry per-walker L x F arrays, biased kernels the running bias:
-            # fetched per sample
+        k0 = self._kernels[0]
+        if isinstance(k0, WangLandau) or k0.bias is not None:
             for _ in range(nsamples):
                 eng.run(thin_by)
-                yield self._current_trace(eng)
+                yield {k: v[None] for k, v in self._current_trace(eng).items()}
             return
-        # Metropolis: samples are recorded on the device (smolmc_run_sampled) and fetched in
-        # chunks sized to ~256 MiB of occupancies, one launch per chunk
-        nw, N = len(self._kernels), self._kernels[0].ensemble.num_sites
-        chunk = max(1, min(nsamples, (256 << 20) // max(1, nw * N * 4)))
-        temps = self._temperatures().reshape(nw, 1)
-        done = 0
-        while done < nsamples:
-            n = min(chunk, nsamples - done)
-            smp = eng.run_sampled(n, thin_by, occupancy=True)
-            for i in range(n):
-                yield Trace(
-                    occupancy=smp["occupancy"][i], features=smp["features"][i],
-                    enthalpy=smp["enthalpy"][i].reshape(nw, 1), temperature=temps,
-                    accepted=smp["accepted"][i].reshape(nw, 1),
-                )
-            done += n
+        nw, N = len(self._kernels), k0.ensemble.num_sites
+        per_block = max(1, min(nsamples, (256 << 20) // max(1, nw * N * 4)))  # ~256 MiB of occupancies
+        temps = self._temperatures().reshape(1, nw, 1)
+        for start in range(0, nsamples, per_block):
+            n = min(per_block, nsamples - start)
+            ring = eng.run_sampled(n, thin_by, occupancy=True)
+            yield dict(occupancy=ring["occupancy"], features=ring["features"],
+                       enthalpy=ring["enthalpy"][..., None], temperature=np.broadcast_to(temps, (n, nw, 1)),
+                       accepted=ring["accepted"][..., None])
+
+    def sample(self, nsteps, initial_occupancies, thin_by=1, progress=False):
+        """Generator over thinned traces, one Trace per sample (sampler.py:164-210)."""
+        for block in self._sample_blocks(nsteps, initial_occupancies, thin_by):
+            for i in range(len(block["occupancy"])):
+                yield Trace(**{k: np.asarray(v[i]) for k, v in block.items()})
 
     def run(self, nsteps, initial_occupancies=None, thin_by=1, progress=False, stream_chunk=0,
             stream_file=None, keep_last_chunk=False, swmr_mode=False):
-        """sampler.py:212-301."""
+        """sampler.py:212-301 (HDF5 streaming arguments are accepted and refused)."""
         if initial_occupancies is None:
-            try:
-                initial_occupancies = self.samples.get_occupancies(flat=False)[-1]
-            except IndexError as index_error:
+            if self.samples.num_samples == 0:
                 raise RuntimeError(
                     "There are no saved samples to obtain the initial occupancies."
                     "These must be provided."
-                ) from index_error
+                )
+            initial_occupancies = self.samples.get_occupancies(flat=False)[-1]
         elif self.samples.num_samples > 0:
             warnings.warn(
                 "Initial occupancies where provided with a pre-existing set of samples.\n Make "
@@ -1173,13 +1245,13 @@ class Sampler:
             )
         if stream_chunk > 0:
             raise NotImplementedError("HDF5 streaming is out of scope here (h5py absent); use to_npz")
-        self.samples.allocate(nsteps // thin_by)
-        for trace in self.sample(nsteps, initial_occupancies, thin_by=thin_by, progress=progress):
-            self.samples.save_sampled_trace(trace, thinned_by=thin_by)
+        for block in self._sample_blocks(nsteps, initial_occupancies, thin_by):
+            self.samples.append_block(block, thinned_by=thin_by)
 
     def anneal(self, temperatures, mcmc_steps, initial_occupancies=None, thin_by=1, progress=False,
                **kwargs):
-        """Simulated annealing (sampler.py:303-384)."""
+        """Simulated annealing (sampler.py:303-384): one ``run`` per temperature, each continuing
+        from the last sample of the previous one."""
         if not isinstance(self._kernels[0], Metropolis):
             raise AttributeError("anneal is only available for samplers with a thermal kernel")
         if temperatures[0] < temperatures[-1]:
@@ -1187,10 +1259,9 @@ class Sampler:
                 "End temperature is greater than start temperature "
                 f"{temperatures[-1]:.2f} > {temperatures[0]:.2f}."
             )
-        for kernel in self._kernels:
-            kernel.temperature = temperatures[0]
-        self.run(mcmc_steps, initial_occupancies=initial_occupancies, thin_by=thin_by, progress=progress)
-        for temperature in temperatures[1:]:
+        start = initial_occupancies
+        for temperature in temperatures:
             for kernel in self._kernels:
                 kernel.temperature = temperature
-            self.run(mcmc_steps, thin_by=thin_by, progress=progress)
+            self.run(mcmc_steps, initial_occupancies=start, thin_by=thin_by, progress=progress)
+            start = None

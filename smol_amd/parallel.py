@@ -33,6 +33,38 @@ def _dist():
     return dist
 
 
+def rank_and_world():
+    """(rank, world) of the initialised torch.distributed group, else (0, 1)."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def collective_device():
+    """Where tensors handed to a collective must live: "cuda" under RCCL ("nccl"), else "cpu"."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return "cuda"
+    return "cpu"
+
+
+def local_device(rank):
+    """HIP device ordinal of a rank: LOCAL_RANK when the launcher exports it (one process per
+    GPU; with per-rank device masking only device 0 is visible), else rank modulo the visible
+    devices, else 0."""
+    import os
+
+    try:
+        import torch
+
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        n = 0
+    lr = int(os.environ.get("LOCAL_RANK", rank))
+    return lr % n if n else 0
+
+
 def global_sums(local, group=None):
     """Sum a float64 tensor over all ranks (RCCL all-reduce); identity for one rank."""
     dist = _dist()
@@ -42,8 +74,9 @@ def global_sums(local, group=None):
 
 
 def _philox_uniforms(seed, counter, n):
-    """n uniforms in [0,1) from Philox4x32-10 keyed by ``seed`` at ``counter`` (same
-    generator as the engine; NumPy's implementation, identical on every rank)."""
+    """n uniforms in [0,1) from NumPy's counter-based Philox (Philox4x64, NOT the engine's
+    Philox4x32-10) keyed by ``seed`` at ``counter``: a pure function of (seed, counter), so
+    every rank draws the identical numbers without communicating."""
     bitgen = np.random.Philox(key=np.uint64(seed), counter=[0, 0, 0, np.uint64(counter)])
     return np.random.Generator(bitgen).random(n)
 
@@ -81,13 +114,16 @@ class ReplicaExchange:
         a = self.rank * self.per_rank
         return self.temperatures[a:a + self.per_rank].copy()
 
-    def gather(self, local_enthalpy):
+    def gather(self, local_enthalpy, force_collective=False):
         """All-gather the per-walker enthalpies (torch tensor, float64, len per_rank) into a
-        NumPy array of all walkers.  8 bytes per walker: latency-bound over xGMI."""
+        NumPy array of all walkers.  8 bytes per walker: latency-bound over xGMI.
+        ``force_collective`` runs the all-gather even for a single rank (a world-size-1 process
+        group), so that the multi-GPU code path can be exercised on one GPU."""
         import torch
 
         dist = _dist()
-        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+        ready = dist.is_available() and dist.is_initialized()
+        if not ready or (self.world == 1 and not force_collective):
             return local_enthalpy.detach().cpu().numpy().astype(np.float64)
         out = torch.empty(self.n, dtype=torch.float64, device=local_enthalpy.device)
         dist.all_gather_into_tensor(out, local_enthalpy.contiguous(), group=self.group)
@@ -116,9 +152,9 @@ class ReplicaExchange:
         self.calls += 1
         return [(int(k), int(k + 1)) for k in won]
 
-    def exchange(self, local_enthalpy):
+    def exchange(self, local_enthalpy, force_collective=False):
         """gather + decide; returns this rank's new temperatures (NumPy, len per_rank)."""
-        self.decide(self.gather(local_enthalpy))
+        self.decide(self.gather(local_enthalpy, force_collective))
         return self.local_temperatures()
 
     @property
@@ -131,29 +167,38 @@ def geometric_ladder(t_min, t_max, n):
     return np.geomspace(t_min, t_max, n)
 
 
-def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None):
+def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, collective=None):
     """Alternate ``steps_between`` MC steps on every walker with one exchange attempt.
 
     ``engine`` is a smol_amd.engine.Engine holding this rank's ``rex.per_rank`` walkers.
-    Multi-rank: the enthalpies are exported device-to-device into a torch tensor (the
-    all-gather runs on RCCL without staging through the host; initialise torch.cuda /
-    the process group BEFORE creating the engine, as bench.py does).  Single rank: no
-    collective is needed and the enthalpies are read back directly.  The new temperatures
-    are uploaded with set_temperature (per_rank doubles)."""
+    Collective path (several ranks, or ``collective=True``): the enthalpies are exported
+    device-to-device into a torch tensor (smolmc_export_enthalpy_dev), all-gathered on RCCL
+    without staging through the host, and the new temperatures go back through a device
+    tensor (smolmc_import_temperature_dev); initialise torch.cuda / the process group BEFORE
+    creating the engine, as bench.py does.  Single rank (default): no collective is needed,
+    the enthalpies are read back directly and the temperatures uploaded with set_temperature.
+    Both paths take the same decisions (tests/test_gpu_device_plumbing.py)."""
     dist = _dist()
-    multi = rex.world > 1 and dist.is_available() and dist.is_initialized()
-    buf = None
+    ready = dist.is_available() and dist.is_initialized()
+    multi = ready and (rex.world > 1 if collective is None else bool(collective))
+    if collective and not ready:
+        raise RuntimeError("collective=True needs an initialised torch.distributed process group")
+    buf = tbuf = None
     if multi:
         import torch
 
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         buf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
+        tbuf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
     engine.set_temperature(rex.local_temperatures())
     for _ in range(n_exchanges):
         engine.run(steps_between)
         if multi:
             engine.export_enthalpy(buf.data_ptr())
-            engine.set_temperature(rex.exchange(buf))
+            new_t = rex.exchange(buf, force_collective=True)
+            tbuf.copy_(torch.from_numpy(new_t))
+            torch.cuda.current_stream().synchronize()
+            engine.import_temperature(tbuf.data_ptr())
         else:
             rex.decide(engine.get_enthalpy())
             engine.set_temperature(rex.local_temperatures())

@@ -1,0 +1,195 @@
+"""The five BASELINE.json configurations (and three shapes outside it) as builders.
+
+One place defines the synthetic workloads so that ``bench.py`` (headline + ``other_configs``),
+``tools/bench_configs.py`` and the full-size tests measure / check the same thing.  Host setup
+only: tables come from smol_amd.synth / smol_amd.ewald, nothing here touches the GPU.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi, ewald, synth
+
+
+class Workload:
+    """tables + engine config + initial state of one configuration (this rank's walkers)."""
+
+    def __init__(self, key, name, sc, tables, config_kwargs, occupancy, seeds, temperature,
+                 flips_per_step, mc_per_launch, extras=None):
+        self.key, self.name, self.sc, self.tables = key, name, sc, tables
+        self.config_kwargs = config_kwargs
+        self.occupancy, self.seeds, self.temperature = occupancy, seeds, temperature
+        self.flips_per_step, self.mc_per_launch = flips_per_step, mc_per_launch
+        self.extras = extras or {}
+
+    @property
+    def n_walkers(self):
+        return len(self.occupancy)
+
+    def make_config(self, device=0):
+        kw = dict(self.config_kwargs)
+        return capi.make_config(self.n_walkers, kw.pop("kernel"), kw.pop("step"), device, **kw)
+
+
+def balanced_binary(sc, first, count, seed=1000):
+    """50/50 occupancies; walker g (global index) always gets the same start, so the job is
+    independent of how the walkers are sharded over ranks."""
+    occ = np.zeros((count, sc.num_sites), dtype=np.int32)
+    for i in range(count):
+        perm = np.random.default_rng(seed + first + i).permutation(sc.num_sites)
+        occ[i, perm[: sc.num_sites // 2]] = 1
+    return occ
+
+
+def random_codes(sc, first, count, seed):
+    nsp = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
+    out = np.zeros((count, sc.num_sites), np.int32)
+    for i in range(count):
+        out[i] = (np.random.default_rng(seed + first + i).random(sc.num_sites) * nsp).astype(np.int32)
+    return out
+
+
+def _seeds(first, count, base):
+    return np.arange(first, first + count, dtype=np.uint64) + np.uint64(base)
+
+
+def neutral_rocksalt_occupancy(sc, first, count, seed=5):
+    """Charge-neutral Li+/Mn3+/Ti4+ start on the cation sublattice of a rocksalt supercell
+    (2 n_Mn + 3 n_Ti = P with codes Li=0, Mn=1, Ti=2)."""
+    P = sc.size
+    n_ti = 2 * (P // 12)
+    n_mn = (P - 3 * n_ti) // 2
+    occ = np.zeros((count, sc.num_sites), np.int32)
+    for i in range(count):
+        perm = np.random.default_rng(seed * 100003 + first + i).permutation(P)
+        occ[i, perm[:n_mn]] = 1
+        occ[i, perm[n_mn:n_mn + n_ti]] = 2
+    return occ
+
+
+HEADLINE_T = 2500.0  # acceptance ~0.38 on the config-2 Hamiltonian (tuned once and frozen)
+
+
+def config2(first=0, count=4096, dim=16, feature_mode=capi.FEATURES_INTERACTIONS, mc=10000):
+    """BASELINE configs[1] (headline): binary FCC dim^3 primitive supercell, point + 4 pair + 2
+    triplet orbits (115 clusters per site), canonical swap Metropolis, ECI U(-0.02, 0.02) eV."""
+    model = synth.build_cluster_model(synth.fcc_prim(a=4.09), {2: 6.0, 3: 5.0})
+    sc = synth.build_supercell(model, [dim] * 3)
+    coefs = synth.random_coefs(model, seed=20260928, scale=0.02)
+    tab = capi.TableSet.from_synth(sc, coefs, feature_mode=feature_mode)
+    trace = "cluster-interaction" if feature_mode == capi.FEATURES_INTERACTIONS else "correlation"
+    return Workload(
+        2, f"binary FCC {dim}x{dim}x{dim} ({sc.num_sites} sites), point+4 pair+2 triplet CE, canonical "
+           f"swap Metropolis, {trace} trace, T=2500K",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_SWAP),
+        balanced_binary(sc, first, count), _seeds(first, count, 12345), HEADLINE_T, 2, mc,
+        extras=dict(model=model, coefs=coefs))
+
+
+def config1(first=0, count=4096, dim=4, mc=5000):
+    """BASELINE configs[0]: binary FCC conventional 4x4x4 (256 sites), pair-only CE."""
+    model = synth.build_cluster_model(synth.fcc_conventional_prim(), {2: 6.0})
+    sc = synth.build_supercell(model, [dim] * 3)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model))
+    return Workload(
+        1, f"config1: binary FCC conventional {dim}^3 ({sc.num_sites} sites), pairs, canonical swap",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_SWAP),
+        balanced_binary(sc, first, count, seed=1), _seeds(first, count, 777), 2500.0, 2, mc)
+
+
+def _rocksalt(dim, cutoffs=None, prim=None):
+    model = synth.build_cluster_model(prim or synth.rocksalt_prim(), cutoffs or {2: 6.0, 3: 5.0})
+    sc = synth.build_supercell(model, [dim] * 3)
+    return model, sc, ewald.supercell_ewald(sc)
+
+
+def config3(first=0, count=2048, dim=12, mc=2000):
+    """BASELINE configs[2]: ternary rocksalt dim^3, triplet CE + Ewald, semigrand flip."""
+    model, sc, ew = _rocksalt(dim)
+    mu = np.zeros((sc.num_sites, 3))
+    mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu)
+    return Workload(
+        3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_FLIP),
+        random_codes(sc, first, count, 3), _seeds(first, count, 777), 3000.0, 1, mc)
+
+
+def config4(first=0, count=1024, dim=16, mc=5000, h0=None):
+    """BASELINE configs[3]: config-2 Hamiltonian, Wang-Landau, 512 bins of 0.5 eV.  ``h0`` (the
+    enthalpy of a 50/50 random start, which centres the window) is evaluated by the caller on the
+    engine; pass it to get the final configuration."""
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.0, 3: 5.0})
+    sc = synth.build_supercell(model, [dim] * 3)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=20260928))
+    occ = balanced_binary(sc, first, count, seed=4)
+    kw = dict(kernel=capi.KERNEL_WANGLANDAU, step=capi.STEP_SWAP)
+    if h0 is not None:
+        # edges incommensurate with the starting enthalpy (NOTES.md: bin-edge ties)
+        kw.update(min_enthalpy=h0 - 160.37, max_enthalpy=h0 + 95.63, bin_size=0.5, flatness=0.8,
+                  check_period=1000)
+    return Workload(
+        4, f"config4: binary FCC {dim}^3 pair+triplet, Wang-Landau swap, 512 bins",
+        sc, tab, kw, occ, _seeds(first, count, 777), 0.0, 2, mc)
+
+
+def config5(first=0, count=2048, dim=12, mc=None, total=None):
+    """BASELINE configs[4]: config-3 lattice, charge-neutral TableFlip (3 Mn3+ <-> Li+ + 2 Ti4+)
+    with a geometric replica-exchange ladder 400-2000 K over ``total`` walkers (this rank holds
+    walkers first .. first+count)."""
+    from . import parallel
+
+    model, sc, ew = _rocksalt(dim)
+    mu = np.zeros((sc.num_sites, 3))
+    mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1,
+                                   mu_table=mu, flip_table=[[1, -3, 2]], swap_weight=0.1)
+    total = total or count
+    ladder = parallel.geometric_ladder(400.0, 2000.0, total)
+    return Workload(
+        5, f"config5: ternary rocksalt {dim}^3 + Ewald, charge-neutral TableFlip, replica-exchange "
+           f"ladder 400-2000 K over {total} walkers",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_TABLE_FLIP),
+        neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777),
+        ladder[first:first + count].copy(), 1, mc or sc.num_sites, extras=dict(ladder=ladder))
+
+
+def config6(first=0, count=2048, dim=12, mc=2000):
+    """(not in BASELINE.json) config-3 lattice, canonical swap with the Ewald term."""
+    model, sc, ew = _rocksalt(dim)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1)
+    return Workload(
+        6, f"config6: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, canonical swap",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_SWAP),
+        random_codes(sc, first, count, 3), _seeds(first, count, 777), 3000.0, 2, mc)
+
+
+def config7(first=0, count=2048, dim=12, mc=1000, with_ewald=True):
+    """(not in BASELINE.json) two ACTIVE sublattices: Li+/Mn3+/Ti4+ cations and O2-/F- anions."""
+    prim = synth.rocksalt_prim(anion_charges=(-2.0, -1.0))
+    model = synth.build_cluster_model(prim, {2: 6.0, 3: 4.5})
+    sc = synth.build_supercell(model, [dim] * 3)
+    ew = ewald.supercell_ewald(sc) if with_ewald else None
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1)
+    return Workload(
+        7, f"config7: rocksalt {dim}^3 ({sc.num_sites} sites), ternary cations + binary anions, CE"
+           f"{' + Ewald' if with_ewald else ''}, canonical swap",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_SWAP),
+        random_codes(sc, first, count, 3), _seeds(first, count, 777), 3000.0, 2, mc)
+
+
+def config8(first=0, count=4096, dim=16, mc=2000):
+    """(not in BASELINE.json) 451 clusters per site on the config-2 lattice."""
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.5, 3: 5.2})
+    sc = synth.build_supercell(model, [dim] * 3)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=20260928))
+    return Workload(
+        8, f"config8: binary FCC {dim}^3 ({sc.num_sites} sites), pairs <= 6.5 A + triplets <= 5.2 A "
+           "(451 clusters/site), canonical swap",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_SWAP),
+        balanced_binary(sc, first, count, seed=1), _seeds(first, count, 777), 2500.0, 2, mc)
+
+
+BUILDERS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: config6, 7: config7,
+            8: config8}

@@ -282,13 +282,22 @@ def test_native_wang_landau_matches_oracle(general, monkeypatch):
         np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"])
 
 
-def test_errors_surface_as_exceptions():
+def test_errors_surface_as_exceptions(monkeypatch):
     tab = tables_for("fcc_prim222_aliased", MODES["int"])
     eng = _engine(tab, capi.make_config(1))
     with pytest.raises(ValueError):
         eng.eval_full(np.zeros((1, 8), dtype=np.float64))
     with pytest.raises(ValueError):
         _engine(tab, capi.make_config(1, capi.KERNEL_WANGLANDAU, min_enthalpy=2.0, max_enthalpy=1.0))
+    # a Wang-Landau walker must start inside the window: the bin of the current enthalpy is used
+    # unchecked afterwards (the reference raises IndexError above it, wanglandau.py:175-180)
+    for lean in (True, False):
+        if not lean:
+            monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+        wl = _engine(tab, capi.make_config(2, capi.KERNEL_WANGLANDAU, min_enthalpy=1.0e3,
+                                           max_enthalpy=1.1e3, bin_size=1.0))
+        with pytest.raises(ValueError, match="outside the Wang-Landau window"):
+            wl.set_state(np.zeros((2, 8), dtype=np.int32), None, 0.0)
 
 
 @pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])

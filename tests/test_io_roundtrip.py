@@ -38,3 +38,34 @@ def test_version_check(tmp_path):
     np.savez(path, format_version=np.array(99))
     with pytest.raises(ValueError):
         io.load_tables(path)
+
+
+def test_table_flip_and_bias_survive_the_roundtrip(tmp_path):
+    """A TableFlip / biased model must not reload as a plain one."""
+    from tests.cases import load_case
+
+    c = load_case("rocksalt444_ewald")
+    tab = capi.TableSet.from_synth(c["sc"], c["coefs"], ewald=c["ewald"], ewald_coef=0.1,
+                                   flip_table=[[1, -3, 2]], flip_weights=[0.7, 0.3], swap_weight=0.25)
+    charges = np.zeros((tab.num_sites, 3))
+    charges[: c["sc"].size] = [1.0, 3.0, 4.0]
+    tab.set_bias(capi.BIAS_SQUARE_CHARGE, charges, penalty=0.75)
+    path = str(tmp_path / "tf.npz")
+    io.save_tables(path, tab)
+    back = io.load_tables(path)
+    assert back.struct.n_flip_vectors == 1 and back.struct.swap_weight == 0.25
+    np.testing.assert_array_equal(back._keep["flip_table"], [[1, -3, 2]])
+    np.testing.assert_array_equal(back._keep["flip_weights"], [0.7, 0.3])
+    assert back.struct.bias_type == capi.BIAS_SQUARE_CHARGE and back.struct.bias_penalty == 0.75
+    np.testing.assert_array_equal(back._keep["bias_table"], charges)
+
+
+def test_unknown_arrays_are_refused(tmp_path):
+    tab = tables_for("fcc_conv444_pairs", capi.FEATURES_INTERACTIONS)
+    path = str(tmp_path / "m.npz")
+    io.save_tables(path, tab)
+    d = dict(np.load(path))
+    d["arr_future_table"] = np.zeros(3)
+    np.savez(path, **d)
+    with pytest.raises(ValueError, match="future_table"):
+        io.load_tables(path)
