@@ -90,13 +90,8 @@ class Engine:
         self._h = _HP()
         rc = self._lib.smolmc_create(C.byref(tables.struct), C.byref(config), C.byref(self._h))
         if rc:
-            msg = self._lib.smolmc_last_error().decode()
             self._h = None
-            # argument problems are ValueErrors like the reference's (expansion.py:97-103,
-            # wanglandau.py:80-88); device problems are RuntimeErrors
-            if any(k in msg for k in ("enthalpy", "mod_factor", "range", "must be", "larger")):
-                raise ValueError(msg)
-            raise EngineError(msg)
+            self._chk(rc)
         self.R = config.n_replicas
         self.N = tables.struct.num_sites
         self.F = self._lib.smolmc_num_features(self._h)
@@ -115,7 +110,12 @@ class Engine:
 
     def _chk(self, rc):
         if rc:
-            raise EngineError(self._lib.smolmc_last_error().decode())
+            msg = self._lib.smolmc_last_error().decode()
+            # argument problems are ValueErrors like the reference's (expansion.py:97-103,
+            # wanglandau.py:80-88); device problems are RuntimeErrors
+            if any(k in msg for k in ("enthalpy", "mod_factor", "range", "must be", "larger")):
+                raise ValueError(msg)
+            raise EngineError(msg)
 
     @staticmethod
     def _occ32(occ, shape):

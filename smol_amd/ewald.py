@@ -176,8 +176,9 @@ def supercell_ewald(sc, eta=None, acc=12.0):
     return inds, np.ascontiguousarray(mat)
 
 
-def _pair_rows(lattice, frac, rep, eta, acc):
-    """Kernel row of site ``rep`` against all sites (real, recip, point, eta)."""
+def _pair_rows(lattice, frac, rep, eta, acc, acc_g=None):
+    """Kernel row of site ``rep`` against all sites (real, recip, point, eta); ``acc_g`` is the
+    accuracy exponent of the reciprocal-space cutoff when it differs from the real-space one."""
     lattice = np.asarray(lattice, float)
     n = len(frac)
     vol = abs(np.linalg.det(lattice))
@@ -185,7 +186,7 @@ def _pair_rows(lattice, frac, rep, eta, acc):
         eta = max((n * 0.01 / vol) ** (1 / 3) * np.pi, 0.05)
     sq = np.sqrt(eta)
     rcut = np.sqrt(acc / eta)
-    gcut = 2 * sq * np.sqrt(acc)
+    gcut = 2 * sq * np.sqrt(acc if acc_g is None else acc_g)
     cart = frac @ lattice
     heights = vol / np.array(
         [
@@ -232,3 +233,64 @@ def _pair_rows(lattice, frac, rep, eta, acc):
         g_recip += np.cos(phase) @ wc
     g_recip *= 2 * np.pi / vol
     return g_real, g_recip, -np.sqrt(eta / np.pi), eta
+
+
+# --------------------------------------------------------------------------------------
+# pymatgen-convention matrix for imported models (smol_amd.mson)
+# --------------------------------------------------------------------------------------
+PMG_ACC = float(np.log(10.0 ** 12))  # EwaldSummation(acc_factor=12): terms below 1e-12 dropped
+PMG_W = 1.0 / np.sqrt(2.0)  # EwaldSummation(w=1/sqrt(2)): real / reciprocal work balance
+
+
+def pmg_eta(n_sites, volume):
+    """Screening parameter pymatgen's EwaldSummation picks when none is given:
+    (n w / V^2)^(1/3) pi with n the number of sites of the structure it is handed -- for smol
+    that is the "Ewald structure" carrying every allowed species (cofe/extern/ewald.py:64-100)."""
+    return (n_sites * PMG_W / volume ** 2) ** (1.0 / 3.0) * np.pi
+
+
+def ewald_matrix_pmg(lattice, frac, site_of, charges, eta=None, real_space_cut=None,
+                     recip_space_cut=None, translation_index=None):
+    """Total Ewald matrix (real + reciprocal, point terms on the diagonal) over M point charges
+    ``charges[k]`` sitting on site ``site_of[k]`` of a periodic cell (several charges may share a
+    site: the allowed species of a disordered site; their mutual entry is the site's own image
+    sum, they never coexist).  Conventions of pymatgen.analysis.ewald.EwaldSummation as smol calls
+    it (moca/processor/ewald.py:83-99): eta from pmg_eta(M, V), cutoffs accf / sqrt(eta) and
+    2 sqrt(eta) accf with accf^2 = ln 1e12, E = sum_ab M[a, b] in eV.  The formulas are the
+    textbook Ewald sum (this module's own implementation); what is taken from pymatgen is only
+    the choice of eta and cutoffs, so that individual matrix entries -- which depend on eta
+    through the neutralising background -- are comparable, not just charge-neutral totals.
+
+    ``translation_index`` (optional, int[P, P]): for supercells whose sites are ordered (prim site
+    major, lattice translation minor), translation_index[t1][t2] = index of the lattice point
+    t2 - t1; then only one kernel row per prim site is summed and the rest follows by translation
+    invariance (O(nb N) instead of O(N^2) lattice sums)."""
+    lattice = np.asarray(lattice, float)
+    frac = np.asarray(frac, float)
+    site_of = np.asarray(site_of, dtype=np.int64)
+    q = np.asarray(charges, float)
+    vol = abs(np.linalg.det(lattice))
+    if eta is None:
+        eta = pmg_eta(len(q), vol)
+    acc_r = PMG_ACC if real_space_cut is None else eta * real_space_cut ** 2
+    acc_g = PMG_ACC if recip_space_cut is None else recip_space_cut ** 2 / (4.0 * eta)
+    n = len(frac)
+    g = np.empty((n, n))
+    point = -np.sqrt(eta / np.pi)
+    if translation_index is None:
+        for i in range(n):
+            g_real, g_recip, point, _ = _pair_rows(lattice, frac, i, eta, acc_r, acc_g)
+            g[i] = g_real + g_recip
+    else:
+        P = len(translation_index)
+        nb = n // P
+        for b1 in range(nb):
+            g_real, g_recip, point, _ = _pair_rows(lattice, frac, b1 * P, eta, acc_r, acc_g)
+            row = (g_real + g_recip).reshape(nb, P)
+            for t1 in range(P):  # site (b1, t1) sees (b2, t2) like (b1, 0) sees (b2, t2 - t1)
+                g[b1 * P + t1] = row[:, translation_index[t1]].reshape(-1)
+    g = 0.5 * (g + g.T)
+    mat = g[np.ix_(site_of, site_of)] * np.outer(q, q)
+    mat[np.diag_indices_from(mat)] += point * q * q
+    mat *= CONV_FACT
+    return np.ascontiguousarray(mat)

@@ -394,6 +394,24 @@ class Ensemble:
         comp.add_processor(EwaldProcessor(supercell, ewald_term, ewald_coefficient))
         return cls(comp, **kwargs)
 
+    @classmethod
+    def from_mson(cls, model, supercell_matrix, processor_type="decomposition", **kwargs):
+        """Ensemble of a model serialized by smol (``ClusterExpansion.as_dict`` JSON / a notebook
+        ``save_work`` file, or an already loaded smol_amd.mson.MsonClusterExpansion) on a
+        supercell: what ``Ensemble.from_cluster_expansion(expansion, supercell_matrix)`` builds in
+        the reference (ensemble.py:133-217) -- a cluster processor, composed with an
+        EwaldProcessor carrying the last fitted coefficient when the subspace has an EwaldTerm."""
+        from . import mson
+
+        ce = model if isinstance(model, mson.MsonClusterExpansion) else mson.load_mson(model)
+        cell = ce.subspace.supercell(supercell_matrix)
+        ewald_term = coef = None
+        if ce.subspace.ewald_term is not None:
+            inds, mat, _ = ce.ewald_tables(cell)
+            ewald_term, coef = (inds, mat), float(ce.coefs[-1])
+        return cls.from_cluster_expansion(cell, ce.ce_coefs, processor_type=processor_type,
+                                          ewald_term=ewald_term, ewald_coefficient=coef, **kwargs)
+
     # -- properties ----------------------------------------------------------------
     @property
     def processor(self):

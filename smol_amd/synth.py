@@ -130,7 +130,10 @@ def find_symops(prim: PrimCell):
     cands = cands[np.abs(dets) == 1]
     # frac row-vector convention: x_frac' = x_frac @ Wt ; metric G' = Wt^T ... use col form
     # cart = frac @ A ; rotation acts on column frac: f' = W f ; metric: W^T Gc W = Gc, Gc = A A^T
-    ok = np.all(np.abs(np.einsum("nji,jk,nkl->nil", cands, G, cands) - G) < 1e-8, axis=(1, 2))
+    # metric preserved to 1e-5 relative: lattices read from files carry ~1e-7 noise (pymatgen's
+    # symmetry finder, which the reference uses, works with a 0.1 A tolerance)
+    tol = 1e-5 * np.abs(G).max()
+    ok = np.all(np.abs(np.einsum("nji,jk,nkl->nil", cands, G, cands) - G) < tol, axis=(1, 2))
     cands = cands[ok]
     f0 = prim.frac_coords
     for W in cands:

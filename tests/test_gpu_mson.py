@@ -1,0 +1,151 @@
+"""The reference's serialized LiNiO2 models on the engine: tables read
+with smol_amd.mson, evaluated through the C-ABI, checked against (i) the feature matrix smol
+stored with the model -- correlation vectors and pymatgen's Ewald energies -- and (ii) the oracle
+on the same imported tables, for the evaluator entry points and for Monte-Carlo runs on a larger
+supercell whose cluster indices are regenerated from the stored orbits."""
+
+import os
+
+import numpy as np
+import pytest
+
+from smol_amd import capi, moca, mson
+from smol_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CE_EWALD = os.path.join(GOLD, "lno_ce_ewald.mson.json.gz")
+RTOL, ATOL = 1e-10, 1e-9
+
+
+@pytest.fixture(scope="module")
+def lno():
+    return mson.load_mson(CE_EWALD), mson.wrangler_entries(CE_EWALD)
+
+
+def test_eval_full_reproduces_the_reference_feature_matrix(lno):
+    ce, entries = lno
+    nc = ce.subspace.num_corr_functions
+    for i, e in enumerate(entries):
+        tab = ce.tables(e["supercell_matrix"], feature_mode=capi.FEATURES_CORRELATIONS)
+        cell = tab.supercell
+        occ = cell.occupancy_from_sites(e["species"], e["site_mapping"])
+        eng = Engine(tab, capi.make_config(1))
+        feats = eng.eval_full(occ[None])[0] / cell.size
+        np.testing.assert_allclose(feats[:nc], ce.feature_matrix[i, :nc], rtol=0, atol=1e-10)
+        assert abs(feats[nc] - ce.feature_matrix[i, nc]) < 5e-9  # pymatgen's Ewald energy per prim
+        # predicted energy of the fitted expansion (what smol's ClusterExpansion.predict returns)
+        np.testing.assert_allclose(feats @ eng.natural_parameters, ce.feature_matrix[i] @ ce.coefs,
+                                   rtol=1e-12, atol=1e-10)
+        eng.close()
+
+
+@pytest.mark.parametrize("mode", ["corr", "int"])
+def test_eval_delta_on_the_imported_model_equals_oracle_and_difference(lno, mode):
+    from oracle import oracle as orc
+
+    ce, entries = lno
+    fmode = capi.FEATURES_CORRELATIONS if mode == "corr" else capi.FEATURES_INTERACTIONS
+    e = entries[7]
+    tab = ce.tables(e["supercell_matrix"], feature_mode=fmode)
+    cell = tab.supercell
+    occ = cell.occupancy_from_sites(e["species"], e["site_mapping"])
+    eng, ora = Engine(tab, capi.make_config(1)), orc.OracleEvaluator(tab)
+    rng = np.random.default_rng(1)
+    P = cell.size
+    for _ in range(25):
+        s1, s2 = rng.choice(2 * P, 2, replace=False)
+        flips = [(int(s1), int(1 - occ[s1])), (int(s2), int(1 - occ[s2]))]
+        d = eng.eval_delta(occ, [flips[0] + flips[1]])[0]
+        np.testing.assert_allclose(d, ora.feature_vector_change(occ, flips), rtol=RTOL, atol=ATOL)
+        new = occ.copy()
+        for s, c in flips:
+            new[s] = c
+        np.testing.assert_allclose(d, eng.eval_full(new[None])[0] - eng.eval_full(occ[None])[0],
+                                   rtol=1e-8, atol=1e-8)
+        occ = new
+
+
+def _big_model(ce, dim=4, **kw):
+    tab = ce.tables(np.diag([dim] * 3), **kw)  # 64 prims, 256 sites: indices regenerated
+    cell = tab.supercell
+    rng = np.random.default_rng(8)
+    return tab, cell, rng
+
+
+def _neutral_occupancies(cell, R, rng, n_li):
+    """Li_x Ni3+_x Ni4+_(1-x) O2: as many Li+ as Ni3+ (codes: Li+ 0 / vacancy 1, Ni3+ 0 / Ni4+ 1)."""
+    P = cell.size
+    occ = np.zeros((R, cell.num_sites), dtype=np.int32)
+    for r in range(R):
+        li = rng.permutation(P)[: n_li]
+        ni3 = P + rng.permutation(P)[: n_li]
+        occ[r, :P] = 1
+        occ[r, li] = 0
+        occ[r, P:2 * P] = 1
+        occ[r, ni3] = 0
+    return occ
+
+
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_canonical_swaps_with_ewald_match_oracle(lno, mode):
+    """Two active sublattices (Li+/vacancy and Ni3+/Ni4+) + Ewald term with a vacancy species,
+    canonical swaps, engine stream == oracle stream -> identical trajectories."""
+    from oracle import oracle as orc
+
+    ce, _ = lno
+    fmode = capi.FEATURES_CORRELATIONS if mode == "corr" else capi.FEATURES_INTERACTIONS
+    tab, cell, rng = _big_model(ce, feature_mode=fmode)
+    R = 6
+    occ = _neutral_occupancies(cell, R, rng, n_li=cell.size // 2)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(50)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, seeds, 900.0)
+    for chunk in (3, 97, 400):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"]), eng.kernel_info()
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=RTOL, atol=1e-8)
+    # composition of each sublattice conserved
+    P = cell.size
+    assert np.all((a["occupancy"][:, :P] == 0).sum(axis=1) == P // 2)
+    assert np.all((a["occupancy"][:, P:2 * P] == 0).sum(axis=1) == P // 2)
+
+
+def test_smol_shaped_api_on_the_imported_model(lno):
+    """Ensemble.from_mson -> Sampler with the charge-neutral TableFlip step whose flip table comes
+    from the CompositionSpace of the model's own sublattices (Li+ + Ni3+ <-> vacancy + Ni4+):
+    every sample stays charge neutral and its trace rows equal a from-scratch evaluation."""
+    ce, _ = lno
+    ens = moca.Ensemble.from_mson(ce, np.diag([4, 4, 4]))
+    assert [s.species for s in ens.sublattices] == [("Li+", "Vacancy"), ("Ni3+", "Ni4+"), ("O2-",)]
+    assert len(ens.natural_parameters) == 12  # 11 orbit interactions + Ewald
+    nw = 8
+    sampler = moca.Sampler.from_ensemble(ens, temperature=1200.0, nwalkers=nw, step_type="table-flip",
+                                         seeds=list(range(nw)))
+    ft = np.asarray(sampler.mckernels[0].usher_kwargs["flip_table"])
+    assert ft.shape == (1, 5) and abs(ft[0]).tolist() == [1, 1, 1, 1, 0]
+    cell = ens.processor.supercell
+    occ = _neutral_occupancies(cell, nw, np.random.default_rng(2), n_li=cell.size // 2)
+    sampler.run(3000, occ, thin_by=500)
+    c = sampler.samples
+    occs = c.get_occupancies(flat=False)
+    P = cell.size
+    n_li = (occs[..., :P] == 0).sum(axis=-1)
+    n_ni3 = (occs[..., P:2 * P] == 0).sum(axis=-1)
+    assert np.array_equal(n_li, n_ni3)  # neutrality: every Li+ is compensated by a Ni3+
+    assert len(np.unique(n_li)) > 1  # and the composition does move
+    feats = c.get_feature_vectors(flat=False)
+    for i in (0, 5):
+        for w in (0, nw - 1):
+            np.testing.assert_allclose(feats[i, w], ens.compute_feature_vector(occs[i, w]), rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(c.get_enthalpies(flat=False)[..., 0], feats @ ens.natural_parameters,
+                               rtol=1e-10, atol=1e-8)
