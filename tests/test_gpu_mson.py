@@ -135,7 +135,7 @@ def test_smol_shaped_api_on_the_imported_model(lno):
     assert ft.shape == (1, 5) and abs(ft[0]).tolist() == [1, 1, 1, 1, 0]
     cell = ens.processor.supercell
     occ = _neutral_occupancies(cell, nw, np.random.default_rng(2), n_li=cell.size // 2)
-    sampler.run(3000, occ, thin_by=500)
+    sampler.run(400, occ, thin_by=20)  # (without a chemical potential the cell fills up with Li within ~1e3 steps)
     c = sampler.samples
     occs = c.get_occupancies(flat=False)
     P = cell.size
@@ -144,7 +144,7 @@ def test_smol_shaped_api_on_the_imported_model(lno):
     assert np.array_equal(n_li, n_ni3)  # neutrality: every Li+ is compensated by a Ni3+
     assert len(np.unique(n_li)) > 1  # and the composition does move
     feats = c.get_feature_vectors(flat=False)
-    for i in (0, 5):
+    for i in (0, 19):
         for w in (0, nw - 1):
             np.testing.assert_allclose(feats[i, w], ens.compute_feature_vector(occs[i, w]), rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(c.get_enthalpies(flat=False)[..., 0], feats @ ens.natural_parameters,
