@@ -419,8 +419,16 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     memset(&h->lp, 0, sizeof(LeanParams));
     // one site class: mc_lean_kernel (NSLOT <= 4); up to four classes or up to 512 clusters per
     // site: mc_lean_multi_kernel (per-class slot records in LDS)
-    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && !corr && N <= 65535 && niter_max <= 8 &&
-        need_mm <= 3 && num_ce_features(t) <= 64) {
+    // Correlation features (ClusterExpansionProcessor, evaluator.pyx:211-265): when every orbit
+    // has a single correlation function (K = 1: every binary system) the correlation delta of a
+    // cluster is one tensor difference exactly like the interaction delta (:267-317), so the lean
+    // kernels serve it with delta tables made from the correlation tensor, the feature index
+    // bit_id instead of the orbit id and the weight coefs[bit_id]: same code, other tables.
+    bool corr_k1 = corr;
+    for (int o = 0; o < t->n_orb; ++o) corr_k1 = corr_k1 && t->orb_nfunc[o] == 1;
+    if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = false; // A/B switch (tests, profiling)
+    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1) && N <= 65535 &&
+        niter_max <= 8 && need_mm <= 3 && num_ce_features(t) <= 64) {
         const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
         const int NCLS = (int)class_rep.size();
         const int MML = need_mm <= 2 ? 2 : 3;
@@ -518,7 +526,9 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             const Slot &k = sl[q];
             const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
             const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
-            const double *T = t->interaction_tensors + t->orb_itensor_off[o];
+            const double *T = corr ? t->corr_tensors + t->orb_ctensor_off[o] // K == 1: the one function
+                                   : t->interaction_tensors + t->orb_itensor_off[o];
+            const int feat = corr ? t->orb_bit_id[o] : t->orb_id[o];
             const int ss = st[k.p];
             const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
             const auto key = std::make_pair(o, k.p);
@@ -561,9 +571,9 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 uint32_t cs = 8u;
                 for (int m = 0; m < I - 1; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
             }
-            L.feat = (uint32_t)t->orb_id[o];
+            L.feat = (uint32_t)feat;
             L.live = 1;
-            L.w = t->ce_coefs[t->orb_id[o]] * scale;
+            L.w = t->ce_coefs[feat] * scale;
             L.fs = scale;
             if (dt.size() > 8000) ok = false; // keep the LDS tables within budget
             double dmax = 0.0;

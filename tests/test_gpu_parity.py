@@ -547,7 +547,10 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("fcc_prim666_triplets", "int", capi.STEP_SWAP, None, "wang-landau", "lean"),
     ("rocksalt444_ewald", "int", capi.STEP_FLIP, "mu3", "metropolis", "lean"),        # compact Ewald + field
     ("rocksalt333_vacancy_ewald", "int", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
-    ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "metropolis", "general"),  # correlation features
+    ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),     # correlation features, K = 1
+    ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "wang-landau", "lean"),
+    ("fcc_conv444_pairs", "corr", capi.STEP_FLIP, "mu2", "metropolis", "lean"),
+    ("rocksalt444_ewald", "corr", capi.STEP_FLIP, "mu3", "metropolis", "general"),    # K > 1 correlation functions
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
