@@ -312,13 +312,16 @@ def test_sample_rows_at_any_phase_of_the_random_batches(offset, thin, kernel, mo
     c = load_case("fcc_prim666_triplets")
     tab = tables_for("fcc_prim666_triplets", MODES["int"])
     R = 3
+    rng = np.random.default_rng(offset + thin)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
     if kernel == "metropolis":
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
     else:
-        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=-40.3, max_enthalpy=40.7,
-                               bin_size=0.5, check_period=37)
-    rng = np.random.default_rng(offset + thin)
-    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+        # the window must contain every walker's starting enthalpy (set_state refuses otherwise)
+        ev = orc.OracleEvaluator(tab)
+        h0 = np.array([ev.feature_vector(o) @ ev.natural_parameters() for o in occ0])
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=h0.min() - 40.3,
+                               max_enthalpy=h0.max() + 40.7, bin_size=0.5, check_period=37)
     seeds = np.arange(R, dtype=np.uint64) + np.uint64(7000 + thin)
     eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
     assert eng.kernel_info().startswith("lean")
@@ -624,13 +627,15 @@ def test_split_launches_equal_one_launch(kernel, monkeypatch):
     c = load_case("fcc_prim666_triplets")
     tab = tables_for("fcc_prim666_triplets", MODES["int"])
     R = 5
+    rng = np.random.default_rng(5)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
     if kernel == "metropolis":
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
     else:
-        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=-40.3, max_enthalpy=40.7,
-                               bin_size=0.5, check_period=40)
-    rng = np.random.default_rng(5)
-    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+        probe = _engine(tab, capi.make_config(1))
+        h0 = probe.eval_full(occ0) @ probe.natural_parameters
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=h0.min() - 40.3,
+                               max_enthalpy=h0.max() + 40.7, bin_size=0.5, check_period=40)
     seeds = np.arange(R, dtype=np.uint64) + np.uint64(500)
     one = _engine(tab, cfg)
     one.set_state(occ0, seeds, 1500.0)
