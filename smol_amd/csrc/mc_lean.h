@@ -513,16 +513,33 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
 
         // -------- enthalpy delta ---------------------------------------------------
+        // Swap (Metropolis): the second flip is the reverse species change of the first
+        // (n2 == o1, o2 == n1), and the delta tables are antisymmetric in (old, new), so both
+        // flips read the SAME (old, new) block -- its offset is added to the slot offsets once --
+        // and the step's delta per slot is the difference of the two reads: one table offset
+        // add, one subtraction and one FMA per slot instead of two adds and two FMAs
+        // (SMOLMC_NO_SWAP_DIFF: the flip-by-flip form, kept for A/B runs).
+#ifdef SMOLMC_NO_SWAP_DIFF
+        constexpr bool DIFF = false;
+#else
+        constexpr bool DIFF = STEP == SMOLMC_STEP_SWAP && !WL;
+#endif
         double e = 0.0, d1[NSLOT], d2[NSLOT];
+        uint32_t dp[NSLOT];
         {
             const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8; // uniform
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
+                if (DIFF) a = dp[it] = doff8[it] + pair1;
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row1, it * MM + m)));
-                d1[it] = SMOLMC_LDS_F64(a + pair1); // (absolute LDS address: a includes the table base)
-                e = fma(wgt[it], d1[it], e);
+                if (DIFF) {
+                    d1[it] = SMOLMC_LDS_F64(a);
+                } else {
+                    d1[it] = SMOLMC_LDS_F64(a + pair1); // (absolute LDS address: a includes the table base)
+                    e = fma(wgt[it], d1[it], e);
+                }
             }
         }
         // index row of the NEXT step's site, straight into row1: its last use (the gathers above)
@@ -551,11 +568,16 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const uint32_t pair2 = (uint32_t)o2 * snt8 + (uint32_t)n2 * nt8;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
-                uint32_t a = doff8[it];
+                uint32_t a = DIFF ? dp[it] : doff8[it];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row2, it * MM + m)));
-                d2[it] = SMOLMC_LDS_F64(a + pair2);
-                e = fma(wgt[it], d2[it], e);
+                if (DIFF) {
+                    d1[it] -= SMOLMC_LDS_F64(a); // D[(o2,n2)] = -D[(o1,n1)]: the step's delta of this slot
+                    e = fma(wgt[it], d1[it], e);
+                } else {
+                    d2[it] = SMOLMC_LDS_F64(a + pair2);
+                    e = fma(wgt[it], d2[it], e);
+                }
             }
             if (HAS_EW) {
                 if (P.ew_field) { // the second flip sees the first through the cross term
@@ -625,11 +647,23 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         };
         // -------- update (kernel/base.py:327-343) --------
+        // SELACC: the per-slot accumulators are updated once, after the decision paths have
+        // merged, as acc = fma(sel, delta, acc) with the wave-uniform sel = 1.0 / 0.0 -- updating
+        // them inside the accept branch makes the register allocator keep two copies and shuffle
+        // them with v_mov_b64 on every path (~5 VALU per step)
+#ifdef SMOLMC_NO_SELACC
+        constexpr bool SELACC = false;
+#else
+        constexpr bool SELACC = DIFF && FAST && !BIAS;
+#endif
+        uint32_t sel_hi = 0u; // high word of sel
         auto on_accept = [&]() {
-            if (!WL) {
+            if (SELACC) {
+                sel_hi = 0x3ff00000u;
+            } else if (!WL) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) acc[it] += d1[it];
-                if (STEP == SMOLMC_STEP_SWAP) {
+                if (STEP == SMOLMC_STEP_SWAP && !DIFF) {
 #pragma unroll
                     for (int it = 0; it < NSLOT; ++it) acc[it] += d2[it];
                 }
@@ -661,7 +695,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             bias_acc += dB;
             charge += dQ;
             if (!FAST) H += dH;
-            nacc_add++;
+            if (!SELACC) nacc_add++;
         };
         auto on_reject = [&]() {
             if (STEP == SMOLMC_STEP_SWAP) {
@@ -684,6 +718,13 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             else if (cr) on_reject();
             else if (exact_decision()) on_accept();
             else on_reject();
+            if (SELACC) {
+                const uint32_t sh = (uint32_t)uni((int)sel_hi);
+                const double sel = __hiloint2double((int)sh, 0);
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) acc[it] = fma(sel, d1[it], acc[it]);
+                nacc_add += sh >> 29; // 0x3ff00000 >> 29 == 1
+            }
         } else {
             accepted = exact_decision();
             if (accepted) on_accept();
