@@ -34,11 +34,13 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 2
+#define SMOLMC_ABI_VERSION 3
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
 #define SMOLMC_BIAS_SQUARE_CHARGE 2
+#define SMOLMC_BIAS_SQUARE_HYPERPLANE 3
+#define SMOLMC_MAX_BIAS_ROWS 4 /* hyperplanes of a SquareHyperplaneBias */
 #define SMOLMC_MAX_CLUSTER_SITES 6 /* largest cluster (sites per cluster) supported */
 
 /* feature_mode */
@@ -142,11 +144,19 @@ typedef struct smolmc_tables {
      *                              1 where unused; bias = sum_sites log(table[site][occ])
      *   SMOLMC_BIAS_SQUARE_CHARGE  SquareChargeBias._c_table (bias.py:256-262): oxidation states,
      *                              0 where unused; bias = -bias_penalty * (sum_sites table)^2
+     *   SMOLMC_BIAS_SQUARE_HYPERPLANE  SquareHyperplaneBias (bias.py:290-366): bias_rows tables
+     *                              [bias_rows x num_sites x bias_width], table r holding
+     *                              A[r][dim_id(site, code)] (the hyperplane normal's entry of the
+     *                              species, get_dim_ids_table occu_utils.py:8-23; 0 where unused)
+     *                              and bias_intercepts[r] = b[r];
+     *                              bias = -bias_penalty * sum_r (sum_sites table_r - b_r)^2
      * Not allowed with Wang-Landau (wanglandau.py:127-128). */
     int32_t bias_type;           /* SMOLMC_BIAS_* */
     int32_t bias_width;
     const double *bias_table;
-    double bias_penalty;         /* SquareChargeBias.penalty (> 0) */
+    double bias_penalty;         /* SquareChargeBias / SquareHyperplaneBias .penalty (> 0) */
+    int32_t bias_rows;           /* hyperplanes (<= SMOLMC_MAX_BIAS_ROWS); 0 or 1 for the other types */
+    const double *bias_intercepts; /* [bias_rows] (NULL = zeros) */
 } smolmc_tables;
 
 typedef struct smolmc_config {

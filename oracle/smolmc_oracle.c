@@ -326,6 +326,20 @@ double orc_compute_bias(const smolmc_tables *t, const int32_t *occ) {
         for (int s = 0; s < N; ++s) c += t->bias_table[(size_t)s * W + occ[s]];
         return -t->bias_penalty * (c * c);
     }
+    if (t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) {
+        /* SquareHyperplaneBias.compute_bias (bias.py:352-366): n = species counts,
+         * -penalty * sum((A n - b)^2); table r holds A[r][dim_id(site, code)], so
+         * A_r . n = sum over the sites of table_r[site][occ] */
+        double sq = 0;
+        for (int k = 0; k < t->bias_rows; ++k) {
+            const double *tab = t->bias_table + (size_t)k * N * W;
+            double c = 0;
+            for (int s = 0; s < N; ++s) c += tab[(size_t)s * W + occ[s]];
+            c -= t->bias_intercepts ? t->bias_intercepts[k] : 0.0;
+            sq += c * c;
+        }
+        return -t->bias_penalty * sq;
+    }
     return 0.0;
 }
 
@@ -358,6 +372,28 @@ double orc_compute_bias_change(const smolmc_tables *t, const int32_t *occ, const
                   t->bias_table[(size_t)site * W + occ[site]];
         }
         return -t->bias_penalty * (cn * cn) - (-t->bias_penalty * (c * c));
+    }
+    if (t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) {
+        /* inherited MCBias.compute_bias_change (bias.py:75-93): bias of the occupancy with the
+         * flips applied (the last flip of a site wins) minus bias of the occupancy */
+        int N = t->num_sites;
+        double sq_new = 0, sq_old = 0;
+        for (int k = 0; k < t->bias_rows; ++k) {
+            const double *tab = t->bias_table + (size_t)k * N * W;
+            double c = 0;
+            for (int s = 0; s < N; ++s) c += tab[(size_t)s * W + occ[s]];
+            c -= t->bias_intercepts ? t->bias_intercepts[k] : 0.0;
+            double cn = c;
+            for (int f = 0; f < nflips; ++f) {
+                int site = flips[2 * f], last = 1;
+                for (int g = f + 1; g < nflips; ++g) last &= flips[2 * g] != site;
+                if (!last) continue;
+                cn += tab[(size_t)site * W + flips[2 * f + 1]] - tab[(size_t)site * W + occ[site]];
+            }
+            sq_old += c * c;
+            sq_new += cn * cn;
+        }
+        return -t->bias_penalty * sq_new - (-t->bias_penalty * sq_old);
     }
     return 0.0;
 }

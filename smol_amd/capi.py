@@ -22,7 +22,7 @@ KERNEL_WANGLANDAU = 1
 STEP_FLIP = 0
 STEP_SWAP = 1
 STEP_TABLE_FLIP = 2
-BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE = 0, 1, 2
+BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE, BIAS_SQUARE_HYPERPLANE = 0, 1, 2, 3
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -83,6 +83,8 @@ class smolmc_tables(C.Structure):
         ("bias_width", C.c_int32),
         ("bias_table", _f64p),
         ("bias_penalty", C.c_double),
+        ("bias_rows", C.c_int32),
+        ("bias_intercepts", _f64p),
     ]
 
 
@@ -356,28 +358,51 @@ class TableSet:
             p.append(-1.0)
         return np.array(p)
 
-    def set_bias(self, bias_type, table=None, penalty=0.0):
+    def set_bias(self, bias_type, table=None, penalty=0.0, intercepts=None):
         """Attach (or clear) an MCBias term (smol/moca/kernel/bias.py): ``table`` is the
         reference's per-(site, species code) table -- fugacity fractions (BIAS_FUGACITY,
-        bias.py:208-226) or oxidation states (BIAS_SQUARE_CHARGE, bias.py:256-262)."""
+        bias.py:208-226), oxidation states (BIAS_SQUARE_CHARGE, bias.py:256-262) or, for
+        BIAS_SQUARE_HYPERPLANE (bias.py:290-366), one table per hyperplane [rows, N, W] with the
+        entry of the normal vector for that species, plus the intercepts b."""
         t = self.struct
         if bias_type == BIAS_NONE:
-            t.bias_type, t.bias_width, t.bias_penalty = 0, 0, 0.0
+            t.bias_type, t.bias_width, t.bias_penalty, t.bias_rows = 0, 0, 0.0, 0
             t.bias_table = _f64p()
+            t.bias_intercepts = _f64p()
             self._keep.pop("bias_table", None)
+            self._keep.pop("bias_intercepts", None)
             return self
-        if bias_type not in (BIAS_FUGACITY, BIAS_SQUARE_CHARGE):
+        if bias_type not in (BIAS_FUGACITY, BIAS_SQUARE_CHARGE, BIAS_SQUARE_HYPERPLANE):
             raise ValueError(f"unknown bias type {bias_type}")
         tb = _arr(table, np.float64, "bias_table")
-        if tb.ndim != 2 or tb.shape[0] != t.num_sites or tb.shape[1] < t.max_species:
+        rows = 1
+        if bias_type == BIAS_SQUARE_HYPERPLANE:
+            if tb.ndim == 2:
+                tb = tb[None]
+            if tb.ndim != 3 or not 1 <= tb.shape[0] <= 4:
+                raise ValueError("hyperplane bias tables must be [1..4 rows x num_sites x species]")
+            rows = tb.shape[0]
+            icpt = np.zeros(rows) if intercepts is None else _arr(intercepts, np.float64, "bias_intercepts")
+            if icpt.shape != (rows,):
+                raise ValueError("one intercept per hyperplane")
+        shape = tb.shape[-2:]
+        if tb.ndim < 2 or shape[0] != t.num_sites or shape[1] < t.max_species:
             raise ValueError("bias table must be [num_sites x >= max species per site]")
         if bias_type == BIAS_FUGACITY and not np.all(tb > 0):
             raise ValueError("fugacity fractions must be positive")
-        if bias_type == BIAS_SQUARE_CHARGE and not penalty > 0:
-            raise ValueError("Penalty factor should be > 0!")  # bias.py:250-251
+        if bias_type != BIAS_FUGACITY and not penalty > 0:
+            raise ValueError("Penalty factor should be > 0!")  # bias.py:250-251, :328-329
+        tb = np.ascontiguousarray(tb)
         self._keep["bias_table"] = tb
-        t.bias_type, t.bias_width, t.bias_penalty = int(bias_type), tb.shape[1], float(penalty)
+        t.bias_type, t.bias_width, t.bias_penalty = int(bias_type), shape[1], float(penalty)
         t.bias_table = _ptr(tb, C.c_double)
+        t.bias_rows = rows
+        if bias_type == BIAS_SQUARE_HYPERPLANE:
+            self._keep["bias_intercepts"] = np.ascontiguousarray(icpt)
+            t.bias_intercepts = _ptr(self._keep["bias_intercepts"], C.c_double)
+        else:
+            self._keep.pop("bias_intercepts", None)
+            t.bias_intercepts = _f64p()
         return self
 
     @classmethod

@@ -818,16 +818,25 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     kp.mu = h->rt.mu;
     // MCBias (smol/moca/kernel/bias.py)
     if (t->bias_type) {
-        if (t->bias_type != SMOLMC_BIAS_FUGACITY && t->bias_type != SMOLMC_BIAS_SQUARE_CHARGE)
+        if (t->bias_type != SMOLMC_BIAS_FUGACITY && t->bias_type != SMOLMC_BIAS_SQUARE_CHARGE &&
+            t->bias_type != SMOLMC_BIAS_SQUARE_HYPERPLANE)
             return bail(fail("unknown bias_type"));
+        const int brows = t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE ? t->bias_rows : 1;
+        if (brows < 1 || brows > SMOLMC_MAX_BIAS_ROWS)
+            return bail(fail("bias_rows must be in [1, SMOLMC_MAX_BIAS_ROWS]"));
         if (wl) return bail(fail("Cannot apply bias to Wang-Landau simulation!")); // wanglandau.py:127-128
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP)
             return bail(fail("bias terms are implemented for Flip / Swap steps"));
         if (!t->bias_table || t->bias_width < t->max_species)
             return bail(fail("bias_table must be [num_sites x >= max_species]"));
-        if (t->bias_type == SMOLMC_BIAS_SQUARE_CHARGE && !(t->bias_penalty > 0.0))
-            return bail(fail("Penalty factor should be > 0!")); // bias.py:250-251
-        h->bias_host.assign(t->bias_table, t->bias_table + (size_t)t->num_sites * t->bias_width);
+        if (t->bias_type != SMOLMC_BIAS_FUGACITY && !(t->bias_penalty > 0.0))
+            return bail(fail("Penalty factor should be > 0!")); // bias.py:250-251, :328-329
+        h->bias_host.assign(t->bias_table, t->bias_table + (size_t)brows * t->num_sites * t->bias_width);
+        h->bias_icpt.assign(SMOLMC_MAX_BIAS_ROWS, 0.0);
+        if (t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE && t->bias_intercepts)
+            for (int k = 0; k < brows; ++k) h->bias_icpt[k] = t->bias_intercepts[k];
+        kp.bias_rows = brows;
+        kp.bias_row_stride = (size_t)t->num_sites * t->bias_width;
         if (t->bias_type == SMOLMC_BIAS_FUGACITY)
             for (double v : h->bias_host)
                 if (!(v > 0.0)) return bail(fail("fugacity fractions must be positive"));
@@ -835,7 +844,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         kp.bias_W = t->bias_width;
         kp.bias_pen = t->bias_penalty;
         if (dev_upload(h, h->bias_host.data(), h->bias_host.size(), &kp.bias_tab)) return bail(1);
-        if (dev_alloc(h, (size_t)cfg->n_replicas, &kp.bias) || dev_alloc(h, (size_t)cfg->n_replicas, &kp.charge))
+        if (dev_alloc(h, (size_t)cfg->n_replicas, &kp.bias) ||
+            dev_alloc(h, (size_t)cfg->n_replicas * SMOLMC_MAX_BIAS_ROWS, &kp.charge))
             return bail(1);
     }
     if (t->has_ewald && t->ewald_charges && getenv("SMOLMC_DENSE_EWALD") == nullptr)
@@ -963,6 +973,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     if (t->mu_table[(size_t)(sbase + i) * t->mu_width + c] != mu_row[c]) lean = false;
         }
         std::vector<double> bias_pair(64, 0.0);
+        if (lean && t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) lean = false; // general kernel
         if (lean && t->bias_type) {
             // the bias row must be the same on every active site (it is defined per sublattice)
             const int W = t->bias_width;
@@ -1314,22 +1325,31 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
     if (kp.bias_type) {
         // MCBias.compute_bias of every initial occupancy (kernel/base.py:362-363), on the host:
         // the occupancies are host arrays here and this runs once per set_state
-        std::vector<double> b0(R), q0(R, 0.0);
+        std::vector<double> b0(R), q0(R * SMOLMC_MAX_BIAS_ROWS, 0.0);
         const int N = h->N, W = kp.bias_W;
         for (size_t r = 0; r < R; ++r) {
             const int32_t *o = occ + r * (size_t)N;
-            double acc = 0.0;
             if (kp.bias_type == SMOLMC_BIAS_FUGACITY) {
+                double acc = 0.0;
                 for (int s = 0; s < N; ++s) acc += log(h->bias_host[(size_t)s * W + o[s]]); // bias.py:174-186
                 b0[r] = acc;
             } else {
-                for (int s = 0; s < N; ++s) acc += h->bias_host[(size_t)s * W + o[s]];
-                q0[r] = acc;
-                b0[r] = -kp.bias_pen * (acc * acc); // bias.py:264-277
+                // SquareChargeBias (bias.py:264-277) = one hyperplane with intercept 0;
+                // SquareHyperplaneBias (bias.py:352-366): -penalty * sum_r (A_r . n - b_r)^2
+                double sq = 0.0;
+                for (int k = 0; k < kp.bias_rows; ++k) {
+                    double acc = 0.0;
+                    const double *tab = h->bias_host.data() + (size_t)k * kp.bias_row_stride;
+                    for (int s = 0; s < N; ++s) acc += tab[(size_t)s * W + o[s]];
+                    acc -= h->bias_icpt[k];
+                    q0[r * SMOLMC_MAX_BIAS_ROWS + k] = acc;
+                    sq += acc * acc;
+                }
+                b0[r] = -kp.bias_pen * sq;
             }
         }
         HIPCHK(hipMemcpy(kp.bias, b0.data(), R * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(kp.charge, q0.data(), R * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(kp.charge, q0.data(), q0.size() * 8, hipMemcpyHostToDevice));
     }
     if (kp.ew_field) {
         LeanParams fp;

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
     double acc_ew = 0.0, acc_mu = 0.0; // Ewald / chemical-work feature deltas (uniform)
     double bias = P.bias_type ? P.bias[r] : 0.0;     // trace.bias (kernel/base.py:362-363)
-    double charge = P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[r] : 0.0;
+    double charge = P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
     int last_acc = 1;
     double wl_m = 0.0;
     long long wl_counter = 0;
@@ -479,18 +479,34 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         // FugacityBias log-ratio per flipped site (bias.py:188-206); SquareChargeBias the
         // difference of -penalty * charge^2 (bias.py:75-93, :264-277) on the running charge
         double dB = 0.0, dQ = 0.0;
+        int bias_orig2 = 0; // species of site 2 BEFORE the step (the second flip sees the first)
         if (!WL && P.bias_type && nfl >= 1) {
             const double *b1 = P.bias_tab + (size_t)s1 * P.bias_W;
             const int orig2 = nfl == 2 ? uni((int)L.occ[s2]) : 0;
+            bias_orig2 = orig2;
             const double *b2 = P.bias_tab + (size_t)s2 * P.bias_W;
             if (P.bias_type == SMOLMC_BIAS_FUGACITY) {
                 dB = log(b1[n1] / b1[o1]);
                 if (nfl == 2) dB += log(b2[n2] / b2[orig2]);
-            } else {
+            } else if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) {
                 dQ = b1[n1] - b1[o1];
                 if (nfl == 2) dQ += b2[n2] - b2[orig2];
                 const double cn = charge + dQ;
                 dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+            } else {
+                // SquareHyperplaneBias (bias.py:290-366; compute_bias_change is the inherited
+                // recompute-and-subtract, :75-93, restated on the running A_r . n - b_r kept per
+                // walker in HBM: a rarely used term, not worth registers in this kernel)
+                double sq_new = 0.0, sq_old = 0.0;
+                for (int k = 0; k < P.bias_rows; ++k) {
+                    const size_t ro = (size_t)k * P.bias_row_stride;
+                    double dq = b1[ro + n1] - b1[ro + o1];
+                    if (nfl == 2) dq += b2[ro + n2] - b2[ro + orig2];
+                    const double c = ((volatile const double *)P.charge)[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k]; // (vector load: written by this wave)
+                    sq_old += c * c;
+                    sq_new += (c + dq) * (c + dq);
+                }
+                dB = -P.bias_pen * sq_new - (-P.bias_pen * sq_old);
             }
             dB = uni_d(dB);
             dQ = uni_d(dQ);
@@ -553,6 +569,18 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             H += dH;
             bias += dB;
             charge += dQ;
+            if (P.bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) {
+                const double *b1 = P.bias_tab + (size_t)s1 * P.bias_W, *b2 = P.bias_tab + (size_t)s2 * P.bias_W;
+                for (int k = 0; k < P.bias_rows; ++k) {
+                    const size_t ro = (size_t)k * P.bias_row_stride;
+                    double dq = b1[ro + n1] - b1[ro + o1];
+                    if (nfl == 2) dq += b2[ro + n2] - b2[ro + bias_orig2];
+                    if (lane == 0) {
+                        volatile double *cq = (volatile double *)P.charge + (size_t)r * SMOLMC_MAX_BIAS_ROWS + k;
+                        *cq = *cq + dq;
+                    }
+                }
+            }
             nacc++;
         }
         last_acc = accepted ? 1 : 0;
@@ -662,7 +690,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         P.nacc[r] = nacc;
         P.last_acc[r] = (uint8_t)last_acc;
         if (P.bias_type) P.bias[r] = bias;
-        if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[r] = charge;
+        if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
     }
 }
 

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // MCBias (separate instantiations, lean_bias_n*.hip: even a never-taken runtime branch costs
     // the unbiased kernel 10 %): biased walkers always take the exact decision path
     const int btype = BIAS ? P.bias_type : 0;
-    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[r] : 0.0;
+    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
     // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
     // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
     // only the rare undecided step pays for the float64 reduction, so decisions are exactly
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
     if (btype && lane == 0) {
         P.bias[r] += bias_acc;
-        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[r] = charge;
+        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
     }
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;

@@ -103,7 +103,9 @@ struct KParams {
     int bias_type, bias_W;
     const double *bias_tab;
     double bias_pen;
-    double *bias, *charge;
+    double *bias, *charge;      // charge: [R x SMOLMC_MAX_BIAS_ROWS] running sum_sites table_r - b_r
+    int bias_rows;              // SquareHyperplaneBias: number of hyperplanes (tables [rows][N][W])
+    size_t bias_row_stride;     // N * W
     // sublattices
     const int *sub_ptr;           // [nsub+1]
     const int *sub_sites;         // concatenated active sites
@@ -412,6 +414,7 @@ struct smolmc_handle {
     double *d_beta = nullptr;
     bool wl_sums = false; // kp.wl_meanf currently holds sums (lean Wang-Landau) instead of means
     std::vector<double> bias_host; // host copy of the MCBias table (initial bias in set_state)
+    std::vector<double> bias_icpt; // SquareHyperplaneBias intercepts (zeros otherwise)
     std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
 };
 

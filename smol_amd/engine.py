@@ -66,7 +66,7 @@ def load_library(path=None):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.smolmc_abi_version() != 2:
+    if lib.smolmc_abi_version() != 3:
         raise RuntimeError("smolmc ABI version mismatch")
     if path is None:
         _LIB = lib

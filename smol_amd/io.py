@@ -16,7 +16,7 @@ from . import capi
 FORMAT_VERSION = 1
 _SCALARS = ("num_sites", "size", "num_orbits", "num_corr", "max_species", "n_orb", "feature_mode",
             "has_ewald", "ewald_dim", "ewald_width", "has_mu", "mu_width", "n_sublattices",
-            "n_flip_vectors", "bias_type", "bias_width")
+            "n_flip_vectors", "bias_type", "bias_width", "bias_rows")
 _FLOATS = ("offset", "ewald_coef", "swap_weight", "bias_penalty")
 # every array a TableSet keeps alive; a file holding anything else was written by a newer
 # exporter and must not be loaded as if the extra tables were absent
@@ -26,7 +26,7 @@ _ARRAYS = frozenset((
     "full_off", "full_idx", "site_ptr", "loc_orbit", "loc_ratio", "loc_nrows", "loc_off", "loc_idx",
     "ce_coefs", "ewald_inds", "ewald_matrix", "ewald_charges", "mu_table", "sub_site_ptr",
     "sub_active_sites", "sub_code_ptr", "sub_codes", "sub_probs", "flip_table", "flip_weights",
-    "bias_table",
+    "bias_table", "bias_intercepts",
 ))
 
 
@@ -98,5 +98,6 @@ def load_tables(path) -> capi.TableSet:
     )
     tab.struct.max_species = int(d["max_species"])
     if "bias_table" in A:  # MCBias term (files written before it was persisted have none)
-        tab.set_bias(int(d["bias_type"]), A["bias_table"], float(d["bias_penalty"]))
+        tab.set_bias(int(d["bias_type"]), A["bias_table"], float(d["bias_penalty"]),
+                     intercepts=A.get("bias_intercepts"))
     return tab

@@ -653,9 +653,58 @@ class SquareChargeBias(MCBias):
         return float(-self.penalty * c**2)
 
 
+class SquareHyperplaneBias(MCBias):
+    """Square hyperplane bias (bias.py:290-366): bias = -penalty * ||A n - b||^2 with n the
+    species counts of the occupancy in "counts" format -- the species of every sublattice in
+    order, concatenated over ALL sublattices (occu_utils.py:8-23,62-100) -- i.e. a penalty on the
+    distance from composition constraints A n = b (per supercell).  Up to four hyperplanes."""
+
+    bias_type = capi.BIAS_SQUARE_HYPERPLANE
+
+    def __init__(self, sublattices, hyperplane_normals, hyperplane_intercepts, penalty=0.5):
+        super().__init__(sublattices)
+        if penalty <= 0:
+            raise ValueError("Penalty factor should be > 0!")
+        self.penalty = float(penalty)
+        self._A = np.atleast_2d(np.array(hyperplane_normals, dtype=int))
+        self._b = np.atleast_1d(np.array(hyperplane_intercepts, dtype=int))
+        self.d = sum(len(s.species) for s in self.sublattices)
+        if self._A.shape != (len(self._b), self.d):
+            raise ValueError(f"hyperplane_normals must be [len(intercepts) x {self.d}] (one column per "
+                             "species of every sublattice)")
+        if not 1 <= len(self._b) <= 4:
+            raise NotImplementedError("the engine supports 1 to 4 hyperplanes")
+        # get_dim_ids_table (occu_utils.py:8-23): dimension of (site, code) in the counts vector
+        n_sites, width = self._shape()
+        self._dim_ids_table = -np.ones((n_sites, width), dtype=int)
+        off = 0
+        for s in self.sublattices:
+            self._dim_ids_table[s.sites[:, None], s.encoding] = off + np.arange(len(s.species))[None, :]
+            off += len(s.species)
+        table = np.zeros((len(self._b), n_sites, width))
+        valid = self._dim_ids_table >= 0
+        for r in range(len(self._b)):
+            table[r][valid] = self._A[r][self._dim_ids_table[valid]]
+        self._table = table
+        self.intercepts = self._b.astype(float)
+        self.spec.update(penalty=self.penalty, hyperplane_normals=self._A.tolist(),
+                         hyperplane_intercepts=self._b.tolist())
+
+    def counts(self, occupancy):
+        """occu_to_counts (occu_utils.py:62-100)."""
+        ids = self._dim_ids_table[np.arange(len(occupancy)), occupancy]
+        return np.bincount(ids[ids >= 0], minlength=self.d)
+
+    def compute_bias(self, occupancy):
+        n = self.counts(np.asarray(occupancy))
+        return float(-self.penalty * np.sum((self._A @ n - self._b) ** 2))
+
+
 BIAS_TYPES = {"fugacity": FugacityBias, "fugacity-bias": FugacityBias, "fugacitybias": FugacityBias,
               "square-charge": SquareChargeBias, "square-charge-bias": SquareChargeBias,
-              "squarechargebias": SquareChargeBias}
+              "squarechargebias": SquareChargeBias,
+              "square-hyperplane": SquareHyperplaneBias, "square-hyperplane-bias": SquareHyperplaneBias,
+              "squarehyperplanebias": SquareHyperplaneBias}
 
 
 def mcbias_factory(bias_type, sublattices, **kwargs):
@@ -663,7 +712,7 @@ def mcbias_factory(bias_type, sublattices, **kwargs):
     key = str(bias_type).lower().replace("_", "-")
     if key not in BIAS_TYPES:
         raise NotImplementedError(f"{bias_type} is not implemented on the MI355X engine "
-                                  f"(available: FugacityBias, SquareChargeBias).")
+                                  f"(available: FugacityBias, SquareChargeBias, SquareHyperplaneBias).")
     return BIAS_TYPES[key](sublattices, **kwargs)
 
 
@@ -672,7 +721,7 @@ class MCKernel:
     the reference keeps per kernel object; the stepping itself happens on the GPU."""
 
     kernel_type = None
-    valid_bias = ("FugacityBias", "SquareChargeBias")
+    valid_bias = ("FugacityBias", "SquareChargeBias", "SquareHyperplaneBias")
 
     def __init__(self, ensemble, step_type, *args, seed=None, bias_type=None, bias_kwargs=None, **kwargs):
         if step_type not in STEP_TYPES:
@@ -1140,7 +1189,8 @@ class Sampler:
         if self._engine is None or self._engine_key != key:
             tables = ens.make_tables(**k0.usher_kwargs)
             if k0.bias is not None:
-                tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty)
+                tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty,
+                                intercepts=getattr(k0.bias, "intercepts", None))
             if isinstance(k0, WangLandau):
                 cfg = capi.make_config(
                     len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], self._device,

@@ -51,7 +51,7 @@ def test_bias_tables_and_validation(rocksalt):
     with pytest.raises(ValueError, match="Penalty factor"):
         moca.SquareChargeBias(ens.sublattices, penalty=0.0)
     with pytest.raises(NotImplementedError):
-        moca.mcbias_factory("square-hyperplane", ens.sublattices)
+        moca.mcbias_factory("nonexistent-bias", ens.sublattices)
     k = moca.Metropolis(ens, "flip", 1000.0, bias_type="square-charge", bias_kwargs={"penalty": 0.3})
     assert isinstance(k.bias, moca.SquareChargeBias) and k.spec["bias"]["penalty"] == 0.3
     with pytest.raises(ValueError, match="Wang-Landau"):  # wanglandau.py:127-128
@@ -134,3 +134,71 @@ def test_oracle_square_charge_bias_confines_the_charge(rocksalt):
     c = np.array([q[np.arange(sc.num_sites), o].sum() for o in st["occupancy"]])
     assert np.abs(c0).mean() > 8 and np.abs(c).max() <= 3
     np.testing.assert_allclose(mc.get_bias(), -0.5 * c**2, atol=1e-9)
+
+
+def _hyperplanes(sc):
+    """Two composition constraints on the counts vector (Li, Mn, Ti | O): n_Mn = P/3 and
+    n_Li - n_Ti = 1 (per supercell, as the reference defines A n = b)."""
+    return [[0, 1, 0, 0], [1, 0, -1, 0]], [sc.size // 3, 1]
+
+
+def test_square_hyperplane_bias_host_and_oracle(rocksalt):
+    """SquareHyperplaneBias (bias.py:290-366): the host record reproduces the reference formula
+    -penalty * ||A n - b||^2 on the species counts, the oracle's table form equals it, and its
+    change equals bias(after) - bias(before) (tests/test_moca/test_bias.py)."""
+    ens = _ensemble(rocksalt)
+    sc = rocksalt[1]
+    A, b = _hyperplanes(sc)
+    bias = moca.mcbias_factory("square-hyperplane", ens.sublattices, hyperplane_normals=A,
+                               hyperplane_intercepts=b, penalty=0.3)
+    assert isinstance(bias, moca.SquareHyperplaneBias) and bias.d == 4
+    assert bias._table.shape == (2, sc.num_sites, 3)
+    np.testing.assert_array_equal(bias._table[1, 0], [1, 0, -1])  # cation site: A[1][Li, Mn, Ti]
+    np.testing.assert_array_equal(bias._table[1, sc.size], [0, 0, 0])  # anion site: A[1][O] = 0, unused codes 0
+    with pytest.raises(ValueError, match="Penalty factor"):
+        moca.SquareHyperplaneBias(ens.sublattices, A, b, penalty=-1.0)
+    with pytest.raises(ValueError, match="one column per"):
+        moca.SquareHyperplaneBias(ens.sublattices, [[1, 0, 0]], [0])
+    tab = ens.make_tables().set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=bias.intercepts)
+    assert tab.struct.bias_rows == 2
+    ev = orc.OracleEvaluator(tab)
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        occ = _rand_occ(sc, rng)
+        n = np.array([(occ[: sc.size] == c).sum() for c in range(3)] + [sc.size])
+        want = -0.3 * float(np.sum((np.array(A) @ n - np.array(b)) ** 2))
+        np.testing.assert_array_equal(bias.counts(occ), n)
+        assert bias.compute_bias(occ) == want
+        np.testing.assert_allclose(ev.bias(occ), want, rtol=1e-13)
+        sites = rng.choice(sc.size, size=rng.integers(1, 4), replace=False)
+        flips = [(int(s), int((occ[s] + rng.integers(1, 3)) % 3)) for s in sites]
+        new = occ.copy()
+        for s_, c in flips:
+            new[s_] = c
+        np.testing.assert_allclose(ev.bias_change(occ, flips), bias.compute_bias(new) - bias.compute_bias(occ),
+                                   rtol=1e-10, atol=1e-10)
+    # the reference's SquareChargeBias is the one-hyperplane special case A = charges, b = 0
+    q = moca.SquareChargeBias(ens.sublattices, penalty=0.3)
+    hq = moca.SquareHyperplaneBias(ens.sublattices, [[1, 3, 4, -2]], [0], penalty=0.3)
+    occ = _rand_occ(sc, rng)
+    assert hq.compute_bias(occ) == q.compute_bias(occ)
+
+
+def test_oracle_square_hyperplane_bias_pulls_onto_the_constraints(rocksalt):
+    model, sc = rocksalt
+    ens = moca.Ensemble.from_cluster_expansion(sc, np.zeros(model.num_corr_functions))
+    A, b = _hyperplanes(sc)
+    bias = moca.SquareHyperplaneBias(ens.sublattices, A, b, penalty=0.5)
+    tab = ens.make_tables().set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=bias.intercepts)
+    R = 6
+    mc = orc.OracleMC(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    rng = np.random.default_rng(8)
+    occ0 = np.zeros((R, sc.num_sites), dtype=np.int32)  # all Li: far from both hyperplanes
+    mc.set_state(occ0, np.arange(R, dtype=np.uint64) + 3, 1000.0)
+    np.testing.assert_allclose(mc.get_bias(), [bias.compute_bias(o) for o in occ0])
+    mc.run(4000)
+    st = mc.get_state()
+    for o in st["occupancy"]:
+        n = bias.counts(o)
+        assert abs(n[1] - sc.size // 3) <= 2 and abs(n[0] - n[2] - 1) <= 3
+    np.testing.assert_allclose(mc.get_bias(), [bias.compute_bias(o) for o in st["occupancy"]], atol=1e-9)

@@ -129,3 +129,43 @@ def test_table_flip_without_table_uses_composition_space():
     q = np.array([1, 3, 4])
     assert np.all((q[occs].sum(axis=-1) - 2 * P) == 0)  # charge neutral at every sample
     assert len({int((o == 2).sum()) for o in occs.reshape(-1, P)}) > 1  # composition moved
+
+
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+def test_square_hyperplane_bias_matches_oracle(rocksalt, step):
+    """SquareHyperplaneBias (bias.py:290-366, two hyperplanes) on the engine == oracle, running
+    bias == recomputation from the species counts, through the smol-shaped Sampler as well."""
+    from oracle import oracle as orc
+
+    model, sc, coefs = rocksalt
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.2)
+    A, b = [[0, 1, 0, 0], [1, 0, -1, 0]], [sc.size // 3, 1]
+    bias = moca.SquareHyperplaneBias(ens.sublattices, A, b, penalty=0.05)
+    tab = ens.make_tables().set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=bias.intercepts)
+    R = 7
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(23)
+    occ0 = _occ(sc, rng, R)
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(977)
+    temps = np.linspace(600.0, 5000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("general")  # a rarely used term: general kernel only
+    eng.set_state(occ0, seeds, temps)
+    ora.set_state(occ0, seeds, temps)
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in occ0], rtol=RTOL, atol=ATOL)
+    for chunk in (1, 16, 400):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b_ = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b_["occupancy"])
+        assert np.array_equal(a["n_accepted"], b_["n_accepted"])
+        np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in a["occupancy"]], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    sampler = moca.Sampler.from_ensemble(ens, temperature=1500.0, step_type="flip", nwalkers=3, seeds=[1, 2, 3],
+                                         bias_type="square-hyperplane",
+                                         bias_kwargs=dict(hyperplane_normals=A, hyperplane_intercepts=b, penalty=0.05))
+    sampler.run(600, occ0[:3], thin_by=200)
+    occs = sampler.samples.get_occupancies(flat=False)
+    got = sampler.samples.get_trace_value("bias", flat=False)[..., 0]
+    np.testing.assert_allclose(got, [[bias.compute_bias(o) for o in row] for row in occs], rtol=RTOL, atol=1e-8)
