@@ -426,8 +426,14 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     // bit_id instead of the orbit id and the weight coefs[bit_id]: same code, other tables.
     bool corr_k1 = corr;
     for (int o = 0; o < t->n_orb; ++o) corr_k1 = corr_k1 && t->orb_nfunc[o] == 1;
-    if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = false; // A/B switch (tests, profiling)
-    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1) && N <= 65535 &&
+    // Several correlation functions per orbit (K <= SMOLMC_LEAN_MAX_KF, one site class): the decision
+    // table of a slot is made from the folded tensor E = sum_k coef_k ct_k and the K function
+    // tables follow it (mc_lean_kernel KF).
+    int kmax = 1;
+    for (int o = 0; o < t->n_orb; ++o) kmax = std::max(kmax, (int)t->orb_nfunc[o]);
+    bool corr_kf = corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && class_rep.size() == 1;
+    if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = corr_kf = false; // A/B switch (tests, profiling)
+    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1 || corr_kf) && N <= 65535 &&
         niter_max <= 8 && need_mm <= 3 && num_ce_features(t) <= 64) {
         const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
         const int NCLS = (int)class_rep.size();
@@ -529,13 +535,25 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             const double *T = corr ? t->corr_tensors + t->orb_ctensor_off[o] // K == 1: the one function
                                    : t->interaction_tensors + t->orb_itensor_off[o];
             const int feat = corr ? t->orb_bit_id[o] : t->orb_id[o];
+            const int K = corr_kf ? t->orb_nfunc[o] : 1;
+            std::vector<double> Efold; // KF: folded tensor sum_k coef_k ct_k (decision table source)
+            if (corr_kf) {
+                Efold.assign((size_t)Nt, 0.0);
+                for (int kk = 0; kk < K; ++kk)
+                    for (int i = 0; i < Nt; ++i) Efold[i] += t->ce_coefs[feat + kk] * T[(size_t)kk * Nt + i];
+            }
             const int ss = st[k.p];
             const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
             const auto key = std::make_pair(o, k.p);
             if (!doff_of.count(key)) {
-                std::vector<double> D(tlen, 0.0);
+                // table group of the slot: [decision table] (+ K correlation-function tables in KF mode)
+                const int ntab = corr_kf ? 1 + K : 1;
+                std::vector<double> D((size_t)ntab * tlen, 0.0);
                 int nb = 1;
                 for (int a = 0; a < I - 1; ++a) nb *= SMAX;
+                for (int tb = 0; tb < ntab; ++tb) {
+                const double *Tsrc = !corr_kf ? T : (tb == 0 ? Efold.data() : T + (size_t)(tb - 1) * Nt);
+                double *Dt = D.data() + (size_t)tb * tlen;
                 for (int b = 0; b < nb; ++b) {
                     // decode b into the species of the other members -> tensor base index
                     long base = 0;
@@ -552,12 +570,13 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                     if (!valid) continue;
                     for (int oldc = 0; oldc < Sself; ++oldc)
                         for (int newc = 0; newc < Sself; ++newc)
-                            D[((size_t)oldc * SMAX + newc) * NTP + b] =
-                                T[base + (long)ss * newc] - T[base + (long)ss * oldc];
+                            Dt[((size_t)oldc * SMAX + newc) * NTP + b] =
+                                Tsrc[base + (long)ss * newc] - Tsrc[base + (long)ss * oldc];
+                }
                 }
                 uint32_t at = 0;
-                for (size_t off = tlen; off + tlen <= dt.size() && !at; off += tlen)
-                    if (memcmp(dt.data() + off, D.data(), tlen * sizeof(double)) == 0) at = (uint32_t)off;
+                for (size_t off = tlen; off + D.size() <= dt.size() && !at; off += tlen)
+                    if (memcmp(dt.data() + off, D.data(), D.size() * sizeof(double)) == 0) at = (uint32_t)off;
                 if (!at) {
                     at = (uint32_t)dt.size();
                     dt.insert(dt.end(), D.begin(), D.end());
@@ -572,10 +591,10 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 for (int m = 0; m < I - 1; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
             }
             L.feat = (uint32_t)feat;
-            L.live = 1;
-            L.w = t->ce_coefs[feat] * scale;
+            L.live = (uint32_t)K;
+            L.w = corr_kf ? scale : t->ce_coefs[feat] * scale; // (KF: the coefficients are folded into the table)
             L.fs = scale;
-            if (dt.size() > 8000) ok = false; // keep the LDS tables within budget
+            if (dt.size() > (corr_kf ? 12000u : 8000u)) ok = false; // keep the LDS tables within budget
             double dmax = 0.0;
             {
                 const double *D = dt.data() + doff_of[key];
@@ -589,6 +608,8 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         // |w * d| over the slots, a float32 conversion + 6-level tree adds at most
         // 7 * 2^-24 of that; 2^-19 leaves a 4.5x margin.
         h->lp.fast_eps = 2.0 * sum_abs_max * ldexp(1.0, -19);
+        h->lp.ktab8 = (uint32_t)tlen * 8u;
+        h->lean_kf = corr_kf ? SMOLMC_LEAN_MAX_KF : 0;
         h->lp.nt8 = (uint32_t)NTP * 8u;
         h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
@@ -974,6 +995,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         }
         std::vector<double> bias_pair(64, 0.0);
         if (lean && t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) lean = false; // general kernel
+        // several correlation functions per orbit: plain Metropolis flip / swap variants only
+        if (lean && h->lean_kf && (wl || t->bias_type || cfg->step_type == SMOLMC_STEP_TABLE_FLIP)) lean = false;
         if (lean && t->bias_type) {
             // the bias row must be the same on every active site (it is defined per sublattice)
             const int W = t->bias_width;
@@ -1080,7 +1103,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             // one wave per workgroup (occupancy at LDS address 0, 32-bit index rows, a private
             // copy of the tables): Metropolis flips / swaps without Ewald term or bias, when 16
             // such workgroups still fit a CU
-            if (lean && !wl && !t->has_ewald && !t->bias_type && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
+            if (lean && !wl && !t->has_ewald && !t->bias_type && !h->lean_kf && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
                 getenv("SMOLMC_NO_SOLO") == nullptr) {
                 const size_t pw = ((size_t)lp.Nlds + 64 * 8 + 15) & ~(size_t)15;
                 const size_t solo_lds = pw + ((size_t)lp.dt_len + 24) * 8;
@@ -1110,7 +1133,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         h->lean = lean;
         // ---- several classes / sublattices (or > 256 clusters per site): mc_lean_multi_kernel
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
-        if (!lean && h->lean_tables && !wl && !t->bias_type && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        if (!lean && h->lean_tables && !h->lean_kf && !wl && !t->bias_type && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
@@ -1422,7 +1445,8 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     if (!h || !buf || n <= 0) return fail("null argument");
     if (h->lean)
         snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu%s", h->lean_multi ? "lean-multi" : "lean",
-                 h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds, h->lean_solo ? " solo=1" : "");
+                 h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds,
+                 h->lean_solo ? " solo=1" : (h->lean_kf ? " kf=1" : ""));
     else
         snprintf(buf, (size_t)n, "general nslot=%d mm=%d field=%d lds=%zu", h->nslot, h->mm, h->kp.ew_field,
                  h->lds_bytes);
@@ -1512,6 +1536,7 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_4(h, lp) : smolmc_launch_multi_8(h, lp));
     if (lp.bias_type && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP)
         return h->lean_nslot == 2 ? smolmc_launch_lean_bias_2(h, lp) : smolmc_launch_lean_bias_4(h, lp);
+    if (h->lean_kf) return h->lean_nslot == 2 ? smolmc_launch_lean_corr_2(h, lp) : smolmc_launch_lean_corr_4(h, lp);
     return h->lean_nslot == 2 ? smolmc_launch_lean_2(h, lp) : smolmc_launch_lean_4(h, lp);
 }
 

@@ -226,8 +226,16 @@ template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_
 // they are -- no per-gather "wave base + unpack u16" instruction (8 VALU per swap step) -- and
 // the site / candidate addresses need no base either.  Costs one copy of the tables per wave,
 // so it is chosen when 16 waves per CU still fit (engine.hip).
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false, bool SOLO = false>
+// KF > 0: correlation features with up to KF correlation functions per orbit (evaluator.pyx:211-265
+// for any number of species).  The accept decision is taken from ONE folded table per slot
+// (E = sum_k coef_k ct_k, so a proposal costs what it costs in interaction mode); the KF
+// correlation-function tables of the slot sit behind it in LDS and are read only on ACCEPTED
+// steps, at the table index the decision already computed, into KF accumulators per slot.
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false, bool SOLO = false,
+          int KF = 0>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
+    static_assert(KF == 0 || (!WL && !BIAS && !SOLO), "correlation-function tables: plain Metropolis layouts only");
+    constexpr int NACC = KF ? KF : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap(); // (no static LDS in this kernel: absolute LDS addresses below)
     const int lane = threadIdx.x & 63;
@@ -276,17 +284,39 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // per-lane slot constants (registers for the whole launch)
     uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
     double wgt[NSLOT], acc[NSLOT], sfs[NSLOT];
+    double accK[NSLOT][NACC]; // KF: per correlation function (acc then only carries the enthalpy)
+    uint32_t kslot[NSLOT];    // KF: number of correlation functions of the slot's orbit
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const LeanSlot sl = P.slots[it * 64 + lane];
         doff8[it] = sl.doff8 + dt_off;
         sfeat[it] = sl.feat;      // only used by the Wang-Landau variant
         sfs[it] = sl.live ? sl.fs : 0.0;
+        kslot[it] = sl.live;
 #pragma unroll
         for (int m = 0; m < MM; ++m) st8[it][m] = sl.stride8[m];
         wgt[it] = sl.w;
         acc[it] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) accK[it][k] = 0.0;
     }
+    // feature read-out: sum over lanes and slots of fs * accumulator into s_feat[feature]
+    auto reduce_features = [&](double *dst) {
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) {
+            if (KF == 0) {
+                __hip_atomic_fetch_add(&dst[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) {
+                    const bool on = (uint32_t)k < kslot[it];
+                    __hip_atomic_fetch_add(&dst[sfeat[it] + (on ? k : 0)], on ? sfs[it] * accK[it][k] : 0.0,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+        }
+    };
     double H = P.enthalpy[r];
     const double nbeta = WL ? 0.0 : -P.beta[r];
     double wl_m = WL ? P.wl.m[r] : 0.0;
@@ -513,7 +543,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
 
         // -------- enthalpy delta ---------------------------------------------------
-        // Swap (Metropolis): the second flip is the reverse species change of the first
+        // Swap: the second flip is the reverse species change of the first
         // (n2 == o1, o2 == n1), and the delta tables are antisymmetric in (old, new), so both
         // flips read the SAME (old, new) block -- its offset is added to the slot offsets once --
         // and the step's delta per slot is the difference of the two reads: one table offset
@@ -522,10 +552,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #ifdef SMOLMC_NO_SWAP_DIFF
         constexpr bool DIFF = false;
 #else
-        constexpr bool DIFF = STEP == SMOLMC_STEP_SWAP && !WL;
+        constexpr bool DIFF = STEP == SMOLMC_STEP_SWAP;
 #endif
         double e = 0.0, d1[NSLOT], d2[NSLOT];
         uint32_t dp[NSLOT];
+        uint32_t ad1[NSLOT], ad2[NSLOT]; // KF: LDS addresses of the two decision reads
         {
             const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8; // uniform
 #pragma unroll
@@ -536,8 +567,10 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row1, it * MM + m)));
                 if (DIFF) {
                     d1[it] = SMOLMC_LDS_F64(a);
+                    if (KF) ad1[it] = a;
                 } else {
                     d1[it] = SMOLMC_LDS_F64(a + pair1); // (absolute LDS address: a includes the table base)
+                    if (KF) ad1[it] = a + pair1;
                     e = fma(wgt[it], d1[it], e);
                 }
             }
@@ -573,9 +606,11 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row2, it * MM + m)));
                 if (DIFF) {
                     d1[it] -= SMOLMC_LDS_F64(a); // D[(o2,n2)] = -D[(o1,n1)]: the step's delta of this slot
+                    if (KF) ad2[it] = a;
                     e = fma(wgt[it], d1[it], e);
                 } else {
                     d2[it] = SMOLMC_LDS_F64(a + pair2);
+                    if (KF) ad2[it] = a + pair2;
                     e = fma(wgt[it], d2[it], e);
                 }
             }
@@ -658,6 +693,25 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #endif
         uint32_t sel_hi = 0u; // high word of sel
         auto on_accept = [&]() {
+            if (KF) {
+                // the K correlation-function tables of each slot, read at the index of the
+                // decision table (table k + 1 of the slot's group, ktab8 bytes apart; slots with
+                // fewer functions read a zero)
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+#pragma unroll
+                    for (int k = 0; k < NACC; ++k) {
+                        const bool on = (uint32_t)k < kslot[it];
+                        const uint32_t off = (uint32_t)(k + 1) * P.ktab8;
+                        double v = SMOLMC_LDS_F64(on ? ad1[it] + off : dt_off);
+                        if (STEP == SMOLMC_STEP_SWAP) {
+                            const double v2 = SMOLMC_LDS_F64(on ? ad2[it] + off : dt_off);
+                            v = DIFF ? v - v2 : v + v2;
+                        }
+                        accK[it][k] += v;
+                    }
+                }
+            }
             if (SELACC) {
                 sel_hi = 0x3ff00000u;
             } else if (!WL) {
@@ -671,7 +725,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 // _do_accept_step (wanglandau.py:204-220): current features += delta features
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) {
-                    const double dd = STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+                    const double dd = (STEP == SMOLMC_STEP_SWAP && !DIFF) ? d1[it] + d2[it] : d1[it];
                     __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * dd, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
@@ -778,10 +832,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (lane < qF) q_feat[row * qF + lane] = s_feat[lane];
             } else {
                 s_feat[lane] = 0.0;
-#pragma unroll
-                for (int it = 0; it < NSLOT; ++it)
-                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                reduce_features(s_feat);
                 if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
             }
             if (!WL && HAS_EW && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
@@ -826,10 +877,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
     } else {
         s_feat[lane] = 0.0;
-#pragma unroll
-        for (int it = 0; it < NSLOT; ++it)
-            __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        reduce_features(s_feat);
         if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     }
     if (FAST) {
@@ -1361,10 +1409,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 }
 
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false, bool SOLO = false>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
-    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO>;
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1427,6 +1475,26 @@ template <int NSLOT> static int launch_lean_bias_nslot(smolmc_handle *h, const L
                     : launch_lean_bias_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
     return swap ? launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp)
                 : launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
+}
+
+// correlation features with several functions per orbit (instantiated in lean_corr_n*.hip only)
+template <int NSLOT, int MM, int STEP>
+static int launch_lean_corr_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    constexpr int KF = SMOLMC_LEAN_MAX_KF;
+    if (ew)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false, false, false, KF>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false, false, false, KF>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, false, false, KF>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, false, false, false, false, KF>(h, lp);
+}
+template <int NSLOT> static int launch_lean_corr_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_lean_corr_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp)
+                    : launch_lean_corr_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
+    return swap ? launch_lean_corr_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp)
+                : launch_lean_corr_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
 }
 
 template <int NSLOT> static int launch_lean_nslot(smolmc_handle *h, const LeanParams &lp) {

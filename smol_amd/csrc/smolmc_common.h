@@ -292,7 +292,8 @@ struct LeanSlot {
     uint32_t doff8;      // byte offset of the slot's delta table
     uint32_t stride8[3]; // 8 * stride of the other members
     uint32_t feat;       // feature index (orbit id)
-    uint32_t live;       // 0 for padded slots
+    uint32_t live;       // 0 for padded slots; else the number of feature tables of the slot (1, or K in
+                         // the several-correlation-functions mode)
     double w;            // natural parameter * size / (ratio * J)
     double fs;           // size / (ratio * J)
 };
@@ -317,6 +318,7 @@ struct LeanParams {
     uint8_t *last_acc;
     int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
     uint32_t nt8, snt8;    // 8*NTP and 8*NTP*S: (old, new) -> byte offset old*snt8 + new*nt8
+    uint32_t ktab8;        // KF mode: byte distance between the tables of one slot's group
     // LDS address of site s = s ^ (((s >> swz_a) & swz_m) << swz_b): a bank swizzle chosen on
     // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
     int swz_a, swz_m, swz_b, Nlds;
@@ -399,6 +401,7 @@ struct smolmc_handle {
     int lean_nslot = 0, lean_mm = 0, lean_ncls = 0;
     bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
     bool lean_solo = false;             // mc_lean_kernel in its one-wave-per-workgroup layout
+    int lean_kf = 0;                    // > 0: correlation features with up to lean_kf functions per orbit
     std::vector<uint16_t> lean_idx_host; // lane-packed index rows (kept for the 32-bit copy)
     std::vector<int> site_class_host;   // site -> class (255 = no clusters)
     size_t lean_lds = 0;
@@ -466,6 +469,9 @@ int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
+#define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
+int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_corr_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_bias_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);

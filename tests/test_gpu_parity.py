@@ -553,7 +553,10 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),     # correlation features, K = 1
     ("fcc_prim666_triplets", "corr", capi.STEP_SWAP, None, "wang-landau", "lean"),
     ("fcc_conv444_pairs", "corr", capi.STEP_FLIP, "mu2", "metropolis", "lean"),
-    ("rocksalt444_ewald", "corr", capi.STEP_FLIP, "mu3", "metropolis", "general"),    # K > 1 correlation functions
+    ("rocksalt444_ewald", "corr", capi.STEP_FLIP, "mu3", "metropolis", "lean"),       # K = 3 / 4 / 6 functions per orbit
+    ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),
+    ("fcc3_indicator_skew", "corr", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
+    ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "wang-landau", "general"),    # WL keeps K > 1 on mc_kernel
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
@@ -571,8 +574,10 @@ def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, e
         cfg = capi.make_config(3, capi.KERNEL_WANGLANDAU, step, min_enthalpy=-50.0, max_enthalpy=50.0, bin_size=0.5)
     info = _engine(tab, cfg).kernel_info()
     assert info.startswith(expected), info
-    if name == "rocksalt444_ewald":
+    if name == "rocksalt444_ewald" and kernel == "metropolis":
         assert "field=1" in info
+    if mode == "corr" and expected == "lean":
+        assert ("kf=1" in info) == (name != "fcc_prim666_triplets" and name != "fcc_conv444_pairs")
 
 
 @pytest.mark.parametrize("name,step,mukind", [("fcc_prim666_triplets", capi.STEP_SWAP, None),
