@@ -1,16 +1,20 @@
+# Round profile of the headline benchmark: bench line, rocprofv3 kernel stats, five PMC passes
+# (separate runs: --pmc must not be combined with tracing domains other than --kernel-trace).
+#   bash tools/run_profile.sh r02       (on the GPU box, from the repo root)
+# Outputs under gpurun_out/ (scratch); copy the summaries you want judged into profiles/.
 set -x
+tag=${1:-r02}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python bench.py > gpurun_out/bench_r01_final.json 2> gpurun_out/bench_r01_final.err
+python bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_final -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_final.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -- python $R/bench.py --no-cpu-baseline --no-other-configs > $R/gpurun_out/prof_${tag}.log 2>&1
 for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-24)
-  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_final_$n -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/pmc_final_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${tag}_$n -- python $R/bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 > $R/gpurun_out/pmc_${tag}_$n.log 2>&1
 done
 cd $R
-python tools/rocpd_summary.py gpurun_out/prof_final gpurun_out/pmc_final_* > gpurun_out/final_summary.txt 2>&1
-tail -5 gpurun_out/bench_r01_final.json
-for c in 1 3 4 5 6 7; do python tools/bench_configs.py --config $c > gpurun_out/config${c}_final.json 2> gpurun_out/config${c}_final.err; done
-cat gpurun_out/config*_final.json
+python tools/rocpd_summary.py gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_pmc.txt
+python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, false, false, false, true" --replicas 4096 --mc 10000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
+tail -c 600 gpurun_out/bench_${tag}.json
