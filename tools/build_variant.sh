@@ -7,5 +7,6 @@ tag=$1; flags=$2
 cd "$(dirname "$0")/../smol_amd/csrc"
 mkdir -p ../exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $flags -c -o /tmp/lean_n2_$tag.o lean_n2.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/libsmolmc_$tag.so engine.o general_n2.o general_n4.o general_n8.o general_n16.o /tmp/lean_n2_$tag.o lean_n4.o lean_bias_n2.o lean_bias_n4.o multi_n2.o multi_n4.o multi_n8.o
+others=$(ls *.o | grep -v '^lean_n2.o$')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/libsmolmc_$tag.so $others /tmp/lean_n2_$tag.o
 echo built smol_amd/exp/libsmolmc_$tag.so
