@@ -1055,6 +1055,13 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     bool head_valid = false;
     unsigned feas_now = 0, lp_valid = 0;
     double sumw = 0.0, vlp = 0.0;
+    // Candidate block: the first 16 positions of the site-candidate stream c_t = W(step, 4 + t/4,
+    // t%4) of FOUR steps, one candidate per lane (lane L: step (step & ~3) + (L >> 4), t = L & 15),
+    // from one Philox call per four steps.  A table step needs |u| <= 8 sites and finds them
+    // among its first 16 candidates 9 times out of 10: those steps skip the 256-candidate round
+    // (a Philox call, 4 gathers and 4 ballots per species) -- see the fast path below.
+    unsigned long long cblk_base = ~0ull;
+    int cb_site = 0, cb_addr = 0;
 
     for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
@@ -1189,7 +1196,48 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             uint32_t round = 0;
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
             bool have_round = false;
-            for (int c = 0; c < nc; ++c) {
+            // ---- fast path: all picks among the first 16 candidates of the stream -------------
+            bool fast_done = false;
+#ifndef SMOLMC_NO_TABLE_FAST
+            {
+                if ((step & ~3ull) != cblk_base) {
+                    cblk_base = step & ~3ull;
+                    const unsigned long long sl = cblk_base + (unsigned)(lane >> 4);
+                    const uint32_t t = (uint32_t)lane & 15u;
+                    const philox_out o = philox4x32_10((uint32_t)sl, (uint32_t)(sl >> 32), 4u + (t >> 2), 0u,
+                                                       key0, key1);
+                    const uint32_t wsel = (t & 3u) == 0u ? o.w[0] : (t & 3u) == 1u ? o.w[1]
+                                        : (t & 3u) == 2u ? o.w[2] : o.w[3];
+                    cb_site = sbase + (int)__umulhi(wsel, nact);
+                    cb_addr = lean_swz(cb_site, swa, swm, swb);
+                }
+                const int g16 = (int)(step & 3ull) * 16;      // first lane of this step's candidates
+                const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
+                uint32_t fpos = 0;                            // next stream position (kept across species)
+                bool ok = true;
+                for (int c = 0; c < nc && ok; ++c) {
+                    int need = -(int)rdlane((uint32_t)vu, c);
+                    if (need <= 0) continue;
+                    uint32_t m = (uint32_t)(__ballot(cvl == c) >> g16) & 0xffffu; // bit t: candidate t has species c
+                    m = fpos < 16u ? (m >> fpos) << fpos : 0u;
+                    while (need > 0) {
+                        if (m == 0u) { ok = false; break; }
+                        const int b = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        fpos = (uint32_t)b + 1u;
+                        const int picked = (int)rdlane((uint32_t)cb_site, g16 + b);
+                        // a site already collected in this step is skipped (choice without replacement)
+                        if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
+                        if (lane == ncol) { vcol = picked; vcsp = c; }
+                        ncol++;
+                        need--;
+                    }
+                }
+                if (ok) fast_done = true;
+                else { vcol = 0; vcsp = 0; ncol = 0; } // not enough candidates in the block: full scan
+            }
+#endif
+            for (int c = 0; c < nc && !fast_done; ++c) {
                 int need = -(int)rdlane((uint32_t)vu, c);
                 unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
                 bool have_masks = false;
