@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #ifdef SMOLMC_NO_SELACC
         constexpr bool SELACC = false;
 #else
-        constexpr bool SELACC = DIFF && FAST && !BIAS;
+        constexpr bool SELACC = DIFF && FAST && !BIAS; // (measured: no gain for the flip / Ewald variants)
 #endif
         uint32_t sel_hi = 0u; // high word of sel
         auto on_accept = [&]() {
@@ -772,17 +772,17 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             else if (cr) on_reject();
             else if (exact_decision()) on_accept();
             else on_reject();
-            if (SELACC) {
-                const uint32_t sh = (uint32_t)uni((int)sel_hi);
-                const double sel = __hiloint2double((int)sh, 0);
-#pragma unroll
-                for (int it = 0; it < NSLOT; ++it) acc[it] = fma(sel, d1[it], acc[it]);
-                nacc_add += sh >> 29; // 0x3ff00000 >> 29 == 1
-            }
         } else {
             accepted = exact_decision();
             if (accepted) on_accept();
             else on_reject();
+        }
+        if (SELACC) {
+            const uint32_t sh = (uint32_t)uni((int)sel_hi);
+            const double sel = __hiloint2double((int)sh, 0);
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) acc[it] = fma(sel, d1[it], acc[it]);
+            nacc_add += sh >> 29; // 0x3ff00000 >> 29 == 1
         }
         s1 = s1n;
         a1 = a1n;
