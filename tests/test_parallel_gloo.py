@@ -137,3 +137,52 @@ def test_vectorised_exchange_decisions_equal_the_pairwise_loop():
         assert rex.decide(H) == want
         assert np.array_equal(rex.rung_of, rung_of)
     assert rex.attempted.sum() == sum(len(range(c & 1, n - 1, 2)) for c in range(12))
+
+
+def _sampler_worker(rank, world, port, q):
+    """Two ranks of the smol-shaped Sampler: each owns its block of the global walkers; the
+    recorded samples are filled in by hand (no GPU here) and reduced with global_statistics."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smol_amd import moca, synth
+
+        model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+        sc = synth.build_supercell(model, [3, 3, 3])
+        ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=1))
+        nw = 6
+        s = moca.Sampler.from_ensemble(ens, temperature=900.0, nwalkers=nw, seeds=list(range(50, 50 + nw)))
+        first, count = s.walker_range  # picked up from the process group
+        F = len(ens.natural_parameters)
+        glob = np.random.default_rng(0).normal(size=(4, nw))  # "enthalpies" of all walkers, same on both ranks
+        acc = np.random.default_rng(1).random((4, nw)) < 0.5
+        s.samples.append_block(dict(
+            occupancy=np.zeros((4, count, sc.num_sites), np.int32), features=np.zeros((4, count, F)),
+            enthalpy=glob[:, first:first + count, None], temperature=np.full((4, count, 1), 900.0),
+            accepted=acc[:, first:first + count, None]), thinned_by=10)
+        st = s.global_statistics()
+        q.put((rank, first, count, s.seeds, st, float(glob.mean()), float(glob.var()), float(acc.mean())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sampler_shards_and_reduces_over_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, f0, c0, seeds0, st0, mean, var, accm), (_, f1, c1, seeds1, st1, _, _, _) = res
+    assert (f0, c0, f1, c1) == (0, 3, 3, 3)
+    assert seeds0 == [50, 51, 52] and seeds1 == [53, 54, 55]  # seeds follow the GLOBAL walker index
+    for st in (st0, st1):  # every rank holds the statistics of ALL walkers
+        assert st["walkers"] == 6 and st["samples"] == 24
+        np.testing.assert_allclose(st["mean_enthalpy"], mean, rtol=1e-12)
+        np.testing.assert_allclose(st["enthalpy_variance"], var, rtol=1e-10)
+        np.testing.assert_allclose(st["acceptance"], accm, rtol=1e-12)
