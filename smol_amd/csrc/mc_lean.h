@@ -216,6 +216,11 @@ template <bool ABS> __device__ __forceinline__ uint8_t occ_ld(const uint8_t *occ
     if constexpr (ABS) return SMOLMC_LDS_U8(a);
     else return occ[a];
 }
+// a uniform value the compiler must treat as freshly defined here (no hoisting of what is derived from it)
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_t a, uint8_t v) {
     if constexpr (ABS) SMOLMC_LDS_U8(a) = v;
     else occ[a] = v;
@@ -938,8 +943,12 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // Flips of a step are evaluated sequentially against the LDS occupancy with each flip
 // applied tentatively (expansion.py:217-229) and undone on rejection.
 // ----------------------------------------------------------------------------
-template <int NSLOT, int MM>
+// EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in LDS.
+// A template parameter, not a runtime flag: the unused variants' pointers and code otherwise stay
+// live across the step loop (the kernel spills SGPRs as it is).
+template <int NSLOT, int MM, int EWM>
 __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
+    constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -947,7 +956,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const int r = uni(blockIdx.x * nwaves + wave);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (P.ew_field ? (size_t)P.ew_nact * 8 : 0);
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (ew_field ? (size_t)P.ew_nact * 8 : 0);
     double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
     // block-shared copies of the flip table (<= 8 vectors x 8 codes), its weights and ln(k)
     double *s_tfw = s_mu + 24;
@@ -959,10 +968,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
     double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64); // Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
-    const bool has_mu = P.mu_row != nullptr, has_ew = P.ew_G != nullptr;
+    const bool has_mu = P.mu_row != nullptr;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (threadIdx.x < 8) s_mu[threadIdx.x] = (has_mu && threadIdx.x < P.ncodes) ? P.mu_row[threadIdx.x] : 0.0;
-    if (P.ew_field && threadIdx.x < 8) {
+    if (ew_field && threadIdx.x < 8) {
         s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
         s_dg[threadIdx.x] = P.ew_dgrow[threadIdx.x];
     }
@@ -976,7 +985,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = 0.0;
         if (lane < 16) s_cnt[lane] = 0;
-        if (P.ew_field)
+        if (ew_field)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
     }
     __syncthreads();
@@ -993,14 +1002,19 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     for (int i = 0; i < 8; ++i) vtf[i] = (i < P.tf_n && lane < P.ncodes) ? s_tf[i * P.ncodes + lane] : 0;
     // bit idx of the result: direction idx (2 i = +vector i, 2 i + 1 = -vector i) keeps every
     // count inside [0, n_active] when applied to the counts vc (flip_weights_mask, math.py:832-867)
+    // (the rarely executed pieces -- feasibility masks, weight sums, a-priori factors: only after an
+    // accepted table step -- re-read their parameters from the kernel-argument segment, see
+    // rare_params: everything read from P stays in SGPRs across the whole step loop otherwise)
     auto feasible = [&](const int vc) -> unsigned {
+        const LeanParamsKernarg Q = rare_params();
+        const int tfn = Q->tf_n, na = Q->nact;
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < P.tf_n) {
+            if (i < tfn) {
                 const int vp = vc + vtf[i], vm = vc - vtf[i];
-                if (__ballot(vp < 0 || vp > P.nact) == 0ull) m |= 1u << (2 * i);
-                if (__ballot(vm < 0 || vm > P.nact) == 0ull) m |= 2u << (2 * i);
+                if (__ballot(vp < 0 || vp > na) == 0ull) m |= 1u << (2 * i);
+                if (__ballot(vm < 0 || vm > na) == 0ull) m |= 2u << (2 * i);
             }
         return m;
     };
@@ -1011,7 +1025,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     };
     auto masked_sum = [&](const unsigned m) -> double { // sum of the weights of the set directions
         double sw = 0.0;
-        for (int idx = 0; idx < 2 * P.tf_n; ++idx)
+        const int n2 = 2 * rare_params()->tf_n;
+        for (int idx = 0; idx < n2; ++idx)
             if ((m >> idx) & 1u) sw += weight_of(idx);
         return sw;
     };
@@ -1032,16 +1047,23 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     double H = P.enthalpy[r];
     const double nbeta = -P.beta[r];
     unsigned long long step = P.nsteps[r];
-    unsigned long long nacc = P.nacc[r];
-    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    uint32_t nacc_add = 0; // accepted steps of this launch (< 2^30 steps per launch)
+    const uint32_t key0_ = (uint32_t)P.seeds[r], key1_ = (uint32_t)(P.seeds[r] >> 32);
+    // The ten Philox round keys (key + i * Weyl constant) are loop invariant and the compiler
+    // parks all twenty of them in SGPRs across the step loop, which then spills; the keys are
+    // made opaque at every call so that the round keys are re-derived there (20 scalar adds per
+    // Philox call, a few calls per 16 steps).
+#define key0 opaque_u32(key0_)
+#define key1 opaque_u32(key1_)
     double acc_mu = 0.0, acc_ew = 0.0;
     int last_acc = 1;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    long long smp_countdown = P.smp.every ? P.smp.every : -1, smp_index = 0; // (-1: never reaches zero)
+    // 32-bit loop state (the host splits launches at 2^30 steps): the kernel is short of SGPRs
+    uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu, smp_index = 0; // (no sampling: never reaches zero)
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
     double logu = 0.0;
-    unsigned long long batch_base = ~0ull;
+    uint32_t batch_base = ~0u; // low word of the batch's first step: consecutive steps change it exactly when the batch changes
     uint32_t w_site_carry = 0;
     constexpr int ROW = NSLOT * MM;
     constexpr int NW = ROW / 2;
@@ -1060,20 +1082,20 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     // from one Philox call per four steps.  A table step needs |u| <= 8 sites and finds them
     // among its first 16 candidates 9 times out of 10: those steps skip the 256-candidate round
     // (a Philox call, 4 gathers and 4 ballots per species) -- see the fast path below.
-    unsigned long long cblk_base = ~0ull;
+    uint32_t cblk_base = ~0u;
     int cb_site = 0, cb_addr = 0;
 
-    for (long long it_step = 0; it_step < P.steps; ++it_step, ++step) {
+    for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
         const unsigned long long base = step & ~15ull;
-        if (base != batch_base) {
-            if (batch_base == base - 16) {
+        if ((uint32_t)base != batch_base) {
+            if (batch_base == (uint32_t)base - 16u) {
                 w_site_carry = rdlane(W1, 60);
             } else {
                 const unsigned long long sp = base - 1ull;
                 w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
                                                                 key0, key1).w[1]);
             }
-            batch_base = base;
+            batch_base = (uint32_t)base;
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
                                                0u, key0, key1);
@@ -1175,12 +1197,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
                 // case away from the composition limits), no division / log needed
                 const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
+                const LeanParamsKernarg Q = rare_params();
                 if (!(w_now == w_back && sum_next == sumw)) {
-                    const double p_now = (1.0 - P.tf_sw) * w_now / sumw;
-                    const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
+                    const double tsw = Q->tf_sw;
+                    const double p_now = (1.0 - tsw) * w_now / sumw;
+                    const double p_next = (1.0 - tsw) * w_back / sum_next;
                     lf = log(p_next / p_now);
                 }
-                lf += table_log_count_ratio(P.tf_ln_len ? s_ln : P.tf_ln, vu, vcnt, nc);
+                lf += table_log_count_ratio(Q->tf_ln_len ? s_ln : Q->tf_ln, vu, vcnt, nc);
                 lf = uni_d(lf);
                 if (lane == dir) vlp = lf;
                 lp_valid |= 1u << dir;
@@ -1200,9 +1224,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             bool fast_done = false;
 #ifndef SMOLMC_NO_TABLE_FAST
             {
-                if ((step & ~3ull) != cblk_base) {
-                    cblk_base = step & ~3ull;
-                    const unsigned long long sl = cblk_base + (unsigned)(lane >> 4);
+                if ((uint32_t)(step & ~3ull) != cblk_base) {
+                    cblk_base = (uint32_t)(step & ~3ull);
+                    const unsigned long long sl = (step & ~3ull) + (unsigned)(lane >> 4);
                     const uint32_t t = (uint32_t)lane & 15u;
                     const philox_out o = philox4x32_10((uint32_t)sl, (uint32_t)(sl >> 32), 4u + (t >> 2), 0u,
                                                        key0, key1);
@@ -1316,7 +1340,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // pair j < i), issued before the flips are evaluated so that its latency (the site
         // kernel lives in L2 / Infinity Cache) overlaps with the cluster-expansion part
         double vG = 0.0;
-        if (has_ew && P.ew_field && nfl > 1) {
+        if (has_ew && ew_field && nfl > 1) {
             const int pi = lane >> 3, pj = lane & 7;
             const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
             if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - sbase)];
@@ -1343,7 +1367,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 pend[it] += d;
             }
             if (has_ew) {
-                if (P.ew_field) {
+                if (ew_field) {
                     // flip f sees the earlier flips of the step through the cross terms
                     const double dq = s_q[nw] - s_q[od];
                     double pot = phi[s - sbase];
@@ -1375,7 +1399,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         double dH = wave_sum_all(e);
         double dEw = 0.0;
         if (has_ew) {
-            dEw = (P.ew_field ? 0.0 : wave_sum_all(ew_part)) + ew_uni;
+            dEw = (ew_field ? 0.0 : wave_sum_all(ew_part)) + ew_uni;
             dH += P.ew_coef * dEw;
         }
         if (has_mu) dH -= dMu;
@@ -1388,7 +1412,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
             if (dir >= 0) head_valid = false;
-            if (P.ew_field)
+            if (ew_field)
                 for (int f = 0; f < nfl; ++f) {
                     const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
                                                         (int)rdlane((uint32_t)__double2loint(vdq), f));
@@ -1397,7 +1421,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;
-            nacc++;
+            nacc_add++;
         } else {
             // undo the tentative flips: lane f restores the site of flip f (the sites of a step
             // are distinct, so the order of the stores does not matter)
@@ -1409,7 +1433,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             const LeanParamsKernarg Q = rare_params(); // (sampling parameters: see rare_params)
             const int qF = Q->F, qFce = Q->Fce;
             double *const q_feat = Q->smp.feat;
-            smp_countdown = Q->smp.every;
+            smp_countdown = (uint32_t)Q->smp.every;
             const size_t rowi = (size_t)smp_index * Q->R + r;
             smp_index++;
             s_feat[lane] = 0.0;
@@ -1433,7 +1457,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
     }
 
-    if (P.ew_field)
+    if (ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
         uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
@@ -1451,12 +1475,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
-        P.nacc[r] = nacc;
+        P.nacc[r] += nacc_add;
         P.last_acc[r] = (uint8_t)last_acc;
     }
 }
 
 
+#undef key0
+#undef key1
 template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
@@ -1490,10 +1516,10 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
     return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
-template <int NSLOT, int MM>
-static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, int EWM>
+static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
-    auto kern = mc_table_kernel<NSLOT, MM>;
+    auto kern = mc_table_kernel<NSLOT, MM, EWM>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1505,6 +1531,12 @@ static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
     return 0;
 }
 
+
+template <int NSLOT, int MM>
+static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
+    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0>(h, lp);
+    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2>(h, lp) : launch_table_ewm<NSLOT, MM, 1>(h, lp);
+}
 
 // biased Metropolis variants (instantiated in lean_bias_n*.hip only)
 template <int NSLOT, int MM, int STEP>
