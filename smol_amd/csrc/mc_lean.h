@@ -236,11 +236,15 @@ template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_
 // (E = sum_k coef_k ct_k, so a proposal costs what it costs in interaction mode); the KF
 // correlation-function tables of the slot sit behind it in LDS and are read only on ACCEPTED
 // steps, at the table index the decision already computed, into KF accumulators per slot.
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool WL, bool BIAS = false, bool SOLO = false,
+template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool WL, bool BIAS = false, bool SOLO = false,
           int KF = 0>
 __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     static_assert(KF == 0 || (!WL && !BIAS && !SOLO), "correlation-function tables: plain Metropolis layouts only");
     constexpr int NACC = KF ? KF : 1;
+    // EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in
+    // LDS.  A template parameter (not the runtime flag ew_field): both variants' pointers and code
+    // otherwise stay live across the step loop and the kernel spills SGPRs.
+    constexpr bool HAS_EW = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap(); // (no static LDS in this kernel: absolute LDS addresses below)
     const int lane = threadIdx.x & 63;
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int nwaves = SOLO ? 1 : blockDim.x >> 6;
     const int r = uni(blockIdx.x * nwaves + wave);
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0) +
-                            ((HAS_EW && P.ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
+                            ((HAS_EW && ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
     double *s_dt = SOLO ? (double *)(smem + ((per_wave + 15) & ~(size_t)15)) : (double *)smem;
     const uint32_t dt_off = SOLO ? (uint32_t)((per_wave + 15) & ~(size_t)15) : 0u; // table base, folded into the slot offsets
     double *s_mu = s_dt + P.dt_len;               // 8 doubles
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
-    if (HAS_EW && P.ew_field && threadIdx.x < 8) {
+    if (HAS_EW && ew_field && threadIdx.x < 8) {
         s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
         s_dg[threadIdx.x] = P.ew_dgrow[threadIdx.x];
     }
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         for (int i = lane; i < P.Npad / 4; i += 64)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = (WL && lane < P.F) ? P.features[(size_t)r * P.F + lane] : 0.0;
-        if (HAS_EW && P.ew_field)
+        if (HAS_EW && ew_field)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
         if (WL)
             for (int i = lane; i < P.wl.L; i += 64) {
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 cand[3] = sbase + (int)__umulhi(o.w[3], nact);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
-                if (HAS_EW && P.ew_field) {
+                if (HAS_EW && ew_field) {
                     // cross term G[candidate][site of the lane's step] of the first-round
                     // candidates of all 16 steps in one gather, issued a batch ahead (the site
                     // kernel lives in L2 / Infinity Cache; a dependent load per step would sit on
@@ -586,7 +590,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         double ew_part = 0.0, ew_uni = 0.0; // lane-partial / uniform parts of the Ewald delta
         double dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
-            if (P.ew_field) { // no global loads: charges / diagonal terms per code from LDS
+            if (ew_field) { // no global loads: charges / diagonal terms per code from LDS
                 dq1 = s_q[n1] - s_q[o1];
                 ew_uni = 2.0 * dq1 * phi[s1 - sbase] + (s_dg[n1] - s_dg[o1]);
             } else {
@@ -620,7 +624,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 }
             }
             if (HAS_EW) {
-                if (P.ew_field) { // the second flip sees the first through the cross term
+                if (ew_field) { // the second flip sees the first through the cross term
                     dq2 = s_q[n2] - s_q[o2];
                     const double cross =
                         fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
@@ -660,7 +664,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         auto exact_decision = [&]() -> bool {
             dH = LEAN_WAVE_SUM(e);
             if (HAS_EW) {
-                dEw = (P.ew_field ? 0.0 : LEAN_WAVE_SUM(ew_part)) + ew_uni;
+                dEw = (ew_field ? 0.0 : LEAN_WAVE_SUM(ew_part)) + ew_uni;
                 dH += P.ew_coef * dEw;
             }
             if (HAS_MU) dH -= dMu;
@@ -740,7 +744,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             if (STEP == SMOLMC_STEP_SWAP) occ_st<SOLO>(occ, (uint32_t)a1, (uint8_t)n1);
 #endif
             if (STEP == SMOLMC_STEP_SWAP) occ_st<SOLO>(occ, (uint32_t)a2, (uint8_t)n2); // (n2 == o1 == occ[a1] when empty)
-            if (HAS_EW && P.ew_field) {
+            if (HAS_EW && ew_field) {
                 if (STEP == SMOLMC_STEP_SWAP) {
                     if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
                 } else if (dq1 != 0.0) {
@@ -863,7 +867,7 @@ __global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
 
     // ---- write back ---------------------------------------------------------------
-    if (HAS_EW && P.ew_field)
+    if (HAS_EW && ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
         uint32_t *dst = (uint32_t *)(P.occ + (size_t)r * P.Npad);
@@ -1483,7 +1487,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
 #undef key0
 #undef key1
-template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
     auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF>;
@@ -1501,15 +1505,15 @@ template <int NSLOT, int MM, int STEP>
 static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
     if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU)
-        return launch_lean_inst<NSLOT, MM, STEP, false, false, true>(h, lp);
+        return launch_lean_inst<NSLOT, MM, STEP, false, 0, true>(h, lp);
     if (ew)
-        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false>(h, lp);
+        return mu ? (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, true, 1, false>(h, lp))
+                  : (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, false, 2, false>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, false, 1, false>(h, lp));
     if (h->lean_solo) // Metropolis without Ewald: one wave per workgroup (see mc_lean_kernel)
-        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, false, true>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, STEP, false, false, false, false, true>(h, lp);
-    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false>(h, lp)
-              : launch_lean_inst<NSLOT, MM, STEP, false, false, false>(h, lp);
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, true>(h, lp);
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, 0, false>(h, lp);
 }
 template <int NSLOT, int MM>
 static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
@@ -1543,10 +1547,10 @@ template <int NSLOT, int MM, int STEP>
 static int launch_lean_bias_me(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
     if (ew)
-        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false, true>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false, true>(h, lp);
-    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, true>(h, lp)
-              : launch_lean_inst<NSLOT, MM, STEP, false, false, false, true>(h, lp);
+        return mu ? (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false, true>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, true, 1, false, true>(h, lp))
+                  : (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, false, 2, false, true>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, false, 1, false, true>(h, lp));
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, true>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, true>(h, lp);
 }
 template <int NSLOT> static int launch_lean_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
     const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
@@ -1563,10 +1567,10 @@ static int launch_lean_corr_me(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
     constexpr int KF = SMOLMC_LEAN_MAX_KF;
     if (ew)
-        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, true, false, false, false, KF>(h, lp)
-                  : launch_lean_inst<NSLOT, MM, STEP, false, true, false, false, false, KF>(h, lp);
-    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, false, false, false, false, KF>(h, lp)
-              : launch_lean_inst<NSLOT, MM, STEP, false, false, false, false, false, KF>(h, lp);
+        return mu ? (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false, false, false, KF>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, true, 1, false, false, false, KF>(h, lp))
+                  : (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, false, 2, false, false, false, KF>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, false, 1, false, false, false, KF>(h, lp));
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, false, KF>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, false, KF>(h, lp);
 }
 template <int NSLOT> static int launch_lean_corr_nslot(smolmc_handle *h, const LeanParams &lp) {
     const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
