@@ -1081,11 +1081,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     bool head_valid = false;
     unsigned feas_now = 0, lp_valid = 0;
     double sumw = 0.0, vlp = 0.0;
-    // Candidate block: the first 16 positions of the site-candidate stream c_t = W(step, 4 + t/4,
-    // t%4) of FOUR steps, one candidate per lane (lane L: step (step & ~3) + (L >> 4), t = L & 15),
-    // from one Philox call per four steps.  A table step needs |u| <= 8 sites and finds them
-    // among its first 16 candidates 9 times out of 10: those steps skip the 256-candidate round
-    // (a Philox call, 4 gathers and 4 ballots per species) -- see the fast path below.
+    // Candidate block: the first 32 positions of the site-candidate stream c_t = W(step, 4 + t/4,
+    // t%4) of TWO steps, one candidate per lane (lane L: step (step & ~1) + (L >> 5), t = L & 31),
+    // from one Philox call per two steps.  A table step needs |u| <= 8 sites and nearly always
+    // finds them among its first 32 candidates: those steps skip the 256-candidate round (a Philox
+    // call, 4 gathers and 4 ballots per species) -- see the fast path below.
     uint32_t cblk_base = ~0u;
     int cb_site = 0, cb_addr = 0;
 
@@ -1228,10 +1228,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             bool fast_done = false;
 #ifndef SMOLMC_NO_TABLE_FAST
             {
-                if ((uint32_t)(step & ~3ull) != cblk_base) {
-                    cblk_base = (uint32_t)(step & ~3ull);
-                    const unsigned long long sl = (step & ~3ull) + (unsigned)(lane >> 4);
-                    const uint32_t t = (uint32_t)lane & 15u;
+                if ((uint32_t)(step & ~1ull) != cblk_base) {
+                    cblk_base = (uint32_t)(step & ~1ull);
+                    const unsigned long long sl = (step & ~1ull) + (unsigned)(lane >> 5);
+                    const uint32_t t = (uint32_t)lane & 31u;
                     const philox_out o = philox4x32_10((uint32_t)sl, (uint32_t)(sl >> 32), 4u + (t >> 2), 0u,
                                                        key0, key1);
                     const uint32_t wsel = (t & 3u) == 0u ? o.w[0] : (t & 3u) == 1u ? o.w[1]
@@ -1239,30 +1239,38 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     cb_site = sbase + (int)__umulhi(wsel, nact);
                     cb_addr = lean_swz(cb_site, swa, swm, swb);
                 }
-                const int g16 = (int)(step & 3ull) * 16;      // first lane of this step's candidates
+                const int g32 = (int)(step & 1ull) * 32;      // first lane of this step's candidates
                 const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
                 uint32_t fpos = 0;                            // next stream position (kept across species)
                 bool ok = true;
                 for (int c = 0; c < nc && ok; ++c) {
                     int need = -(int)rdlane((uint32_t)vu, c);
                     if (need <= 0) continue;
-                    uint32_t m = (uint32_t)(__ballot(cvl == c) >> g16) & 0xffffu; // bit t: candidate t has species c
-                    m = fpos < 16u ? (m >> fpos) << fpos : 0u;
-                    while (need > 0) {
-                        if (m == 0u) { ok = false; break; }
+                    uint32_t m = (uint32_t)(__ballot(cvl == c) >> g32); // bit t: candidate t has species c
+                    m = fpos < 32u ? (m >> fpos) << fpos : 0u;
+                    if (__popc(m) < need) { ok = false; break; }
+                    // the first `need` set bits, in stream order (duplicates are dealt with below)
+                    if (lane >= ncol && lane < ncol + need) vcsp = c;
+                    do {
                         const int b = __ffs((int)m) - 1;
                         m &= m - 1u;
                         fpos = (uint32_t)b + 1u;
-                        const int picked = (int)rdlane((uint32_t)cb_site, g16 + b);
-                        // a site already collected in this step is skipped (choice without replacement)
-                        if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
-                        if (lane == ncol) { vcol = picked; vcsp = c; }
+                        const int picked = (int)rdlane((uint32_t)cb_site, g32 + b);
+                        if (lane == ncol) vcol = picked;
                         ncol++;
-                        need--;
+                    } while (--need > 0);
+                }
+                // choice without replacement: the stream may name a site twice (then the second
+                // occurrence must be skipped and one more candidate taken); rare -- p ~ ncol^2 / (2 n)
+                // -- so a repeated site among the picks sends the step to the sequential scan
+                if (ok) {
+                    for (int d = 1; d < ncol; ++d) {
+                        const int other = __shfl(vcol, lane + d); // (lanes >= ncol hold stale values: masked)
+                        if (__ballot(lane + d < ncol && vcol == other) != 0ull) { ok = false; break; }
                     }
                 }
                 if (ok) fast_done = true;
-                else { vcol = 0; vcsp = 0; ncol = 0; } // not enough candidates in the block: full scan
+                else { vcol = 0; vcsp = 0; ncol = 0; } // block exhausted or repeated site: full scan
             }
 #endif
             for (int c = 0; c < nc && !fast_done; ++c) {
