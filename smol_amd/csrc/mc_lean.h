@@ -237,8 +237,12 @@ template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_
 // correlation-function tables of the slot sit behind it in LDS and are read only on ACCEPTED
 // steps, at the table index the decision already computed, into KF accumulators per slot.
 template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool WL, bool BIAS = false, bool SOLO = false,
-          int KF = 0>
-__global__ void __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
+          int KF = 0, int OCC = 0>
+// OCC: waves per SIMD the register allocation is held to (0 = the compiler's choice, which is 4
+// for the headline instantiation at 113 VGPRs).  OCC = 6 (80 VGPRs, a few spills) is launched
+// when there are more walkers than 4 waves per SIMD can hold, see launch_lean_me.
+__global__ void __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
+__launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     static_assert(KF == 0 || (!WL && !BIAS && !SOLO), "correlation-function tables: plain Metropolis layouts only");
     constexpr int NACC = KF ? KF : 1;
     // EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in
@@ -1495,10 +1499,11 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
 #undef key0
 #undef key1
-template <int NSLOT, int MM, int STEP, bool MU, int EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0,
+          int OCC = 0>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
-    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF>;
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF, OCC>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1517,6 +1522,9 @@ static int launch_lean_me(smolmc_handle *h, const LeanParams &lp) {
     if (ew)
         return mu ? (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, true, 1, false>(h, lp))
                   : (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, false, 2, false>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, false, 1, false>(h, lp));
+    if (h->lean_solo && h->lean_occ == 6)
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, true, 0, 6>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, true, 0, 6>(h, lp);
     if (h->lean_solo) // Metropolis without Ewald: one wave per workgroup (see mc_lean_kernel)
         return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, true>(h, lp)
                   : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, true>(h, lp);

@@ -401,6 +401,7 @@ struct smolmc_handle {
     int lean_nslot = 0, lean_mm = 0, lean_ncls = 0;
     bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
     bool lean_solo = false;             // mc_lean_kernel in its one-wave-per-workgroup layout
+    int lean_occ = 0;                   // > 0: the solo instantiation held to this many waves per SIMD
     int lean_kf = 0;                    // > 0: correlation features with up to lean_kf functions per orbit
     std::vector<uint16_t> lean_idx_host; // lane-packed index rows (kept for the 32-bit copy)
     std::vector<int> site_class_host;   // site -> class (255 = no clusters)

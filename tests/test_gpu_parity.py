@@ -623,6 +623,45 @@ def test_one_wave_per_workgroup_layout_equals_shared_layout(name, step, mukind, 
     np.testing.assert_allclose(sa["enthalpy"], sb["enthalpy"], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("name,step,mukind", [("fcc_prim666_triplets", capi.STEP_SWAP, None),
+                                              ("fcc3_indicator_skew", capi.STEP_FLIP, "mu3")])
+def test_six_waves_per_simd_instantiation_equals_default_and_oracle(name, step, mukind, monkeypatch):
+    """More walkers than 4 waves per SIMD keep resident (16 x CU count) select the SOLO
+    instantiation whose registers are held to 6 waves per SIMD (kernel_info "occ=6"): same
+    trajectories as the default instantiation (SMOLMC_NO_OCC6) and the oracle."""
+    import torch
+    from oracle import oracle as orc
+
+    for v in ("SMOLMC_FORCE_GENERAL", "SMOLMC_NO_SOLO", "SMOLMC_NO_OCC6"):
+        monkeypatch.delenv(v, raising=False)
+    c = load_case(name)
+    tab = tables_for(name, MODES["int"], mu_table=_mu(mukind, c))
+    R = 16 * torch.cuda.get_device_properties(0).multi_processor_count + 37
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(78)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (rng.random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    seeds = np.arange(R, dtype=np.uint64) * np.uint64(13) + np.uint64(5)
+    temps = np.linspace(500.0, 5000.0, R)
+    six = _engine(tab, cfg)
+    assert "solo=1 occ=6" in six.kernel_info(), six.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_OCC6", "1")
+    four = _engine(tab, cfg)
+    assert "solo=1" in four.kernel_info() and "occ" not in four.kernel_info()
+    ora = orc.OracleMC(tab, cfg)
+    for e in (six, four, ora):
+        e.set_state(occ0, seeds, temps)
+    for chunk in (1, 63, 200):
+        for e in (six, four, ora):
+            e.run(chunk)
+        a = six.get_state()
+        for x in (four.get_state(), ora.get_state()):
+            assert np.array_equal(a["occupancy"], x["occupancy"])
+            assert np.array_equal(a["n_accepted"], x["n_accepted"])
+            np.testing.assert_allclose(a["enthalpy"], x["enthalpy"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(a["features"], x["features"], rtol=RTOL, atol=1e-8)
+
+
 @pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])
 def test_split_launches_equal_one_launch(kernel, monkeypatch):
     """The lean kernels count steps in 32 bits, so the host splits long runs into several
