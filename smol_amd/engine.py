@@ -62,6 +62,14 @@ def load_library(path=None):
             f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; "
             "g.build()' or make -C smol_amd/csrc). smol_amd has no CPU fallback."
         )
+    # One HIP runtime per process.  PyTorch's wheel bundles a libamdhip64 with the same soname as
+    # /opt/rocm's; whichever is mapped first serves both, and torch finds "No HIP GPUs" when the
+    # system copy got in before it (engine created first, torch imported later for a collective
+    # or a stream).  So when torch is installed it is imported before the engine library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

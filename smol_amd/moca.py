@@ -867,7 +867,7 @@ class SampleContainer:
         # name -> (dtype, per-sample shape): the schema of a block
         self._schema = {k: (v.dtype, tuple(v.shape[1:])) for k, v in sample_trace.items()}
         self._blocks = [{k: v for k, v in sample_trace.items()}] if len(sample_trace.occupancy) else []
-        self._joined = None
+        self._joined = {}
         self._total_steps = 0
 
     # ---- block store ---------------------------------------------------------------
@@ -879,20 +879,31 @@ class SampleContainer:
             arr = np.asarray(block[name], dtype=dtype)
             entry[name] = arr.reshape((n,) + shape)
         self._blocks.append(entry)
-        self._joined = None
+        self._joined = {}
         self._total_steps += n * int(thinned_by)
 
     def save_sampled_trace(self, trace, thinned_by):
         """One sample (container.py:384-397): a block of length one."""
         self.append_block({k: np.asarray(v)[None] for k, v in trace.items()}, thinned_by)
 
+    def _col(self, name):
+        """All samples of one traced value, (nsamples, nwalkers, ...).  Joined per name and on
+        demand: a mean enthalpy does not concatenate gigabytes of occupancies."""
+        if name not in self._joined:
+            dt, shape = self._schema[name]
+            parts = [b[name] for b in self._blocks]
+            self._joined[name] = (parts[0] if len(parts) == 1 else np.concatenate(parts) if parts
+                                  else np.empty((0,) + shape, dtype=dt))
+            if len(parts) > 1:  # keep one copy: the blocks now alias the joined array
+                at = 0
+                for b in self._blocks:
+                    n = len(b[name])
+                    b[name] = self._joined[name][at:at + n]
+                    at += n
+        return self._joined[name]
+
     def _all(self):
-        if self._joined is None:
-            if len(self._blocks) > 1:
-                self._blocks = [{k: np.concatenate([b[k] for b in self._blocks]) for k in self._schema}]
-            self._joined = self._blocks[0] if self._blocks else {
-                k: np.empty((0,) + shape, dtype=dt) for k, (dt, shape) in self._schema.items()}
-        return self._joined
+        return {k: self._col(k) for k in self._schema}
 
     @property
     def _trace(self):
@@ -905,7 +916,11 @@ class SampleContainer:
         """No-op: there is no slack to give back (container.py:415-418)."""
 
     def clear(self):
-        self._blocks, self._joined, self._total_steps = [], None, 0
+        self._blocks, self._joined, self._total_steps = [], {}, 0
+
+    def last_occupancy(self):
+        """Occupancies (nwalkers, N) of the most recent sample (no join of the blocks)."""
+        return self._blocks[-1]["occupancy"][-1]
 
     # ---- bookkeeping -----------------------------------------------------------------
     ensemble = property(lambda self: self._ensemble)
@@ -920,7 +935,7 @@ class SampleContainer:
 
     def sampling_efficiency(self, discard=0, flat=True):
         """Fraction of recorded samples whose last step was accepted (container.py:131-142)."""
-        acc = self._all()["accepted"][discard:]
+        acc = self._col("accepted")[discard:]
         eff = acc.mean(axis=0)
         return eff.mean() if flat else eff
 
@@ -928,7 +943,7 @@ class SampleContainer:
     def get_trace_value(self, name, discard=0, thin_by=1, flat=True):
         """Samples discard + thin_by - 1, discard + 2 thin_by - 1, ... of one traced value
         (the reference's selection rule, container.py:181-199)."""
-        picked = self._all()[name][discard + thin_by - 1:: thin_by]
+        picked = self._col(name)[discard + thin_by - 1:: thin_by]
         return _merge_walkers(picked) if flat else picked
 
     def mean_trace_value(self, name, discard=0, thin_by=1, flat=True):
@@ -1083,6 +1098,8 @@ class Sampler:
         self._engine_key = None
         self._walker_range = walker_range or (0, len(kernels))
         self._device, self._world = int(device), int(world_size)
+        self._state_loaded = False  # walker states uploaded to the engine at least once
+        self._resume_at = None      # (container, its sample count) the device state equals, see _load_state
 
     @classmethod
     def from_ensemble(cls, ensemble, *args, step_type=None, kernel_type=None, seeds=None,
@@ -1212,7 +1229,7 @@ class Sampler:
     def _local_occupancies(self, occupancies):
         """Accepts this rank's walkers (count, N), all walkers (nwalkers, N) -- the rank takes
         its block -- or a 1-D occupancy for a single walker (sampler.py:442-end)."""
-        occ = np.array(occupancies)
+        occ = np.asarray(occupancies)
         first, count = self._walker_range
         nglobal = self.samples.metadata.get("walker_range", (0, count, count))[2]
         N = self.samples.shape[1]
@@ -1227,19 +1244,31 @@ class Sampler:
                 "The given initial occupancies have incompompatible dimensions. Shape should be "
                 f"{self.samples.shape}."
             )
-        return occ.astype(np.int32)
+        return occ.astype(np.int32, copy=False)  # (the engine copies it to the device)
 
-    def setup_sample(self, initial_occupancies):
-        """sampler.py:386-434: copy / reshape occupancies, set aux states, initial trace."""
-        occupancies = self._local_occupancies(initial_occupancies)
+    def _load_state(self, initial_occupancies):
+        """Walker states on the device.  ``None`` = continue from the last recorded sample: that
+        IS the device state when nothing else touched the engine or the container since the
+        last run (the steps after the last sample of a run are never taken), so nothing is
+        uploaded -- only the temperatures are refreshed (anneal changes them between runs)."""
         eng = self._get_engine()
+        if initial_occupancies is None:
+            if self._state_loaded and self._resume_at == (id(self.samples), self.samples.num_samples):
+                eng.set_temperature(self._temperatures())
+                return None
+            initial_occupancies = self.samples.last_occupancy()
+        occupancies = self._local_occupancies(initial_occupancies)
         seeds = np.array([k.seed64 for k in self._kernels], dtype=np.uint64)
         # a kernel's Generator, accept counters and WL aux arrays persist across run()
         # calls of one sampler (sampler.py:254-262): only the first call starts fresh
-        fresh = not getattr(self, "_state_loaded", False)
-        eng.set_state(occupancies, seeds, self._temperatures(), reset_aux=fresh)
+        eng.set_state(occupancies, seeds, self._temperatures(), reset_aux=not self._state_loaded)
         self._state_loaded = True
-        return occupancies, self._current_trace(eng)
+        return occupancies
+
+    def setup_sample(self, initial_occupancies):
+        """sampler.py:386-434: copy / reshape occupancies, set aux states, initial trace."""
+        occupancies = self._load_state(initial_occupancies)
+        return occupancies, self._current_trace(self._get_engine())
 
     def _current_trace(self, eng):
         st = eng.get_state()
@@ -1270,7 +1299,8 @@ class Sampler:
                 f"{nsteps % thin_by} will be ignored.",
                 category=RuntimeWarning,
             )
-        self.setup_sample(initial_occupancies)
+        self._load_state(initial_occupancies)
+        self._resume_at = None
         eng = self._get_engine()
         nsamples = nsteps // thin_by
         k0 = self._kernels[0]
@@ -1304,7 +1334,6 @@ class Sampler:
                     "There are no saved samples to obtain the initial occupancies."
                     "These must be provided."
                 )
-            initial_occupancies = self.samples.get_occupancies(flat=False)[-1]
         elif self.samples.num_samples > 0:
             warnings.warn(
                 "Initial occupancies where provided with a pre-existing set of samples.\n Make "
@@ -1315,6 +1344,8 @@ class Sampler:
             raise NotImplementedError("HDF5 streaming is out of scope here (h5py absent); use to_npz")
         for block in self._sample_blocks(nsteps, initial_occupancies, thin_by):
             self.samples.append_block(block, thinned_by=thin_by)
+        # the device now holds the last recorded sample (see _load_state)
+        self._resume_at = (id(self.samples), self.samples.num_samples)
 
     def anneal(self, temperatures, mcmc_steps, initial_occupancies=None, thin_by=1, progress=False,
                **kwargs):

@@ -149,6 +149,30 @@ def test_sampler_matches_oracle_stream(fcc):
                                    rtol=1e-10, atol=1e-9)
 
 
+def test_continuing_on_the_device_equals_reloading_the_last_sample(fcc):
+    """run(n) + run(n) without occupancies continues from the device state (no upload); forcing
+    the re-upload of the last recorded sample instead gives the same chain, and so does clearing
+    the bookkeeping by running through sample()."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = np.vstack([_rand_occ(np.random.default_rng(21), sc)[0] for _ in range(4)])
+    out = []
+    for reload_each_time in (False, True):
+        sampler = moca.Sampler.from_ensemble(ens, temperature=1500, nwalkers=4, seeds=[1, 2, 3, 4])
+        sampler.run(300, occu, thin_by=50)
+        for _ in range(3):
+            if reload_each_time:
+                sampler._resume_at = None
+            else:
+                assert sampler._resume_at == (id(sampler.samples), sampler.samples.num_samples)
+            sampler.run(200, thin_by=50)
+        out.append((sampler.samples.get_occupancies(flat=False), sampler.samples.get_enthalpies(flat=False),
+                    sampler.samples.get_trace_value("accepted", flat=False)))
+    assert out[0][0].shape == (18, 4, sc.num_sites)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-11, atol=1e-9)
+
+
 def test_anneal(fcc):
     """tests/test_moca/test_sampler.py:89-113."""
     model, sc, coefs = fcc
