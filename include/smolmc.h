@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 3
+#define SMOLMC_ABI_VERSION 4
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
@@ -234,6 +234,12 @@ int smolmc_sync(smolmc_handle *h);
 int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags);
 int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
                        uint8_t *accepted, int32_t *occupancy);
+/* smolmc_get_samples with the occupancies as bytes, [nsamples x R x N] uint8 -- the device
+ * ring's own format: a quarter of the PCIe traffic and host memory of the int32 form the
+ * reference's trace uses (trace.occupancy is int32, sampler/sampler.py:411-415; codes are
+ * < 256 by construction, smolmc_tables.n_codes). */
+int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double *features,
+                          uint8_t *accepted, uint8_t *occupancy);
 /* Same loop driven by host-provided proposals ("replay mode"):
  * steps [R x nsteps x 4] = (site1, code1, site2, code2), -1 = no flip;
  * uniforms [R x nsteps] = the number rng.random() returned (NaN if not drawn).

@@ -1625,8 +1625,10 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
     return run_steps(h, nsamples * thin_by, h->smp);
 }
 
-extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
-                                  uint8_t *accepted, int32_t *occupancy) {
+// rows of the device ring to the host: scalars always, occupancies as int32 (the reference's
+// trace dtype) or as the ring's own bytes
+static int get_samples_impl(smolmc_handle *h, double *enthalpy, double *features, uint8_t *accepted,
+                            int32_t *occ32, uint8_t *occ8) {
     if (!h) return fail("null handle");
     if (h->smp_n == 0) return fail("no samples recorded: call smolmc_run_sampled first");
     HIPCHK(hipSetDevice(h->device));
@@ -1635,20 +1637,35 @@ extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *fe
     if (enthalpy) HIPCHK(hipMemcpy(enthalpy, h->smp.H, rows * 8, hipMemcpyDeviceToHost));
     if (features) HIPCHK(hipMemcpy(features, h->smp.feat, rows * h->F * 8, hipMemcpyDeviceToHost));
     if (accepted) HIPCHK(hipMemcpy(accepted, h->smp.acc, rows, hipMemcpyDeviceToHost));
-    if (occupancy) {
-        if (!h->smp_has_occ) return fail("occupancies were not recorded (flags bit 0)");
+    if ((occ32 || occ8) && !h->smp_has_occ) return fail("occupancies were not recorded (flags bit 0)");
+    if (occ32) {
         int *d32 = nullptr;
         const size_t total = rows * h->N;
         HIPCHK(hipMalloc((void **)&d32, total * 4));
         hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                            h->stream, h->smp.occ, d32, h->N, h->Npad, total);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(occupancy, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(occ32, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         hipFree(d32);
         if (e != hipSuccess) return fail(std::string("sample download: ") + hipGetErrorString(e));
     }
+    if (occ8) { // ring rows are Npad bytes apart, the host rows N
+        if (h->Npad == h->N)
+            HIPCHK(hipMemcpy(occ8, h->smp.occ, rows * h->N, hipMemcpyDeviceToHost));
+        else
+            HIPCHK(hipMemcpy2D(occ8, (size_t)h->N, h->smp.occ, (size_t)h->Npad, (size_t)h->N, rows,
+                               hipMemcpyDeviceToHost));
+    }
     return 0;
+}
+extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
+                                  uint8_t *accepted, int32_t *occupancy) {
+    return get_samples_impl(h, enthalpy, features, accepted, occupancy, nullptr);
+}
+extern "C" int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double *features,
+                                     uint8_t *accepted, uint8_t *occupancy) {
+    return get_samples_impl(h, enthalpy, features, accepted, nullptr, occupancy);
 }
 
 extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,

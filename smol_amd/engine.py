@@ -41,6 +41,7 @@ SYMBOLS = {
     "smolmc_sync": (C.c_int, [_HP]),
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
     "smolmc_get_samples": (C.c_int, [_HP, _f64p, _f64p, _u8p, _i32p]),
+    "smolmc_get_samples_u8": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p]),
     "smolmc_replay": (C.c_int, [_HP, C.c_int64, _i32p, _f64p, _u8p, _f64p]),
     "smolmc_last_kernel_ms": (C.c_int, [_HP, C.POINTER(C.c_float)]),
     "smolmc_eval_full": (C.c_int, [_HP, _i32p, C.c_int, _f64p]),
@@ -74,7 +75,7 @@ def load_library(path=None):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.smolmc_abi_version() != 3:
+    if lib.smolmc_abi_version() != 4:
         raise RuntimeError("smolmc ABI version mismatch")
     if path is None:
         _LIB = lib
@@ -235,18 +236,23 @@ class Engine:
     def sync(self):
         self._chk(self._lib.smolmc_sync(self._h))
 
-    def run_sampled(self, nsamples, thin_by, occupancy=True):
+    def run_sampled(self, nsamples, thin_by, occupancy=True, packed=False):
         """Advance nsamples*thin_by steps recording one sample per walker every thin_by steps
         on the device; returns dict(enthalpy (ns,R), features (ns,R,F), accepted (ns,R) bool,
-        occupancy (ns,R,N) int32 or None)."""
+        occupancy (ns,R,N) or None).  Occupancies come back as int32 (the reference's trace
+        dtype) or, with ``packed``, as the ring's own uint8 -- a quarter of the transfer."""
         ns = int(nsamples)
         self._chk(self._lib.smolmc_run_sampled(self._h, ns, int(thin_by), 1 if occupancy else 0))
-        H = np.zeros((ns, self.R))
-        feat = np.zeros((ns, self.R, self.F))
-        acc = np.zeros((ns, self.R), dtype=np.uint8)
-        occ = np.zeros((ns, self.R, self.N), dtype=np.int32) if occupancy else None
-        self._chk(self._lib.smolmc_get_samples(self._h, _p(H, C.c_double), _p(feat, C.c_double),
-                                               _p(acc, C.c_uint8), _p(occ, C.c_int32)))
+        H = np.empty((ns, self.R))
+        feat = np.empty((ns, self.R, self.F))
+        acc = np.empty((ns, self.R), dtype=np.uint8)
+        occ = np.empty((ns, self.R, self.N), dtype=np.uint8 if packed else np.int32) if occupancy else None
+        if packed:
+            self._chk(self._lib.smolmc_get_samples_u8(self._h, _p(H, C.c_double), _p(feat, C.c_double),
+                                                      _p(acc, C.c_uint8), _p(occ, C.c_uint8)))
+        else:
+            self._chk(self._lib.smolmc_get_samples(self._h, _p(H, C.c_double), _p(feat, C.c_double),
+                                                   _p(acc, C.c_uint8), _p(occ, C.c_int32)))
         return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=occ)
 
     def last_kernel_ms(self):

@@ -920,7 +920,7 @@ class SampleContainer:
 
     def last_occupancy(self):
         """Occupancies (nwalkers, N) of the most recent sample (no join of the blocks)."""
-        return self._blocks[-1]["occupancy"][-1]
+        return self._blocks[-1]["occupancy"][-1].astype(np.int32)
 
     # ---- bookkeeping -----------------------------------------------------------------
     ensemble = property(lambda self: self._ensemble)
@@ -940,10 +940,15 @@ class SampleContainer:
         return eff.mean() if flat else eff
 
     # ---- selection + reductions --------------------------------------------------------
+    def _select(self, name, discard, thin_by):
+        """Samples discard + thin_by - 1, discard + 2 thin_by - 1, ... of one traced value in
+        its storage dtype (the reference's selection rule, container.py:181-199)."""
+        return self._col(name)[discard + thin_by - 1:: thin_by]
+
     def get_trace_value(self, name, discard=0, thin_by=1, flat=True):
-        """Samples discard + thin_by - 1, discard + 2 thin_by - 1, ... of one traced value
-        (the reference's selection rule, container.py:181-199)."""
-        picked = self._col(name)[discard + thin_by - 1:: thin_by]
+        picked = self._select(name, discard, thin_by)
+        if name == "occupancy":  # stored as bytes, the reference's trace.occupancy is int32
+            picked = picked.astype(np.int32)
         return _merge_walkers(picked) if flat else picked
 
     def mean_trace_value(self, name, discard=0, thin_by=1, flat=True):
@@ -967,8 +972,11 @@ class SampleContainer:
 
     def _argmin_occupancy(self, values, discard, thin_by, flat):
         where = values.argmin(axis=0)
-        occ = self.get_trace_value("occupancy", discard, thin_by, flat)
-        return occ[where] if flat else occ[where, np.arange(self.shape[0])][0]
+        occ = self._select("occupancy", discard, thin_by)
+        if flat:
+            occ = _merge_walkers(occ)
+            return occ[where].astype(np.int32)
+        return occ[where, np.arange(self.shape[0])][0].astype(np.int32)
 
     def get_minimum_enthalpy_occupancy(self, discard=0, thin_by=1, flat=True):
         return self._argmin_occupancy(self.get_enthalpies(discard, thin_by, flat), discard, thin_by, flat)
@@ -985,8 +993,9 @@ class SampleContainer:
                 "Sublattice provided is not recognized.\n Provide one included in the sublattices "
                 "attribute of this SampleContainer."
             )
-        occ = self.get_trace_value("occupancy", discard, thin_by, flat=False)[..., sublattice.sites]
-        counts = (occ[..., None] == np.asarray(sublattice.encoding)).sum(axis=-2).astype(float)
+        occ = self._select("occupancy", discard, thin_by)[..., sublattice.sites]
+        counts = np.stack([(occ == code).sum(axis=-1) for code in np.asarray(sublattice.encoding)],
+                          axis=-1).astype(float)
         return _merge_walkers(counts) if flat else counts
 
     def get_species_counts(self, discard=0, thin_by=1, flat=True):
@@ -1124,7 +1133,9 @@ class Sampler:
                    for s in local_seeds]
         k0 = kernels[0]
         F = len(ensemble.natural_parameters)
-        per_walker = dict(occupancy=((ensemble.num_sites,), np.int32), features=((F,), np.float64),
+        # occupancies are STORED as the device ring's bytes (a quarter of the int32 the reference
+        # keeps) and handed out as int32 by the container's getters
+        per_walker = dict(occupancy=((ensemble.num_sites,), np.uint8), features=((F,), np.float64),
                           enthalpy=((1,), np.float64))
         if isinstance(k0, Metropolis):
             per_walker["temperature"] = ((1,), np.float64)
@@ -1310,11 +1321,11 @@ class Sampler:
                 yield {k: v[None] for k, v in self._current_trace(eng).items()}
             return
         nw, N = len(self._kernels), k0.ensemble.num_sites
-        per_block = max(1, min(nsamples, (256 << 20) // max(1, nw * N * 4)))  # ~256 MiB of occupancies
+        per_block = max(1, min(nsamples, (256 << 20) // max(1, nw * N)))  # ~256 MiB of occupancy bytes
         temps = self._temperatures().reshape(1, nw, 1)
         for start in range(0, nsamples, per_block):
             n = min(per_block, nsamples - start)
-            ring = eng.run_sampled(n, thin_by, occupancy=True)
+            ring = eng.run_sampled(n, thin_by, occupancy=True, packed=True)
             yield dict(occupancy=ring["occupancy"], features=ring["features"],
                        enthalpy=ring["enthalpy"][..., None], temperature=np.broadcast_to(temps, (n, nw, 1)),
                        accepted=ring["accepted"][..., None])
@@ -1323,7 +1334,9 @@ class Sampler:
         """Generator over thinned traces, one Trace per sample (sampler.py:164-210)."""
         for block in self._sample_blocks(nsteps, initial_occupancies, thin_by):
             for i in range(len(block["occupancy"])):
-                yield Trace(**{k: np.asarray(v[i]) for k, v in block.items()})
+                tr = Trace(**{k: np.asarray(v[i]) for k, v in block.items()})
+                tr.occupancy = tr.occupancy.astype(np.int32)  # (trace.occupancy is int32 in the reference)
+                yield tr
 
     def run(self, nsteps, initial_occupancies=None, thin_by=1, progress=False, stream_chunk=0,
             stream_file=None, keep_last_chunk=False, swmr_mode=False):

@@ -2,6 +2,7 @@
 committed reference-core fixtures.  Tolerances: accept masks / occupancies bit-exact;
 float64 1e-10 relative (BASELINE.json north_star)."""
 
+import ctypes as C
 import os
 
 import numpy as np
@@ -340,6 +341,34 @@ def test_sample_rows_at_any_phase_of_the_random_batches(offset, thin, kernel, mo
         np.testing.assert_allclose(smp["features"][i], st["features"], rtol=RTOL, atol=1e-8)
     a, b = eng.get_state(), ora.get_state()
     assert np.array_equal(a["n_steps"], b["n_steps"]) and np.array_equal(a["n_accepted"], b["n_accepted"])
+
+
+@pytest.mark.parametrize("name", ["fcc_prim666_triplets", "fcc3_indicator_skew", "rocksalt333_vacancy_ewald"])
+def test_packed_sample_download_equals_int32_download(name):
+    """smolmc_get_samples_u8 (occupancies as the ring's bytes; row pitch Npad on the device, N on
+    the host -- 216 / 27 / 54 sites are not multiples of the padding) == smolmc_get_samples."""
+    c = load_case(name)
+    tab = tables_for(name, MODES["int"])
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP)
+    nsp = np.array([c["model"].prim.nspecies[b] for b in c["sc"].site_b])
+    occ0 = (np.random.default_rng(3).random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+    out = []
+    for packed in (False, True):
+        eng = _engine(tab, cfg)
+        eng.set_state(occ0, np.arange(R, dtype=np.uint64) + np.uint64(3), 2500.0)
+        out.append(eng.run_sampled(7, 13, occupancy=True, packed=packed))
+        if packed:  # the int32 entry point still serves the same ring
+            again = np.zeros((7, R, eng.N), dtype=np.int32)
+            eng._chk(eng._lib.smolmc_get_samples(eng._h, None, None, None,
+                                                 again.ctypes.data_as(C.POINTER(C.c_int32))))
+            assert np.array_equal(again, out[0]["occupancy"])
+    assert out[0]["occupancy"].dtype == np.int32 and out[1]["occupancy"].dtype == np.uint8
+    assert out[1]["occupancy"].shape == (7, R, c["sc"].num_sites)
+    assert np.array_equal(out[0]["occupancy"], out[1]["occupancy"])
+    assert len(np.unique(out[1]["occupancy"], axis=0)) > 1
+    for k in ("enthalpy", "features", "accepted"):
+        assert np.array_equal(out[0][k], out[1][k])
 
 
 @pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
