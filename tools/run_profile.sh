@@ -14,7 +14,14 @@ for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VAL
   n=$(echo $c | tr ' ' '_' | cut -c1-24)
   rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${tag}_$n -- python $R/bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 > $R/gpurun_out/pmc_${tag}_$n.log 2>&1
 done
+# LDS pipe of the headline kernel (index-active / conflict cycles, FIFO stalls, shader clock)
+i=0
+for c in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/ldspmc_${tag}_$i -- python $R/bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 > $R/gpurun_out/ldspmc_${tag}_$i.log 2>&1
+done
 cd $R
+python tools/rocpd_summary.py gpurun_out/ldspmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_lds_pmc.txt
 python tools/rocpd_summary.py gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_pmc.txt
-python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, false, false, false, true" --replicas 4096 --mc 10000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
+python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, 0, false, false, true" --replicas 4096 --mc 10000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
 tail -c 600 gpurun_out/bench_${tag}.json
