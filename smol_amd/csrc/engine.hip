@@ -1197,21 +1197,37 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             // LDS: shared tables + slot records, per wave occupancy + scratch + accumulators (+ field)
             const size_t nrec = (size_t)h->lean_ncls * h->lean_nslot * 64;
             const size_t shared = ((size_t)lp.dt_len + 96 + (table ? 80 : 0)) * 8 + nrec * 24;
-            // the potential field goes to LDS only while it stays small beside the rest of the
-            // wave's state (else the HBM copy is used in place: ew_field 2)
-            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * (table ? 16 : 8);
-            const bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2 &&
-                                 getenv("SMOLMC_MULTI_PHI_HBM") == nullptr; // (test hook: force the HBM field)
-            const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
             // waves per workgroup: the shared tables are paid once per workgroup, so pick the size
             // that keeps the most waves resident per CU (160 KiB of LDS)
-            int wpb = 0, best_waves = 0;
-            for (int w : {8, 4, 2, 1}) {
-                const size_t need = shared + per_wave * w;
-                if (need > 160 * 1024 - 512) continue;
-                const int waves = (int)((160 * 1024) / need) * w;
-                if (waves > best_waves) { best_waves = waves; wpb = w; }
+            auto layout = [&](size_t per_wave_bytes, int &wpb_out) {
+                int best_waves = 0;
+                wpb_out = 0;
+                for (int w : {8, 4, 2, 1}) {
+                    const size_t need = shared + per_wave_bytes * w;
+                    if (need > 160 * 1024 - 512) continue;
+                    const int waves = (int)((160 * 1024) / need) * w;
+                    if (waves > best_waves) { best_waves = waves; wpb_out = w; }
+                }
+                return best_waves;
+            };
+            // The potential field goes to LDS while it stays small beside the rest of the wave's
+            // state, or when all walkers still fit the chip in one round with it there (an
+            // accepted flip then reads its G row only, no read-modify-write of phi through L2:
+            // LiNiO2 8^3, 2048 walkers: swap 9.6e8 -> 1.16e9 steps/s); else the HBM copy is used
+            // in place (ew_field 2).  SMOLMC_MULTI_PHI_HBM / _LDS force either (test hooks).
+            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * (table ? 16 : 8);
+            bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
+            if (t->has_ewald && !phi_lds) {
+                int cus = 0, w = 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+                const int waves = layout(base_wave + (size_t)kp.ew_nact * 8, w);
+                if ((long)waves * cus >= (long)cfg->n_replicas || getenv("SMOLMC_MULTI_PHI_LDS") != nullptr)
+                    phi_lds = waves > 0;
             }
+            if (getenv("SMOLMC_MULTI_PHI_HBM") != nullptr) phi_lds = false;
+            const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
+            int wpb = 0;
+            layout(per_wave, wpb);
             if (wpb == 0) ok = false;
             if (ok) {
                 if (t->has_mu && dev_upload(h, mu_rows.data(), 32, &lp.m_mu)) return bail(1);

@@ -149,3 +149,35 @@ def test_smol_shaped_api_on_the_imported_model(lno):
             np.testing.assert_allclose(feats[i, w], ens.compute_feature_vector(occs[i, w]), rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(c.get_enthalpies(flat=False)[..., 0], feats @ ens.natural_parameters,
                                rtol=1e-10, atol=1e-8)
+
+
+def test_ewald_field_placement_follows_residency(lno, monkeypatch):
+    """Multi-sublattice kernel: the potential field of the 8^3 LiNiO2 cell (8 KiB per walker) lives
+    in LDS while all walkers stay resident in one round with it there (16 x CU-count / 2 here), in
+    HBM beyond; both placements run the same chain."""
+    import torch
+
+    monkeypatch.delenv("SMOLMC_MULTI_PHI_HBM", raising=False)
+    monkeypatch.delenv("SMOLMC_MULTI_PHI_LDS", raising=False)
+    ce, _ = lno
+    tab = ce.tables(np.diag([8, 8, 8]))
+    cell = tab.supercell
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small, big = 64, 16 * cus
+    out = {}
+    for R in (small, big):
+        rng = np.random.default_rng(5)
+        occ = _neutral_occupancies(cell, small, rng, n_li=cell.size // 2)
+        occ = np.tile(occ, (R // small, 1))
+        eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+        info = eng.kernel_info()
+        assert info.startswith("lean-multi") and ("field=1" if R == small else "field=2") in info, info
+        seeds = np.tile(np.arange(small, dtype=np.uint64) + np.uint64(9), R // small)
+        eng.set_state(occ, seeds, 1100.0)
+        eng.run(300)
+        st = eng.get_state()
+        out[R] = (st["occupancy"][:small], st["enthalpy"][:small], st["n_accepted"][:small])
+        eng.close()
+    assert np.array_equal(out[small][0], out[big][0]) and np.array_equal(out[small][2], out[big][2])
+    np.testing.assert_allclose(out[small][1], out[big][1], rtol=RTOL, atol=1e-8)
+    assert out[small][2].sum() > 0
