@@ -1142,12 +1142,16 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         h->lean = lean;
         // ---- several classes / sublattices (or > 256 clusters per site): mc_lean_multi_kernel
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
-        if (!lean && h->lean_tables && !h->lean_kf && !wl && !t->bias_type && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        // (MCBias: Fugacity / SquareCharge with flips or swaps; the hyperplane bias and biased
+        // TableFlip take the general kernel)
+        const bool multi_bias_ok = !t->bias_type || (t->bias_type != SMOLMC_BIAS_SQUARE_HYPERPLANE &&
+                                                     cfg->step_type != SMOLMC_STEP_TABLE_FLIP);
+        if (!lean && h->lean_tables && !h->lean_kf && !wl && multi_bias_ok && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
             bool ok = true;
-            std::vector<double> mu_rows(32, 0.0), q_rows(32, 0.0), dg_rows(32, 0.0);
+            std::vector<double> mu_rows(32, 0.0), q_rows(32, 0.0), dg_rows(32, 0.0), bias_pairs(256, 0.0);
             double cum = 0.0, mmax = 0.0;
             for (int k = 0; k < ns && ok; ++k) {
                 const int64_t a0 = t->sub_site_ptr[k], a1 = t->sub_site_ptr[k + 1];
@@ -1175,6 +1179,18 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                         for (int i = 0; i < na; ++i)
                             if (t->mu_table[(size_t)(sb + i) * t->mu_width + c] != v) ok = false;
                     }
+                }
+                if (t->bias_type) { // one bias row per sublattice (it is defined per sublattice)
+                    const int W = t->bias_width;
+                    if (W < ncod) ok = false;
+                    for (int i = 0; ok && i < na; ++i)
+                        for (int c = 0; c < ncod; ++c)
+                            if (h->bias_host[(size_t)(sb + i) * W + c] != h->bias_host[(size_t)sb * W + c]) ok = false;
+                    for (int o = 0; ok && o < ncod; ++o)
+                        for (int n = 0; n < ncod; ++n) {
+                            const double a = h->bias_host[(size_t)sb * W + n], b = h->bias_host[(size_t)sb * W + o];
+                            bias_pairs[k * 64 + o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
+                        }
                 }
                 if (t->has_ewald) {
                     if (kp.ew_W > 8 || sb < kp.ew_act_base || sb + na > kp.ew_act_base + kp.ew_nact) ok = false;
@@ -1234,6 +1250,13 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 if (t->has_ewald &&
                     (dev_upload(h, q_rows.data(), 32, &lp.m_q) || dev_upload(h, dg_rows.data(), 32, &lp.m_dg)))
                     return bail(1);
+                if (t->bias_type) {
+                    if (dev_upload(h, bias_pairs.data(), bias_pairs.size(), &lp.bias_pair)) return bail(1);
+                    lp.bias_type = t->bias_type;
+                    lp.bias_pen = t->bias_penalty;
+                    lp.bias = kp.bias;
+                    lp.charge = kp.charge;
+                }
                 if (t->has_mu) lp.fast_eps += 4.0 * mmax * ldexp(1.0, -19);
                 if (getenv("SMOLMC_NO_FAST_ACCEPT")) lp.fast_eps = 0.0;
                 if (const char *sc = getenv("SMOLMC_FAST_EPS_SCALE")) lp.fast_eps *= atof(sc);
@@ -1556,6 +1579,9 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
 
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
+    if (h->lean_multi && lp.bias_type)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_bias_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_4(h, lp) : smolmc_launch_multi_bias_8(h, lp));
     if (h->lean_multi)
         return h->lean_nslot == 2 ? smolmc_launch_multi_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_4(h, lp) : smolmc_launch_multi_8(h, lp));

@@ -29,7 +29,10 @@ struct MultiRec { // slot record, 24 bytes
 
 // ONE: a single site class (the 257..512-clusters-per-site models): the slot records stay in
 // registers for the whole launch instead of being re-read from LDS for every flip.
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool ONE = false>
+// BIAS: FugacityBias / SquareChargeBias (bias.py:96-287) with one bias row per sublattice,
+// P.bias_pair[sub][old * 8 + new]; biased walkers always take the exact decision path (as in
+// mc_lean_kernel).  Separate instantiations (multi_bias_n*.hip).
+template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool ONE = false, bool BIAS = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -89,7 +92,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     const uint32_t nt8 = P.nt8, snt8 = P.snt8;
     const int abase = P.ew_act_base;
     double acc_mu = 0.0, acc_ew = 0.0;
-    constexpr bool FAST = !HAS_EW; // float32 accept pre-test (Ewald variants take the exact path)
+    constexpr bool FAST = !HAS_EW && !BIAS; // float32 accept pre-test (Ewald / biased variants take the exact path)
+    const int btype = BIAS ? P.bias_type : 0;
+    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
     float thr_lo = 0.0f, thr_hi = 0.0f;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
@@ -315,9 +320,23 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             dMu = s_mu[sub1 * 8 + n1] - s_mu[sub1 * 8 + o1];
             if (nfl == 2) dMu += s_mu[sub1 * 8 + n2] - s_mu[sub1 * 8 + o2];
         }
+        // compute_bias_change against the original occupancy (kernel/base.py:307-311; bias.py)
+        double dB = 0.0, dQ = 0.0;
+        if (BIAS && nfl >= 1) {
+            const double *bp = P.bias_pair + sub1 * 64;
+            double x = bp[o1 * 8 + n1];
+            if (nfl == 2) x += bp[o2 * 8 + n2];
+            if (btype == SMOLMC_BIAS_FUGACITY) {
+                dB = x;
+            } else {
+                dQ = x;
+                const double cn = charge + dQ;
+                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+            }
+        }
         double dH = 0.0, dEw = HAS_EW ? ew_uni : 0.0;
         bool accepted = false, decided = false;
-        if (!HAS_EW) { // float32 pre-test (see mc_lean_kernel)
+        if (FAST) { // float32 pre-test (see mc_lean_kernel)
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
             const unsigned long long bit = 1ull << l4;
@@ -332,11 +351,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             if (HAS_MU) dH -= dMu;
             const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
                                                (int)rdlane((uint32_t)__double2loint(logu), l4));
-            const double exponent = nbeta * dH + 0.0;
+            const double exponent = nbeta * dH + 0.0 + dB; // metropolis.py:41-44
             accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         }
         nacc_before = nacc_add;
         if (accepted) {
+            bias_acc += dB;
+            charge += dQ;
             double *cell = s_acc + ((size_t)cls1 * NSLOT) * 64 + lane;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it)
@@ -420,6 +441,10 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
     if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     H += wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0);
+    if (btype && lane == 0) {
+        P.bias[r] += bias_acc;
+        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
+    }
     if (lane == 0) {
         if (HAS_EW) featp[P.Fce] += acc_ew;
         if (HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
@@ -430,13 +455,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW>
+template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool BIAS = false>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
     // one site class with more than 256 clusters per site: slot records in registers
-    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8>
-                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false>;
+    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8, BIAS>
+                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false, BIAS>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -447,18 +472,21 @@ static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     h->timed = true;
     return 0;
 }
-template <int NSLOT, int MM> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, bool BIAS = false> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.m_mu != nullptr, ew = lp.ew_field != 0;
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) {
-        if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, true>(h, lp)
-                          : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, true>(h, lp);
-        return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, false>(h, lp)
-                  : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, false>(h, lp);
+        if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, true, BIAS>(h, lp)
+                          : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, true, BIAS>(h, lp);
+        return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, false, BIAS>(h, lp)
+                  : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, false, BIAS>(h, lp);
     }
-    if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, true>(h, lp)
-                      : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, true>(h, lp);
-    return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, false>(h, lp)
-              : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, false>(h, lp);
+    if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, true, BIAS>(h, lp)
+                      : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, true, BIAS>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, false, BIAS>(h, lp)
+              : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, false, BIAS>(h, lp);
+}
+template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2, true>(h, lp) : launch_multi_nm<NSLOT, 3, true>(h, lp);
 }
 
 

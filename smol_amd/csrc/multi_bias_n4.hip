@@ -1,0 +1,6 @@
+// mc_lean_multi_kernel instantiations with an MCBias term, NSLOT = 4
+#include "mc_lean_multi.h"
+
+int smolmc_launch_multi_bias_4(smolmc_handle *h, const LeanParams &lp) {
+    return launch_multi_bias_nslot<4>(h, lp);
+}

@@ -305,7 +305,8 @@ struct LeanParams {
     const LeanSlot *slots; // [NSLOT][64]
     const double *mu_row;  // [ncodes] chemical potentials of the active sublattice (or null)
     // MCBias on the single active sublattice: bias_pair[old * 8 + new] = log(f_new / f_old)
-    // (FugacityBias) or q_new - q_old (SquareChargeBias); running bias / net charge per walker
+    // (FugacityBias) or q_new - q_old (SquareChargeBias); running bias / net charge per walker.
+    // mc_lean_multi_kernel: one such table per sublattice, bias_pair[sub * 64 + old * 8 + new].
     int bias_type;
     const double *bias_pair;
     double bias_pen;
@@ -478,3 +479,6 @@ int smolmc_launch_lean_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_8(smolmc_handle *h, const LeanParams &lp);

@@ -70,6 +70,65 @@ def test_biased_trajectories_match_oracle(rocksalt, kind, step, ewald, general, 
         np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in occ0], atol=1e-9)
 
 
+@pytest.fixture(scope="module")
+def oxyfluoride():
+    """Two active sublattices: Li+ / Mn3+ / Ti4+ cations, O2- / F- anions."""
+    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 6.0, 3: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    return model, sc, synth.random_coefs(model, seed=14)
+
+
+@pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+@pytest.mark.parametrize("kind", ["fugacity", "square-charge"])
+def test_biased_trajectories_two_sublattices(oxyfluoride, kind, step, ewald, monkeypatch):
+    """MCBias on the multi-sublattice lean kernel (one bias row per sublattice): same chain as the
+    oracle and as the general kernel; trace.bias equals a recomputation."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    model, sc, coefs = oxyfluoride
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.15 if ewald else None)
+    cat, an = ens.active_sublattices[0].species, ens.active_sublattices[1].species
+    bias = (moca.FugacityBias(ens.sublattices, [{cat[0]: 0.15, cat[1]: 0.25, cat[2]: 0.6}, {an[0]: 0.7, an[1]: 0.3}])
+            if kind == "fugacity" else moca.SquareChargeBias(ens.sublattices, penalty=0.05))
+    tab = ens.make_tables().set_bias(bias.bias_type, bias._table, bias.penalty)
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    rng = np.random.default_rng(22)
+    occ0 = np.zeros((R, sc.num_sites), dtype=np.int32)
+    occ0[:, : sc.size] = rng.integers(0, 3, size=(R, sc.size))
+    occ0[:, sc.size:] = rng.integers(0, 2, size=(R, sc.size))
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(7919)
+    temps = np.linspace(700.0, 5000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean-multi"), eng.kernel_info()
+    monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    gen = Engine(tab, cfg)
+    assert gen.kernel_info().startswith("general")
+    for e in (eng, gen, ora):
+        e.set_state(occ0, seeds, temps)
+    for chunk in (1, 16, 17, 300):
+        for e in (eng, gen, ora):
+            e.run(chunk)
+        a = eng.get_state()
+        for x in (gen, ora):
+            b = x.get_state()
+            assert np.array_equal(a["occupancy"], b["occupancy"])
+            assert np.array_equal(a["n_accepted"], b["n_accepted"])
+            np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(eng.get_bias(), x.get_bias(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in a["occupancy"]],
+                               rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    smp = eng.run_sampled(3, 11)  # the sample rows of a biased multi-sublattice walker
+    for e in (gen, ora):
+        e.run(33)
+    np.testing.assert_allclose(smp["enthalpy"][-1], ora.get_state()["enthalpy"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(smp["occupancy"][-1], gen.get_state()["occupancy"])
+
+
 def test_bias_errors_surface(rocksalt):
     model, sc, coefs = rocksalt
     ens = moca.Ensemble.from_cluster_expansion(sc, coefs)

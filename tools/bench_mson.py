@@ -62,6 +62,32 @@ def main():
                               "steps_per_s": a.walkers * a.mc / (np.mean(ms) * 1e-3),
                               "acceptance": float(st["n_accepted"].sum() / st["n_steps"].sum())}), flush=True)
             eng.close()
+    # through the smol-shaped API: charge-neutral TableFlip (flip table from the model's own
+    # CompositionSpace) and semigrand flips under a SquareChargeBias
+    from smol_amd import moca
+
+    ens = moca.Ensemble.from_mson(ce, np.diag([a.dim] * 3))
+    cell = ens.processor.supercell
+    occ = neutral(cell, a.walkers, rng, cell.size // 2)
+    for name, kw in (("table-flip", dict(step_type="table-flip")),
+                     ("flip + square-charge bias", dict(step_type="flip", bias_type="square-charge",
+                                                        bias_kwargs={"penalty": 0.5}))):
+        sampler = moca.Sampler.from_ensemble(ens, temperature=a.temperature, nwalkers=a.walkers,
+                                             seeds=list(range(a.walkers)), **kw)
+        sampler.setup_sample(occ)
+        eng = sampler.engine
+        eng.run(a.mc)
+        eng.sync()
+        ms = []
+        for _ in range(3):
+            eng.run(a.mc)
+            ms.append(eng.last_kernel_ms())
+        st = eng.get_state(occupancy=False)
+        print(json.dumps({"model": "LiNiO2 + Ewald (reference .mson)", "sites": int(cell.num_sites),
+                          "walkers": a.walkers, "features": "int", "step": name,
+                          "kernel": eng.kernel_info(), "kernel_ms": float(np.mean(ms)),
+                          "steps_per_s": a.walkers * a.mc / (np.mean(ms) * 1e-3),
+                          "acceptance": float(st["n_accepted"].sum() / st["n_steps"].sum())}), flush=True)
 
 
 if __name__ == "__main__":
