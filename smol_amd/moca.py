@@ -25,7 +25,10 @@ Everything here drives the HIP engine through smol_amd.engine; there is no CPU p
 
 from __future__ import annotations
 
+import json
+import os
 import warnings
+from datetime import datetime
 from types import SimpleNamespace
 
 import numpy as np
@@ -1040,6 +1043,34 @@ class SampleContainer:
         np.savez_compressed(path, nsamples=self.num_samples, total_mc_steps=self._total_steps,
                             **{f"trace/{k}": v for k, v in self._all().items()})
 
+    # Streaming backend: a directory of part-NNNNNN.npz files + manifest.json.  It stands in for the
+    # HDF5 file of the reference (container.py:420-437 flush_to_backend, :439-504 get_backend; h5py is
+    # not available here): every flush writes the samples held in memory as the next part and drops
+    # them, so a long run keeps at most one chunk on the host.  Appending to an existing directory
+    # continues its numbering, as the reference appends to an existing file.
+    def get_backend(self, file_path, alloc_nsamples=0, swmr_mode=False):
+        return NpzStream(file_path, self)
+
+    def flush_to_backend(self, backend):
+        backend.write(self)
+        self.clear()
+
+    @classmethod
+    def from_stream(cls, path, ensemble):
+        """All parts of a streaming directory as one container (the reference's from_hdf5)."""
+        man = NpzStream.read_manifest(path)
+        c = None
+        for i in range(man["nparts"]):
+            d = np.load(os.path.join(path, f"part-{i:06d}.npz"))
+            arrays = {k[6:]: d[k] for k in d.files if k.startswith("trace/")}
+            if c is None:
+                c = cls(ensemble, Trace(**{k: v[:0] for k, v in arrays.items()}), man.get("metadata"))
+            c.append_block(arrays, 0)
+        if c is None:
+            raise ValueError(f"{path} holds no samples")
+        c._total_steps = int(man["total_mc_steps"])
+        return c
+
     @classmethod
     def from_npz(cls, path, ensemble):
         d = np.load(path)
@@ -1049,6 +1080,63 @@ class SampleContainer:
         c.append_block(arrays, 0)
         c._total_steps = int(d["total_mc_steps"])
         return c
+
+
+class NpzStream:
+    """Writer side of the streaming directory (see SampleContainer.get_backend)."""
+
+    def __init__(self, path, container):
+        self.path = str(path)
+        os.makedirs(self.path, exist_ok=True)
+        if os.path.exists(os.path.join(self.path, "manifest.json")):
+            self.manifest = self.read_manifest(self.path)
+            if self.manifest["traced_values"] != list(container.traced_values) or \
+                    self.manifest["shape"] != list(container.shape):
+                raise RuntimeError(
+                    f"Backend file {self.path} holds samples of another shape / set of traced values."
+                )
+        else:
+            self.manifest = dict(nparts=0, nsamples=0, total_mc_steps=0, shape=list(container.shape),
+                                 traced_values=list(container.traced_values),
+                                 metadata=_jsonable(container.metadata))
+            self._save_manifest()
+
+    @staticmethod
+    def read_manifest(path):
+        with open(os.path.join(path, "manifest.json")) as f:
+            return json.load(f)
+
+    def _save_manifest(self):
+        tmp = os.path.join(self.path, "manifest.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump(self.manifest, f)
+        os.replace(tmp, os.path.join(self.path, "manifest.json"))  # readers never see a torn manifest
+
+    def write(self, container):
+        n = container.num_samples
+        if n == 0:
+            return
+        np.savez(os.path.join(self.path, f"part-{self.manifest['nparts']:06d}.npz"),
+                 **{f"trace/{k}": v for k, v in container._all().items()})
+        self.manifest["nparts"] += 1
+        self.manifest["nsamples"] += n
+        self.manifest["total_mc_steps"] += container.total_mc_steps
+        self._save_manifest()
+
+    def close(self):
+        pass
+
+
+def _jsonable(x):
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (np.integer, np.floating, np.bool_)):
+        return x.item()
+    return x if isinstance(x, (str, int, float, bool, type(None))) else repr(x)
 
 
 def _install_reductions():
@@ -1109,6 +1197,7 @@ class Sampler:
         self._device, self._world = int(device), int(world_size)
         self._state_loaded = False  # walker states uploaded to the engine at least once
         self._resume_at = None      # (container, its sample count) the device state equals, see _load_state
+        self._kept_last = False     # the container holds the one sample a streamed run kept (keep_last_chunk)
 
     @classmethod
     def from_ensemble(cls, ensemble, *args, step_type=None, kernel_type=None, seeds=None,
@@ -1299,7 +1388,7 @@ class Sampler:
             tr.mod_factor = wl["mod_factor"].reshape(nw, 1)
         return tr
 
-    def _sample_blocks(self, nsteps, initial_occupancies, thin_by):
+    def _sample_blocks(self, nsteps, initial_occupancies, thin_by, max_block=0, state_loaded=False):
         """Generator over blocks of thinned samples, dict name -> (n, nwalkers, ...): the unit
         the device ring delivers.  Metropolis without bias: ``smolmc_run_sampled`` records n
         samples inside one launch; Wang-Landau and biased kernels (per-walker L x F arrays /
@@ -1310,7 +1399,8 @@ class Sampler:
                 f"{nsteps % thin_by} will be ignored.",
                 category=RuntimeWarning,
             )
-        self._load_state(initial_occupancies)
+        if not state_loaded:
+            self._load_state(initial_occupancies)
         self._resume_at = None
         eng = self._get_engine()
         nsamples = nsteps // thin_by
@@ -1322,6 +1412,8 @@ class Sampler:
             return
         nw, N = len(self._kernels), k0.ensemble.num_sites
         per_block = max(1, min(nsamples, (256 << 20) // max(1, nw * N)))  # ~256 MiB of occupancy bytes
+        if max_block > 0:
+            per_block = min(per_block, int(max_block))
         temps = self._temperatures().reshape(1, nw, 1)
         for start in range(0, nsamples, per_block):
             n = min(per_block, nsamples - start)
@@ -1340,7 +1432,8 @@ class Sampler:
 
     def run(self, nsteps, initial_occupancies=None, thin_by=1, progress=False, stream_chunk=0,
             stream_file=None, keep_last_chunk=False, swmr_mode=False):
-        """sampler.py:212-301 (HDF5 streaming arguments are accepted and refused)."""
+        """sampler.py:212-301.  ``stream_chunk`` > 0 writes every chunk of samples to the streaming
+        directory ``stream_file`` (see SampleContainer.get_backend) and keeps none in memory."""
         if initial_occupancies is None:
             if self.samples.num_samples == 0:
                 raise RuntimeError(
@@ -1353,10 +1446,26 @@ class Sampler:
                 "real sure that is what you want. If not, reset the samples in the sampler.",
                 RuntimeWarning,
             )
-        if stream_chunk > 0:
-            raise NotImplementedError("HDF5 streaming is out of scope here (h5py absent); use to_npz")
-        for block in self._sample_blocks(nsteps, initial_occupancies, thin_by):
+        backend, last = None, None
+        if stream_chunk > 0:  # sampler.py:264-301; the backend is a directory of .npz parts here
+            if stream_file is None:
+                stream_file = os.path.join(os.getcwd(), "moca-samples-" + datetime.now().strftime("%Y-%m-%d-%H%M%S%f"))
+            backend = self.samples.get_backend(stream_file, nsteps // thin_by, swmr_mode=swmr_mode)
+        self._load_state(initial_occupancies)
+        if backend is not None and self._kept_last:
+            self.samples.clear()  # the sample kept by the previous streamed run is already in its stream
+        self._kept_last = False
+        for block in self._sample_blocks(nsteps, None, thin_by, max_block=stream_chunk, state_loaded=True):
             self.samples.append_block(block, thinned_by=thin_by)
+            if backend is not None and self.samples.num_samples >= stream_chunk:
+                last = {k: v[-1:] for k, v in block.items()}
+                self.samples.flush_to_backend(backend)
+        if backend is not None:
+            self.samples.flush_to_backend(backend)  # (the tail shorter than a chunk)
+            backend.close()
+            if keep_last_chunk and last is not None:  # the last sample stays in memory, e.g. to start the next run from it
+                self.samples.append_block(last, thinned_by=0)
+                self._kept_last = True
         # the device now holds the last recorded sample (see _load_state)
         self._resume_at = (id(self.samples), self.samples.num_samples)
 

@@ -173,6 +173,34 @@ def test_continuing_on_the_device_equals_reloading_the_last_sample(fcc):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-11, atol=1e-9)
 
 
+def test_streamed_run_equals_in_memory_run(fcc, tmp_path):
+    """Sampler.run(stream_chunk, stream_file) (sampler.py:264-301): chunks go to the streaming
+    directory, none stays in memory (one sample with keep_last_chunk), the next run continues
+    the chain, and the directory holds exactly the in-memory run's samples."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = np.vstack([_rand_occ(np.random.default_rng(31), sc)[0] for _ in range(3)])
+    mem = moca.Sampler.from_ensemble(ens, temperature=1400, nwalkers=3, seeds=[7, 8, 9])
+    mem.run(1100, occu, thin_by=100)
+    mem.run(500, thin_by=100)
+    st = moca.Sampler.from_ensemble(ens, temperature=1400, nwalkers=3, seeds=[7, 8, 9])
+    path = str(tmp_path / "samples")
+    st.run(1100, occu, thin_by=100, stream_chunk=4, stream_file=path, keep_last_chunk=True)
+    assert st.samples.num_samples == 1  # only the last sample is kept
+    st.run(500, thin_by=100, stream_chunk=4, stream_file=path)
+    assert st.samples.num_samples == 0
+    with pytest.raises(RuntimeError):
+        st.run(100, thin_by=100)  # nothing in memory to start from (as in the reference)
+    back = moca.SampleContainer.from_stream(path, ens)
+    assert back.num_samples == 16 and back.total_mc_steps == 1600
+    assert np.array_equal(back.get_occupancies(flat=False), mem.samples.get_occupancies(flat=False))
+    np.testing.assert_allclose(back.get_enthalpies(flat=False), mem.samples.get_enthalpies(flat=False),
+                               rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(back.get_feature_vectors(flat=False), mem.samples.get_feature_vectors(flat=False),
+                               rtol=1e-12, atol=1e-10)
+    assert back.sampling_efficiency() == mem.samples.sampling_efficiency()
+
+
 def test_anneal(fcc):
     """tests/test_moca/test_sampler.py:89-113."""
     model, sc, coefs = fcc

@@ -176,3 +176,43 @@ def test_sublattice_restriction(ensemble):  # sublattice.py:84-107
     finally:
         ensemble.reset_restricted_sites()
     assert len(sub.active_sites) == ensemble.num_sites
+
+
+def test_streaming_directory_round_trip(tmp_path):
+    """SampleContainer.get_backend / flush_to_backend / from_stream (the stand-in for the
+    reference's HDF5 backend, container.py:420-504): flushed chunks come back in order, an existing
+    directory is appended to, a mismatching one is refused."""
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=1))
+    s = moca.Sampler.from_ensemble(ens, temperature=900.0, nwalkers=3, seeds=[1, 2, 3])
+    c = s.samples
+    F = len(ens.natural_parameters)
+    rng = np.random.default_rng(0)
+
+    def block(n):
+        return dict(occupancy=rng.integers(0, 2, (n, 3, sc.num_sites)), features=rng.normal(size=(n, 3, F)),
+                    enthalpy=rng.normal(size=(n, 3, 1)), temperature=np.full((n, 3, 1), 900.0),
+                    accepted=rng.random((n, 3, 1)) < 0.5)
+
+    blocks = [block(4), block(4), block(2)]
+    path = tmp_path / "stream"
+    backend = c.get_backend(str(path))
+    for b in blocks[:2]:
+        c.append_block(b, thinned_by=10)
+        c.flush_to_backend(backend)
+        assert c.num_samples == 0
+    backend.close()
+    backend = c.get_backend(str(path))  # append to the existing directory
+    c.append_block(blocks[2], thinned_by=10)
+    c.flush_to_backend(backend)
+    back = moca.SampleContainer.from_stream(str(path), ens)
+    assert back.num_samples == 10 and back.total_mc_steps == 100
+    np.testing.assert_array_equal(back.get_occupancies(flat=False),
+                                  np.concatenate([b["occupancy"] for b in blocks]))
+    np.testing.assert_array_equal(back.get_enthalpies(flat=False), np.concatenate([b["enthalpy"] for b in blocks]))
+    assert back.get_occupancies().dtype == np.int32
+    np.testing.assert_allclose(back.sampling_efficiency(), np.concatenate([b["accepted"] for b in blocks]).mean())
+    other = moca.Sampler.from_ensemble(ens, temperature=900.0, nwalkers=2, seeds=[1, 2]).samples
+    with pytest.raises(RuntimeError):
+        other.get_backend(str(path))
