@@ -460,6 +460,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         int l64 = (int)(step & 63ull); // lane of this step's acceptance uniform / thresholds
         do {
         // site of the next step (depends only on random words; its index row is fetched below)
+#ifndef SMOLMC_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(1); // wave priority rises through the step, see the decision below
+#endif
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
         // LDS address of site 1 as a VGPR, made once per step (the compiler would re-make the
@@ -546,6 +549,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 
         // data-dependent row of site 2: issued before flip 1 is evaluated (s2 == s1 for the
         // rare empty step, the loaded row is then unused)
+#ifndef SMOLMC_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) {
 #ifdef SMOLMC_EXP_ROW2 // timing experiment only: row of an early-known site (wrong results)
@@ -566,9 +572,6 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         constexpr bool DIFF = false;
 #else
         constexpr bool DIFF = STEP == SMOLMC_STEP_SWAP;
-#endif
-#ifndef SMOLMC_NO_SETPRIO
-        __builtin_amdgcn_s_setprio(1); // wave priority rises through the step, see the decision below
 #endif
         double e = 0.0, d1[NSLOT], d2[NSLOT];
         uint32_t dp[NSLOT];
@@ -778,14 +781,15 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // "decided / accepted" pair of flags costs the common path extra compare-and-branch steps).
         nacc_before = nacc_add;
         bool accepted = false; // (read after this point by the Wang-Landau post-step only)
-        // Wave priority rises through the step: 0 during the proposal, 1 from the first gathers,
-        // 2 for the decision chain (reduction, accept test, updates) -- the wave furthest into its
-        // step issues first and reaches its next memory instructions sooner.  Headline: 5.17 ->
-        // 4.87 ms (two levels: 5.03; a fourth level at the second flip's gathers: 4.93; one constant
-        // level or bare scheduling barriers at the same places: slower than nothing); 1-3 % on the
-        // other variants.
+        // Wave priority rises through the step: 0 in the loop skeleton (random batches), 1 during
+        // the proposal, 2 from the row fetch / gathers, 3 for the decision chain (reduction, accept
+        // test, updates) -- the wave furthest into its step issues first and reaches its next
+        // memory instructions sooner.  Headline: 5.17 -> 4.66 ms (two levels: 5.03; three: 4.87 /
+        // 4.73 depending on where level 1 starts; one constant level or bare scheduling barriers at
+        // the same places: slower than nothing; the decision at the LOWEST level: 5.10); 0-3 % on
+        // the other variants, -2 % at one wave per SIMD.
 #ifndef SMOLMC_NO_SETPRIO
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(3);
 #endif
         if (FAST && !BIAS) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
@@ -1127,6 +1131,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
         const int l4 = (int)(step & 15ull) * 4;
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
+#ifndef SMOLMC_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(1); // wave priority rises through the step (see mc_lean_kernel)
+#endif
 
         // flips of this step live lane-indexed: lane f holds flip f
         int vsite = 0, vnew = 0, vold = 0;
@@ -1364,6 +1371,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
         }
 
+#ifndef SMOLMC_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
         double vdq = 0.0; // lane f holds the charge change of flip f (potential-field mode)
@@ -1428,7 +1438,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         for (int f = 4; f < nfl; ++f)
             eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
 #ifndef SMOLMC_NO_SETPRIO
-        __builtin_amdgcn_s_setprio(1); // (decision chain ahead of other waves' proposals, see mc_lean_kernel)
+        __builtin_amdgcn_s_setprio(3);
 #endif
         double dH = wave_sum_all(e);
         double dEw = 0.0;
