@@ -177,6 +177,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             have_row1 = false;
         }
         const int l4 = (int)(step & 15ull) * 4;
+#ifndef SMOLMC_NO_SETPRIO
+        if (!ONE) __builtin_amdgcn_s_setprio(1); // wave priority rises through the step (see mc_lean_kernel; no gain for ONE)
+#endif
         const int s1 = (int)rdlane((uint32_t)vsite, l4), a1 = (int)rdlane((uint32_t)vaddr, l4);
         const int sub1 = (int)rdlane((uint32_t)vsub, l4);
         const int cls1 = sel4(P.m_cls, sub1);
@@ -263,6 +266,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #undef SMOLMC_CAND_TAKE
             n1 = o2;
         }
+#ifndef SMOLMC_NO_SETPRIO
+        if (!ONE) __builtin_amdgcn_s_setprio(2);
+#endif
         RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
 
@@ -320,6 +326,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             dMu = s_mu[sub1 * 8 + n1] - s_mu[sub1 * 8 + o1];
             if (nfl == 2) dMu += s_mu[sub1 * 8 + n2] - s_mu[sub1 * 8 + o2];
         }
+#ifndef SMOLMC_NO_SETPRIO
+        if (!ONE) __builtin_amdgcn_s_setprio(3);
+#endif
         // compute_bias_change against the original occupancy (kernel/base.py:307-311; bias.py)
         double dB = 0.0, dQ = 0.0;
         if (BIAS && nfl >= 1) {
@@ -387,6 +396,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             occ[a1] = (uint8_t)o1;
         }
         if (!ONE) row1 = rown;
+#ifndef SMOLMC_NO_SETPRIO
+        if (!ONE) __builtin_amdgcn_s_setprio(0);
+#endif
 
         if (--smp_countdown == 0) {
             const LeanParamsKernarg Q = rare_params(); // (sampling parameters re-read from the kernel arguments)
