@@ -330,6 +330,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
     };
+#ifdef SMOLMC_EXP_CLOCK // experiment: shader clock during the launch (s_memtime vs the 100 MHz s_memrealtime)
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
     double H = P.enthalpy[r];
     const double nbeta = WL ? 0.0 : -P.beta[r];
     double wl_m = WL ? P.wl.m[r] : 0.0;
@@ -889,6 +892,13 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         }
     }
 
+#ifdef SMOLMC_EXP_CLOCK
+    if ((r == 0 || r == 2049) && lane == 0) {
+        const long long dc = clock64() - ck0, dw = wall_clock64() - wk0;
+        printf("walker %d: %lld shader cycles in %lld ticks of 10 ns -> %.1f MHz, %.1f cycles per step\n", r, dc, dw,
+               (double)dc / (double)dw * 100.0, (double)dc / (double)P.steps);
+    }
+#endif
     // ---- write back ---------------------------------------------------------------
     if (HAS_EW && ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
