@@ -938,7 +938,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         if (kp.wl_check <= 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
         if (h->F > 64) return bail(fail("Wang-Landau supports at most 64 features"));
         if (dev_alloc(h, R * h->L, &kp.wl_entropy) || dev_alloc(h, R * h->L, &kp.wl_hist) ||
-            dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F, &kp.wl_meanf) ||
+            dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F + 64, &kp.wl_meanf) || // (+64: the lean kernel's all-lane atomic, see mc_lean.h)
             dev_alloc(h, R, &kp.wl_m) || dev_alloc(h, R, &kp.wl_counter))
             return bail(1);
         std::vector<double> m0(R, cfg->wl_mod_factor);
@@ -1073,7 +1073,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.sum_mode = 1;
             }
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
-                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 16 : 0));
+                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 24 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
             // Ewald potential field in LDS when the changeable sites are the active
             // sublattice and it fits beside the occupancies

@@ -255,7 +255,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     const int wave = SOLO ? 0 : threadIdx.x >> 6;
     const int nwaves = SOLO ? 1 : blockDim.x >> 6;
     const int r = uni(blockIdx.x * nwaves + wave);
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 16 : 0) +
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + (WL ? (size_t)P.wl.L * 24 : 0) +
                             ((HAS_EW && ew_field) ? 64 + (size_t)P.ew_nact * 8 : 0);
     double *s_dt = SOLO ? (double *)(smem + ((per_wave + 15) & ~(size_t)15)) : (double *)smem;
     const uint32_t dt_off = SOLO ? (uint32_t)((per_wave + 15) & ~(size_t)15) : 0u; // table base, folded into the slot offsets
@@ -268,6 +268,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double *s_feat = (double *)(wbase + P.Nlds);
     double *wl_S = s_feat + 64;                   // WL: entropy [L]
     long long *wl_Hh = (long long *)(wl_S + (WL ? P.wl.L : 0)); // WL: histogram [L]
+    long long *wl_Oc = wl_Hh + (WL ? P.wl.L : 0);                // WL: occurrences [L]
     double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64);     // Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -289,6 +290,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             for (int i = lane; i < P.wl.L; i += 64) {
                 wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
                 wl_Hh[i] = P.wl.hist[(size_t)r * P.wl.L + i];
+                wl_Oc[i] = P.wl.occur[(size_t)r * P.wl.L + i];
             }
     }
     __syncthreads();
@@ -313,6 +315,25 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
         for (int k = 0; k < NACC; ++k) accK[it][k] = 0.0;
     }
+    // Wang-Landau keeps the CURRENT feature vector in s_feat and adds every accepted step's
+    // per-slot deltas to it with LDS atomics.  Lanes of one orbit hit the same cell (up to ~40
+    // lanes per address on the headline model) and the LDS serialises them -- ~430 cycles per
+    // ds_add_f64, a quarter of a step at one wave per SIMD, and every later LDS operation queues
+    // behind it.  The 64 doubles of s_feat therefore hold WLK shadow copies of the vector
+    // (WLK = min(8, 64 / F), packed back to back); lane l adds into copy l % WLK, which divides the
+    // multiplicity per address by WLK; a reader sums the copies (wl_cur_feat).
+    const int wl_stride = WL ? P.F : 64;                     // copies packed back to back
+    const int wl_k = WL ? min(8, 64 / max(wl_stride, 1)) : 1; // (F <= 64 for Wang-Landau)
+    uint32_t sfeat_wl[NSLOT];
+#pragma unroll
+    for (int it = 0; it < NSLOT; ++it) sfeat_wl[it] = sfeat[it] + (uint32_t)((lane % wl_k) * wl_stride);
+    auto wl_cur_feat = [&]() -> double { // lane f < F: current feature f (other lanes: unused)
+        const int f = lane < wl_stride ? lane : 0;
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = k < wl_k ? s_feat[f + (k < wl_k ? k : 0) * wl_stride] : 0.0;
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    };
     // feature read-out: sum over lanes and slots of fs * accumulator into s_feat[feature]
     auto reduce_features = [&](double *dst) {
 #pragma unroll
@@ -402,6 +423,19 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // next sample row or the end of the launch, whichever comes first, so that the step loop
     // itself carries one down-counter and the two lane indices (a per-step batch test, sample
     // countdown, 64-bit step increment and launch counter cost ~10 SALU instructions per step).
+    // Wang-Landau: the per-bin feature sums are the one global-memory update of a step.  Two things
+    // about it matter at one wave per SIMD (measured 5.5 -> 4.x ms per 5000 steps):
+    //  * vmcnt counts in order, so the atomic must be YOUNGER than the step's row fetches -- issued
+    //    in the post-step it sits ahead of the next step's fetch of the partner's row, whose wait
+    //    then covers the atomic's round trip to L2 as well.  A step therefore only notes its cell
+    //    and value (wl_pend, wl_pend_val); the next step issues the atomic right behind its row
+    //    fetch, the last one is flushed after the loop;
+    //  * it must be issued on EVERY path and from ALL lanes (lanes >= F add 0.0 to the cells
+    //    behind, the array is padded by 64): behind a branch or an exec mask the compiler's
+    //    s_waitcnt insertion can no longer count it and falls back to vmcnt(0) at the row waits.
+    //    The occurrence counts live in LDS beside the histogram for the same reason.
+    double *wl_pend = WL ? P.wl.meanf + (size_t)r * P.wl.L * P.F : nullptr;
+    double wl_pend_val = 0.0;
     uint32_t steps_left = (uint32_t)P.steps; // the host splits launches at 2^30 steps
     while (steps_left != 0u) {
         // -------- random words (generated 16 steps at a time) --------
@@ -562,6 +596,10 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #else
             row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
 #endif
+        }
+        if (WL) {
+            unsafeAtomicAdd(wl_pend + lane, wl_pend_val);
+            wl_pend_val = 0.0;
         }
 
         // -------- enthalpy delta ---------------------------------------------------
@@ -748,7 +786,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) {
                     const double dd = (STEP == SMOLMC_STEP_SWAP && !DIFF) ? d1[it] + d2[it] : d1[it];
-                    __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * dd, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(&s_feat[sfeat_wl[it]], sfs[it] * dd, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
@@ -834,14 +872,15 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 const int b = (int)bq;
                 wl_counter++;
                 if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
-                double *cellf = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
-                if (lane < P.F) unsafeAtomicAdd(cellf + lane, s_feat[lane]);
+                wl_pend = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
+                const double fcur = wl_cur_feat();
+                wl_pend_val = lane < P.F ? fcur : 0.0;
                 if (lane == 0) {
                     // LDS atomics without return value: a read-modify-write would put one more
                     // LDS round trip on the step's dependency chain (one wave per SIMD here)
                     __hip_atomic_fetch_add(&wl_S[b], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __hip_atomic_fetch_add(&wl_Hh[b], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    atomicAdd((unsigned long long *)(P.wl.occur + (size_t)r * P.wl.L + b), 1ull);
+                    __hip_atomic_fetch_add(&wl_Oc[b], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             if (wl_rem_check == 0) {
@@ -864,7 +903,8 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
             if (WL) {
-                if (lane < qF) q_feat[row * qF + lane] = s_feat[lane];
+                const double fcur = wl_cur_feat();
+                if (lane < qF) q_feat[row * qF + lane] = fcur;
             } else {
                 s_feat[lane] = 0.0;
                 reduce_features(s_feat);
@@ -908,10 +948,13 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
     if (WL) {
-        if (lane < P.F) featp[lane] = s_feat[lane];
+        const double fcur = wl_cur_feat();
+        unsafeAtomicAdd(wl_pend + lane, wl_pend_val); // the last step's per-bin sums
+        if (lane < P.F) featp[lane] = fcur;
         for (int i = lane; i < P.wl.L; i += 64) {
             P.wl.entropy[(size_t)r * P.wl.L + i] = wl_S[i];
             P.wl.hist[(size_t)r * P.wl.L + i] = wl_Hh[i];
+            P.wl.occur[(size_t)r * P.wl.L + i] = wl_Oc[i];
         }
         if (lane == 0) {
             P.wl.m[r] = wl_m;
