@@ -32,8 +32,13 @@ struct MultiRec { // slot record, 24 bytes
 // BIAS: FugacityBias / SquareChargeBias (bias.py:96-287) with one bias row per sublattice,
 // P.bias_pair[sub][old * 8 + new]; biased walkers always take the exact decision path (as in
 // mc_lean_kernel).  Separate instantiations (multi_bias_n*.hip).
-template <int NSLOT, int MM, int STEP, bool HAS_MU, bool HAS_EW, bool ONE = false, bool BIAS = false>
+// EWM: 0 = no Ewald term, 1 = potential field in LDS, 2 = potential field in HBM.  A template
+// parameter: with the placement as a runtime flag the field reads are memory instructions "on some
+// paths only", which the compiler's s_waitcnt insertion cannot count (conservative waits at the
+// index-row fetches, see mc_lean.h).
+template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
+    constexpr bool HAS_EW = EWM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -48,13 +53,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     const int nrec = NC * NSLOT * 64;
     // per wave: occupancy [Nlds] | zero pad 64 | feature scratch [64] | acc cells [NC][NSLOT][64] | phi
     const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 8 +
-                            ((HAS_EW && P.ew_field == 1) ? (size_t)P.ew_nact * 8 : 0);
+                            ((EWM == 1) ? (size_t)P.ew_nact * 8 : 0);
     unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     double *s_feat = (double *)(wbase + P.Nlds + 64);
     double *s_acc = s_feat + 64;
     // Ewald potential field: LDS copy (ew_field 1) or the walker's HBM array itself (ew_field 2)
-    const bool phi_lds = HAS_EW && P.ew_field == 1;
+    constexpr bool phi_lds = EWM == 1;
     double *phi = phi_lds ? s_acc + nrec : P.ew_phi + (size_t)r * P.ew_nact;
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -115,7 +120,6 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     double vGc = 0.0;
     unsigned long long batch_base = ~0ull;
     RowWords<NW> row1;
-    bool have_row1 = false;
 
     MultiRec rcs[ONE ? NSLOT : 1];
     if (ONE) {
@@ -172,9 +176,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 cand[3] = sb + (int)__umulhi(o.w[3], na);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
-                if (HAS_EW && P.ew_field) vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (vsite - abase)];
+                if (HAS_EW) vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (vsite - abase)];
             }
-            have_row1 = false;
+            // index row of the batch's first step (the other steps' rows are prefetched one step
+            // ahead, see below).  Every step issues the same loads in the same order whatever
+            // path it takes: a load that exists on some paths only makes the compiler's s_waitcnt
+            // insertion wait with vmcnt(0) -- for the prefetch and the partner's row -- before
+            // the first gathers (mc_lean.h, NOTES.md).
+            row1 = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, (int)(step & 15ull) * 4) * SITE_BYTES);
         }
         const int l4 = (int)(step & 15ull) * 4;
 #ifndef SMOLMC_NO_SETPRIO
@@ -183,15 +192,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         const int s1 = (int)rdlane((uint32_t)vsite, l4), a1 = (int)rdlane((uint32_t)vaddr, l4);
         const int sub1 = (int)rdlane((uint32_t)vsub, l4);
         const int cls1 = sel4(P.m_cls, sub1);
-        if (!have_row1) row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
         // prefetch the next step's row while this one runs (not across a batch boundary).  ONE:
         // issued after the gathers of flip 1, straight into row1 (no second register set, no
         // copy per step); with several classes the earlier issue is worth more than the copy.
+        // (last step of a batch: the next site is not known yet -- its sublattice comes from the
+        // next batch's words --, the own row is fetched once more instead and dropped)
+        const uint32_t nsite_pf = rdlane((uint32_t)vsite, l4 < 60 ? l4 + 4 : l4);
         RowWords<NW> rown = row1;
-        if (!ONE) {
-            have_row1 = l4 < 60;
-            if (have_row1) rown = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
-        }
+        if (!ONE) rown = load_row<NW>(idx_rs, lane_voff, nsite_pf * SITE_BYTES);
 
         const int o1 = uni((int)occ[a1]);
         int nfl, s2, a2, n1, n2 = 0, o2 = 0, fb = -1; // (swap: s2 / a2 / o2 are set by every proposal outcome)
@@ -269,6 +277,16 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(2);
 #endif
+        // potential at the two sites (HBM copy of the field: global loads, issued AHEAD of the
+        // partner's row so that the wait for that row does not cover them as well)
+        double p1 = 0.0, p2 = 0.0;
+        if (HAS_EW) {
+            p1 = phi_lds ? phi[s1 - abase]
+                         : __hip_atomic_load(&phi[s1 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STEP == SMOLMC_STEP_SWAP)
+                p2 = phi_lds ? phi[s2 - abase]
+                             : __hip_atomic_load(&phi[s2 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
 
@@ -287,15 +305,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 e = fma(rc.w, d1[it], e);
             }
         }
-        if (ONE) { // (see above: row1's last use, the gathers of flip 1, has been issued)
-            have_row1 = l4 < 60;
-            if (have_row1) row1 = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, l4 + 4) * SITE_BYTES);
-        }
+        if (ONE) // (see above: row1's last use, the gathers of flip 1, has been issued)
+            row1 = load_row<NW>(idx_rs, lane_voff, nsite_pf * SITE_BYTES);
         double ew_uni = 0.0, dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
             dq1 = s_q[sub1 * 8 + n1] - s_q[sub1 * 8 + o1];
-            const double p1 = phi_lds ? phi[s1 - abase]
-                                      : __hip_atomic_load(&phi[s1 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ew_uni = 2.0 * dq1 * p1 + (s_dg[sub1 * 8 + n1] - s_dg[sub1 * 8 + o1]);
         }
         if (STEP == SMOLMC_STEP_SWAP) {
@@ -316,8 +330,6 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                     fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
                                                (int)rdlane((uint32_t)__double2loint(vGc), fb))
                             : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - abase)];
-                const double p2 = phi_lds ? phi[s2 - abase]
-                                          : __hip_atomic_load(&phi[s2 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ew_uni += 2.0 * dq2 * (p2 + dq1 * cross) + (s_dg[sub1 * 8 + n2] - s_dg[sub1 * 8 + o2]);
             }
         }
@@ -467,7 +479,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, bool EW, bool BIAS = false>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
@@ -484,18 +496,17 @@ static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     h->timed = true;
     return 0;
 }
+template <int NSLOT, int MM, int STEP, bool BIAS> static int launch_multi_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.m_mu != nullptr;
+    if (lp.ew_field == 1)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, BIAS>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, BIAS>(h, lp);
+    if (lp.ew_field == 2)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, BIAS>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, BIAS>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, BIAS>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, BIAS>(h, lp);
+}
 template <int NSLOT, int MM, bool BIAS = false> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
-    const bool mu = lp.m_mu != nullptr, ew = lp.ew_field != 0;
-    if (h->cfg.step_type == SMOLMC_STEP_SWAP) {
-        if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, true, BIAS>(h, lp)
-                          : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, true, BIAS>(h, lp);
-        return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, true, false, BIAS>(h, lp)
-                  : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_SWAP, false, false, BIAS>(h, lp);
-    }
-    if (ew) return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, true, BIAS>(h, lp)
-                      : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, true, BIAS>(h, lp);
-    return mu ? launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, true, false, BIAS>(h, lp)
-              : launch_multi_inst<NSLOT, MM, SMOLMC_STEP_FLIP, false, false, BIAS>(h, lp);
+    if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_multi_me<NSLOT, MM, SMOLMC_STEP_SWAP, BIAS>(h, lp);
+    return launch_multi_me<NSLOT, MM, SMOLMC_STEP_FLIP, BIAS>(h, lp);
 }
 template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
     return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2, true>(h, lp) : launch_multi_nm<NSLOT, 3, true>(h, lp);
