@@ -523,7 +523,8 @@ template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const 
 // mc_lean_multi_kernel; sites of the depleted species are drawn sublattice by sublattice from
 // ONE candidate stream, exactly as the oracle does.
 // ----------------------------------------------------------------------------
-template <int NSLOT, int MM>
+// EWM: 0 = no Ewald term, 1 = potential field in LDS, 2 = in HBM (compile time, see mc_lean_multi_kernel)
+template <int NSLOT, int MM, int EWM>
 __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -531,7 +532,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     const int nwaves = blockDim.x >> 6;
     const int r = uni(blockIdx.x * nwaves + wave);
     const int NC = P.m_ncls, NS = P.m_nsub;
-    const bool has_mu = P.m_mu != nullptr, has_ew = P.ew_field != 0;
+    const bool has_mu = P.m_mu != nullptr;
+    constexpr bool has_ew = EWM != 0;
     // block-shared: dt | mu [4][8] | q [4][8] | dg [4][8] | weights [16] | flip table [8][16] ints | records
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len;
@@ -541,7 +543,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     MultiRec *s_rec = (MultiRec *)(s_tfw + 16 + 64);
     const int nrec = NC * NSLOT * 64;
     // per wave: occupancy | 64 B (species counts) | feature scratch [64] | acc cells | pending cells | phi
-    const bool phi_lds = has_ew && P.ew_field == 1;
+    constexpr bool phi_lds = EWM == 1;
     const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 16 + (phi_lds ? (size_t)P.ew_nact * 8 : 0);
     unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
@@ -1016,7 +1018,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 template <int NSLOT, int MM> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = mc_table_multi_kernel<NSLOT, MM>;
+    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1>
+                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2> : mc_table_multi_kernel<NSLOT, MM, 0>);
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
