@@ -1227,17 +1227,23 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 return best_waves;
             };
             // The potential field goes to LDS while it stays small beside the rest of the wave's
-            // state, or when all walkers still fit the chip in one round with it there (an
-            // accepted flip then reads its G row only, no read-modify-write of phi through L2:
-            // LiNiO2 8^3, 2048 walkers: swap 9.6e8 -> 1.16e9 steps/s); else the HBM copy is used
-            // in place (ew_field 2).  SMOLMC_MULTI_PHI_HBM / _LDS force either (test hooks).
+            // state, when all walkers still fit the chip in one round with it there (an accepted
+            // flip then reads its G row only, no read-modify-write of phi through L2), or for
+            // canonical swaps whenever it fits; else the HBM copy is used in place (ew_field 2).  SMOLMC_MULTI_PHI_HBM / _LDS force either (test hooks).
             const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * (table ? 16 : 8);
             bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
             if (t->has_ewald && !phi_lds) {
                 int cus = 0, w = 0;
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
                 const int waves = layout(base_wave + (size_t)kp.ew_nact * 8, w);
-                if ((long)waves * cus >= (long)cfg->n_replicas || getenv("SMOLMC_MULTI_PHI_LDS") != nullptr)
+                // canonical swaps update the field at two sites per accepted step and gain from
+                // the LDS copy even when the walkers then need several rounds (LiNiO2 8^3, 4096
+                // walkers: 1.13e9 -> 1.58e9 steps/s); flips only while one round holds them all
+                // (beyond: 4.1e9 with the HBM field against 3.0e9)
+                // -- provided at least 8 waves per CU stay resident: at 3 (config 7, 27 KiB of field
+                // per walker) the LDS copy measured 9.6 against 7.4 us per step
+                if ((long)waves * cus >= (long)cfg->n_replicas || (cfg->step_type == SMOLMC_STEP_SWAP && waves >= 8) ||
+                    getenv("SMOLMC_MULTI_PHI_LDS") != nullptr)
                     phi_lds = waves > 0;
             }
             if (getenv("SMOLMC_MULTI_PHI_HBM") != nullptr) phi_lds = false;

@@ -152,9 +152,10 @@ def test_smol_shaped_api_on_the_imported_model(lno):
 
 
 def test_ewald_field_placement_follows_residency(lno, monkeypatch):
-    """Multi-sublattice kernel: the potential field of the 8^3 LiNiO2 cell (8 KiB per walker) lives
-    in LDS while all walkers stay resident in one round with it there (16 x CU-count / 2 here), in
-    HBM beyond; both placements run the same chain."""
+    """Multi-sublattice kernel: for flips the potential field of the 8^3 LiNiO2 cell (8 KiB per
+    walker) lives in LDS while all walkers stay resident in one round with it there (16 x CU-count
+    / 2 here), in HBM beyond; canonical swaps keep it in LDS whenever it fits.  Both placements run
+    the same chain."""
     import torch
 
     monkeypatch.delenv("SMOLMC_MULTI_PHI_HBM", raising=False)
@@ -169,7 +170,11 @@ def test_ewald_field_placement_follows_residency(lno, monkeypatch):
         rng = np.random.default_rng(5)
         occ = _neutral_occupancies(cell, small, rng, n_li=cell.size // 2)
         occ = np.tile(occ, (R // small, 1))
-        eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+        if R == big:
+            swp = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+            assert "field=1" in swp.kernel_info(), swp.kernel_info()
+            swp.close()
+        eng = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
         info = eng.kernel_info()
         assert info.startswith("lean-multi") and ("field=1" if R == small else "field=2") in info, info
         seeds = np.tile(np.arange(small, dtype=np.uint64) + np.uint64(9), R // small)
