@@ -1165,6 +1165,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     uint32_t cblk_base = ~0u;
     int cb_site = 0, cb_addr = 0;
 
+#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
+    long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph2[2] = {0, 0};
+    long long ph_t = clock64();
+#endif
     for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
         const unsigned long long base = step & ~15ull;
         if ((uint32_t)base != batch_base) {
@@ -1183,6 +1187,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             logu = log(philox_u53(o.w[2], o.w[3]));
         }
         const int l4 = (int)(step & 15ull) * 4;
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; }
+#endif
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1); // wave priority rises through the step (see mc_lean_kernel)
@@ -1191,6 +1198,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // flips of this step live lane-indexed: lane f holds flip f
         int vsite = 0, vnew = 0, vold = 0;
         int nfl = 0, dir = -1;
+
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
@@ -1294,6 +1302,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
             log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
                                           (int)rdlane((uint32_t)__double2loint(vlp), dir));
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[1] += tn - ph_t; ph_t = tn; }
+#endif
             // pick the sites of the depleted species from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4): 256 candidates per wave round, lane l holds
             // t = 256 round + 4 l + j.  The scan is scalar: per species four ballots (one per j),
@@ -1318,6 +1329,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     cb_site = sbase + (int)__umulhi(wsel, nact);
                     cb_addr = lean_swz(cb_site, swa, swm, swb);
                 }
+#ifdef SMOLMC_EXP_PHASES
+                { const long long tn = clock64(); ph2[0] += tn - ph_t; ph_t = tn; }
+#endif
                 const int g32 = (int)(step & 1ull) * 32;      // first lane of this step's candidates
                 const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
                 uint32_t fpos = 0;                            // next stream position (kept across species)
@@ -1335,19 +1349,19 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                         m &= m - 1u;
                         fpos = (uint32_t)b + 1u;
                         const int picked = (int)rdlane((uint32_t)cb_site, g32 + b);
+                        // choice without replacement: the stream may name a site twice (then the
+                        // second occurrence must be skipped and one more candidate taken); rare --
+                        // p ~ ncol^2 / (2 n) -- so a repeated site among the picks sends the step to
+                        // the sequential scan (one compare per pick against the sites held in the
+                        // lanes below ncol; a cross-lane permute per pair cost two LDS round trips)
+                        if ((__ballot(vcol == picked) & ((1ull << ncol) - 1ull)) != 0ull) ok = false;
                         if (lane == ncol) vcol = picked;
                         ncol++;
                     } while (--need > 0);
                 }
-                // choice without replacement: the stream may name a site twice (then the second
-                // occurrence must be skipped and one more candidate taken); rare -- p ~ ncol^2 / (2 n)
-                // -- so a repeated site among the picks sends the step to the sequential scan
-                if (ok) {
-                    for (int d = 1; d < ncol; ++d) {
-                        const int other = __shfl(vcol, lane + d); // (lanes >= ncol hold stale values: masked)
-                        if (__ballot(lane + d < ncol && vcol == other) != 0ull) { ok = false; break; }
-                    }
-                }
+#ifdef SMOLMC_EXP_PHASES
+                { const long long tn = clock64(); ph2[1] += tn - ph_t; ph_t = tn; }
+#endif
                 if (ok) fast_done = true;
                 else { vcol = 0; vcsp = 0; ncol = 0; } // block exhausted or repeated site: full scan
             }
@@ -1400,6 +1414,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                     need--;
                 }
             }
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[2] += tn - ph_t; ph_t = tn; }
+#endif
             // random assignment of the collected sites to the enriched species (:627-631)
             int qdraw = 0;
             for (int c = 0; c < nc; ++c) {
@@ -1426,6 +1443,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(2);
+#endif
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[3] += tn - ph_t; ph_t = tn; }
 #endif
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
@@ -1485,13 +1505,78 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             if (has_mu) dMu += s_mu[nw] - s_mu[od];
             occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative (every lane, same byte)
         };
+        // The first four flips in two phases: (A) every flip's occupancy gathers, its potential read
+        // and its tentative write are ISSUED back to back -- the LDS executes in order, so flip
+        // f + 1 sees flip f without anybody waiting --, (B) table reads and arithmetic.  One
+        // gather round trip and one table round trip per step instead of one of each per flip
+        // (the step is latency-bound: at most two waves share a SIMD here).  The compact Ewald
+        // form without field (EWM 1) sums over the tentative occupancy per flip and keeps the
+        // flip-by-flip order.
+        constexpr bool TWO_PHASE = !has_ew || ew_field;
+        // (straight-line code per flip count: with a branch per flip inside, the compiler's wait
+        // insertion drains the LDS counter at every flip and nothing overlaps)
+        auto two_phase = [&](auto nflips) {
+            constexpr int NF = decltype(nflips)::value;
+            int fsite[NF], fnw[NF], fod[NF];
+            uint32_t g[NF][NSLOT * MM];
+            double fpot[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-            if (f < nfl) eval_flip(f, rows[f]);
+            for (int f = 0; f < NF; ++f) {
+                fsite[f] = (int)rdlane((uint32_t)vsite, f);
+                fnw[f] = (int)rdlane((uint32_t)vnew, f);
+                fod[f] = (int)rdlane((uint32_t)vold, f);
+#pragma unroll
+                for (int q = 0; q < NSLOT * MM; ++q) g[f][q] = (uint32_t)occ[row_entry<NW>(rows[f], q)];
+                fpot[f] = ew_field ? phi[fsite[f] - sbase] : 0.0;
+                occ[lean_swz(fsite[f], swa, swm, swb)] = (uint8_t)fnw[f]; // tentative (every lane, same byte)
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int nw = fnw[f], od = fod[f];
+                const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    uint32_t a = doff8[it];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], g[f][it * MM + m]);
+                    const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
+                    e = fma(wgt[it], d, e);
+                    pend[it] += d;
+                }
+                if (ew_field) { // flip f sees the earlier flips of the step through the cross terms
+                    const double dq = s_q[nw] - s_q[od];
+                    double pot = fpot[f];
+#pragma unroll
+                    for (int m = 0; m < f; ++m) {
+                        const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
+                                                            (int)rdlane((uint32_t)__double2loint(vdq), m));
+                        const double gfm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vG), 8 * f + m),
+                                                            (int)rdlane((uint32_t)__double2loint(vG), 8 * f + m));
+                        pot = fma(dqm, gfm, pot);
+                    }
+                    ew_uni += 2.0 * dq * pot + (s_dg[nw] - s_dg[od]);
+                    if (lane == f) vdq = dq;
+                }
+                if (has_mu) dMu += s_mu[nw] - s_mu[od];
+            }
+        };
+        if (TWO_PHASE) {
+            if (nfl == 3) two_phase(std::integral_constant<int, 3>{});
+            else if (nfl == 2) two_phase(std::integral_constant<int, 2>{});
+            else if (nfl >= 4) two_phase(std::integral_constant<int, 4>{});
+            else if (nfl == 1) two_phase(std::integral_constant<int, 1>{});
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (f < nfl) eval_flip(f, rows[f]);
+        }
         for (int f = 4; f < nfl; ++f)
             eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[4] += tn - ph_t; ph_t = tn; }
 #endif
         double dH = wave_sum_all(e);
         double dEw = 0.0;
@@ -1524,6 +1609,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             // are distinct, so the order of the stores does not matter)
             if (lane < nfl) occ[lean_swz(vsite, swa, swm, swb)] = (uint8_t)vold;
         }
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[5] += tn - ph_t; ph_t = tn; }
+#endif
         last_acc = accepted ? 1 : 0;
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
@@ -1557,6 +1645,13 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
     }
 
+#ifdef SMOLMC_EXP_PHASES
+    if (r == 0 && lane == 0)
+        printf("phases (cycles per step): skeleton %.0f | head %.0f | picks %.0f | assign/swap %.0f | eval %.0f | decide %.0f | picks: block %.0f, species loop %.0f\n",
+               (double)ph_acc[0] / (double)P.steps, (double)ph_acc[1] / (double)P.steps, (double)ph_acc[2] / (double)P.steps,
+               (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps, (double)ph_acc[5] / (double)P.steps,
+               (double)ph2[0] / (double)P.steps, (double)ph2[1] / (double)P.steps);
+#endif
     if (ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
