@@ -520,6 +520,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         size_t tlen = (size_t)SMAX * SMAX * NTP;
         if ((tlen & 1) == 0) tlen += 1;
         std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
+        std::vector<double> dtk; // KF: correlation-function tables (global memory), see LeanParams::dtk
         std::vector<LeanSlot> ls((size_t)NCLS * NSL * 64);
         memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
         std::map<std::pair<int, int>, uint32_t> doff_of;
@@ -546,7 +547,8 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
             const auto key = std::make_pair(o, k.p);
             if (!doff_of.count(key)) {
-                // table group of the slot: [decision table] (+ K correlation-function tables in KF mode)
+                // tables of the slot: the decision table (LDS) and, in KF mode, K correlation-function
+                // tables (global memory, read on accepted steps only)
                 const int ntab = corr_kf ? 1 + K : 1;
                 std::vector<double> D((size_t)ntab * tlen, 0.0);
                 int nb = 1;
@@ -574,12 +576,24 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                                 Tsrc[base + (long)ss * newc] - Tsrc[base + (long)ss * oldc];
                 }
                 }
-                uint32_t at = 0;
-                for (size_t off = tlen; off + D.size() <= dt.size() && !at; off += tlen)
-                    if (memcmp(dt.data() + off, D.data(), D.size() * sizeof(double)) == 0) at = (uint32_t)off;
+                uint32_t at = 0; // (identical tables are shared; KF: decision AND function tables identical)
+                for (size_t off = tlen; off + tlen <= dt.size() && !at; off += tlen) {
+                    if (memcmp(dt.data() + off, D.data(), (size_t)tlen * sizeof(double)) != 0) continue;
+                    if (corr_kf) {
+                        std::vector<double> want((size_t)SMOLMC_LEAN_MAX_KF * tlen, 0.0);
+                        std::copy(D.begin() + tlen, D.end(), want.begin());
+                        if (memcmp(dtk.data() + off * SMOLMC_LEAN_MAX_KF, want.data(), want.size() * sizeof(double)) != 0)
+                            continue;
+                    }
+                    at = (uint32_t)off;
+                }
                 if (!at) {
                     at = (uint32_t)dt.size();
-                    dt.insert(dt.end(), D.begin(), D.end());
+                    dt.insert(dt.end(), D.begin(), D.begin() + tlen);
+                    if (corr_kf) {
+                        dtk.resize(dt.size() * SMOLMC_LEAN_MAX_KF, 0.0);
+                        std::copy(D.begin() + tlen, D.end(), dtk.begin() + (size_t)at * SMOLMC_LEAN_MAX_KF);
+                    }
                 }
                 doff_of[key] = at;
             }
@@ -594,7 +608,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.live = (uint32_t)K;
             L.w = corr_kf ? scale : t->ce_coefs[feat] * scale; // (KF: the coefficients are folded into the table)
             L.fs = scale;
-            if (dt.size() > (corr_kf ? 12000u : 8000u)) ok = false; // keep the LDS tables within budget
+            if (dt.size() > 8000u) ok = false; // keep the LDS tables within budget
             double dmax = 0.0;
             {
                 const double *D = dt.data() + doff_of[key];
@@ -616,6 +630,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             TRY(dev_upload(h, lidx.data(), lidx.size(), &h->lp.idx));
             h->lean_idx_host = std::move(lidx);
             TRY(dev_upload(h, dt.data(), dt.size(), &h->lp.dt));
+            if (corr_kf) TRY(dev_upload(h, dtk.data(), dtk.size(), &h->lp.dtk));
             TRY(dev_upload(h, ls.data(), ls.size(), &h->lp.slots));
             h->lp.dt_len = (int)dt.size();
             h->lean_tables = true;

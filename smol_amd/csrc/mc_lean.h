@@ -754,18 +754,22 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         uint32_t sel_hi = 0u; // high word of sel
         auto on_accept = [&]() {
             if (KF) {
-                // the K correlation-function tables of each slot, read at the index of the
-                // decision table (table k + 1 of the slot's group, ktab8 bytes apart; slots with
-                // fewer functions read a zero)
+                // the K correlation-function tables of each slot (global memory, L2-resident),
+                // read at the index the decision already computed: byte ad - doff8 inside table k
+                // of the slot's group, which starts at doff8 * MAX_KF (LeanParams::dtk); slots
+                // with fewer functions add a zero
+                const unsigned char *kb = (const unsigned char *)P.dtk;
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) {
+                    const uint32_t g1 = doff8[it] * (uint32_t)(SMOLMC_LEAN_MAX_KF - 1) + ad1[it];
+                    const uint32_t g2 = doff8[it] * (uint32_t)(SMOLMC_LEAN_MAX_KF - 1) + ad2[it];
 #pragma unroll
                     for (int k = 0; k < NACC; ++k) {
                         const bool on = (uint32_t)k < kslot[it];
-                        const uint32_t off = (uint32_t)(k + 1) * P.ktab8;
-                        double v = SMOLMC_LDS_F64(on ? ad1[it] + off : dt_off);
+                        const uint32_t off = (uint32_t)k * P.ktab8;
+                        double v = on ? *(const double *)(kb + (g1 + off)) : 0.0;
                         if (STEP == SMOLMC_STEP_SWAP) {
-                            const double v2 = SMOLMC_LDS_F64(on ? ad2[it] + off : dt_off);
+                            const double v2 = on ? *(const double *)(kb + (g2 + off)) : 0.0;
                             v = DIFF ? v - v2 : v + v2;
                         }
                         accK[it][k] += v;

@@ -319,7 +319,11 @@ struct LeanParams {
     uint8_t *last_acc;
     int dt_len, R, N, Npad, F, Fce, sbase, nact, ncodes;
     uint32_t nt8, snt8;    // 8*NTP and 8*NTP*S: (old, new) -> byte offset old*snt8 + new*nt8
-    uint32_t ktab8;        // KF mode: byte distance between the tables of one slot's group
+    uint32_t ktab8;        // KF mode: byte size of one table
+    // KF mode: the correlation-function tables, in HBM / L2 (they are read on accepted steps only;
+    // in LDS they cost config 3 its second workgroup per CU).  The group of the slot whose decision
+    // table starts at byte D of dt holds SMOLMC_LEAN_MAX_KF tables from byte D * SMOLMC_LEAN_MAX_KF.
+    const double *dtk;
     // LDS address of site s = s ^ (((s >> swz_a) & swz_m) << swz_b): a bank swizzle chosen on
     // the host (bank-conflict model over the cluster tables); idx rows hold swizzled addresses
     int swz_a, swz_m, swz_b, Nlds;
