@@ -1155,12 +1155,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const __amdgpu_buffer_rsrc_t idx_rs =
         __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
     const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
-    const int nf2 = 2 * P.tf_n;
     // cached between accepted table steps: feasible directions at the current counts, their weight
     // sum, and (lane dir of vlp, bit dir of lp_valid) the log a-priori factor of direction dir
     bool head_valid = false;
     unsigned feas_now = 0, lp_valid = 0;
-    double sumw = 0.0, vlp = 0.0;
+    double sumw = 0.0, vlp = 0.0, vcum = 0.0;
+    int last_feas = -1;
     // Candidate block: the first 32 positions of the site-candidate stream c_t = W(step, 4 + t/4,
     // t%4) of TWO steps, one candidate per lane (lane L: step (step & ~1) + (L >> 5), t = L & 31),
     // from one Philox call per two steps.  A table step needs |u| <= 8 sites and nearly always
@@ -1214,6 +1214,18 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 sumw = masked_sum(feas_now);
                 head_valid = true;
                 lp_valid = 0u;
+                // running sums of the feasible weights, lane idx <-> direction idx, added in the
+                // order choose_section_from_partition adds them: the per-step choice below is then
+                // one compare + ballot instead of a loop of readlanes and float64 adds
+                double c = 0.0;
+                last_feas = -1;
+                const int n2 = 2 * rare_params()->tf_n;
+                for (int idx = 0; idx < n2; ++idx)
+                    if ((feas_now >> idx) & 1u) {
+                        c += weight_of(idx);
+                        if (lane == idx) vcum = c;
+                        last_feas = idx;
+                    }
             }
             if (!(sumw > 0.0)) do_swap = true;
         }
@@ -1271,15 +1283,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         } else {
             // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
             const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
-            double cum = 0.0;
-            int last = -1;
-            for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
-                if (!((feas_now >> idx) & 1u)) continue;
-                last = idx;
-                cum += weight_of(idx);
-                if (target < cum) dir = idx;
+            {
+                const uint32_t hit = (uint32_t)__ballot(target < vcum) & feas_now; // first feasible idx with target < running sum
+                dir = hit ? __ffs((int)hit) - 1 : last_feas;
             }
-            if (dir < 0) dir = last;
             const int usg = (dir & 1) ? -1 : 1;
             // column values of the chosen vector, lane-indexed (register array -> select chain)
 #pragma unroll

@@ -661,7 +661,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     const int nf2 = 2 * P.tf_n;
     bool head_valid = false; // feasibility mask / weight sum / a-priori factors cached between count changes
     unsigned feas_now = 0, lp_valid = 0;
-    double sumw = 0.0, vlp = 0.0;
+    double sumw = 0.0, vlp = 0.0, vcum = 0.0;
+    int last_feas = -1;
 
     const uint32_t nsteps32 = (uint32_t)P.steps;
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
@@ -696,6 +697,15 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 sumw = masked_sum(feas_now);
                 head_valid = true;
                 lp_valid = 0u;
+                // running sums of the feasible weights, lane idx <-> direction idx (mc_table_kernel)
+                double c = 0.0;
+                last_feas = -1;
+                for (int idx = 0; idx < nf2; ++idx)
+                    if ((feas_now >> idx) & 1u) {
+                        c += weight_of(idx);
+                        if (lane == idx) vcum = c;
+                        last_feas = idx;
+                    }
             }
             if (!(sumw > 0.0)) do_swap = true;
         }
@@ -757,15 +767,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         } else {
             // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
             const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
-            double cum = 0.0;
-            int last = -1;
-            for (int idx = 0; idx < nf2 && dir < 0; ++idx) {
-                if (!((feas_now >> idx) & 1u)) continue;
-                last = idx;
-                cum += weight_of(idx);
-                if (target < cum) dir = idx;
+            {
+                const uint32_t hit = (uint32_t)__ballot(target < vcum) & feas_now; // first feasible idx with target < running sum
+                dir = hit ? __ffs((int)hit) - 1 : last_feas;
             }
-            if (dir < 0) dir = last;
 #pragma unroll
             for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
             vu *= (dir & 1) ? -1 : 1;
