@@ -1202,6 +1202,23 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // flips of this step live lane-indexed: lane f holds flip f
         int vsite = 0, vnew = 0, vold = 0;
         int nfl = 0, dir = -1;
+        // Index rows of the first four flips and the Ewald cross terms G[s_i][s_j] of all flip
+        // pairs (lane 8 i + j holds pair j < i): fetched by the proposal as soon as the SITES
+        // are known -- for a table step right after the picks, so that the random assignment
+        // hides the fetch -- on both proposal paths alike (see mc_lean_kernel on loads that exist
+        // on some paths only).
+        RowWords<NW> rows[4];
+        double vG = 0.0;
+        auto fetch_rows = [&]() {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                rows[f] = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f < nfl ? f : 0) * SITE_BYTES);
+            if (has_ew && ew_field) {
+                const int pi = lane >> 3, pj = lane & 7;
+                const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
+                if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - sbase)];
+            }
+        };
 
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
@@ -1280,6 +1297,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 vnew = lane == 0 ? fo : o1;
                 vold = lane == 0 ? o1 : fo;
             }
+            fetch_rows();
         } else {
             // choose_section_from_partition (math.py:870-893) with W(step, 1, 0)
             const double target = (double)rdlane(W0, l4 + 1) * (1.0 / 4294967296.0) * sumw;
@@ -1428,26 +1446,40 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[2] += tn - ph_t; ph_t = tn; }
 #endif
-            // random assignment of the collected sites to the enriched species (:627-631)
-            int qdraw = 0;
-            for (int c = 0; c < nc; ++c) {
-                const int u = (int)rdlane((uint32_t)vu, c);
-                for (int k = 0; k < u; ++k) {
-                    const int wl = l4 + 2 + (qdraw >> 2);
-                    const int wj = qdraw & 3;
-                    const uint32_t word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
-                    qdraw++;
-                    const int rr = (int)__umulhi(word, (uint32_t)ncol);
-                    const int site = (int)rdlane((uint32_t)vcol, rr);
-                    const int od = (int)rdlane((uint32_t)vcsp, rr); // (known from the scan: no LDS read)
-                    if (lane == nfl) { vsite = site; vnew = c; vold = od; }
-                    nfl++;
-                    // list.remove keeps the order of the rest: lanes >= rr take their right neighbour
-                    // (DPP wave shift, not a cross-lane LDS permute)
-                    const int nxt = __builtin_amdgcn_update_dpp(0, vcol, 0x130, 0xf, 0xf, false);
-                    const int nxs = __builtin_amdgcn_update_dpp(0, vcsp, 0x130, 0xf, 0xf, false);
-                    if (lane >= rr) { vcol = nxt; vcsp = nxs; }
-                    ncol--;
+            // The flips of the step are the picks in PICK order (site and old species are known from
+            // the scan); their rows are fetched now.  The random assignment to the enriched species
+            // (:627-631) then only has to say which pick gets which species: the oracle removes the
+            // rr-th entry of the remaining list, i.e. the rr-th pick still available -- a scalar
+            // bit mask -- and evaluates the flips in the order it draws them; any order of the same
+            // flips gives the same step (the deltas telescope), up to the rounding of the sums.
+            vsite = vcol;
+            vold = vcsp;
+            nfl = ncol;
+            fetch_rows();
+            {
+                const uint32_t w4[4] = {rdlane(W0, l4 + 2), rdlane(W1, l4 + 2), rdlane(W2, l4 + 2), rdlane(W3, l4 + 2)};
+                uint32_t avail = ncol >= 32 ? 0xffffffffu : (1u << ncol) - 1u;
+                int qdraw = 0, left = ncol;
+                for (int c = 0; c < nc; ++c) {
+                    const int u = (int)rdlane((uint32_t)vu, c);
+                    for (int k = 0; k < u; ++k) {
+                        uint32_t word;
+                        if (qdraw < 4) {
+                            word = qdraw == 0 ? w4[0] : qdraw == 1 ? w4[1] : qdraw == 2 ? w4[2] : w4[3];
+                        } else {
+                            const int wl = l4 + 2 + (qdraw >> 2);
+                            const int wj = qdraw & 3;
+                            word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
+                        }
+                        qdraw++;
+                        const int rr = (int)__umulhi(word, (uint32_t)left);
+                        uint32_t m = avail;
+                        for (int z = 0; z < rr; ++z) m &= m - 1u; // drop the rr lowest available picks
+                        const int pj = __ffs((int)m) - 1;
+                        avail &= ~(1u << pj);
+                        left--;
+                        if (lane == pj) vnew = c;
+                    }
                 }
             }
         }
@@ -1461,23 +1493,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, pend[NSLOT], ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
         double vdq = 0.0; // lane f holds the charge change of flip f (potential-field mode)
-        // cross terms G[s_i][s_j] of all flip pairs of the step in ONE gather (lane 8 i + j holds
-        // pair j < i), issued before the flips are evaluated so that its latency (the site
-        // kernel lives in L2 / Infinity Cache) overlaps with the cluster-expansion part
-        double vG = 0.0;
-        if (has_ew && ew_field && nfl > 1) {
-            const int pi = lane >> 3, pj = lane & 7;
-            const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
-            if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - sbase)];
-        }
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) pend[it] = 0.0;
-        // the index rows of the first four flips are fetched together (their sites are known),
-        // so that only one memory latency is exposed per step
-        RowWords<NW> rows[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-            if (f < nfl) rows[f] = load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES);
         auto eval_flip = [&](const int f, const RowWords<NW> &row) {
             const int s = (int)rdlane((uint32_t)vsite, f), nw = (int)rdlane((uint32_t)vnew, f);
             const int od = (int)rdlane((uint32_t)vold, f);
