@@ -1363,30 +1363,57 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #endif
                 const int g32 = (int)(step & 1ull) * 32;      // first lane of this step's candidates
                 const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
-                uint32_t fpos = 0;                            // next stream position (kept across species)
+                // Lane-parallel picks: per depleted species one ballot gives the candidates of that
+                // species at or after the running stream position, v_mbcnt their rank in stream
+                // order; the first `need` of them are the picks, and the position behind the last
+                // one (one more ballot) is where the next species starts.  The picked candidates
+                // are then compacted into lanes 0 .. ncol-1 (species-major, stream order) through
+                // the feature scratch in LDS.  (The scalar form -- ffs, readlane, compare and
+                // select per pick -- spent most of its time waiting between the scalar and the
+                // vector unit: ~1250 of a step's ~7000 cycles.)
+                uint32_t fpos = 0; // next stream position (kept across species)
                 bool ok = true;
-                for (int c = 0; c < nc && ok; ++c) {
-                    int need = -(int)rdlane((uint32_t)vu, c);
-                    if (need <= 0) continue;
+                int vdst = -1;      // lane t: destination lane of candidate t if it is picked
+                uint32_t dep = (uint32_t)__ballot(vu < 0) & ((1u << nc) - 1u); // depleted species
+                while (dep != 0u && ok) {
+                    const int c = __ffs((int)dep) - 1;
+                    dep &= dep - 1u;
+                    const int need = -(int)rdlane((uint32_t)vu, c);
                     uint32_t m = (uint32_t)(__ballot(cvl == c) >> g32); // bit t: candidate t has species c
                     m = fpos < 32u ? (m >> fpos) << fpos : 0u;
                     if (__popc(m) < need) { ok = false; break; }
-                    // the first `need` set bits, in stream order (duplicates are dealt with below)
+                    const unsigned long long m64 = (unsigned long long)m << g32;
+                    const int rnk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
+                    const bool mine = ((m64 >> lane) & 1ull) != 0ull && rnk < need;
+                    if (mine) vdst = ncol + rnk;
                     if (lane >= ncol && lane < ncol + need) vcsp = c;
-                    do {
-                        const int b = __ffs((int)m) - 1;
-                        m &= m - 1u;
-                        fpos = (uint32_t)b + 1u;
-                        const int picked = (int)rdlane((uint32_t)cb_site, g32 + b);
-                        // choice without replacement: the stream may name a site twice (then the
-                        // second occurrence must be skipped and one more candidate taken); rare --
-                        // p ~ ncol^2 / (2 n) -- so a repeated site among the picks sends the step to
-                        // the sequential scan (one compare per pick against the sites held in the
-                        // lanes below ncol; a cross-lane permute per pair cost two LDS round trips)
-                        if ((__ballot(vcol == picked) & ((1ull << ncol) - 1ull)) != 0ull) ok = false;
-                        if (lane == ncol) vcol = picked;
-                        ncol++;
-                    } while (--need > 0);
+                    const unsigned long long lastm = __ballot(mine && rnk == need - 1);
+                    fpos = (uint32_t)(__ffsll((long long)lastm) - 1 - g32) + 1u;
+                    ncol += need;
+                }
+                if (ok) {
+                    int *scr = (int *)s_feat; // (64 doubles of per-wave scratch, free between sample rows)
+                    if (vdst >= 0) scr[vdst] = cb_site;
+                    vcol = scr[lane];
+                    // choice without replacement: the stream may name a site twice (then the second
+                    // occurrence must be skipped and one more candidate taken); rare -- p ~ ncol^2 /
+                    // (2 n) -- so a repeated site among the picks sends the step to the sequential scan
+                    bool dup = false;
+#define SMOLMC_DUP_SHIFT(D, CTRL)                                                                  \
+    if (ncol > D) {                                                                                \
+        const int other = __builtin_amdgcn_update_dpp(0, vcol, CTRL, 0xf, 0xf, false);             \
+        dup |= lane >= D && lane < ncol && vcol == other;                                          \
+    }
+                    SMOLMC_DUP_SHIFT(1, 0x111) // row_shr:1 .. 7 (ncol <= 8 picks sit in one row of 16 lanes)
+                    SMOLMC_DUP_SHIFT(2, 0x112)
+                    SMOLMC_DUP_SHIFT(3, 0x113)
+                    SMOLMC_DUP_SHIFT(4, 0x114)
+                    SMOLMC_DUP_SHIFT(5, 0x115)
+                    SMOLMC_DUP_SHIFT(6, 0x116)
+                    SMOLMC_DUP_SHIFT(7, 0x117)
+#undef SMOLMC_DUP_SHIFT
+                    if (ncol > 8 || __ballot(dup) != 0ull) ok = false;
                 }
 #ifdef SMOLMC_EXP_PHASES
                 { const long long tn = clock64(); ph2[1] += tn - ph_t; ph_t = tn; }
