@@ -664,6 +664,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     double sumw = 0.0, vlp = 0.0, vcum = 0.0;
     int last_feas = -1;
 
+#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
+    long long ph_acc[5] = {0, 0, 0, 0, 0};
+    long long ph_t = clock64();
+#endif
     const uint32_t nsteps32 = (uint32_t)P.steps;
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
@@ -683,6 +687,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             logu = log(philox_u53(o.w[2], o.w[3]));
         }
         const int l4 = (int)(step & 15ull) * 4;
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; }
+#endif
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
 
         // flips of this step, lane-indexed: lane f holds flip f (site, new / old code, sublattice)
@@ -790,6 +797,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             }
             log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
                                           (int)rdlane((uint32_t)__double2loint(vlp), dir));
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[1] += tn - ph_t; ph_t = tn; }
+#endif
             // sites of the depleted species, sublattice by sublattice, from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4) (256 candidates per wave round, position kept across
             // species AND sublattices); then the random assignment to the enriched species
@@ -799,7 +809,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             for (int sl = 0; sl < NS; ++sl) {
                 const int sb = sel4(P.m_sbase, sl), ncod = sel4(P.m_ncodes, sl);
                 const uint32_t na = (uint32_t)sel4(P.m_nact, sl);
-                int vcol = 0, ncol = 0; // sites collected in this sublattice, lane-indexed
+                int vcol = 0, vcsp = 0, ncol = 0; // sites collected in this sublattice and their (depleted) species, lane-indexed
                 int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
                 bool have_sites = false; // cs / cv valid for (round, sl)
                 for (int c = 0; c < ncod; ++c) {
@@ -841,7 +851,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                         const int bl = (int)(best >> 2), bj = (int)(best & 3u);
                         const int picked = (int)rdlane((uint32_t)(bj == 0 ? cs[0] : bj == 1 ? cs[1] : bj == 2 ? cs[2] : cs[3]), bl);
                         if (__ballot(lane < ncol && vcol == picked) != 0ull) continue;
-                        if (lane == ncol) vcol = picked;
+                        if (lane == ncol) { vcol = picked; vcsp = c; }
                         ncol++;
                         need--;
                     }
@@ -855,11 +865,14 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                         qdraw++;
                         const int rr = (int)__umulhi(word, (uint32_t)ncol);
                         const int site = (int)rdlane((uint32_t)vcol, rr);
-                        const int od = uni((int)occ[lean_swz(site, swa, swm, swb)]);
+                        const int od = (int)rdlane((uint32_t)vcsp, rr); // (known from the scan: no LDS read)
                         if (lane == nfl) { vsite = site; vnew = c; vold = od; vfsub = sl; }
                         nfl++;
-                        const int nxt = __shfl_down(vcol, 1);
-                        if (lane >= rr) vcol = nxt;
+                        // list.remove keeps the order of the rest: lanes >= rr take their right neighbour
+                        // (DPP wave shift, not a cross-lane LDS permute)
+                        const int nxt = __builtin_amdgcn_update_dpp(0, vcol, 0x130, 0xf, 0xf, false);
+                        const int nxs = __builtin_amdgcn_update_dpp(0, vcsp, 0x130, 0xf, 0xf, false);
+                        if (lane >= rr) { vcol = nxt; vcsp = nxs; }
                         ncol--;
                     }
                 }
@@ -867,6 +880,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             }
         }
 
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[2] += tn - ph_t; ph_t = tn; }
+#endif
         // -------- sequential evaluation of the flips of this step -----------------------
         double e = 0.0, ew_uni = 0.0, dMu = 0.0;
         double vdq = 0.0;
@@ -921,6 +937,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             if (f < nfl) eval_flip(f, rows[f]);
         for (int f = 4; f < nfl; ++f)
             eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[3] += tn - ph_t; ph_t = tn; }
+#endif
         double dH = wave_sum_all(e);
         const double dEw = has_ew ? ew_uni : 0.0;
         if (has_ew) dH += P.ew_coef * dEw;
@@ -963,6 +982,9 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             }
         }
 
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[4] += tn - ph_t; ph_t = tn; }
+#endif
         if (P.smp.every && --smp_countdown == 0) {
             smp_countdown = (uint32_t)P.smp.every;
             const size_t row = (size_t)smp_index * P.R + r;
@@ -992,6 +1014,12 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         }
     }
 
+#ifdef SMOLMC_EXP_PHASES
+    if (r == 0 && lane == 0)
+        printf("multi phases (cycles per step): skeleton %.0f | head %.0f | picks+assign/swap %.0f | eval %.0f | decide+update %.0f\n",
+               (double)ph_acc[0] / (double)P.steps, (double)ph_acc[1] / (double)P.steps, (double)ph_acc[2] / (double)P.steps,
+               (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps);
+#endif
     if (phi_lds)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {
