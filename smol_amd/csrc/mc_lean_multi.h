@@ -13,6 +13,12 @@
 #pragma once
 #include "mc_lean.h"
 
+#ifdef SMOLMC_NO_TABLE_FAST // A/B switch: every table step through the full candidate scan
+#define SMOLMC_TABLE_MULTI_FAST false
+#else
+#define SMOLMC_TABLE_MULTI_FAST true
+#endif
+
 // element k (< 4) of a kernel-argument array without dynamic indexing (which would go through scratch)
 __device__ __forceinline__ int sel4(const int (&a)[4], int k) {
     return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3]));
@@ -663,6 +669,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     unsigned feas_now = 0, lp_valid = 0;
     double sumw = 0.0, vlp = 0.0, vcum = 0.0;
     int last_feas = -1;
+    // Candidate block (see mc_table_kernel): the first 32 words of the candidate stream of TWO
+    // steps, one per lane, from one Philox call per two steps.  A sublattice maps the same words to
+    // its own sites; a step that finds all its picks among them skips the 256-candidate rounds.
+    uint32_t cblk_base = ~0u, cb_word = 0u;
 
 #ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
     long long ph_acc[5] = {0, 0, 0, 0, 0};
@@ -695,6 +705,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         // flips of this step, lane-indexed: lane f holds flip f (site, new / old code, sublattice)
         int vsite = 0, vnew = 0, vold = 0, vfsub = 0;
         int nfl = 0, dir = -1;
+        bool fast_ok = false;
         int vu = 0; // table step: lane d holds the change of count dimension d
         double log_priori = 0.0;
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
@@ -803,16 +814,76 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             // sites of the depleted species, sublattice by sublattice, from the candidate stream
             // c_t = W(step, 4 + t / 4, t % 4) (256 candidates per wave round, position kept across
             // species AND sublattices); then the random assignment to the enriched species
+            if ((uint32_t)(step & ~1ull) != cblk_base) {
+                cblk_base = (uint32_t)(step & ~1ull);
+                const unsigned long long sl2 = (step & ~1ull) + (unsigned)(lane >> 5);
+                const uint32_t tt = (uint32_t)lane & 31u;
+                const philox_out o = philox4x32_10((uint32_t)sl2, (uint32_t)(sl2 >> 32), 4u + (tt >> 2), 0u, key0, key1);
+                cb_word = (tt & 3u) == 0u ? o.w[0] : (tt & 3u) == 1u ? o.w[1] : (tt & 3u) == 2u ? o.w[2] : o.w[3];
+            }
+            const int g32 = (int)(step & 1ull) * 32; // first lane of this step's candidates in the block
+            bool fast = SMOLMC_TABLE_MULTI_FAST; // first the candidate block; after a miss the full scan
+            for (bool done = false; !done; fast = false) {
+            nfl = 0;
+            fast_ok = fast;
+            uint32_t fpos = 0; // block path: next stream position (kept across species and sublattices)
             uint32_t tpos = 0, round = 0, ow[4] = {0, 0, 0, 0};
             bool have_round = false;
             int qdraw = 0, dbase = 0;
-            for (int sl = 0; sl < NS; ++sl) {
+            for (int sl = 0; sl < NS && (fast_ok || !fast); ++sl) {
                 const int sb = sel4(P.m_sbase, sl), ncod = sel4(P.m_ncodes, sl);
                 const uint32_t na = (uint32_t)sel4(P.m_nact, sl);
                 int vcol = 0, vcsp = 0, ncol = 0; // sites collected in this sublattice and their (depleted) species, lane-indexed
                 int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
                 bool have_sites = false; // cs / cv valid for (round, sl)
-                for (int c = 0; c < ncod; ++c) {
+                if (fast) {
+                    // lane-parallel picks among the block's candidates (mc_table_kernel)
+                    uint32_t dep = (uint32_t)__ballot(vu < 0) & (((1u << ncod) - 1u) << dbase);
+                    if (dep != 0u) {
+                        const int site_l = sb + (int)__umulhi(cb_word, na);
+                        const int cvl = (int)occ[lean_swz(site_l, swa, swm, swb)];
+                        int vdst = -1;
+                        while (dep != 0u && fast_ok) {
+                            const int d = __ffs((int)dep) - 1;
+                            dep &= dep - 1u;
+                            const int need = -(int)rdlane((uint32_t)vu, d);
+                            uint32_t m = (uint32_t)(__ballot(cvl == d - dbase) >> g32);
+                            m = fpos < 32u ? (m >> fpos) << fpos : 0u;
+                            if (__popc(m) < need) { fast_ok = false; break; }
+                            const unsigned long long m64 = (unsigned long long)m << g32;
+                            const int rnk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
+                            const bool mine = ((m64 >> lane) & 1ull) != 0ull && rnk < need;
+                            if (mine) vdst = ncol + rnk;
+                            if (lane >= ncol && lane < ncol + need) vcsp = d - dbase;
+                            const unsigned long long lastm = __ballot(mine && rnk == need - 1);
+                            fpos = (uint32_t)(__ffsll((long long)lastm) - 1 - g32) + 1u;
+                            ncol += need;
+                        }
+                        if (fast_ok) {
+                            int *scr = (int *)s_feat; // (per-wave scratch, free between sample rows)
+                            if (vdst >= 0) scr[vdst] = site_l;
+                            vcol = scr[lane];
+                            bool dup = false; // a site named twice: leave the step to the full scan
+#define SMOLMC_DUP_SHIFT(D, CTRL)                                                                  \
+    if (ncol > D) {                                                                                \
+        const int other = __builtin_amdgcn_update_dpp(0, vcol, CTRL, 0xf, 0xf, false);             \
+        dup |= lane >= D && lane < ncol && vcol == other;                                          \
+    }
+                            SMOLMC_DUP_SHIFT(1, 0x111)
+                            SMOLMC_DUP_SHIFT(2, 0x112)
+                            SMOLMC_DUP_SHIFT(3, 0x113)
+                            SMOLMC_DUP_SHIFT(4, 0x114)
+                            SMOLMC_DUP_SHIFT(5, 0x115)
+                            SMOLMC_DUP_SHIFT(6, 0x116)
+                            SMOLMC_DUP_SHIFT(7, 0x117)
+#undef SMOLMC_DUP_SHIFT
+                            if (ncol > 8 || __ballot(dup) != 0ull) fast_ok = false;
+                        }
+                    }
+                    if (!fast_ok) break;
+                }
+                for (int c = 0; c < ncod && !fast; ++c) {
                     int need = -(int)rdlane((uint32_t)vu, dbase + c);
                     unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
                     bool have_masks = false;
@@ -878,6 +949,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 }
                 dbase += ncod;
             }
+            done = !fast || fast_ok;
+            } // (block attempt, then full scan)
         }
 
 #ifdef SMOLMC_EXP_PHASES
