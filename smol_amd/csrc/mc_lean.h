@@ -435,7 +435,16 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     //    s_waitcnt insertion can no longer count it and falls back to vmcnt(0) at the row waits.
     //    The occurrence counts live in LDS beside the histogram for the same reason.
     double *wl_pend = WL ? P.wl.meanf + (size_t)r * P.wl.L * P.F : nullptr;
-    double wl_pend_val = 0.0;
+    // (the value: the shadow copies as they were READ in the post-step, summed only where the atomic
+    // is issued in the next step -- the post-step then never waits for its own LDS atomics)
+    double wl_pc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    auto wl_pend_sum = [&]() -> double {
+        return ((wl_pc[0] + wl_pc[1]) + (wl_pc[2] + wl_pc[3])) + ((wl_pc[4] + wl_pc[5]) + (wl_pc[6] + wl_pc[7]));
+    };
+#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
+    long long lph[5] = {0, 0, 0, 0, 0};
+    long long lph_t = clock64();
+#endif
     uint32_t steps_left = (uint32_t)P.steps; // the host splits launches at 2^30 steps
     while (steps_left != 0u) {
         // -------- random words (generated 16 steps at a time) --------
@@ -499,6 +508,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         // site of the next step (depends only on random words; its index row is fetched below)
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1); // wave priority rises through the step, see the decision below
+#endif
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); lph[0] += tn - lph_t; lph_t = tn; }
 #endif
         const int s1n = (int)rdlane((uint32_t)nsite, l4);
         const int a1n = (int)rdlane((uint32_t)naddr, l4);
@@ -598,10 +610,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #endif
         }
         if (WL) {
-            unsafeAtomicAdd(wl_pend + lane, wl_pend_val);
-            wl_pend_val = 0.0;
+            unsafeAtomicAdd(wl_pend + lane, wl_pend_sum());
         }
 
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); lph[1] += tn - lph_t; lph_t = tn; }
+#endif
         // -------- enthalpy delta ---------------------------------------------------
         // Swap: the second flip is the reverse species change of the first
         // (n2 == o1, o2 == n1), and the delta tables are antisymmetric in (old, new), so both
@@ -691,6 +705,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 }
             }
         }
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); lph[2] += tn - lph_t; lph_t = tn; }
+#endif
         double dMu = 0.0;
         if (HAS_MU && nfl >= 1) {
             dMu = s_mu[n1] - s_mu[o1];
@@ -864,6 +881,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         __builtin_amdgcn_s_setprio(0);
 #endif
 
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); lph[3] += tn - lph_t; lph_t = tn; }
+#endif
         if (WL) {
             // WangLandau._do_post_step (wanglandau.py:222-266)
             // the bin only moves on accepted steps, to the one computed by the accept test
@@ -877,8 +897,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 wl_counter++;
                 if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
                 wl_pend = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
-                const double fcur = wl_cur_feat();
-                wl_pend_val = lane < P.F ? fcur : 0.0;
+                {
+                    const int f = lane < wl_stride ? lane : 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        wl_pc[k] = (k < wl_k && lane < P.F) ? s_feat[f + (k < wl_k ? k : 0) * wl_stride] : 0.0;
+                }
                 if (lane == 0) {
                     // LDS atomics without return value: a read-modify-write would put one more
                     // LDS round trip on the step's dependency chain (one wave per SIMD here)
@@ -893,6 +917,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
         }
 
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); lph[4] += tn - lph_t; lph_t = tn; }
+#endif
         l4 += 4;
         l64 += 1;
         } while (--chunk != 0u);
@@ -943,6 +970,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                (double)dc / (double)dw * 100.0, (double)dc / (double)P.steps);
     }
 #endif
+#ifdef SMOLMC_EXP_PHASES
+    if (r == 0 && lane == 0)
+        printf("lean phases (cycles per step): skeleton %.0f | proposal %.0f | gathers+tables %.0f | decision+update %.0f | post-step %.0f\n",
+               (double)lph[0] / (double)P.steps, (double)lph[1] / (double)P.steps, (double)lph[2] / (double)P.steps,
+               (double)lph[3] / (double)P.steps, (double)lph[4] / (double)P.steps);
+#endif
     // ---- write back ---------------------------------------------------------------
     if (HAS_EW && ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
@@ -953,7 +986,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
     if (WL) {
         const double fcur = wl_cur_feat();
-        unsafeAtomicAdd(wl_pend + lane, wl_pend_val); // the last step's per-bin sums
+        unsafeAtomicAdd(wl_pend + lane, wl_pend_sum()); // the last step's per-bin sums
         if (lane < P.F) featp[lane] = fcur;
         for (int i = lane; i < P.wl.L; i += 64) {
             P.wl.entropy[(size_t)r * P.wl.L + i] = wl_S[i];
