@@ -985,7 +985,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
         bool lean = h->lean_tables && h->F <= 64 &&
-                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 &&
+                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 && h->F <= 63 && // (cell 63 of the feature scratch is the kernel's zero)
                              getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
                     h->lean_nslot <= 4 && getenv("SMOLMC_FORCE_GENERAL") == nullptr;

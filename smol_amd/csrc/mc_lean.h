@@ -323,10 +323,14 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // (WLK = min(8, 64 / F), packed back to back); lane l adds into copy l % WLK, which divides the
     // multiplicity per address by WLK; a reader sums the copies (wl_cur_feat).
     const int wl_stride = WL ? P.F : 64;                     // copies packed back to back
-    const int wl_k = WL ? min(8, 64 / max(wl_stride, 1)) : 1; // (F <= 64 for Wang-Landau)
+    const int wl_k = WL ? max(1, min(8, 63 / max(wl_stride, 1))) : 1; // (cell 63 stays zero: the address of "no copy")
     uint32_t sfeat_wl[NSLOT];
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) sfeat_wl[it] = sfeat[it] + (uint32_t)((lane % wl_k) * wl_stride);
+    // per-lane read addresses of the copies (doubles): copy k of the lane's feature, or the zero cell
+    int wl_rd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wl_rd[k] = (WL && k < wl_k && lane < wl_stride) ? lane + k * wl_stride : 63;
     auto wl_cur_feat = [&]() -> double { // lane f < F: current feature f (other lanes: unused)
         const int f = lane < wl_stride ? lane : 0;
         double t[8];
@@ -897,12 +901,8 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 wl_counter++;
                 if (++wl_rem_check == P.wl.check) wl_rem_check = 0;
                 wl_pend = P.wl.meanf + ((size_t)r * P.wl.L + b) * P.F;
-                {
-                    const int f = lane < wl_stride ? lane : 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        wl_pc[k] = (k < wl_k && lane < P.F) ? s_feat[f + (k < wl_k ? k : 0) * wl_stride] : 0.0;
-                }
+                for (int k = 0; k < 8; ++k) wl_pc[k] = s_feat[wl_rd[k]];
                 if (lane == 0) {
                     // LDS atomics without return value: a read-modify-write would put one more
                     // LDS round trip on the step's dependency chain (one wave per SIMD here)
