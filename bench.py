@@ -40,9 +40,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_REPLICAS = 4096  # per GPU (weak) or in total (strong)
-MC_PER_STEP = 10000  # Metropolis steps per walker per bench step (launch)
+# Metropolis steps per walker per bench step (launch).  SURVEY 8d asks for >= 1e6 timed steps per
+# replica and the timed region should last >= 1 s: the driver's --steps 20 gives 2.5e6 steps per
+# replica and ~1.2 s of kernel time on one MI355X (r2 timed 2e5 steps = 93 ms).
+MC_PER_STEP = 125000
 ALGO_BYTES_PER_FLIP = 56.0  # D*s_occ + p_acc*s_occ, D=55 distinct sites, int8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_MEASURED_FALLBACK_GBS = 6000.0  # tools/hbm_triad.py on this pool (read 6.0, triad 5.9 TB/s), used when the live probe fails
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth
 METRIC = "attempted MC flips/s (node) + ns/flip/replica, 4096-site FCC canonical"
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
@@ -82,6 +86,38 @@ def pmc_constants():
         return {}
 
 
+def measure_hbm_peak(n=1 << 28):
+    """Achievable HBM bandwidth of this GPU, measured live (tools/hbm_triad.py in short): read and
+    triad over float64 arrays of 2 GiB each -- far beyond the 256 MiB Infinity Cache.  torch is
+    only the allocator / launcher of the elementwise kernels.  Returns GB/s figures or None."""
+    try:
+        import torch
+
+        a = torch.empty(n, dtype=torch.float64, device="cuda")
+        b = torch.rand(n, dtype=torch.float64, device="cuda")
+        c = torch.rand(n, dtype=torch.float64, device="cuda")
+
+        def timed(fn, reps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        out = {"read_GBs": n * 8 / timed(lambda: b.sum()) / 1e9,
+               "triad_GBs": 3 * n * 8 / timed(lambda: torch.add(b, c, alpha=3.0, out=a)) / 1e9}
+        del a, b, c
+        torch.cuda.empty_cache()
+        return out
+    except Exception:  # the probe must never cost the benchmark line
+        return None
+
+
 # --------------------------------------------------------------------------------------
 # CPU baseline (oracle timed on the host cores; fresh interpreter)
 # --------------------------------------------------------------------------------------
@@ -114,9 +150,24 @@ def cpu_baseline_child(seconds=12.0):
         one.run(20000)
         n1 += 20000
     single = 2.0 * n1 / (time.perf_counter() - t1)
+    # BASELINE configs[0], "1 replica on smol CPU path": the 256-site pair-only model, one walker,
+    # one thread (the arithmetic of the reference's compiled core + kernel logic; the reference's
+    # own end-to-end Python rate for such a chain is 2e3 - 1e4 steps/s)
+    w1 = workloads.config1(0, 1)
+    c1 = orc.OracleMC(w1.tables, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    c1.set_state(w1.occupancy[:1], w1.seeds[:1], w1.temperature)
+    c1.run(2000)
+    m1, t2 = 0, time.perf_counter()
+    while time.perf_counter() - t2 < 3.0:
+        c1.run(20000)
+        m1 += 20000
+    t2 = time.perf_counter() - t2
     print(json.dumps({
         "value": 2.0 * R * done / dt,
         "single_thread_value": single,
+        "config1_single_replica": {
+            "value": 2.0 * m1 / t2, "unit": "attempted flips/s", "ns_per_flip": t2 / (2.0 * m1) * 1e9,
+            "cores": 1, "sample": f"config 1 (256 sites, pair-only), 1 walker x {m1} swap steps, 1 thread, {t2:.1f} s"},
         "unit": "attempted flips/s",
         "cores": cores,
         "cpu_model": cpu_model(),
@@ -169,113 +220,260 @@ def launch_ranks(args, argv):
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + argv, env=env,
             stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+    # rank 0's stdout is drained by a thread while ALL children are polled: a rank that dies early
+    # (bad device, import error) ends the job at once with its code, instead of leaving rank 0 in the
+    # rendezvous until the store timeout
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        time.sleep(0.05)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    if chunks and chunks[0]:
+        sys.stdout.write(chunks[0])
         sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(bad[0][1] if bad[0][1] > 0 else 1)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
+        raise SystemExit(failed[1] if failed[1] > 0 else 1)
 
 
 # --------------------------------------------------------------------------------------
-# other configurations (after the headline's timed region; rank 0, N=1 only)
+# other configurations (after the headline's timed region)
+#   one rank : configs 1, 3, 4, 5
+#   N ranks  : configs 4 and 5, the two BASELINE.json defines as N-rank workloads -- config 4 as
+#              1024 independent Wang-Landau walkers per rank, config 5 as ONE temperature ladder
+#              over 2048 N walkers whose exchange step (all-gather of 8 B per walker + temperature
+#              moves, smol_amd/parallel.py) runs inside the timed region.  All ranks take part,
+#              rank 0 reports.
 # --------------------------------------------------------------------------------------
-def time_other_configs(device, launches=3):
-    """Configs 1, 3, 4, 5 of BASELINE.json: a few launches each, kernel time from HIP events on
-    the launch stream, with the roofline that actually bounds each."""
+OTHER_CONFIGS_TIMEOUT_S = 300
+EQUIL_STEPS = {3: 600_000, 5: 400_000}  # untimed steps per walker before the steady-state figures
+
+
+class _Clock:
+    """Barrier-bracketed wall clock, MAX over ranks (the bench contract's timing rule)."""
+
+    def __init__(self, world, red_dev, gpu=True):
+        self.world, self.red_dev, self.gpu = world, red_dev, gpu
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.gpu:
+            torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        if self.gpu:
+            torch.cuda.synchronize()
+
+    def time(self, fn):
+        import torch
+        import torch.distributed as dist
+
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def sum(self, values):
+        import torch
+        from smol_amd import parallel
+
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.red_dev)
+        return parallel.global_sums(t).cpu().numpy()
+
+
+def hbm_ce(rec):  # SURVEY 8d: 56 algorithmic bytes per CE flip
+    a = rec["flips_per_s"] * ALGO_BYTES_PER_FLIP / 1e9
+    return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
+                note="CE flip, occupancy LDS-resident: nominal HBM fraction (56 B/flip)")
+
+
+def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None):
+    """transient (first `launches` launches after a warm-up launch) and, after `equil` more
+    untimed steps per walker, steady-state figures of one workload on this rank's walkers;
+    with `rex` every launch is followed by one exchange attempt of the global ladder."""
+    from smol_amd import parallel
+
+    eng = Engine(wl.tables, wl.make_config(device))
+    eng.set_state(wl.occupancy, wl.seeds, wl.temperature)
+
+    def launch(n=1):
+        if rex is None:
+            for _ in range(n):
+                eng.run(mc)
+        else:
+            parallel.run_replica_exchange(eng, rex, n, mc)
+
+    def measure():
+        launch(1)
+        eng.sync()
+        s0 = eng.get_state(occupancy=False)
+        kms = []
+
+        def body():
+            for _ in range(launches):
+                launch(1)
+                kms.append(eng.last_kernel_ms())
+            eng.sync()
+
+        dt = clock.time(body)
+        s1 = eng.get_state(occupancy=False)
+        acc, walkers, kms_sum = clock.sum([float((s1["n_accepted"] - s0["n_accepted"]).sum()),
+                                           float(wl.n_walkers), float(np.mean(kms))])
+        steps = walkers * mc * launches
+        return dict(kernel_ms=kms_sum / clock.world, wall_s=dt, mc_steps_per_s=steps / dt,
+                    mc_steps_per_s_kernel_only=walkers * mc / (kms_sum / clock.world * 1e-3),
+                    flips_per_s=wl.flips_per_step * walkers * mc / (kms_sum / clock.world * 1e-3),
+                    acceptance=acc / steps, timed_steps_per_replica=mc * launches)
+
+    first = measure()
+    steady = None
+    if equil:
+        done = (launches + 1) * mc
+        while done < equil:
+            launch(10)
+            done += 10 * mc
+        eng.sync()
+        steady = measure()
+        steady["equilibration_steps_per_replica"] = done
+    info = eng.kernel_info()
+    eng.close()
+    return info, first, steady
+
+
+def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
+    """Configs 1, 3, 4, 5 of BASELINE.json on one rank; configs 4 and 5 on N ranks.  Kernel time
+    from HIP events on the launch stream, wall time barrier-bracketed with the MAX over ranks,
+    and the roofline that actually bounds each.  Configs 3 and 5 start from random
+    occupancies: their figures are reported for the first launches (transient) AND after
+    EQUIL_STEPS more steps per walker (steady state), each with its acceptance."""
     from smol_amd import capi, parallel, workloads
     from smol_amd.engine import Engine
 
+    clock = _Clock(world, red_dev)
     out = []
 
-    def run(wl, extra):
-        eng = Engine(wl.tables, wl.make_config(device))
-        eng.set_state(wl.occupancy, wl.seeds, wl.temperature)
-        eng.run(wl.mc_per_launch, sync=True)
-        s0 = eng.get_state(occupancy=False)
-        ms = []
-        for _ in range(launches):
-            eng.run(wl.mc_per_launch, sync=True)
-            ms.append(eng.last_kernel_ms())
-        s1 = eng.get_state(occupancy=False)
-        k_ms = float(np.mean(ms))
-        steps = wl.n_walkers * wl.mc_per_launch
-        acc = float((s1["n_accepted"] - s0["n_accepted"]).sum()) / (launches * steps)
-        rec = dict(config=wl.name, kernel=eng.kernel_info(), replicas=wl.n_walkers,
-                   mc_steps_per_launch=wl.mc_per_launch, kernel_ms=k_ms,
-                   mc_steps_per_s=steps / (k_ms * 1e-3),
-                   flips_per_s=wl.flips_per_step * steps / (k_ms * 1e-3), acceptance=acc)
-        rec["roofline"] = extra(rec, wl, eng)
-        eng.close()
+    def record(wl, info, first, steady, roof, replicas, launches, **extra):
+        main = steady or first
+        rec = dict(config=wl.name, kernel=info, n_gpus=world, replicas=replicas,
+                   mc_steps_per_launch=main["timed_steps_per_replica"] // launches,
+                   kernel_ms=main["kernel_ms"], mc_steps_per_s=main["mc_steps_per_s"],
+                   mc_steps_per_s_kernel_only=main["mc_steps_per_s_kernel_only"],
+                   flips_per_s=main["flips_per_s"], acceptance=main["acceptance"],
+                   timed_steps_per_replica=main["timed_steps_per_replica"], **extra)
+        if steady:
+            rec["state"] = "steady"
+            rec["equilibration_steps_per_replica"] = steady["equilibration_steps_per_replica"]
+            rec["transient"] = dict(kernel_ms=first["kernel_ms"], mc_steps_per_s=first["mc_steps_per_s"],
+                                    flips_per_s=first["flips_per_s"], acceptance=first["acceptance"])
+        rec["roofline"] = roof(rec)
         out.append(rec)
 
-    def hbm_ce(rec, wl, eng):  # SURVEY 8d: 56 algorithmic bytes per CE flip
-        a = rec["flips_per_s"] * ALGO_BYTES_PER_FLIP / 1e9
-        return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
-                    note="CE flip, occupancy LDS-resident: nominal HBM fraction (56 B/flip)")
+    if world == 1:
+        wl = workloads.config1()
+        info, first, _ = _engine_run(Engine, wl, device, clock, 5, 100_000)
+        record(wl, info, first, None, hbm_ce, wl.n_walkers, launches=5)
 
-    run(workloads.config1(), hbm_ce)
+        wl3 = workloads.config3()
 
-    def ewald_field(rec, wl, eng):
-        # potential-field formulation: a proposal reads O(1) LDS words; only an ACCEPTED flip
-        # streams one row of the site kernel G (n_act doubles, from L2 / Infinity Cache: the
-        # 48 MB kernel exceeds the 32 MB of L2) and read-modify-writes phi in LDS.  The
-        # 2-rows-per-proposal figure of SURVEY 8d does not describe this algorithm.
-        n_act = wl.sc.size
-        row_bytes = n_act * 8.0
-        a = rec["flips_per_s"] * rec["acceptance"] * row_bytes / 1e9
-        return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
-                    l2_peak=L2_PEAK_GBS, acceptance=rec["acceptance"], row_bytes_per_accepted_flip=row_bytes,
-                    note="accepted-flip row traffic (n_act*8 B each, served by L2/MALL) over kernel "
-                         "time; depends on the acceptance; the dense two-row formulation "
-                         "(58752 B/flip) is HBM-capped at 1.36e8 flips/s")
+        def ewald_roof(rec):
+            # potential-field formulation: a proposal reads O(1) LDS words; only an ACCEPTED flip
+            # updates the walker's field from one row of the site kernel (n_act doubles).  The
+            # 2-rows-per-proposal figure of SURVEY 8d does not describe this algorithm.
+            row_bytes = wl3.sc.size * 8.0
+            a = rec["flips_per_s"] * rec["acceptance"] * row_bytes / 1e9
+            return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
+                        l2_peak=L2_PEAK_GBS, acceptance=rec["acceptance"],
+                        row_bytes_per_accepted_flip=row_bytes,
+                        note="accepted-flip row bytes (n_act*8 B each) over kernel time; depends on the "
+                             "acceptance; the dense two-row formulation (58752 B/flip) is HBM-capped at "
+                             "1.36e8 flips/s")
 
-    wl3 = workloads.config3()
-    run(wl3, ewald_field)
+        info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3])
+        record(wl3, info, first, steady, ewald_roof, wl3.n_walkers, launches=10)
 
-    # config 4: the window is centred on the starting enthalpy, evaluated on the engine
-    wl4 = workloads.config4()
+    # config 4: 1024 independent Wang-Landau walkers per rank; the window is centred on the
+    # starting enthalpy, evaluated on the engine
+    wl4 = workloads.config4(first=rank * 1024)
     probe = Engine(wl4.tables, capi.make_config(1, device=device))
-    h0 = float(probe.natural_parameters @ probe.eval_full(wl4.occupancy[:1])[0])
+    h0 = float(probe.natural_parameters @ probe.eval_full(workloads.config4(count=1).occupancy[:1])[0])
     probe.close()
-    run(workloads.config4(h0=h0), hbm_ce)
+    wl4 = workloads.config4(first=rank * 1024, h0=h0)
+    info, first, _ = _engine_run(Engine, wl4, device, clock, 5, 50_000)
+    record(wl4, info, first, None, hbm_ce, wl4.n_walkers * world, launches=5,
+           sharding="independent walkers, no collective")
 
-    # config 5: TableFlip + exchange ladder (single rank: decisions on the host, temperatures move)
-    wl5 = workloads.config5()
-    eng = Engine(wl5.tables, wl5.make_config(device))
-    eng.set_state(wl5.occupancy, wl5.seeds, wl5.temperature)
-    rex = parallel.ReplicaExchange(wl5.extras["ladder"], wl5.n_walkers, seed=11)
-    parallel.run_replica_exchange(eng, rex, 1, wl5.mc_per_launch)
-    s0 = eng.get_state(occupancy=False)
-    eng.sync()
-    t1 = time.perf_counter()
-    kms = []
-    for _ in range(launches):
-        parallel.run_replica_exchange(eng, rex, 1, wl5.mc_per_launch)
-        kms.append(eng.last_kernel_ms())
-    eng.sync()
-    wall = time.perf_counter() - t1
-    s1 = eng.get_state(occupancy=False)
-    steps = wl5.n_walkers * wl5.mc_per_launch * launches
-    acc = float((s1["n_accepted"] - s0["n_accepted"]).sum()) / steps
-    k_ms = float(np.mean(kms))
-    out.append(dict(
-        config=wl5.name + f", exchange every {wl5.mc_per_launch} steps", kernel=eng.kernel_info(),
-        replicas=wl5.n_walkers, mc_steps_per_launch=wl5.mc_per_launch, kernel_ms=k_ms,
-        mc_steps_per_s=steps / wall, mc_steps_per_s_kernel_only=steps / launches / (k_ms * 1e-3),
-        acceptance=acc, exchange_acceptance_mean=float(rex.acceptance.mean()),
-        roofline=dict(bound="issue", note="TableFlip proposal is scalar-issue bound (DESIGN.md §5); "
-                                          "no byte roofline applies; wall time includes the exchange")))
-    eng.close()
+    # config 5: TableFlip + ONE replica-exchange ladder over all ranks' walkers; every launch is
+    # followed by an exchange attempt (one rank: decisions from a direct read-back; N ranks: RCCL
+    # all-gather of the enthalpies, identical decisions on every rank, temperatures move)
+    per = 2048
+    wl5 = workloads.config5(first=rank * per, count=per, total=per * world)
+    rex = parallel.ReplicaExchange(wl5.extras["ladder"], per, rank, world, seed=11)
+    info, first, steady = _engine_run(Engine, wl5, device, clock, 30, wl5.mc_per_launch,
+                                      equil=EQUIL_STEPS[5], rex=rex)
+    record(wl5, info, first, steady,
+           lambda rec: dict(bound="issue", note="TableFlip proposal is instruction-issue bound (DESIGN.md §5); no "
+                                                "byte roofline applies; mc_steps_per_s is wall time including the "
+                                                "exchange step, mc_steps_per_s_kernel_only from the HIP events"),
+           per * world, launches=30, exchange_every_steps=wl5.mc_per_launch,
+           exchange_acceptance_mean=float(rex.acceptance.mean()),
+           exchange_path="collective (all-gather over %d ranks)" % world if world > 1 else "single rank (direct read-back)")
     return out
 
 
 # --------------------------------------------------------------------------------------
+class _DryEngine:
+    """Stand-in for smol_amd.engine.Engine in --dry-run (no GPU): made-up enthalpies, so that the
+    N-rank control flow of configs 4 / 5 -- sharding, ladder, host-staged all-gather, identical
+    decisions, temperature moves, barrier-bracketed timing, reductions -- runs over gloo."""
+
+    def __init__(self, n, seed):
+        self.n, self.rng, self.T = n, np.random.default_rng(seed), np.full(n, 1000.0)
+        self.steps = 0
+
+    def set_temperature(self, t):
+        self.T = np.broadcast_to(np.asarray(t, dtype=np.float64), (self.n,)).copy()
+
+    def run(self, nsteps, sync=False):
+        self.steps += int(nsteps)
+
+    def sync(self):
+        pass
+
+    def get_enthalpy(self):
+        return self.rng.normal(0.0, 0.5, self.n) - 3000.0 / self.T
+
+
 def dry_run(args, rank, world):
     """The multi-rank control flow without a GPU (gloo): rendezvous, barrier, timed loop of
-    no-ops, MAX-reduce of the time, SUM-reduce of the statistics."""
+    no-ops, MAX-reduce of the time, SUM-reduce of the statistics; then the N-rank forms of
+    configs 4 (independent shards) and 5 (global ladder, exchange inside the timed region)."""
     import torch
     import torch.distributed as dist
 
@@ -295,12 +493,35 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    # configs 4 / 5 as N-rank workloads
+    clock = _Clock(world, "cpu", gpu=False)
+    per4, per5, sweeps = 1024, 2048, 6
+    e4 = _DryEngine(per4, 100 + rank)
+    t4 = clock.time(lambda: e4.run(50_000))
+    w4 = clock.sum([per4])[0]
+    ladder = parallel.geometric_ladder(400.0, 2000.0, per5 * world)
+    rex = parallel.ReplicaExchange(ladder, per5, rank, world, seed=11)
+    e5 = _DryEngine(per5, 200 + rank)
+    t5 = clock.time(lambda: parallel.run_replica_exchange(e5, rex, sweeps, 3456))
+    check = float((rex.rung_of * np.arange(1, rex.n + 1)).sum())  # order-sensitive checksum of the ladder
+    check_mean = clock.sum([check])[0] / world                   # == check when every rank decided alike
     if rank == 0:
         print(json.dumps({
             "metric": METRIC, "value": None, "unit": "attempted flips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
             "scaling": args.scaling, "dry_run": True, "walkers_total": int(stats[3].item()),
             "walkers_rank0": [first, count],
+            "other_configs": [
+                {"config": "config4 (dry run)", "n_gpus": world, "replicas": int(w4), "wall_s": t4,
+                 "sharding": "independent walkers, no collective"},
+                {"config": "config5 (dry run)", "n_gpus": world, "replicas": rex.n, "wall_s": t5,
+                 "exchanges": rex.calls, "exchange_attempts": int(rex.attempted.sum()),
+                 "exchange_accepted": int(rex.accepted.sum()),
+                 "rungs_are_a_permutation": bool(sorted(rex.rung_of) == list(range(rex.n))),
+                 "ranks_agree": bool(abs(check_mean - check) < 0.5),
+                 "exchange_path": "collective (all-gather over %d ranks, host-staged: gloo)" % world
+                 if world > 1 else "single rank"},
+            ],
         }))
     if world > 1:
         dist.destroy_process_group()
@@ -309,8 +530,8 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--replicas", type=int, default=N_REPLICAS,
                     help="walkers per GPU (weak) or in total (strong)")
@@ -424,6 +645,12 @@ def main():
         flips_per_launch = 2.0 * args.mc_per_step * R
         achieved = flips_per_launch * ALGO_BYTES_PER_FLIP / (k_ms * 1e-3) / 1e9
         pmc = pmc_constants().get(f"{R}x{args.mc_per_step}", {}) if args.features == "interactions" else {}
+        from smol_amd.engine import source_digest
+
+        # the counters were collected on the build whose source digest the file carries
+        pmc_stale = bool(pmc) and pmc.get("csrc_sha256") != source_digest()
+        probe = measure_hbm_peak()
+        measured_peak = max(probe.values()) if probe else HBM_MEASURED_FALLBACK_GBS
         roof = {
             "bound": "hbm",
             "kernel": eng.kernel_info(),
@@ -431,6 +658,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "measured_peak": measured_peak,
+            "measured_peak_source": ("live read / triad probe over 2 GiB float64 arrays: " + json.dumps(probe))
+            if probe else "tools/hbm_triad.py figure of this pool (live probe failed)",
+            "frac_of_measured_peak": achieved / measured_peak,
+            "pmc_stale": pmc_stale,
             "traffic": pmc.get("hbm_bytes_per_launch"),
             "traffic_unit": "bytes per launch (rocprofv3 PMC passes, " + pmc.get("source", "none for this shape") + ")",
             "algorithmic_bytes_per_launch": flips_per_launch * ALGO_BYTES_PER_FLIP,
@@ -477,12 +709,43 @@ def main():
             "roofline": roof,
         }
         assert int(n_walk) == total_walkers
-        eng.close()
-        if world == 1 and not args.no_other_configs:
-            try:
-                out["other_configs"] = time_other_configs(device)
-            except Exception as exc:  # the headline measurement must not be lost with it
-                out["other_configs"] = [{"error": f"{type(exc).__name__}: {exc}"[:300]}]
+    eng.close()
+    # Every rank takes part in the N-rank forms of configs 4 / 5 (rank 0 reports).  The headline
+    # line must survive whatever happens there: a rank that fails alone leaves the others inside a
+    # collective, so on N ranks a watchdog ends every rank after OTHER_CONFIGS_TIMEOUT_S, rank 0
+    # printing the line with what it has.
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(True)
+            print(json.dumps(out), flush=True)
+
+    def bail():
+        if rank == 0:
+            out.setdefault("other_configs", [{"error": "the N-rank configs 4/5 did not finish within "
+                                                       f"{OTHER_CONFIGS_TIMEOUT_S} s"}])
+        emit()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1:
+        import threading
+
+        watchdog = threading.Timer(OTHER_CONFIGS_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    other = None
+    if not args.no_other_configs:
+        try:
+            other = time_other_configs(device, rank, world, red_dev)
+        except Exception as exc:  # the headline measurement must not be lost with it
+            other = [{"error": f"rank {rank}: {type(exc).__name__}: {exc}"[:300]}]
+            if rank != 0:
+                sys.stderr.write(other[0]["error"] + "\n")
+    if rank == 0:
+        if other is not None:
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
@@ -490,10 +753,12 @@ def main():
             except Exception as exc:  # the GPU measurement must not be lost with it
                 out["cpu_baseline"] = {"value": None, "unit": "attempted flips/s", "cores": usable_cores(),
                                        "kind": "port", "sample": f"failed: {exc}"[:300]}
-        print(json.dumps(out))
+        emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

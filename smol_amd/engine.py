@@ -52,6 +52,24 @@ SYMBOLS = {
 }
 
 
+def source_digest():
+    """sha256 over the kernel sources (smol_amd/csrc/*.h, *.hip, Makefile and include/smolmc.h, by
+    sorted name): profiles/pmc_constants.json carries the digest of the build its counters were
+    collected on, and bench.py flags the constants as stale when the sources have moved on."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.hip")))
+    files += [os.path.join(src, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "smolmc.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def load_library(path=None):
     """Load libsmolmc_hip.so; raises RuntimeError when it has not been built."""
     global _LIB

@@ -131,6 +131,7 @@ class Processor:
         tab = capi.TableSet.from_synth(
             self.supercell, kw["ce_coefs_expansion"], feature_mode=kw["feature_mode"],
             ewald=kw.get("ewald"), ewald_coef=kw.get("ewald_coef", 1.0), mu_table=mu_table,
+            ewald_charges=kw.get("ewald_charges", "auto"),
         )
         if kw.get("ce_natural") is not None:
             tab._keep["ce_coefs"][:] = kw["ce_natural"]
@@ -279,8 +280,10 @@ class ClusterDecompositionProcessor(Processor):
 class EwaldProcessor(Processor):
     """Electrostatic feature (smol/moca/processor/ewald.py:26-203).
 
-    ``ewald_term`` is ``(ewald_inds, ewald_matrix)``; when None it is computed with the
-    build's own Ewald sum (smol_amd.ewald; values unpinned vs pymatgen)."""
+    ``ewald_term`` is ``(ewald_inds, ewald_matrix[, charges])``; when None it is computed with the
+    build's own Ewald sum (smol_amd.ewald; values unpinned vs pymatgen).  The optional
+    per-entry ``charges`` (length M) let the engine factorise the matrix (compact Ewald / potential
+    field); without them they are taken from the prim cell's oxidation states."""
 
     _scalar_feature = True
 
@@ -292,6 +295,8 @@ class EwaldProcessor(Processor):
             ewald_term = _ew.supercell_ewald(supercell)
         self._ewald_inds = np.ascontiguousarray(ewald_term[0], dtype=np.int32)
         self.ewald_matrix = np.ascontiguousarray(ewald_term[1], dtype=np.float64)
+        self._ewald_charges = (np.ascontiguousarray(ewald_term[2], dtype=np.float64)
+                               if len(ewald_term) > 2 and ewald_term[2] is not None else "auto")
         self._feature_slice = slice(supercell.model.num_orbits, supercell.model.num_orbits + 1)
 
     def _table_kwargs(self):
@@ -302,6 +307,7 @@ class EwaldProcessor(Processor):
             ce_natural=np.zeros(m.num_orbits),
             ewald=(self._ewald_inds, self.ewald_matrix),
             ewald_coef=float(self.coefs),
+            ewald_charges=self._ewald_charges,
         )
 
     def compute_property(self, occupancy):
@@ -341,6 +347,7 @@ class CompositeProcessor(Processor):
             ew = self._processors[1]
             kw["ewald"] = (ew._ewald_inds, ew.ewald_matrix)
             kw["ewald_coef"] = float(ew.coefs)
+            kw["ewald_charges"] = ew._ewald_charges
         return kw
 
 
@@ -410,8 +417,7 @@ class Ensemble:
         cell = ce.subspace.supercell(supercell_matrix)
         ewald_term = coef = None
         if ce.subspace.ewald_term is not None:
-            inds, mat, _ = ce.ewald_tables(cell)
-            ewald_term, coef = (inds, mat), float(ce.coefs[-1])
+            ewald_term, coef = ce.ewald_tables(cell), float(ce.coefs[-1])  # (inds, matrix, charges)
         return cls.from_cluster_expansion(cell, ce.ce_coefs, processor_type=processor_type,
                                           ewald_term=ewald_term, ewald_coefficient=coef, **kwargs)
 
@@ -1295,6 +1301,12 @@ class Sampler:
         if k0.bias is not None:
             h.update(np.ascontiguousarray(k0.bias._table).tobytes())
             h.update(repr((k0.bias.bias_type, k0.bias.penalty)).encode())
+            icpt = getattr(k0.bias, "intercepts", None)
+            if icpt is not None:
+                h.update(b"icpt" + np.ascontiguousarray(icpt, dtype=np.float64).tobytes())
+        for name in sorted(k0.usher_kwargs):  # flip table / weights / swap_weight are baked in too
+            v = k0.usher_kwargs[name]
+            h.update(name.encode() + (b"none" if v is None else np.ascontiguousarray(v, dtype=np.float64).tobytes()))
         return h.hexdigest(), self._device
 
     def _get_engine(self, device=None):
@@ -1457,9 +1469,12 @@ class Sampler:
         self._kept_last = False
         for block in self._sample_blocks(nsteps, None, thin_by, max_block=stream_chunk, state_loaded=True):
             self.samples.append_block(block, thinned_by=thin_by)
-            if backend is not None and self.samples.num_samples >= stream_chunk:
-                last = {k: v[-1:] for k, v in block.items()}
-                self.samples.flush_to_backend(backend)
+            if backend is not None:
+                # the most recent sample, whether or not this block fills a chunk: the tail flush
+                # below must leave the FINAL recorded sample behind, not the end of the last full chunk
+                last = {k: np.array(v[-1:]) for k, v in block.items()}
+                if self.samples.num_samples >= stream_chunk:
+                    self.samples.flush_to_backend(backend)
         if backend is not None:
             self.samples.flush_to_backend(backend)  # (the tail shorter than a chunk)
             backend.close()

@@ -27,9 +27,23 @@ def shard(total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-def _dist():
-    import torch.distributed as dist
+class _NoDist:
+    """torch is optional for single-GPU use (engine.load_library treats it the same way)."""
 
+    @staticmethod
+    def is_available():
+        return False
+
+    @staticmethod
+    def is_initialized():
+        return False
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return _NoDist
     return dist
 
 
@@ -171,34 +185,40 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
     """Alternate ``steps_between`` MC steps on every walker with one exchange attempt.
 
     ``engine`` is a smol_amd.engine.Engine holding this rank's ``rex.per_rank`` walkers.
-    Collective path (several ranks, or ``collective=True``): the enthalpies are exported
-    device-to-device into a torch tensor (smolmc_export_enthalpy_dev), all-gathered on RCCL
+    Collective path (several ranks, or ``collective=True``) on RCCL: the enthalpies are exported
+    device-to-device into a torch tensor (smolmc_export_enthalpy_dev), all-gathered
     without staging through the host, and the new temperatures go back through a device
     tensor (smolmc_import_temperature_dev); initialise torch.cuda / the process group BEFORE
-    creating the engine, as bench.py does.  Single rank (default): no collective is needed,
-    the enthalpies are read back directly and the temperatures uploaded with set_temperature.
-    Both paths take the same decisions (tests/test_gpu_device_plumbing.py)."""
+    creating the engine, as bench.py does.  Collective path on a CPU backend (gloo: the CPU
+    tests, ``bench.py --oversubscribe`` / ``--dry-run``): the same all-gather over host tensors.
+    Single rank (default): no collective is needed, the enthalpies are read back directly and
+    the temperatures uploaded with set_temperature.  All paths take the same decisions
+    (tests/test_gpu_device_plumbing.py, tests/test_parallel_gloo.py)."""
     dist = _dist()
     ready = dist.is_available() and dist.is_initialized()
     multi = ready and (rex.world > 1 if collective is None else bool(collective))
     if collective and not ready:
         raise RuntimeError("collective=True needs an initialised torch.distributed process group")
+    on_device = multi and (device is not None or collective_device() == "cuda")
     buf = tbuf = None
     if multi:
         import torch
-
+    if on_device:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         buf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
         tbuf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
     engine.set_temperature(rex.local_temperatures())
     for _ in range(n_exchanges):
         engine.run(steps_between)
-        if multi:
+        if on_device:
             engine.export_enthalpy(buf.data_ptr())
             new_t = rex.exchange(buf, force_collective=True)
             tbuf.copy_(torch.from_numpy(new_t))
             torch.cuda.current_stream().synchronize()
             engine.import_temperature(tbuf.data_ptr())
+        elif multi:
+            mine = torch.from_numpy(np.ascontiguousarray(engine.get_enthalpy(), dtype=np.float64))
+            engine.set_temperature(rex.exchange(mine, force_collective=True))
         else:
             rex.decide(engine.get_enthalpy())
             engine.set_temperature(rex.local_temperatures())

@@ -69,6 +69,10 @@ def neutral_rocksalt_occupancy(sc, first, count, seed=5):
 
 
 HEADLINE_T = 2500.0  # acceptance ~0.38 on the config-2 Hamiltonian (tuned once and frozen)
+# configs 3 and 5: temperature / chemical-potential scale (round 2 values; see tools/equil_sweep.py)
+CONFIG3_T, CONFIG3_MU = 3000.0, 0.5
+CONFIG5_T, CONFIG5_MU = (400.0, 2000.0), 0.5
+CONFIG9_T, CONFIG9_PENALTY = 3000.0, 0.05
 
 
 def config2(first=0, count=4096, dim=16, feature_mode=capi.FEATURES_INTERACTIONS, mc=10000):
@@ -104,16 +108,22 @@ def _rocksalt(dim, cutoffs=None, prim=None):
     return model, sc, ewald.supercell_ewald(sc)
 
 
-def config3(first=0, count=2048, dim=12, mc=2000):
+def _mu_rows(sc, scale):
+    mu = np.zeros((sc.num_sites, 3))
+    mu[: sc.size] = np.random.default_rng(7).uniform(-scale, scale, 3)[None, :]
+    return mu
+
+
+def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=None):
     """BASELINE configs[2]: ternary rocksalt dim^3, triplet CE + Ewald, semigrand flip."""
     model, sc, ew = _rocksalt(dim)
-    mu = np.zeros((sc.num_sites, 3))
-    mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
+    temperature = CONFIG3_T if temperature is None else temperature
+    mu = _mu_rows(sc, CONFIG3_MU if mu_scale is None else mu_scale)
     tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu)
     return Workload(
         3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip",
         sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_FLIP),
-        random_codes(sc, first, count, 3), _seeds(first, count, 777), 3000.0, 1, mc)
+        random_codes(sc, first, count, 3), _seeds(first, count, 777), temperature, 1, mc)
 
 
 def config4(first=0, count=1024, dim=16, mc=5000, h0=None):
@@ -134,22 +144,22 @@ def config4(first=0, count=1024, dim=16, mc=5000, h0=None):
         sc, tab, kw, occ, _seeds(first, count, 777), 0.0, 2, mc)
 
 
-def config5(first=0, count=2048, dim=12, mc=None, total=None):
+def config5(first=0, count=2048, dim=12, mc=None, total=None, t_lo=None, t_hi=None, mu_scale=None):
     """BASELINE configs[4]: config-3 lattice, charge-neutral TableFlip (3 Mn3+ <-> Li+ + 2 Ti4+)
     with a geometric replica-exchange ladder 400-2000 K over ``total`` walkers (this rank holds
     walkers first .. first+count)."""
     from . import parallel
 
     model, sc, ew = _rocksalt(dim)
-    mu = np.zeros((sc.num_sites, 3))
-    mu[: sc.size] = np.random.default_rng(7).uniform(-0.5, 0.5, 3)[None, :]
+    mu = _mu_rows(sc, CONFIG5_MU if mu_scale is None else mu_scale)
     tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1,
                                    mu_table=mu, flip_table=[[1, -3, 2]], swap_weight=0.1)
     total = total or count
-    ladder = parallel.geometric_ladder(400.0, 2000.0, total)
+    t_lo, t_hi = (CONFIG5_T[0] if t_lo is None else t_lo), (CONFIG5_T[1] if t_hi is None else t_hi)
+    ladder = parallel.geometric_ladder(t_lo, t_hi, total)
     return Workload(
         5, f"config5: ternary rocksalt {dim}^3 + Ewald, charge-neutral TableFlip, replica-exchange "
-           f"ladder 400-2000 K over {total} walkers",
+           f"ladder {t_lo:g}-{t_hi:g} K over {total} walkers",
         sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_TABLE_FLIP),
         neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777),
         ladder[first:first + count].copy(), 1, mc or sc.num_sites, extras=dict(ladder=ladder))
@@ -191,5 +201,29 @@ def config8(first=0, count=4096, dim=16, mc=2000):
         balanced_binary(sc, first, count, seed=1), _seeds(first, count, 777), 2500.0, 2, mc)
 
 
+def config9(first=0, count=2048, dim=12, mc=2000, temperature=None, penalty=None, mu_scale=None):
+    """(not in BASELINE.json) config 3 made well-posed: the same lattice, CE, Ewald term and
+    semigrand single flips, plus a SquareChargeBias (smol/moca/kernel/bias.py:229-287; the
+    reference's recipe for charge-neutral semigrand sampling with Flip steps,
+    docs/src/notebooks/running-charge-balanced-gcmc.ipynb) and a charge-neutral start.  Config 3
+    as specified has no mixed steady state: its Ewald energy without the charged-cell term is
+    concave in the net charge Q (-1.3e-3 eV Q^2 at coefficient 0.1), unconstrained flips run away
+    to a pure composition and the steady-state acceptance is ~1e-6 (profiles/r03_equil_sweep.jsonl)."""
+    model, sc, ew = _rocksalt(dim)
+    temperature = CONFIG9_T if temperature is None else temperature
+    mu = _mu_rows(sc, CONFIG3_MU if mu_scale is None else mu_scale)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu)
+    q = np.zeros((sc.num_sites, 3))
+    for s in range(sc.num_sites):
+        ch = model.prim.charges[sc.site_b[s]]
+        q[s, :len(ch)] = [c or 0.0 for c in ch]
+    tab.set_bias(capi.BIAS_SQUARE_CHARGE, q, CONFIG9_PENALTY if penalty is None else penalty)
+    return Workload(
+        9, f"config9: config 3 + SquareChargeBias (charge-neutral semigrand flips), ternary rocksalt {dim}^3 "
+           f"({sc.num_sites} sites), triplet CE + Ewald",
+        sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_FLIP),
+        neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777), temperature, 1, mc)
+
+
 BUILDERS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: config6, 7: config7,
-            8: config8}
+            8: config8, 9: config9}

@@ -27,6 +27,12 @@ def test_self_spawn_dry_run_weak_and_strong():
     rec = _line(out)
     assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["walkers_total"] == 8192 and rec["walkers_rank0"] == [0, 4096]
+    # configs 4 and 5 as N-rank workloads: independent shards / one ladder over all ranks with the
+    # exchange (host-staged all-gather here) inside the timed region
+    c4, c5 = rec["other_configs"]
+    assert c4["n_gpus"] == 2 and c4["replicas"] == 2048
+    assert c5["replicas"] == 4096 and c5["exchanges"] == 6 and c5["exchange_attempts"] > 0
+    assert c5["rungs_are_a_permutation"] and c5["ranks_agree"] and "all-gather over 2 ranks" in c5["exchange_path"]
     out = _run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--scaling", "strong"])
     assert out.returncode == 0, out.stderr
     rec = _line(out)

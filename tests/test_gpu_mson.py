@@ -136,6 +136,13 @@ def test_smol_shaped_api_on_the_imported_model(lno):
     cell = ens.processor.supercell
     occ = _neutral_occupancies(cell, nw, np.random.default_rng(2), n_li=cell.size // 2)
     sampler.run(400, occ, thin_by=20)  # (without a chemical potential the cell fills up with Li within ~1e3 steps)
+    # the Ensemble path hands the Ewald charges to the engine like MsonClusterExpansion.tables does:
+    # same (lean, compact-Ewald) kernel, not the general one
+    info = sampler._get_engine().kernel_info()
+    direct = Engine(ce.tables(np.diag([4, 4, 4]), flip_table=ft[:, :4]),
+                    capi.make_config(nw, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP))
+    assert info.startswith("lean") and info == direct.kernel_info(), (info, direct.kernel_info())
+    direct.close()
     c = sampler.samples
     occs = c.get_occupancies(flat=False)
     P = cell.size

@@ -216,3 +216,36 @@ def test_streaming_directory_round_trip(tmp_path):
     other = moca.Sampler.from_ensemble(ens, temperature=900.0, nwalkers=2, seeds=[1, 2]).samples
     with pytest.raises(RuntimeError):
         other.get_backend(str(path))
+
+
+def test_streamed_run_keeps_the_final_sample(tmp_path, monkeypatch):
+    """Sampler.run(stream_chunk, keep_last_chunk=True): the sample left in memory is the LAST one
+    recorded, also when the number of samples is not a multiple of the chunk (the tail flush) or
+    smaller than one chunk (the end of the last FULL chunk used to be kept, and nothing
+    at all for a run shorter than a chunk).  The device ring is replaced by numbered blocks."""
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=1))
+    F = len(ens.natural_parameters)
+
+    def fake_blocks(self, nsteps, initial_occupancies, thin_by, max_block=0, state_loaded=False):
+        nsamples, sid = nsteps // thin_by, 0
+        while sid < nsamples:
+            n = min(max_block or nsamples, nsamples - sid)
+            ids = np.arange(sid, sid + n, dtype=np.float64)
+            yield dict(occupancy=np.zeros((n, 2, sc.num_sites), np.uint8) + (ids.astype(np.uint8) % 2)[:, None, None],
+                       features=np.zeros((n, 2, F)), enthalpy=np.broadcast_to(ids[:, None, None], (n, 2, 1)).copy(),
+                       temperature=np.full((n, 2, 1), 900.0), accepted=np.ones((n, 2, 1), bool))
+            sid += n
+
+    monkeypatch.setattr(moca.Sampler, "_sample_blocks", fake_blocks)
+    monkeypatch.setattr(moca.Sampler, "_load_state", lambda self, occ: None)
+    for nsamples, chunk in ((11, 4), (3, 4), (8, 4)):
+        s = moca.Sampler.from_ensemble(ens, temperature=900.0, nwalkers=2, seeds=[1, 2])
+        s.run(nsamples * 10, np.zeros((2, sc.num_sites), np.int32), thin_by=10, stream_chunk=chunk,
+              stream_file=str(tmp_path / f"s{nsamples}"), keep_last_chunk=True)
+        assert s.samples.num_samples == 1
+        np.testing.assert_array_equal(s.samples.get_enthalpies(flat=False)[0, :, 0], nsamples - 1)
+        assert (s.samples.get_occupancies(flat=False)[0] == (nsamples - 1) % 2).all()
+        back = moca.SampleContainer.from_stream(str(tmp_path / f"s{nsamples}"), ens)
+        assert back.num_samples == nsamples

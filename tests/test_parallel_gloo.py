@@ -186,3 +186,62 @@ def test_sampler_shards_and_reduces_over_ranks():
         np.testing.assert_allclose(st["mean_enthalpy"], mean, rtol=1e-12)
         np.testing.assert_allclose(st["enthalpy_variance"], var, rtol=1e-10)
         np.testing.assert_allclose(st["acceptance"], accm, rtol=1e-12)
+
+
+class _StubEngine:
+    """What run_replica_exchange needs from an Engine, without a GPU: enthalpies that depend on
+    the walker's current temperature through a fixed per-walker offset (so that the exchange
+    decisions feed back into later ones, as they do in a real run)."""
+
+    def __init__(self, first, n, total):
+        self.offset = np.random.default_rng(17).normal(0.0, 0.3, total)[first:first + n]
+        self.T = np.full(n, 1000.0)
+        self.steps = 0
+
+    def set_temperature(self, t):
+        self.T = np.broadcast_to(np.asarray(t, dtype=np.float64), self.T.shape).copy()
+
+    def run(self, nsteps, sync=False):
+        self.steps += int(nsteps)
+
+    def get_enthalpy(self):
+        return self.offset - 2.0e3 / self.T + 1e-3 * self.steps
+
+
+def _rex_driver_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = 5
+        ladder = parallel.geometric_ladder(400.0, 2000.0, per * world)
+        rex = parallel.ReplicaExchange(ladder, per, rank, world, seed=3)
+        eng = _StubEngine(rank * per, per, per * world)
+        parallel.run_replica_exchange(eng, rex, 25, 100)  # host-staged all-gather (gloo) inside
+        q.put((rank, rex.rung_of.copy(), eng.T.copy(), eng.steps, rex.accepted.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_replica_exchange_two_ranks_equals_one_rank():
+    """The N-rank driver loop of config 5 (bench.py at world > 1): two ranks holding five walkers
+    each must walk the global ladder exactly as one rank holding all ten does."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rex_driver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ladder = parallel.geometric_ladder(400.0, 2000.0, 10)
+    rex1 = parallel.ReplicaExchange(ladder, 10, seed=3)
+    eng1 = _StubEngine(0, 10, 10)
+    parallel.run_replica_exchange(eng1, rex1, 25, 100)
+    (_, rung0, T0, steps0, acc0), (_, rung1, T1, steps1, acc1) = res
+    assert np.array_equal(rung0, rung1) and np.array_equal(rung0, rex1.rung_of)
+    assert np.array_equal(acc0, rex1.accepted) and rex1.accepted.sum() > 0
+    np.testing.assert_array_equal(np.concatenate([T0, T1]), eng1.T)
+    assert steps0 == steps1 == eng1.steps == 2500

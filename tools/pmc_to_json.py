@@ -16,6 +16,10 @@ import glob
 import json
 import os
 import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smol_amd.engine import source_digest  # noqa: E402
 
 
 def main():
@@ -52,7 +56,10 @@ def main():
         v, n = tot[c]
         return v / n
 
-    rec = {"source": a.source, "kernel": a.kernel, "waves_per_simd": waves_per_simd}
+    # the digest of the kernel sources these counters were collected on: bench.py compares it with
+    # the tree it runs from and prints "pmc_stale": true when they differ
+    rec = {"source": a.source, "kernel": a.kernel, "waves_per_simd": waves_per_simd,
+           "csrc_sha256": source_digest()}
     for c, k in (("SQ_INSTS_VALU", "valu_per_step"), ("SQ_INSTS_SALU", "salu_per_step"),
                  ("SQ_INSTS_LDS", "lds_per_step"), ("SQ_INSTS_VMEM_RD", "vmem_per_step")):
         if c in tot:
