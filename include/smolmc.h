@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 4
+#define SMOLMC_ABI_VERSION 5
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
@@ -215,6 +215,21 @@ int smolmc_get_bias(smolmc_handle *h, double *bias /*R*/);
 int smolmc_get_wl(smolmc_handle *h, double *entropy /*RxL*/, int64_t *histogram /*RxL*/,
                   int64_t *occurrences /*RxL*/, double *mean_features /*RxLxF*/,
                   double *mod_factor /*R*/);
+
+/* Restore of a kernel's auxiliary state in a fresh handle / process: the inverse of smolmc_get_wl
+ * (WangLandau._entropy, _histogram, _occurrences, _mean_features, _m, wanglandau.py:107-122, which
+ * set_aux_state resets, :290-300; the reference's SampleContainer carries an `aux_checkpoint`
+ * placeholder it never fills, sampler/container.py:89,539-541).  Arrays as smolmc_get_wl returns
+ * them; NULL = leave as it is.  Also what a host-side `mod_update` callable needs
+ * (wanglandau.py:100-105): download, apply, upload. */
+int smolmc_set_wl(smolmc_handle *h, const double *entropy /*RxL*/, const int64_t *histogram /*RxL*/,
+                  const int64_t *occurrences /*RxL*/, const double *mean_features /*RxLxF*/,
+                  const double *mod_factor /*R*/);
+/* Step / accept counters of every walker.  n_steps is the walker's position in its random stream
+ * (Philox counter) and, for Wang-Landau, the step counter the check period refers to
+ * (WangLandau._steps_counter): with smolmc_set_state(reset_aux = 0) + these two calls a run resumes
+ * bit-for-bit in another process.  NULL = leave as it is. */
+int smolmc_set_counters(smolmc_handle *h, const uint64_t *n_steps /*R*/, const uint64_t *n_accepted /*R*/);
 
 /* ---- the hot path -------------------------------------------------------- */
 /* Advance every walker nsteps MC steps: the body of Sampler.sample

@@ -1,4 +1,6 @@
 // engine.hip -- C-ABI (include/smolmc.h), host-side table preparation and the evaluation kernels.
+#include <array>
+
 #include "smolmc_common.h"
 
 thread_local std::string smolmc_g_err;
@@ -712,6 +714,95 @@ static int build_ref_tables(smolmc_handle *h, const smolmc_tables *t) {
 }
 
 // Check M[a][b] == q_a q_b G[site_a][site_b] (a, b on different sites) and build G.
+// Translation-compressed site kernel.  On a supercell of a periodic lattice the site
+// kernel G[s][j] of the compact Ewald form depends on the sublattices of s and j and on the lattice
+// translation between them only (smol/utils/cluster/ewald.pyx:38-58 reads the same numbers N times
+// over).  When the changeable sites come as contiguous blocks of P = `size` sites in the
+// lexicographic order of the translation coordinates of a d1 x d2 x d3 supercell -- the order of
+// pymatgen's lattice_points_in_supercell (and smol_amd.synth) for diagonal supercell matrices; no
+// coordinates travel through the C ABI, the structure is found and then VERIFIED on every entry of
+// G -- one table per block pair over the coordinate differences -(d-1) .. d-1 replaces the rows in the
+// potential-field updates (field_sweep_gx, smolmc_common.h): entry (s, j) at byte E8[j] + S8[s].
+// Anything else (non-diagonal supercells, other site orders) keeps the rows of G.
+static int compress_ewald_rows(smolmc_handle *h, const smolmc_tables *t, const std::vector<double> &Gact,
+                               const std::vector<int> &act) {
+    const size_t na = act.size();
+    const int P = t->size;
+    if (getenv("SMOLMC_NO_EWALD_GX") != nullptr || P <= 1 || na == 0 || na % (size_t)P != 0) return 0;
+    const int nbk = (int)(na / (size_t)P);
+    for (size_t j = 0; j < na; ++j)
+        if (act[j] != act[0] + (int)j) return 0; // (the field mode needs contiguous changeable sites anyway)
+    auto Gat = [&](size_t js, size_t j) { return Gact[(size_t)act[js] * na + j]; };
+    double gmax = 0.0;
+    for (size_t js = 0; js < na; ++js)
+        for (size_t j = 0; j < na; ++j) gmax = std::max(gmax, std::fabs(Gat(js, j)));
+    const double tol = 1e-12 * std::max(gmax, 1e-300);
+    // entry (block k, translation t) x (block k2, translation t2) against row "translation 0" of
+    // block k at the wrapped coordinate difference
+    auto rows_match = [&](const int d[3], int k, int tt) {
+        const int x = tt / (d[1] * d[2]), y = (tt / d[2]) % d[1], z = tt % d[2];
+        for (int k2 = 0; k2 < nbk; ++k2)
+            for (int t2 = 0; t2 < P; ++t2) {
+                const int x2 = t2 / (d[1] * d[2]), y2 = (t2 / d[2]) % d[1], z2 = t2 % d[2];
+                const int rel = (((x2 - x + d[0]) % d[0]) * d[1] + (y2 - y + d[1]) % d[1]) * d[2] + (z2 - z + d[2]) % d[2];
+                if (std::fabs(Gat((size_t)k * P + tt, (size_t)k2 * P + t2) - Gat((size_t)k * P, (size_t)k2 * P + rel)) > tol)
+                    return false;
+            }
+        return true;
+    };
+    // factorisations d1 d2 d3 = P, the most balanced first; a few rows screen a candidate, then
+    // every row confirms it
+    std::vector<std::array<int, 3>> cand;
+    for (int a = 1; a <= P; ++a)
+        if (P % a == 0)
+            for (int b = 1; b <= P / a; ++b)
+                if ((P / a) % b == 0) cand.push_back({a, b, P / a / b});
+    std::sort(cand.begin(), cand.end(), [](const std::array<int, 3> &u, const std::array<int, 3> &v) {
+        auto spread = [](const std::array<int, 3> &w) { return std::max({w[0], w[1], w[2]}) - std::min({w[0], w[1], w[2]}); };
+        return spread(u) < spread(v);
+    });
+    int d[3] = {0, 0, 0};
+    bool found = false;
+    for (const auto &c : cand) {
+        const int dd[3] = {c[0], c[1], c[2]};
+        bool ok = true;
+        for (int probe : {1, P / 2 + 1, P - 1, (int)((2654435761u % (unsigned)P))})
+            if (ok && probe > 0 && probe < P) ok = rows_match(dd, nbk - 1, probe);
+        for (int k = 0; ok && k < nbk; ++k)
+            for (int tt = 0; ok && tt < P; ++tt) ok = rows_match(dd, k, tt);
+        if (ok) { d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2]; found = true; break; }
+    }
+    if (!found) return 0;
+    const int e[3] = {2 * d[0] - 1, 2 * d[1] - 1, 2 * d[2] - 1};
+    const size_t EXT = (size_t)e[0] * e[1] * e[2];
+    if ((size_t)nbk * nbk * EXT * 8 >= ((size_t)1 << 31)) return 0; // 32-bit byte offsets
+    std::vector<double> gx((size_t)nbk * nbk * EXT);
+    for (int k = 0; k < nbk; ++k)
+        for (int k2 = 0; k2 < nbk; ++k2)
+            for (int a = 0; a < e[0]; ++a)
+                for (int b = 0; b < e[1]; ++b)
+                    for (int c = 0; c < e[2]; ++c) {
+                        const int rel = (((a - (d[0] - 1) + d[0]) % d[0]) * d[1] + (b - (d[1] - 1) + d[1]) % d[1]) * d[2] +
+                                        (c - (d[2] - 1) + d[2]) % d[2];
+                        gx[((size_t)k * nbk + k2) * EXT + ((size_t)a * e[1] + b) * e[2] + c] = Gat((size_t)k * P, (size_t)k2 * P + rel);
+                    }
+    const size_t center = ((size_t)(d[0] - 1) * e[1] + (d[1] - 1)) * e[2] + (d[2] - 1);
+    std::vector<uint32_t> E8(na), S8(na);
+    for (int k = 0; k < nbk; ++k)
+        for (int tt = 0; tt < P; ++tt) {
+            const int x = tt / (d[1] * d[2]), y = (tt / d[2]) % d[1], z = tt % d[2];
+            const size_t E = ((size_t)x * e[1] + y) * e[2] + z;
+            E8[(size_t)k * P + tt] = (uint32_t)(8 * ((size_t)k * EXT + E));
+            S8[(size_t)k * P + tt] = (uint32_t)(8 * ((size_t)k * nbk * EXT + center - E));
+        }
+    TRY(dev_upload(h, gx.data(), gx.size(), &h->kp.ew_gx));
+    TRY(dev_upload(h, E8.data(), E8.size(), &h->kp.ew_E8));
+    TRY(dev_upload(h, S8.data(), S8.size(), &h->kp.ew_S8));
+    h->ew_gx_dims[0] = d[0]; h->ew_gx_dims[1] = d[1]; h->ew_gx_dims[2] = d[2];
+    h->ew_gx_blocks = nbk;
+    return 0;
+}
+
 static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
     const int N = t->num_sites, W = t->ewald_width;
     const size_t M = (size_t)t->ewald_dim;
@@ -780,6 +871,7 @@ static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
     for (size_t j = 0; j < na; ++j)
         if (act[j] != act[0] + (int)j) h->kp.ew_act_base = -1;
     G.swap(Gact);
+    TRY(compress_ewald_rows(h, t, G, act));
     TRY(dev_upload(h, G.data(), G.size(), &h->kp.ew_G));
     TRY(dev_upload(h, qs.data(), qs.size(), &h->kp.ew_qs));
     TRY(dev_upload(h, dg.data(), dg.size(), &h->kp.ew_dg));
@@ -985,7 +1077,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
         bool lean = h->lean_tables && h->F <= 64 &&
-                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 && h->F <= 63 && // (cell 63 of the feature scratch is the kernel's zero)
+                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
                              getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
                     h->lean_nslot <= 4 && getenv("SMOLMC_FORCE_GENERAL") == nullptr;
@@ -1069,6 +1161,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.ew_dg = kp.ew_dg;
                 lp.ew_frozen = kp.ew_frozen;
                 lp.ew_coef = kp.ew_coef;
+                lp.ew_gx = kp.ew_gx; lp.ew_E8 = kp.ew_E8; lp.ew_S8 = kp.ew_S8;
             }
             if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
                 if (dev_upload(h, t->flip_table, (size_t)t->n_flip_vectors * nc, &lp.tf_table) ||
@@ -1087,8 +1180,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
                 lp.wl.sum_mode = 1;
             }
+            // (Wang-Landau: per-bin records and the cached rows of per-bin feature sums, mc_wl.h)
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
-                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 24 : 0));
+                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 24 + (size_t)SMOLMC_WL_ROWS * h->F * 8 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
             // Ewald potential field in LDS when the changeable sites are the active
             // sublattice and it fits beside the occupancies
@@ -1300,6 +1394,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 if (t->has_ewald) {
                     lp.ew_W = kp.ew_W; lp.ew_nact = kp.ew_nact; lp.ew_act_base = kp.ew_act_base;
                     lp.ew_G = kp.ew_G; lp.ew_coef = kp.ew_coef; lp.ew_phi = kp.ew_phi;
+                    lp.ew_gx = kp.ew_gx; lp.ew_E8 = kp.ew_E8; lp.ew_S8 = kp.ew_S8;
                     lp.ew_field = phi_lds ? 1 : 2;
                     lp.sbase = kp.ew_act_base; // field_apply indexes phi relative to it
                 }
@@ -1519,6 +1614,14 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     else
         snprintf(buf, (size_t)n, "general nslot=%d mm=%d field=%d lds=%zu", h->nslot, h->mm, h->kp.ew_field,
                  h->lds_bytes);
+    {   // suffixes: the translation-compressed Ewald kernel in use, the Wang-Landau kernel generation
+        const size_t used = strlen(buf);
+        if (h->lean && h->lp.ew_field && h->lp.ew_gx && used + 40 < (size_t)n)
+            snprintf(buf + used, (size_t)n - used, " gx=%dx%dx%dx%d", h->ew_gx_blocks, h->ew_gx_dims[0], h->ew_gx_dims[1],
+                     h->ew_gx_dims[2]);
+        else if (h->lean && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && used + 8 < (size_t)n)
+            snprintf(buf + used, (size_t)n - used, getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3");
+    }
     return 0;
 }
 
@@ -1588,6 +1691,44 @@ extern "C" int smolmc_get_wl(smolmc_handle *h, double *entropy, int64_t *histogr
     return 0;
 }
 
+extern "C" int smolmc_set_wl(smolmc_handle *h, const double *entropy, const int64_t *histogram,
+                             const int64_t *occurrences, const double *mean_features, const double *mod_factor) {
+    if (!h) return fail("null handle");
+    if (h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU) return fail("handle is not a Wang-Landau kernel");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t RL = (size_t)h->R * h->L;
+    KParams &kp = h->kp;
+    // occurrences and mean features belong together: bring the device copy to running MEANS (what
+    // the caller holds) before either is replaced
+    TRY(wl_set_representation(h, false));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (mod_factor)
+        for (int r = 0; r < h->R; ++r)
+            if (!(mod_factor[r] > 0)) return fail("mod_factor must be greater than 0.");
+    if (entropy) HIPCHK(hipMemcpy(kp.wl_entropy, entropy, RL * 8, hipMemcpyHostToDevice));
+    if (histogram) HIPCHK(hipMemcpy(kp.wl_hist, histogram, RL * 8, hipMemcpyHostToDevice));
+    if (occurrences) HIPCHK(hipMemcpy(kp.wl_occur, occurrences, RL * 8, hipMemcpyHostToDevice));
+    if (mean_features) HIPCHK(hipMemcpy(kp.wl_meanf, mean_features, RL * h->F * 8, hipMemcpyHostToDevice));
+    if (mod_factor) HIPCHK(hipMemcpy(kp.wl_m, mod_factor, (size_t)h->R * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int smolmc_set_counters(smolmc_handle *h, const uint64_t *n_steps, const uint64_t *n_accepted) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    KParams &kp = h->kp;
+    const size_t R = (size_t)h->R;
+    if (n_steps) {
+        HIPCHK(hipMemcpy(kp.nsteps, n_steps, R * 8, hipMemcpyHostToDevice));
+        if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU) // the check period counts the same steps
+            HIPCHK(hipMemcpy(kp.wl_counter, n_steps, R * 8, hipMemcpyHostToDevice));
+    }
+    if (n_accepted) HIPCHK(hipMemcpy(kp.nacc, n_accepted, R * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
 // ---- kernel dispatch (instantiations live in general_n*.hip / lean_n*.hip) --------------
 static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
     switch (h->nslot) {
@@ -1609,6 +1750,11 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     if (lp.bias_type && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP)
         return h->lean_nslot == 2 ? smolmc_launch_lean_bias_2(h, lp) : smolmc_launch_lean_bias_4(h, lp);
     if (h->lean_kf) return h->lean_nslot == 2 ? smolmc_launch_lean_corr_2(h, lp) : smolmc_launch_lean_corr_4(h, lp);
+    // Wang-Landau: the dedicated kernel (mc_wl.h); SMOLMC_WL_V2 keeps round 2's variant of
+    // mc_lean_kernel reachable for A/B runs
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP &&
+        getenv("SMOLMC_WL_V2") == nullptr)
+        return h->lean_nslot == 2 ? smolmc_launch_wl_2(h, lp) : smolmc_launch_wl_4(h, lp);
     return h->lean_nslot == 2 ? smolmc_launch_lean_2(h, lp) : smolmc_launch_lean_4(h, lp);
 }
 

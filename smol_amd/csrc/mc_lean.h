@@ -109,15 +109,68 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
 // changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous); the own entry
 // is left as it was (phi excludes the self term): it is saved here and put back after the sweep.
 __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
-#ifdef SMOLMC_EXP_GROW0 // timing experiment only (wrong results): every row read hits the same 14 KB
-    const double *g = P.ew_G + (size_t)(s & 1) * P.ew_nact;
-#else
-    const double *g = P.ew_G + (size_t)s * P.ew_nact;
-#endif
     const int js = s - P.sbase;
     const double keep = phi[js];
-    field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
+    // (the compressed tables' pointers are re-read from the kernel arguments: see rare_params)
+    const LeanParamsKernarg Q = rare_params();
+    const unsigned char *gx = (const unsigned char *)Q->ew_gx;
+    if (gx != nullptr) {
+        const uint32_t *E8 = Q->ew_E8;
+        const uint32_t sa = Q->ew_S8[js];
+        field_sweep_gx<false>(phi, E8, gx, lane, P.ew_nact, sa, sa, dq, 0.0);
+    } else {
+        const double *g = P.ew_G + (size_t)s * P.ew_nact;
+        field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
+    }
     phi[js] = keep; // (every lane stores the same value)
+}
+
+// the flips of an accepted TableFlip step (lane f of vsite / vdq: site and charge change of flip f):
+// with the translation-compressed kernel all of them in one pass over phi (up to four at a time),
+// else one sweep per flip
+__device__ __forceinline__ void field_apply_flips(const LeanParams &P, double *phi, int lane, int nfl, int vsite,
+                                                  double vdq) {
+    const LeanParamsKernarg Q = rare_params();
+    const unsigned char *gx = (const unsigned char *)Q->ew_gx;
+    auto site_of = [&](int f) { return (int)rdlane((uint32_t)vsite, f); };
+    auto dq_of = [&](int f) {
+        return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f), (int)rdlane((uint32_t)__double2loint(vdq), f));
+    };
+    if (gx == nullptr) {
+        for (int f = 0; f < nfl; ++f) {
+            const double dqf = dq_of(f);
+            if (dqf != 0.0) field_apply(P, phi, lane, site_of(f), dqf);
+        }
+        return;
+    }
+    const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
+    const int sb = P.sbase, na = P.ew_nact;
+    for (int f0 = 0; f0 < nfl; f0 += 4) {
+        const int n = min(4, nfl - f0);
+        uint32_t s8[4];
+        double dq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // (flips beyond n repeat flip f0 with a zero charge change)
+            const int f = k < n ? f0 + k : f0;
+            s8[k] = S8[site_of(f) - sb];
+            dq[k] = k < n ? dq_of(f) : 0.0;
+        }
+        if (n == 1) {
+            const uint32_t a[1] = {s8[0]};
+            const double d[1] = {dq[0]};
+            field_sweep_gx_multi<1>(phi, E8, gx, lane, na, a, d);
+        } else if (n == 2) {
+            const uint32_t a[2] = {s8[0], s8[1]};
+            const double d[2] = {dq[0], dq[1]};
+            field_sweep_gx_multi<2>(phi, E8, gx, lane, na, a, d);
+        } else if (n == 3) {
+            const uint32_t a[3] = {s8[0], s8[1], s8[2]};
+            const double d[3] = {dq[0], dq[1], dq[2]};
+            field_sweep_gx_multi<3>(phi, E8, gx, lane, na, a, d);
+        } else {
+            field_sweep_gx_multi<4>(phi, E8, gx, lane, na, s8, dq);
+        }
+    }
 }
 
 // both flips of a swap in one pass over phi (one read-modify-write per entry instead of two)
@@ -129,7 +182,14 @@ __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, i
     // after the sweep from the values saved here
     const double keep1 = phi[j1], keep2 = phi[j2];
     const double c12 = g2[j1], c21 = g1[j2]; // cross terms G[s2][s1], G[s1][s2]
-    field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
+    const LeanParamsKernarg Q = rare_params();
+    const unsigned char *gx = (const unsigned char *)Q->ew_gx;
+    if (gx != nullptr) {
+        const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
+        field_sweep_gx<true>(phi, E8, gx, lane, P.ew_nact, S8[j1], S8[j2], dq1, dq2);
+    } else {
+        field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
+    }
     if (j1 != j2) {
         phi[j1] = fma(dq2, c12, keep1);
         phi[j2] = fma(dq1, c21, keep2);
@@ -1135,6 +1195,19 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
         return m;
     };
+    // lane idx (< 2 tf_n): the enriched species of direction idx in the order the assignment draws
+    // them (species ascending, u_c entries each; mcusher.py:627-631) as packed nibbles -- up to
+    // SMOLMC_MAX_STEP_FLIPS = 8 of them
+    uint32_t venr = 0;
+    if (lane < 2 * P.tf_n) {
+        const int sgn = (lane & 1) ? -1 : 1;
+        int k = 0;
+        for (int c = 0; c < P.ncodes; ++c) {
+            const int u = sgn * s_tf[(lane >> 1) * P.ncodes + c];
+            for (int z = 0; z < u && k < 8; ++z, ++k) venr |= (uint32_t)c << (4 * k);
+        }
+    }
+    const uint32_t lane4 = (uint32_t)(lane & 7) * 4u;
     const double vw = lane < 2 * P.tf_n ? s_tfw[lane] : 0.0; // lane idx: weight of direction idx
     auto weight_of = [&](const int idx) -> double {
         return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vw), idx),
@@ -1396,57 +1469,34 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #endif
                 const int g32 = (int)(step & 1ull) * 32;      // first lane of this step's candidates
                 const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
-                // Lane-parallel picks: per depleted species one ballot gives the candidates of that
-                // species at or after the running stream position, v_mbcnt their rank in stream
-                // order; the first `need` of them are the picks, and the position behind the last
-                // one (one more ballot) is where the next species starts.  The picked candidates
-                // are then compacted into lanes 0 .. ncol-1 (species-major, stream order) through
-                // the feature scratch in LDS.  (The scalar form -- ffs, readlane, compare and
-                // select per pick -- spent most of its time waiting between the scalar and the
-                // vector unit: ~1250 of a step's ~7000 cycles.)
+                // Picks on the scalar unit: per depleted species one ballot gives the candidates of
+                // that species at or after the running stream position; each pick is the lowest
+                // set bit (s_ff1), its site one v_readlane, and it goes straight into lane ncol of
+                // the lane-indexed pick registers -- a table step picks 1 .. 8 sites,
+                // typically 3.  (The lane-parallel form of round 2 -- ranks by v_mbcnt, compaction
+                // through LDS, DPP duplicate check -- cost two LDS round trips and ~150
+                // instructions for the same three picks.)  A site the stream names twice (choice
+                // without replacement) or a block that runs out sends the step to the full scan.
                 uint32_t fpos = 0; // next stream position (kept across species)
                 bool ok = true;
-                int vdst = -1;      // lane t: destination lane of candidate t if it is picked
                 uint32_t dep = (uint32_t)__ballot(vu < 0) & ((1u << nc) - 1u); // depleted species
                 while (dep != 0u && ok) {
                     const int c = __ffs((int)dep) - 1;
                     dep &= dep - 1u;
-                    const int need = -(int)rdlane((uint32_t)vu, c);
+                    int need = -(int)rdlane((uint32_t)vu, c);
                     uint32_t m = (uint32_t)(__ballot(cvl == c) >> g32); // bit t: candidate t has species c
                     m = fpos < 32u ? (m >> fpos) << fpos : 0u;
-                    if (__popc(m) < need) { ok = false; break; }
-                    const unsigned long long m64 = (unsigned long long)m << g32;
-                    const int rnk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
-                    const bool mine = ((m64 >> lane) & 1ull) != 0ull && rnk < need;
-                    if (mine) vdst = ncol + rnk;
-                    if (lane >= ncol && lane < ncol + need) vcsp = c;
-                    const unsigned long long lastm = __ballot(mine && rnk == need - 1);
-                    fpos = (uint32_t)(__ffsll((long long)lastm) - 1 - g32) + 1u;
-                    ncol += need;
-                }
-                if (ok) {
-                    int *scr = (int *)s_feat; // (64 doubles of per-wave scratch, free between sample rows)
-                    if (vdst >= 0) scr[vdst] = cb_site;
-                    vcol = scr[lane];
-                    // choice without replacement: the stream may name a site twice (then the second
-                    // occurrence must be skipped and one more candidate taken); rare -- p ~ ncol^2 /
-                    // (2 n) -- so a repeated site among the picks sends the step to the sequential scan
-                    bool dup = false;
-#define SMOLMC_DUP_SHIFT(D, CTRL)                                                                  \
-    if (ncol > D) {                                                                                \
-        const int other = __builtin_amdgcn_update_dpp(0, vcol, CTRL, 0xf, 0xf, false);             \
-        dup |= lane >= D && lane < ncol && vcol == other;                                          \
-    }
-                    SMOLMC_DUP_SHIFT(1, 0x111) // row_shr:1 .. 7 (ncol <= 8 picks sit in one row of 16 lanes)
-                    SMOLMC_DUP_SHIFT(2, 0x112)
-                    SMOLMC_DUP_SHIFT(3, 0x113)
-                    SMOLMC_DUP_SHIFT(4, 0x114)
-                    SMOLMC_DUP_SHIFT(5, 0x115)
-                    SMOLMC_DUP_SHIFT(6, 0x116)
-                    SMOLMC_DUP_SHIFT(7, 0x117)
-#undef SMOLMC_DUP_SHIFT
-                    if (ncol > 8 || __ballot(dup) != 0ull) ok = false;
+                    if (__popc(m) < need || ncol + need > 8) { ok = false; break; }
+                    do {
+                        const int t = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const int site = (int)rdlane((uint32_t)cb_site, g32 + t);
+                        if ((__ballot(vcol == site) & ((1ull << ncol) - 1ull)) != 0ull) { ok = false; break; }
+                        vcol = lane == ncol ? site : vcol; // (v_writelane needs its lane select in M0 here: a compare + select is as cheap)
+                        vcsp = lane == ncol ? c : vcsp;
+                        ncol++;
+                        fpos = (uint32_t)t + 1u;
+                    } while (--need > 0);
                 }
 #ifdef SMOLMC_EXP_PHASES
                 { const long long tn = clock64(); ph2[1] += tn - ph_t; ph_t = tn; }
@@ -1517,30 +1567,25 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             nfl = ncol;
             fetch_rows();
             {
-                const uint32_t w4[4] = {rdlane(W0, l4 + 2), rdlane(W1, l4 + 2), rdlane(W2, l4 + 2), rdlane(W3, l4 + 2)};
-                uint32_t avail = ncol >= 32 ? 0xffffffffu : (1u << ncol) - 1u;
-                int qdraw = 0, left = ncol;
-                for (int c = 0; c < nc; ++c) {
-                    const int u = (int)rdlane((uint32_t)vu, c);
-                    for (int k = 0; k < u; ++k) {
-                        uint32_t word;
-                        if (qdraw < 4) {
-                            word = qdraw == 0 ? w4[0] : qdraw == 1 ? w4[1] : qdraw == 2 ? w4[2] : w4[3];
-                        } else {
-                            const int wl = l4 + 2 + (qdraw >> 2);
-                            const int wj = qdraw & 3;
-                            word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
-                        }
-                        qdraw++;
-                        const int rr = (int)__umulhi(word, (uint32_t)left);
-                        uint32_t m = avail;
-                        for (int z = 0; z < rr; ++z) m &= m - 1u; // drop the rr lowest available picks
-                        const int pj = __ffs((int)m) - 1;
-                        avail &= ~(1u << pj);
-                        left--;
-                        if (lane == pj) vnew = c;
-                    }
+                // k-th draw: the rr-th pick still available gets the k-th enriched species of the
+                // direction (venr); all on the scalar unit, the new species of pick p collected as
+                // nibble p of one word
+                const uint32_t enr = rdlane(venr, dir);
+                uint32_t avail = (1u << ncol) - 1u, newpack = 0u;
+                uint32_t left = (uint32_t)ncol;
+                for (int k = 0; k < ncol; ++k) {
+                    const int wl = l4 + 2 + (k >> 2);
+                    const int wj = k & 3;
+                    const uint32_t word = rdlane(wj == 0 ? W0 : wj == 1 ? W1 : wj == 2 ? W2 : W3, wl);
+                    const int rr = (int)__umulhi(word, left);
+                    uint32_t m = avail;
+                    for (int z = 0; z < rr; ++z) m &= m - 1u; // drop the rr lowest available picks
+                    const int pj = __ffs((int)m) - 1;
+                    avail &= ~(1u << pj);
+                    left--;
+                    newpack |= ((enr >> (4 * k)) & 15u) << (4 * pj);
                 }
+                vnew = (int)((newpack >> lane4) & 15u);
             }
         }
 
@@ -1682,12 +1727,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
             if (dir >= 0) head_valid = false;
-            if (ew_field)
-                for (int f = 0; f < nfl; ++f) {
-                    const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
-                                                        (int)rdlane((uint32_t)__double2loint(vdq), f));
-                    if (dqf != 0.0) field_apply(P, phi, lane, (int)rdlane((uint32_t)vsite, f), dqf);
-                }
+            if (ew_field) field_apply_flips(P, phi, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;

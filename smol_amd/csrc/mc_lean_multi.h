@@ -1036,15 +1036,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         if (accepted) {
             vcnt += vu;
             if (dir >= 0) head_valid = false;
-            if (has_ew)
-                for (int f = 0; f < nfl; ++f) {
-                    const double dqf = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f),
-                                                        (int)rdlane((uint32_t)__double2loint(vdq), f));
-                    if (dqf == 0.0) continue;
-                    const int sf = (int)rdlane((uint32_t)vsite, f);
-                    if (phi_lds) field_apply(P, phi, lane, sf, dqf);
-                    else field_apply(P, P.ew_phi + (size_t)r * P.ew_nact, lane, sf, dqf);
-                }
+            if (has_ew) field_apply_flips(P, phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             nacc_add++;

@@ -98,6 +98,9 @@ struct KParams {
     // over the changeable sites (contiguous, ew_act_base >= 0); see DESIGN 4.4
     int ew_field;
     double *ew_phi;               // [R][ew_nact]
+    // translation-compressed site kernel (null: none), see field_sweep_gx
+    const double *ew_gx;
+    const uint32_t *ew_E8, *ew_S8; // [ew_nact] byte offsets: entry of (s, j) at E8[j] + S8[s]
     const double *mu;             // [N][mu_W]
     // MCBias (smol/moca/kernel/bias.py): table [N][bias_W], running bias / net charge [R]
     int bias_type, bias_W;
@@ -263,6 +266,117 @@ __device__ __forceinline__ void field_sweep(double *phi, const double *ga, const
     }
 }
 
+// The same sweep from the TRANSLATION-COMPRESSED site kernel (engine.hip, compress_ewald_rows): on a
+// supercell of a periodic lattice G[s][j] depends on the sublattices of s and j and on the
+// translation between them only, so one table per sublattice pair, extended over the differences
+// -(d-1) .. d-1 of each translation coordinate (no modular arithmetic), replaces the N rows:
+// the entry of (s, j) sits at byte E8[j] + S8[s] of gx.  For BASELINE config 3 that is 97 KB shared
+// by every walker (L2-resident) instead of a 13.8 KB row of a 48 MB matrix per accepted flip.
+template <int U, bool TWO>
+__device__ __forceinline__ void field_sweep_gx_batch(double *phi, const uint32_t *E8, const unsigned char *gx,
+                                                     int lane, int g0, int gdone, uint32_t sa, uint32_t sb,
+                                                     double dq1, double dq2) {
+    const int j = g0 * 64 + lane;
+    const uint32_t *pe = E8 + j;
+    double *pp = phi + j;
+    uint32_t e[U];
+    double va[U], vb[U], pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        va[u] = *(const double *)(gx + (size_t)(e[u] + sa));
+        if (TWO) vb[u] = *(const double *)(gx + (size_t)(e[u] + sb));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool fresh = g0 + u >= gdone; // wave-uniform
+        double v = fma(fresh ? dq1 : 0.0, va[u], pv[u]);
+        if (TWO) v = fma(fresh ? dq2 : 0.0, vb[u], v);
+        pp[64 * u] = v;
+    }
+}
+
+template <bool TWO, int UB = 0>
+__device__ __forceinline__ void field_sweep_gx(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
+                                               int na, uint32_t sa, uint32_t sb, double dq1, double dq2) {
+    constexpr int U = UB ? UB : (TWO ? 6 : 9);
+    const int ngf = na >> 6; // full groups of 64 entries
+    int g = 0;
+    if (ngf >= U) {
+        do {
+            const int g0 = min(g, ngf - U);
+            field_sweep_gx_batch<U, TWO>(phi, E8, gx, lane, g0, g, sa, sb, dq1, dq2);
+            g = g0 + U;
+        } while (g < ngf);
+    }
+    for (; g + 4 <= ngf; g += 4) field_sweep_gx_batch<4, TWO>(phi, E8, gx, lane, g, g, sa, sb, dq1, dq2);
+    for (; g < ngf; ++g) field_sweep_gx_batch<1, TWO>(phi, E8, gx, lane, g, g, sa, sb, dq1, dq2);
+    const int j = ngf * 64 + lane;
+    if (j < na) { // ragged tail
+        const uint32_t e = E8[j];
+        double v = fma(dq1, *(const double *)(gx + (size_t)(e + sa)), phi[j]);
+        if (TWO) v = fma(dq2, *(const double *)(gx + (size_t)(e + sb)), v);
+        phi[j] = v;
+    }
+}
+
+// Several flips of one accepted step (TableFlip: up to SMOLMC_MAX_STEP_FLIPS) in ONE pass over phi:
+// every entry gains sum_f dq[f] * G[s_f][j] -- NF gathers from the compressed tables, one
+// read-modify-write of phi -- instead of one full sweep per flip.  (G[s][s] == 0 by construction:
+// the entry of a flipped site sees the other flips of the step and not its own.)
+template <int U, int NF>
+__device__ __forceinline__ void field_sweep_gx_multi_batch(double *phi, const uint32_t *E8, const unsigned char *gx,
+                                                           int lane, int g0, int gdone, const uint32_t (&s8)[NF],
+                                                           const double (&dq)[NF]) {
+    const int j = g0 * 64 + lane;
+    const uint32_t *pe = E8 + j;
+    double *pp = phi + j;
+    uint32_t e[U];
+    double v[U][NF], pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[u][f] = *(const double *)(gx + (size_t)(e[u] + s8[f]));
+#pragma unroll
+    for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool fresh = g0 + u >= gdone; // wave-uniform
+        double x = pv[u];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x = fma(fresh ? dq[f] : 0.0, v[u][f], x);
+        pp[64 * u] = x;
+    }
+}
+template <int NF>
+__device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
+                                                     int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
+    constexpr int U = NF <= 2 ? 6 : 4;
+    const int ngf = na >> 6;
+    int g = 0;
+    if (ngf >= U) {
+        do {
+            const int g0 = min(g, ngf - U);
+            field_sweep_gx_multi_batch<U, NF>(phi, E8, gx, lane, g0, g, s8, dq);
+            g = g0 + U;
+        } while (g < ngf);
+    }
+    for (; g < ngf; ++g) field_sweep_gx_multi_batch<1, NF>(phi, E8, gx, lane, g, g, s8, dq);
+    const int j = ngf * 64 + lane;
+    if (j < na) { // ragged tail
+        const uint32_t e = E8[j];
+        double x = phi[j];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x = fma(dq[f], *(const double *)(gx + (size_t)(e + s8[f])), x);
+        phi[j] = x;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // lean Metropolis kernel (parameter blocks; the kernel itself is in mc_lean.h): one site class, one contiguous active sublattice with the
 // default encoding, cluster-interaction features, no Ewald term, engine RNG.
@@ -357,6 +471,10 @@ struct LeanParams {
     double tf_sw;           // swap_weight
     const double *tf_ln;    // [tf_ln_len] ln(k), host libm (LDS copy; 0 = compute on the device)
     int tf_ln_len;
+    // translation-compressed site kernel for the potential-field updates (null: rows of ew_G);
+    // read through rare_params() where an accepted flip needs them, never live across the step loop
+    const double *ew_gx;
+    const uint32_t *ew_E8, *ew_S8;
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -425,6 +543,7 @@ struct smolmc_handle {
     std::vector<double> bias_host; // host copy of the MCBias table (initial bias in set_state)
     std::vector<double> bias_icpt; // SquareHyperplaneBias intercepts (zeros otherwise)
     std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
+    int ew_gx_dims[3] = {0, 0, 0}, ew_gx_blocks = 0; // translation-compressed site kernel (0: none)
 };
 
 static void free_samples(smolmc_handle *h);
@@ -475,9 +594,12 @@ int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
+#define SMOLMC_WL_ROWS 32  // mc_wl_kernel: cached rows of per-bin feature sums per walker (LDS)
 #define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
 int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_corr_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_wl_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_wl_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_bias_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);

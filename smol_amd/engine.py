@@ -35,6 +35,8 @@ SYMBOLS = {
     "smolmc_set_temperature": (C.c_int, [_HP, _f64p]),
     "smolmc_get_state": (C.c_int, [_HP, _i32p, _f64p, _f64p, _u64p, _u64p, _u8p]),
     "smolmc_get_wl": (C.c_int, [_HP, _f64p, _i64p, _i64p, _f64p, _f64p]),
+    "smolmc_set_wl": (C.c_int, [_HP, _f64p, _i64p, _i64p, _f64p, _f64p]),
+    "smolmc_set_counters": (C.c_int, [_HP, _u64p, _u64p]),
     "smolmc_get_bias": (C.c_int, [_HP, _f64p]),
     "smolmc_kernel_info": (C.c_int, [_HP, C.c_char_p, C.c_int]),
     "smolmc_run": (C.c_int, [_HP, C.c_int64]),
@@ -93,7 +95,7 @@ def load_library(path=None):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.smolmc_abi_version() != 4:
+    if lib.smolmc_abi_version() != 5:
         raise RuntimeError("smolmc ABI version mismatch")
     if path is None:
         _LIB = lib
@@ -220,6 +222,31 @@ class Engine:
             )
         )
         return dict(entropy=S, histogram=hist, occurrences=occ, mean_features=mf, mod_factor=m)
+
+    def set_wl(self, entropy=None, histogram=None, occurrences=None, mean_features=None, mod_factor=None):
+        """Upload Wang-Landau aux arrays (the inverse of get_wl; None = keep what the device has)."""
+        def arr(x, dt, shape):
+            if x is None:
+                return None
+            x = np.ascontiguousarray(x, dtype=dt)
+            if x.shape != shape:
+                raise ValueError(f"expected an array of shape {shape}, got {x.shape}")
+            return x
+
+        RL = (self.R, self.L)
+        S, hist, occ = arr(entropy, np.float64, RL), arr(histogram, np.int64, RL), arr(occurrences, np.int64, RL)
+        mf, m = arr(mean_features, np.float64, RL + (self.F,)), arr(mod_factor, np.float64, (self.R,))
+        self._chk(self._lib.smolmc_set_wl(self._h, _p(S, C.c_double), _p(hist, C.c_int64), _p(occ, C.c_int64),
+                                          _p(mf, C.c_double), _p(m, C.c_double)))
+
+    def set_counters(self, n_steps=None, n_accepted=None):
+        """Step / accept counters of every walker (n_steps is the position in the random stream)."""
+        ns = None if n_steps is None else np.ascontiguousarray(n_steps, dtype=np.uint64)
+        na = None if n_accepted is None else np.ascontiguousarray(n_accepted, dtype=np.uint64)
+        for x in (ns, na):
+            if x is not None and x.shape != (self.R,):
+                raise ValueError(f"expected {self.R} counters")
+        self._chk(self._lib.smolmc_set_counters(self._h, _p(ns, C.c_uint64), _p(na, C.c_uint64)))
 
     def audit_drift(self):
         """Drift of the running trace against a from-scratch evaluation of the current

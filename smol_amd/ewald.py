@@ -121,8 +121,10 @@ def ewald_matrix(lattice, frac, charges, eta=None, acc=12.0):
     return np.ascontiguousarray(0.5 * (m + m.T))
 
 
-def supercell_ewald(sc, eta=None, acc=12.0):
-    """(ewald_inds int32[N,Smax], matrix float64[M,M]) for a SupercellTables.
+def supercell_ewald(sc, eta=None, acc=12.0, use_term="total"):
+    """(ewald_inds int32[N,Smax], matrix float64[M,M]) for a SupercellTables; ``use_term`` as in
+    EwaldTerm (cofe/extern/ewald.py:159-177): the total matrix or its real-space / reciprocal-space /
+    point part.
 
     Exploits translation invariance: the geometric kernel is evaluated for the
     first lattice point of each basis site against all sites (nb x N block), then
@@ -149,7 +151,7 @@ def supercell_ewald(sc, eta=None, acc=12.0):
         # place representative first; kernel of (rep, all sites)
         rep = b * P
         g_real, g_recip, point, eta = _pair_rows(sc_lat, frac_sc, rep, eta, acc)
-        g_rows[b] = g_real + g_recip
+        g_rows[b], with_point = _select_term(g_real, g_recip, use_term)
     # expand by translation: g[s1, s2] = g_rows[b1][ b2*P + idx(t2 - t1) ]
     pts = sc.lattice_points
     g_full = np.empty((N, N))
@@ -171,7 +173,8 @@ def supercell_ewald(sc, eta=None, acc=12.0):
     mat = g_full[np.ix_(site_of, site_of)] * np.outer(qs, qs)
     # two species on the same site never coexist; keep kernel value (as the
     # reference's overlapping-site structure would) but the self term only on diag
-    mat[np.diag_indices_from(mat)] += point * qs * qs
+    if with_point:
+        mat[np.diag_indices_from(mat)] += point * qs * qs
     mat *= CONV_FACT
     return inds, np.ascontiguousarray(mat)
 
@@ -249,8 +252,27 @@ def pmg_eta(n_sites, volume):
     return (n_sites * PMG_W / volume ** 2) ** (1.0 / 3.0) * np.pi
 
 
+USE_TERMS = ("total", "real", "reciprocal", "point")  # EwaldTerm.ewald_term_options (cofe/extern/ewald.py:28)
+
+
+def _select_term(g_real, g_recip, use_term):
+    """Geometric kernel of the chosen term and whether the point (self) term joins the diagonal:
+    EwaldTerm.get_ewald_matrix (cofe/extern/ewald.py:159-177) picks pymatgen's total / real-space /
+    reciprocal-space matrix or the diagonal matrix of the point energies."""
+    if use_term not in USE_TERMS:
+        raise AttributeError(f"Provided use_term {use_term} is not a valid option. Please choose one of "
+                             f"{USE_TERMS}.")  # the reference's message, ewald.py:52-56
+    if use_term == "total":
+        return g_real + g_recip, True
+    if use_term == "real":
+        return g_real, False
+    if use_term == "reciprocal":
+        return g_recip, False
+    return np.zeros_like(g_real), True
+
+
 def ewald_matrix_pmg(lattice, frac, site_of, charges, eta=None, real_space_cut=None,
-                     recip_space_cut=None, translation_index=None):
+                     recip_space_cut=None, translation_index=None, use_term="total"):
     """Total Ewald matrix (real + reciprocal, point terms on the diagonal) over M point charges
     ``charges[k]`` sitting on site ``site_of[k]`` of a periodic cell (several charges may share a
     site: the allowed species of a disordered site; their mutual entry is the site's own image
@@ -280,17 +302,19 @@ def ewald_matrix_pmg(lattice, frac, site_of, charges, eta=None, real_space_cut=N
     if translation_index is None:
         for i in range(n):
             g_real, g_recip, point, _ = _pair_rows(lattice, frac, i, eta, acc_r, acc_g)
-            g[i] = g_real + g_recip
+            g[i], with_point = _select_term(g_real, g_recip, use_term)
     else:
         P = len(translation_index)
         nb = n // P
         for b1 in range(nb):
             g_real, g_recip, point, _ = _pair_rows(lattice, frac, b1 * P, eta, acc_r, acc_g)
-            row = (g_real + g_recip).reshape(nb, P)
+            row, with_point = _select_term(g_real, g_recip, use_term)
+            row = row.reshape(nb, P)
             for t1 in range(P):  # site (b1, t1) sees (b2, t2) like (b1, 0) sees (b2, t2 - t1)
                 g[b1 * P + t1] = row[:, translation_index[t1]].reshape(-1)
     g = 0.5 * (g + g.T)
     mat = g[np.ix_(site_of, site_of)] * np.outer(q, q)
-    mat[np.diag_indices_from(mat)] += point * q * q
+    if with_point:
+        mat[np.diag_indices_from(mat)] += point * q * q
     mat *= CONV_FACT
     return np.ascontiguousarray(mat)

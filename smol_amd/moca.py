@@ -287,12 +287,12 @@ class EwaldProcessor(Processor):
 
     _scalar_feature = True
 
-    def __init__(self, supercell, ewald_term=None, coefficient=1.0):
+    def __init__(self, supercell, ewald_term=None, coefficient=1.0, use_term="total"):
         super().__init__(supercell, np.asarray(coefficient, dtype=np.float64))
-        if ewald_term is None:
+        if ewald_term is None:  # (use_term: EwaldTerm.ewald_term_options, cofe/extern/ewald.py:28,159-177)
             from . import ewald as _ew
 
-            ewald_term = _ew.supercell_ewald(supercell)
+            ewald_term = _ew.supercell_ewald(supercell, use_term=use_term)
         self._ewald_inds = np.ascontiguousarray(ewald_term[0], dtype=np.int32)
         self.ewald_matrix = np.ascontiguousarray(ewald_term[1], dtype=np.float64)
         self._ewald_charges = (np.ascontiguousarray(ewald_term[2], dtype=np.float64)
@@ -804,6 +804,16 @@ class Metropolis(MCKernel):
         self.beta = 1.0 / (self.kB * self._temperature)  # kernel/base.py:418-422
 
 
+class UniformlyRandom(MCKernel):
+    """A kernel that accepts every proposed step (smol/moca/kernel/random.py:16-38): the infinite-
+    temperature limit of Metropolis -- exponent = log a-priori factor (+ delta bias) -- which is
+    exactly what the engine's Metropolis kernels compute at beta = 0.  No ``temperature`` in its
+    trace, as in the reference (it is not a thermal kernel)."""
+
+    kernel_type = capi.KERNEL_METROPOLIS
+    engine_temperature = np.inf  # beta = 1 / (kB T) = 0 on the device
+
+
 class WangLandau(MCKernel):
     """Wang-Landau kernel (smol/moca/kernel/wanglandau.py:17-300)."""
 
@@ -821,13 +831,15 @@ class WangLandau(MCKernel):
             )
         if mod_factor <= 0:
             raise ValueError("mod_factor must be greater than 0.")
-        if callable(mod_update):
-            raise NotImplementedError("callable mod_update is not supported on the device; pass a number")
         super().__init__(ensemble, step_type, *args, seed=seed, **kwargs)
         self.flatness, self.check_period, self.update_period = flatness, check_period, update_period
         self._m0 = mod_factor
         self._window = (min_enthalpy, max_enthalpy, bin_size)
-        self._mod_divisor = 2.0 if mod_update is None else float(mod_update)
+        # mod_update (wanglandau.py:100-105): a number divides the modification factor on the device;
+        # a callable is applied by the host at every flatness check (Sampler._wl_host_checks: the
+        # launches are then split at the check period and the device never checks by itself)
+        self._mod_callable = mod_update if callable(mod_update) else None
+        self._mod_divisor = 2.0 if (mod_update is None or callable(mod_update)) else float(mod_update)
         self._levels = np.arange(min_enthalpy, max_enthalpy, bin_size)
         self.spec.update(min_enthalpy=min_enthalpy, max_enthalpy=max_enthalpy, bin_size=bin_size,
                          flatness=flatness, check_period=check_period, update_period=update_period,
@@ -838,7 +850,8 @@ class WangLandau(MCKernel):
         return self._window[2]
 
 
-KERNELS = {"metropolis": Metropolis, "wanglandau": WangLandau, "wang-landau": WangLandau}
+KERNELS = {"metropolis": Metropolis, "wanglandau": WangLandau, "wang-landau": WangLandau,
+           "uniformlyrandom": UniformlyRandom, "uniformly-random": UniformlyRandom, "random": UniformlyRandom}
 
 
 def mckernel_factory(kernel_type, ensemble, step_type, *args, **kwargs):
@@ -1321,11 +1334,14 @@ class Sampler:
                 tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty,
                                 intercepts=getattr(k0.bias, "intercepts", None))
             if isinstance(k0, WangLandau):
+                # (a callable mod_update: flatness checks on the host, the device's own period is
+                # set out of reach)
                 cfg = capi.make_config(
                     len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], self._device,
                     min_enthalpy=k0._window[0], max_enthalpy=k0._window[1], bin_size=k0._window[2],
                     flatness=k0.flatness, mod_factor=k0._m0, mod_update=k0._mod_divisor,
-                    check_period=k0.check_period, update_period=k0.update_period,
+                    check_period=(1 << 31) - 1 if k0._mod_callable is not None else k0.check_period,
+                    update_period=k0.update_period,
                 )
             else:
                 cfg = capi.make_config(len(self._kernels), capi.KERNEL_METROPOLIS,
@@ -1336,7 +1352,10 @@ class Sampler:
         return self._engine
 
     def _temperatures(self):
-        return np.array([getattr(k, "temperature", 0.0) for k in self._kernels], dtype=np.float64)
+        """Temperature of every walker as the engine wants it (Wang-Landau: unused; UniformlyRandom:
+        infinite, i.e. beta = 0)."""
+        return np.array([getattr(k, "temperature", getattr(k, "engine_temperature", 0.0)) for k in self._kernels],
+                        dtype=np.float64)
 
     def _local_occupancies(self, occupancies):
         """Accepts this rank's walkers (count, N), all walkers (nwalkers, N) -- the rank takes
@@ -1418,8 +1437,12 @@ class Sampler:
         nsamples = nsteps // thin_by
         k0 = self._kernels[0]
         if isinstance(k0, WangLandau) or k0.bias is not None:
+            host_checks = isinstance(k0, WangLandau) and k0._mod_callable is not None
             for _ in range(nsamples):
-                eng.run(thin_by)
+                if host_checks:
+                    self._wl_run_with_host_checks(eng, thin_by)
+                else:
+                    eng.run(thin_by)
                 yield {k: v[None] for k, v in self._current_trace(eng).items()}
             return
         nw, N = len(self._kernels), k0.ensemble.num_sites
@@ -1430,9 +1453,67 @@ class Sampler:
         for start in range(0, nsamples, per_block):
             n = min(per_block, nsamples - start)
             ring = eng.run_sampled(n, thin_by, occupancy=True, packed=True)
-            yield dict(occupancy=ring["occupancy"], features=ring["features"],
-                       enthalpy=ring["enthalpy"][..., None], temperature=np.broadcast_to(temps, (n, nw, 1)),
-                       accepted=ring["accepted"][..., None])
+            block = dict(occupancy=ring["occupancy"], features=ring["features"],
+                         enthalpy=ring["enthalpy"][..., None], temperature=np.broadcast_to(temps, (n, nw, 1)),
+                         accepted=ring["accepted"][..., None])
+            if not isinstance(k0, Metropolis):  # (UniformlyRandom: no temperature in the trace)
+                del block["temperature"]
+            yield block
+
+    def _wl_run_with_host_checks(self, eng, nsteps):
+        """``nsteps`` Wang-Landau steps with the flatness check of wanglandau.py:253-264 done on the
+        host, so that ``mod_update`` can be any callable (:100-105): the launches end where the step
+        counter reaches a multiple of ``check_period``; there every walker whose histogram is flat
+        (all visited bins above ``flatness`` times their mean, at least two visited) gets its
+        histogram cleared and its modification factor mapped through the callable."""
+        k0 = self._kernels[0]
+        period = int(k0.check_period)
+        done = int(eng.get_state(occupancy=False)["n_steps"][0])  # (all walkers of a sampler step together)
+        left = int(nsteps)
+        while left > 0:
+            n = min(left, period - done % period)
+            eng.run(n)
+            done += n
+            left -= n
+            if done % period == 0:
+                wl = eng.get_wl()
+                S, hist, m = wl["entropy"], wl["histogram"], wl["mod_factor"]
+                changed = False
+                for r in range(len(m)):
+                    seen = S[r] > 0
+                    if seen.sum() >= 2 and (hist[r][seen] > k0.flatness * hist[r][seen].mean()).all():
+                        hist[r] = 0
+                        m[r] = self._kernels[r]._mod_callable(m[r])
+                        changed = True
+                if changed:
+                    eng.set_wl(histogram=hist, mod_factor=m)
+
+    def aux_checkpoint(self):
+        """Everything beyond the occupancies that a run needs to continue bit-for-bit in another
+        process -- the reference reserves ``aux_checkpoint`` for this and never fills it
+        (sampler/container.py:89,539-541): step / accept counters (the walkers' positions in their
+        random streams) and, for Wang-Landau, the entropy / histogram / occurrences / mean-feature
+        arrays and the modification factors.  Restore with ``restore_aux`` after ``setup_sample`` (or
+        a first ``run``) with the checkpoint's ``occupancy``."""
+        eng = self._get_engine()
+        st = eng.get_state()
+        ck = dict(occupancy=st["occupancy"], n_steps=st["n_steps"], n_accepted=st["n_accepted"])
+        if isinstance(self._kernels[0], WangLandau):
+            ck.update({"wl_" + k: v for k, v in eng.get_wl().items()})
+        return ck
+
+    def restore_aux(self, checkpoint):
+        """Put a checkpoint of ``aux_checkpoint`` back: occupancies (continuation: the aux state is
+        not reset), counters and the Wang-Landau arrays."""
+        eng = self._get_engine()
+        seeds = np.array([k.seed64 for k in self._kernels], dtype=np.uint64)
+        eng.set_state(self._local_occupancies(checkpoint["occupancy"]), seeds, self._temperatures(), reset_aux=True)
+        eng.set_counters(checkpoint["n_steps"], checkpoint["n_accepted"])
+        if isinstance(self._kernels[0], WangLandau):
+            eng.set_wl(checkpoint["wl_entropy"], checkpoint["wl_histogram"], checkpoint["wl_occurrences"],
+                       checkpoint["wl_mean_features"], checkpoint["wl_mod_factor"])
+        self._state_loaded = True
+        self._resume_at = (id(self.samples), self.samples.num_samples)
 
     def sample(self, nsteps, initial_occupancies, thin_by=1, progress=False):
         """Generator over thinned traces, one Trace per sample (sampler.py:164-210)."""

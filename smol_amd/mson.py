@@ -399,7 +399,7 @@ class MsonSupercell:
                             active_sites=np.array(sites if len(names) > 1 else [], dtype=np.int64)))
         return out
 
-    def ewald_tables(self, eta=None, real_space_cut=None, recip_space_cut=None):
+    def ewald_tables(self, eta=None, real_space_cut=None, recip_space_cut=None, use_term="total"):
         """(ewald_inds int32[N, max_species], matrix f64[M, M], charges f64[M]).
 
         Index table: running counter over (site, non-vacancy species) in site order, -1 elsewhere
@@ -430,7 +430,7 @@ class MsonSupercell:
                 trans = None
         mat = ewald_mod.ewald_matrix_pmg(self.lattice, self.frac_coords, site_of, q, eta=eta,
                                          real_space_cut=real_space_cut, recip_space_cut=recip_space_cut,
-                                         translation_index=trans)
+                                         translation_index=trans, use_term=use_term)
         return inds, mat, q
 
 
@@ -500,9 +500,8 @@ class MsonClusterExpansion:
         """Ewald index table, matrix and charges of a supercell with the parameters of the
         model's EwaldTerm (cofe/extern/ewald.py:30-58; defaults when the model has none)."""
         t = self.subspace.ewald_term or {}
-        if t.get("use_term", "total") != "total":
-            raise NotImplementedError("only the total Ewald matrix is generated here")
-        return cell.ewald_tables(t.get("eta"), t.get("real_space_cut"), t.get("recip_space_cut"))
+        return cell.ewald_tables(t.get("eta"), t.get("real_space_cut"), t.get("recip_space_cut"),
+                                 use_term=t.get("use_term", "total"))  # EwaldTerm.use_term, ewald.py:44-58
 
 
 def _read_json(path_or_dict):

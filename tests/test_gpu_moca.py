@@ -287,3 +287,77 @@ def test_accumulated_drift_stays_at_rounding_level(fcc):
     eng.run(200_000)
     df, dh = eng.audit_drift()
     assert df < 1e-8 and dh < 1e-8
+
+
+def test_uniformly_random_kernel(fcc):
+    """UniformlyRandom (smol/moca/kernel/random.py:16-38): every proposed step is accepted -- the
+    engine's Metropolis kernel at beta = 0 -- and the trace stays consistent."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    sampler = moca.Sampler.from_ensemble(ens, kernel_type="UniformlyRandom", nwalkers=3, seeds=[4, 5, 6])
+    occu = np.vstack([_rand_occ(np.random.default_rng(8), sc)[0] for _ in range(3)])
+    sampler.run(600, occu, thin_by=100)
+    c = sampler.samples
+    assert "temperature" not in c.traced_values
+    st = sampler.engine.get_state()
+    assert np.array_equal(st["n_accepted"], st["n_steps"]) and st["n_steps"][0] == 600
+    assert c.sampling_efficiency() == 1.0
+    occs, feats = c.get_occupancies(flat=False), c.get_feature_vectors(flat=False)
+    assert np.array_equal(occs.sum(axis=-1), np.broadcast_to(occu.sum(axis=-1), occs.shape[:2]))  # swaps conserve
+    np.testing.assert_allclose(feats[-1, 1], ens.compute_feature_vector(occs[-1, 1]), rtol=1e-10, atol=1e-9)
+
+
+def _wl_sampler(ens, h0, **kw):
+    return moca.Sampler.from_ensemble(ens, h0 - 8.0, h0 + 8.0, 0.5, kernel_type="Wang-Landau", nwalkers=3,
+                                      seeds=[1, 2, 3], check_period=150, flatness=0.2, **kw)
+
+
+def test_wang_landau_callable_mod_update(fcc):
+    """mod_update may be any callable (wanglandau.py:100-105): it is applied by the host at every
+    flatness check; with m -> m / 2 the run must equal the device's own divide-by-2 exactly."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = _rand_occ(np.random.default_rng(5), sc)[0]
+    h0 = float(ens.natural_parameters @ ens.compute_feature_vector(occu))
+    start = np.vstack([occu] * 3)
+    dev = _wl_sampler(ens, h0)
+    dev.run(3000, start, thin_by=500)
+    host = _wl_sampler(ens, h0, mod_update=lambda m: m / 2.0)
+    host.run(3000, start, thin_by=500)
+    m = dev.samples.get_trace_value("mod_factor", flat=False)
+    assert (m[-1] < 1.0).all()  # the histograms did get flat
+    for name in ("entropy", "histogram", "occurrences", "mod_factor", "occupancy"):
+        assert np.array_equal(dev.samples.get_trace_value(name, flat=False), host.samples.get_trace_value(name, flat=False)), name
+    # a different schedule: m -> m ** 0.5 wherever a check passes
+    root = _wl_sampler(ens, h0, mod_factor=0.5, mod_update=lambda m: m ** 0.5)
+    root.run(1500, start, thin_by=500)
+    mr = root.samples.get_trace_value("mod_factor", flat=False)[-1, :, 0]
+    assert all(any(np.isclose(x, 0.5 ** (0.5 ** k)) for k in range(12)) for x in mr) and (mr > 0.5).any()
+
+
+def test_wang_landau_resumes_in_a_fresh_engine(fcc):
+    """aux_checkpoint / restore_aux (smolmc_set_wl + smolmc_set_counters): a Wang-Landau run split
+    over two engines (as over two processes) equals the uninterrupted run bit for bit."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = _rand_occ(np.random.default_rng(5), sc)[0]
+    h0 = float(ens.natural_parameters @ ens.compute_feature_vector(occu))
+    start = np.vstack([occu] * 3)
+    whole = _wl_sampler(ens, h0)
+    whole.run(2400, start, thin_by=1200)
+    first = _wl_sampler(ens, h0)
+    first.run(1200, start, thin_by=1200)
+    ck = first.aux_checkpoint()
+    first.engine.close()
+    second = _wl_sampler(ens, h0)
+    second._engine = None  # a fresh handle, as a new process would have
+    second.restore_aux(ck)
+    second.run(1200, ck["occupancy"], thin_by=1200)
+    a, b = whole.engine.get_state(), second.engine.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"]) and np.array_equal(a["n_accepted"], b["n_accepted"])
+    assert np.array_equal(a["n_steps"], b["n_steps"])
+    wa, wb = whole.engine.get_wl(), second.engine.get_wl()
+    for k in ("entropy", "histogram", "occurrences", "mod_factor"):
+        assert np.array_equal(wa[k], wb[k]), k
+    np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-12, atol=1e-9)

@@ -283,6 +283,49 @@ def test_native_wang_landau_matches_oracle(general, monkeypatch):
         np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"])
 
 
+@pytest.mark.parametrize("scale", ["1", "40", "3000"])
+def test_wang_landau_bin_pretest_is_decision_neutral(scale, monkeypatch):
+    """The lean Wang-Landau kernel takes the bin of the proposed enthalpy from a float32 wave sum
+    and a carried enthalpy with a rigorous error bound, and falls back to the exact float64 path near
+    bin edges / window ends and whenever the bound has grown to 0.5 % of a bin (mc_wl.h).  With the
+    bound scaled up the two paths interleave at every rate (x3000: every accepted step is followed
+    by an exact rebuild); histograms, entropies and occupancies must not notice."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    monkeypatch.setenv("SMOLMC_FAST_EPS_SCALE", scale)
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    c = load_case("fcc_prim666_triplets")
+    R = 8
+    rng = np.random.default_rng(77)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    ev = orc.OracleEvaluator(tab)
+    h0 = np.array([ev.feature_vector(o) @ ev.natural_parameters() for o in occ0])
+    # a narrow window (walkers bounce off both ends) with 0.11 eV bins: many bin changes per walker
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=h0.min() - 1.337,
+                           max_enthalpy=h0.max() + 1.219, bin_size=0.11, check_period=64)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean")
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(4242)
+    eng.set_state(occ0, seeds)
+    ora.set_state(occ0, seeds, 0.0)
+    for chunk in (1, 17, 700, 2500):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+        wa, wb = eng.get_wl(), ora.get_wl()
+        np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=0, atol=0)
+        assert np.array_equal(wa["histogram"], wb["histogram"])
+        assert np.array_equal(wa["occurrences"], wb["occurrences"])
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"])
+    assert wa["histogram"].sum() > 0 and (wa["occurrences"] > 0).sum(axis=1).min() > 3
+
+
 def test_errors_surface_as_exceptions(monkeypatch):
     tab = tables_for("fcc_prim222_aliased", MODES["int"])
     eng = _engine(tab, capi.make_config(1))

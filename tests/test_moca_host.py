@@ -77,8 +77,13 @@ def test_sampler_from_ensemble_defaults_and_errors(ensemble):
     # TableFlip without a table builds it from a CompositionSpace (mcusher.py:489-518)
     s3 = moca.Sampler.from_ensemble(ensemble, temperature=500, step_type="table-flip")
     assert np.abs(s3.mckernels[0].usher_kwargs["flip_table"]).tolist() == [[1, 1]]
+    # UniformlyRandom (kernel/random.py:16-38): beta = 0 on the device, no temperature in the trace
+    s4 = moca.Sampler.from_ensemble(ensemble, kernel_type="UniformlyRandom", nwalkers=2)
+    assert [type(k).__name__ for k in s4.mckernels] == ["UniformlyRandom"] * 2
+    assert s4.samples.traced_values == ("occupancy", "features", "enthalpy", "accepted")
+    assert np.isinf(s4._temperatures()).all()
     with pytest.raises(NotImplementedError):
-        moca.Sampler.from_ensemble(ensemble, temperature=500, kernel_type="UniformlyRandom")
+        moca.Sampler.from_ensemble(ensemble, temperature=500, kernel_type="Multicell-Metropolis")
 
 
 def test_kb_value():  # tests/test_moca/test_kernel.py:191-197

@@ -192,3 +192,33 @@ def test_species_ordering_rule():
     assert names == ("O2-", "F-")
     with pytest.raises(ValueError, match="electronegativity"):
         mson.site_space_of([mk("Xx", 1, 1.0)])
+
+
+def test_ewald_use_term_parts_add_up_and_are_honoured_by_the_importer(lno):
+    """EwaldTerm.use_term (cofe/extern/ewald.py:28,159-177): the real-space, reciprocal-space and
+    point matrices add up to the total one, the point matrix is diagonal, an invalid option raises
+    the reference's AttributeError, and a model whose stored EwaldTerm says use_term = "real" gets
+    the real-space matrix from the importer."""
+    import copy
+
+    from smol_amd import ewald
+
+    ce, entries = lno
+    cell = ce.subspace.supercell(entries[3]["supercell_matrix"])
+    parts = {t: cell.ewald_tables(use_term=t)[1] for t in ewald.USE_TERMS}
+    np.testing.assert_allclose(parts["real"] + parts["reciprocal"] + parts["point"], parts["total"], rtol=1e-12,
+                               atol=1e-12)
+    assert np.count_nonzero(parts["point"] - np.diag(np.diag(parts["point"]))) == 0 and np.all(np.diag(parts["point"]) < 0)
+    assert np.all(np.diag(parts["reciprocal"]) > 0)  # own-image sums of the reciprocal part
+    with pytest.raises(AttributeError, match="not a valid option"):
+        cell.ewald_tables(use_term="madelung")
+    other = copy.copy(ce)
+    other.subspace = copy.copy(ce.subspace)
+    other.subspace.ewald_term = dict(ce.subspace.ewald_term, use_term="real")
+    np.testing.assert_array_equal(other.ewald_tables(cell)[1], parts["real"])
+    # the synthetic generator takes the same option
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 4.5})
+    sc = synth.build_supercell(model, [2, 2, 2])
+    tot = ewald.supercell_ewald(sc)[1]
+    np.testing.assert_allclose(sum(ewald.supercell_ewald(sc, use_term=t)[1] for t in ("real", "reciprocal", "point")),
+                               tot, rtol=1e-12, atol=1e-12)
