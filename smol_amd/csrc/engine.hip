@@ -645,6 +645,55 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     return 0;
 }
 
+// Bounds checks of every gather index the kernels will use, done once at create (the
+// reference's compiled core runs with boundscheck=False and reads garbage for a bad index).  The
+// kernels themselves never check: every index they form comes from these tables and from occupancy
+// codes, which smolmc_set_state checks against the tables.  -DSMOLMC_BOUNDS adds device-side traps
+// at the gathers of the lean kernels for debugging the kernels' own address arithmetic.
+static int validate_tables(const smolmc_tables *t) {
+    const int N = t->num_sites, n = t->n_orb;
+    if (N <= 0 || n < 0 || t->size <= 0) return fail("num_sites / size / n_orb must be positive");
+    int nstr = 0;
+    for (int o = 0; o < n; ++o) {
+        if (t->orb_nsites[o] <= 0 || t->orb_nfunc[o] <= 0 || t->orb_tensor_len[o] <= 0)
+            return fail("orbit record with a non-positive size");
+        if (t->orb_stride_off[o] != nstr) return fail("orb_stride_off does not follow the orbit sizes");
+        nstr += t->orb_nsites[o];
+        // the largest flat tensor index a cluster of this orbit can form must lie inside the tensor
+        long long reach = 0;
+        for (int m = 0; m < t->orb_nsites[o]; ++m) {
+            const int st = t->tensor_indices[t->orb_stride_off[o] + m];
+            if (st <= 0) return fail("tensor stride must be positive");
+            reach = std::max<long long>(reach, st);
+        }
+        if (reach > t->orb_tensor_len[o]) return fail("tensor stride larger than its tensor");
+        const int64_t a = t->full_off[o], b = t->full_off[o + 1];
+        if (b < a || (b - a) % t->orb_nsites[o] != 0) return fail("full_off does not describe whole cluster rows");
+        for (int64_t i = a; i < b; ++i)
+            if (t->full_idx[i] < 0 || t->full_idx[i] >= N) return fail("cluster site index out of range (full table)");
+    }
+    for (int s = 0; s < N; ++s)
+        if (t->site_ptr[s + 1] < t->site_ptr[s]) return fail("site_ptr must be non-decreasing");
+    const int64_t nloc = t->site_ptr[N];
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int o = t->loc_orbit[r];
+        if (o < 0 || o >= n) return fail("local record refers to an orbit out of range");
+        if (t->loc_nrows[r] <= 0 || !(t->loc_ratio[r] > 0)) return fail("local record with a non-positive size / ratio");
+        const int64_t cnt = (int64_t)t->loc_nrows[r] * t->orb_nsites[o];
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int v = t->loc_idx[t->loc_off[r] + i];
+            if (v < 0 || v >= N) return fail("cluster site index out of range (local table)");
+        }
+    }
+    if (t->has_ewald) {
+        if (t->ewald_width <= 0 || t->ewald_dim <= 0) return fail("Ewald table with a non-positive size");
+        for (int64_t i = 0; i < (int64_t)N * t->ewald_width; ++i)
+            if (t->ewald_inds[i] < -1 || t->ewald_inds[i] >= t->ewald_dim) return fail("Ewald index out of range");
+    }
+    if (t->has_mu && t->mu_width <= 0) return fail("chemical-potential table with a non-positive width");
+    return 0;
+}
+
 static int build_ref_tables(smolmc_handle *h, const smolmc_tables *t) {
     RefTables &rt = h->rt;
     memset(&rt, 0, sizeof(rt));
@@ -927,6 +976,18 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     memset(&h->kp, 0, sizeof(KParams));
     memset(&h->smp, 0, sizeof(SampleBufs));
     KParams &kp = h->kp;
+    if (int rc = validate_tables(t)) return bail(rc);
+    // species codes a site may carry: max_species by default, the largest sublattice code + 1 on
+    // the sites of an active sublattice
+    h->site_ncodes.assign((size_t)t->num_sites, (uint8_t)std::min(255, std::max(1, t->max_species)));
+    for (int k = 0; k < t->n_sublattices; ++k) {
+        int top = 0;
+        for (int64_t c = t->sub_code_ptr[k]; c < t->sub_code_ptr[k + 1]; ++c) top = std::max(top, t->sub_codes[c]);
+        for (int64_t i = t->sub_site_ptr[k]; i < t->sub_site_ptr[k + 1]; ++i) {
+            const int st = t->sub_active_sites[i];
+            if (st >= 0 && st < t->num_sites) h->site_ncodes[st] = (uint8_t)std::min(255, top + 1);
+        }
+    }
     if (int rc = build_mc_tables(h, t)) return bail(rc);
     if (int rc = build_ref_tables(h, t)) return bail(rc);
     kp.N = h->N;
@@ -1466,8 +1527,17 @@ static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, d
 
 static int upload_occ(smolmc_handle *h, const int32_t *occ, size_t nocc, uint8_t *d_occ8) {
     const size_t n32 = nocc * h->N;
-    for (size_t i = 0; i < n32; ++i)
-        if (occ[i] < 0 || occ[i] > 255) return fail("occupancy code out of range [0, 255]");
+    // every code must exist on its site: a larger one would index past the tensors / tables on the
+    // device (the reference reads garbage there, SURVEY 8b "error conventions")
+    const uint8_t *lim = h->site_ncodes.data();
+    const size_t N = (size_t)h->N;
+    for (size_t i = 0, s = 0; i < n32; ++i, s = (s + 1 == N ? 0 : s + 1))
+        if (occ[i] < 0 || occ[i] >= (int)lim[s]) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "occupancy code %d out of range on site %zu (%d species codes there)", occ[i], s,
+                     (int)lim[s]);
+            return fail(msg);
+        }
     int *d32 = nullptr;
     HIPCHK(hipMalloc((void **)&d32, std::max<size_t>(n32 * 4, 16)));
     hipError_t e = hipMemcpyAsync(d32, occ, n32 * 4, hipMemcpyHostToDevice, h->stream);

@@ -116,8 +116,9 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
     const unsigned char *gx = (const unsigned char *)Q->ew_gx;
     if (gx != nullptr) {
         const uint32_t *E8 = Q->ew_E8;
-        const uint32_t sa = Q->ew_S8[js];
-        field_sweep_gx<false>(phi, E8, gx, lane, P.ew_nact, sa, sa, dq, 0.0);
+        const uint32_t s8[1] = {Q->ew_S8[js]};
+        const double d[1] = {dq};
+        field_sweep_gx_multi<1>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         const double *g = P.ew_G + (size_t)s * P.ew_nact;
         field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
@@ -186,7 +187,9 @@ __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, i
     const unsigned char *gx = (const unsigned char *)Q->ew_gx;
     if (gx != nullptr) {
         const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
-        field_sweep_gx<true>(phi, E8, gx, lane, P.ew_nact, S8[j1], S8[j2], dq1, dq2);
+        const uint32_t s8[2] = {S8[j1], S8[j2]};
+        const double d[2] = {dq1, dq2};
+        field_sweep_gx_multi<2>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
     }
@@ -196,6 +199,19 @@ __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, i
     } else {
         phi[j1] = keep1;
     }
+}
+
+// -DSMOLMC_BOUNDS (make bounds -> libsmolmc_hip_bounds.so): trap when a gather address formed from an
+// index row leaves the walker's occupancy in LDS.  The tables the rows are built from are checked on
+// the host at create (validate_tables, engine.hip); this build checks the kernels' own packing /
+// swizzle / unpack arithmetic on top of that.
+__device__ __forceinline__ uint32_t bounded(uint32_t a, uint32_t lim) {
+#ifdef SMOLMC_BOUNDS
+    if (a >= lim) __builtin_trap();
+#else
+    (void)lim;
+#endif
+    return a;
 }
 
 // Index row of one site: ROW u16 entries per lane, fetched with raw buffer loads
@@ -702,7 +718,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 uint32_t a = doff8[it];
                 if (DIFF) a = dp[it] = doff8[it] + pair1;
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row1, it * MM + m)));
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, bounded(row_addr<SOLO, NW>(row1, it * MM + m), (uint32_t)P.Nlds)));
                 if (DIFF) {
                     d1[it] = SMOLMC_LDS_F64(a);
                     if (KF) ad1[it] = a;
@@ -741,7 +757,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = DIFF ? dp[it] : doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, row_addr<SOLO, NW>(row2, it * MM + m)));
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, bounded(row_addr<SOLO, NW>(row2, it * MM + m), (uint32_t)P.Nlds)));
                 if (DIFF) {
                     d1[it] -= SMOLMC_LDS_F64(a); // D[(o2,n2)] = -D[(o1,n1)]: the step's delta of this slot
                     if (KF) ad2[it] = a;
@@ -1182,9 +1198,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     // (the rarely executed pieces -- feasibility masks, weight sums, a-priori factors: only after an
     // accepted table step -- re-read their parameters from the kernel-argument segment, see
     // rare_params: everything read from P stays in SGPRs across the whole step loop otherwise)
-    auto feasible = [&](const int vc) -> unsigned {
-        const LeanParamsKernarg Q = rare_params();
-        const int tfn = Q->tf_n, na = Q->nact;
+    // (one batch of scalar loads per recomputation: every separate one costs a full wait)
+    auto feasible = [&](const int vc, const int tfn, const int na) -> unsigned {
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1213,9 +1228,9 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vw), idx),
                                 (int)rdlane((uint32_t)__double2loint(vw), idx));
     };
-    auto masked_sum = [&](const unsigned m) -> double { // sum of the weights of the set directions
+    auto masked_sum = [&](const unsigned m, const int tfn) -> double { // sum of the weights of the set directions
         double sw = 0.0;
-        const int n2 = 2 * rare_params()->tf_n;
+        const int n2 = 2 * tfn;
         for (int idx = 0; idx < n2; ++idx)
             if ((m >> idx) & 1u) sw += weight_of(idx);
         return sw;
@@ -1333,8 +1348,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             // the species counts only change on accepted table steps: the feasibility mask, its
             // weight sum and the a-priori factor of every direction are kept until then
             if (!head_valid) {
-                feas_now = feasible(vcnt);
-                sumw = masked_sum(feas_now);
+                const LeanParamsKernarg Q = rare_params();
+                const int tfn = Q->tf_n, na = Q->nact;
+                feas_now = feasible(vcnt, tfn, na);
+                sumw = masked_sum(feas_now, tfn);
                 head_valid = true;
                 lp_valid = 0u;
                 // running sums of the feasible weights, lane idx <-> direction idx, added in the
@@ -1342,7 +1359,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 // one compare + ballot instead of a loop of readlanes and float64 adds
                 double c = 0.0;
                 last_feas = -1;
-                const int n2 = 2 * rare_params()->tf_n;
+                const int n2 = 2 * tfn;
                 for (int idx = 0; idx < n2; ++idx)
                     if ((feas_now >> idx) & 1u) {
                         c += weight_of(idx);
@@ -1418,19 +1435,21 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             vu *= usg; // lane c: change of the count of species c
             // compute_log_priori_factor (mcusher.py:656-711), cached per direction (lane dir of vlp)
             if (!((lp_valid >> dir) & 1u)) {
-                const double sum_next = masked_sum(feasible(vcnt + vu));
+                const LeanParamsKernarg Q = rare_params();
+                const int tfn = Q->tf_n, na = Q->nact, lnlen = Q->tf_ln_len;
+                const double tsw = Q->tf_sw;
+                const double *lng = Q->tf_ln;
+                const double sum_next = masked_sum(feasible(vcnt + vu, tfn, na), tfn);
                 double lf = 0.0;
                 // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
                 // case away from the composition limits), no division / log needed
                 const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
-                const LeanParamsKernarg Q = rare_params();
                 if (!(w_now == w_back && sum_next == sumw)) {
-                    const double tsw = Q->tf_sw;
                     const double p_now = (1.0 - tsw) * w_now / sumw;
                     const double p_next = (1.0 - tsw) * w_back / sum_next;
                     lf = log(p_next / p_now);
                 }
-                lf += table_log_count_ratio(Q->tf_ln_len ? s_ln : Q->tf_ln, vu, vcnt, nc);
+                lf += table_log_count_ratio(lnlen ? s_ln : lng, vu, vcnt, nc);
                 lf = uni_d(lf);
                 if (lane == dir) vlp = lf;
                 lp_valid |= 1u << dir;
@@ -1608,7 +1627,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) {
                 uint32_t a = doff8[it];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row, it * MM + m)]);
+                for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[bounded(row_entry<NW>(row, it * MM + m), (uint32_t)P.Nlds)]);
                 const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
                 e = fma(wgt[it], d, e);
                 pend[it] += d;
@@ -1659,7 +1678,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 fnw[f] = (int)rdlane((uint32_t)vnew, f);
                 fod[f] = (int)rdlane((uint32_t)vold, f);
 #pragma unroll
-                for (int q = 0; q < NSLOT * MM; ++q) g[f][q] = (uint32_t)occ[row_entry<NW>(rows[f], q)];
+                for (int q = 0; q < NSLOT * MM; ++q) g[f][q] = (uint32_t)occ[bounded(row_entry<NW>(rows[f], q), (uint32_t)P.Nlds)];
                 fpot[f] = ew_field ? phi[fsite[f] - sbase] : 0.0;
                 occ[lean_swz(fsite[f], swa, swm, swb)] = (uint8_t)fnw[f]; // tentative (every lane, same byte)
             }
@@ -1774,7 +1793,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     }
 
 #ifdef SMOLMC_EXP_PHASES
-    if (r == 0 && lane == 0)
+    if ((r == 0 || r == P.R / 2 || r == P.R - 1) && lane == 0)
         printf("phases (cycles per step): skeleton %.0f | head %.0f | picks %.0f | assign/swap %.0f | eval %.0f | decide %.0f | picks: block %.0f, species loop %.0f\n",
                (double)ph_acc[0] / (double)P.steps, (double)ph_acc[1] / (double)P.steps, (double)ph_acc[2] / (double)P.steps,
                (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps, (double)ph_acc[5] / (double)P.steps,

@@ -168,15 +168,23 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     // below compiles to scalar code and scalar branches
     int b = uni((int)floordiv_exact(H0 - vmin, bin));
     b = min(max(b, 0), Lm1);
-    // carried enthalpy relative to the window start, and the bound on its error IN BINS (tolb also
-    // holds the bound of the step being tested and a floor for the roundings of the position)
+    // Carried enthalpy relative to the window start (float64: gains the float32 sum of every accepted
+    // step) and its position in bins as a float32.  The pre-test works in float32 bins against ONE
+    // fixed tolerance tolb: the bound on the carried enthalpy at its largest (resync_after accepted
+    // steps of e1 each since the last exact rebuild, then an exact step is forced), the float32 sum
+    // of the step being tested, and the float32 roundings of the position itself -- the position
+    // (< L) and each of the two thresholds it is compared with are rounded once, 2^-24 L each, and
+    // the multiply-add once more.
     double hoff = H0 - vmin;
     const double e1 = P.fast_eps + 1e-13;     // float32 sum of one step + the float64 add
-    const double e1b = e1 * inv_bin, tol0 = e1b + 1e-9;
-    double tolb = tol0;
+    const double e1b = e1 * inv_bin, tol0 = e1b + 1e-9 + ((double)P.wl.L + 4.0) * ldexp(1.0, -22);
     const double span_b = span * inv_bin;
-    // accepted steps after which the bound reaches WL_RESYNC_FRAC of a bin: exact rebuild
     const uint32_t resync_after = (uint32_t)uni((int)fmin(1.0e9, fmax(1.0, (WL_RESYNC_FRAC - tol0) / e1b)));
+    const double tolb = tol0 + (double)resync_after * e1b;
+    const float invbin32 = uni_f((float)inv_bin);
+    const float tol32 = uni_f((float)tolb * 1.000001f), omt32 = uni_f(1.0f - tol32);
+    const float hi32 = uni_f((float)span_b - tol32), hiout32 = uni_f((float)span_b + tol32);
+    float xb32 = (float)(hoff * inv_bin);
     uint32_t since_sync = 0;
     const bool never_fast = __ballot(!(P.fast_eps > 0.0)) != 0ull; // SMOLMC_NO_FAST_ACCEPT: every step exact
     bool force_exact = never_fast;
@@ -405,7 +413,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 for (int it = 0; it < NSLOT; ++it) {
                     uint32_t a = dp[it] = doff8[it] + pair1;
 #pragma unroll
-                    for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
+                    for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[bounded(row_entry<NW>(row1, it * MM + m), (uint32_t)P.Nlds)]);
                     d1[it] = *(const double *)((const unsigned char *)s_dt + a);
                     if (!DIFF) e = fma(wgt[it], d1[it], e);
                 }
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 for (int it = 0; it < NSLOT; ++it) {
                     uint32_t a = dp[it];
 #pragma unroll
-                    for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
+                    for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ[bounded(row_entry<NW>(row2, it * MM + m), (uint32_t)P.Nlds)]);
                     d1[it] -= *(const double *)((const unsigned char *)s_dt + a); // D[(o2,n2)] = -D[(o1,n1)]
                     e = fma(wgt[it], d1[it], e);
                 }
@@ -444,10 +452,10 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 const float S32 = wave_sum_f32_uniform((float)e);
                 dHa = (double)S32;
                 // proposed enthalpy in bins from the window start; the bin is certain when the
-                // fractional part is further from 0 and 1 than the carried bound (and the value
-                // inside the window by the same margin)
-                const double x = (hoff + dHa) * inv_bin, fl = floor(x), fr = x - fl;
-                const bool inside = (fr > tolb) & (fr < 1.0 - tolb) & (x >= 0.0) & (x < span_b - tolb);
+                // fractional part is further from 0 and 1 than the tolerance (and the value inside
+                // the window by the same margin)
+                const float x = __builtin_fmaf(S32, invbin32, xb32), fl = __builtin_floorf(x), fr = x - fl;
+                const bool inside = (fr > tol32) & (fr < omt32) & (x >= 0.0f) & (x < hi32);
                 if (__ballot(inside) != 0ull) {
                     nb = uni((int)fl);
                     const int dl = nb - b + 8;
@@ -460,7 +468,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                     const double ex = win - Snb + 0.0; // lane 8: S[bin] - S[new bin]
                     accepted = ((__ballot((ex >= 0.0) | (ex > lu)) >> 8) & 1ull) != 0ull;
                     decided = true;
-                } else if (__ballot((x < -tolb) | (x > span_b + tolb)) != 0ull) {
+                } else if (__ballot((x < -tol32) | (x > hiout32)) != 0ull) {
                     decided = true; // new_h outside [min, max): rejected
                 }
             }
@@ -469,7 +477,6 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 const double Hx = exact_enthalpy();
                 const double new_h = Hx + dH;
                 hoff = Hx - vmin;
-                tolb = tol0;
                 since_sync = 0;
                 force_exact = never_fast;
                 dHa = dH;
@@ -489,7 +496,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
                 sel_hi = 0x3ff00000u;
                 hoff += dHa;
-                tolb += e1b;
+                xb32 = (float)(hoff * inv_bin);
                 if (++since_sync >= resync_after) force_exact = true;
 #ifndef WL_EXP_NOFLUSH
                 changed = nb != b;

@@ -178,6 +178,9 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
+__device__ __forceinline__ float uni_f(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 __device__ __forceinline__ double uni_d(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
     int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -272,72 +275,22 @@ __device__ __forceinline__ void field_sweep(double *phi, const double *ga, const
 // -(d-1) .. d-1 of each translation coordinate (no modular arithmetic), replaces the N rows:
 // the entry of (s, j) sits at byte E8[j] + S8[s] of gx.  For BASELINE config 3 that is 97 KB shared
 // by every walker (L2-resident) instead of a 13.8 KB row of a 48 MB matrix per accepted flip.
-template <int U, bool TWO>
-__device__ __forceinline__ void field_sweep_gx_batch(double *phi, const uint32_t *E8, const unsigned char *gx,
-                                                     int lane, int g0, int gdone, uint32_t sa, uint32_t sb,
-                                                     double dq1, double dq2) {
-    const int j = g0 * 64 + lane;
-    const uint32_t *pe = E8 + j;
-    double *pp = phi + j;
-    uint32_t e[U];
-    double va[U], vb[U], pv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        va[u] = *(const double *)(gx + (size_t)(e[u] + sa));
-        if (TWO) vb[u] = *(const double *)(gx + (size_t)(e[u] + sb));
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool fresh = g0 + u >= gdone; // wave-uniform
-        double v = fma(fresh ? dq1 : 0.0, va[u], pv[u]);
-        if (TWO) v = fma(fresh ? dq2 : 0.0, vb[u], v);
-        pp[64 * u] = v;
-    }
-}
-
-template <bool TWO, int UB = 0>
-__device__ __forceinline__ void field_sweep_gx(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
-                                               int na, uint32_t sa, uint32_t sb, double dq1, double dq2) {
-    constexpr int U = UB ? UB : (TWO ? 6 : 9);
-    const int ngf = na >> 6; // full groups of 64 entries
-    int g = 0;
-    if (ngf >= U) {
-        do {
-            const int g0 = min(g, ngf - U);
-            field_sweep_gx_batch<U, TWO>(phi, E8, gx, lane, g0, g, sa, sb, dq1, dq2);
-            g = g0 + U;
-        } while (g < ngf);
-    }
-    for (; g + 4 <= ngf; g += 4) field_sweep_gx_batch<4, TWO>(phi, E8, gx, lane, g, g, sa, sb, dq1, dq2);
-    for (; g < ngf; ++g) field_sweep_gx_batch<1, TWO>(phi, E8, gx, lane, g, g, sa, sb, dq1, dq2);
-    const int j = ngf * 64 + lane;
-    if (j < na) { // ragged tail
-        const uint32_t e = E8[j];
-        double v = fma(dq1, *(const double *)(gx + (size_t)(e + sa)), phi[j]);
-        if (TWO) v = fma(dq2, *(const double *)(gx + (size_t)(e + sb)), v);
-        phi[j] = v;
-    }
-}
-
-// Several flips of one accepted step (TableFlip: up to SMOLMC_MAX_STEP_FLIPS) in ONE pass over phi:
-// every entry gains sum_f dq[f] * G[s_f][j] -- NF gathers from the compressed tables, one
-// read-modify-write of phi -- instead of one full sweep per flip.  (G[s][s] == 0 by construction:
-// the entry of a flipped site sees the other flips of the step and not its own.)
-template <int U, int NF>
-__device__ __forceinline__ void field_sweep_gx_multi_batch(double *phi, const uint32_t *E8, const unsigned char *gx,
-                                                           int lane, int g0, int gdone, const uint32_t (&s8)[NF],
-                                                           const double (&dq)[NF]) {
-    const int j = g0 * 64 + lane;
-    const uint32_t *pe = E8 + j;
-    double *pp = phi + j;
-    uint32_t e[U];
+//
+// NF flips of one accepted step (a flip: 1; a swap: 2; TableFlip: up to SMOLMC_MAX_STEP_FLIPS, four
+// at a time) in ONE pass over phi: every entry gains sum_f dq[f] * G[s_f][j] -- NF gathers from the
+// compressed tables, one read-modify-write of phi.  (G[s][s] == 0 by construction: the entry of a
+// flipped site sees the other flips of the step and not its own, no patching needed.)
+// The update of an accepted step is a chain of dependent memory round trips, ~1300 cycles each
+// (measured on config 5: 14 of them per accepted 3-flip step, 19 000 cycles): the E8 entries of up
+// to GX_CHUNK groups are therefore fetched in one go, then the gathers run in batches of GX_UB
+// groups, each one round trip (config 3 / 5, 27 groups: 1 + 3 instead of 6 / 14).
+#define SMOLMC_GX_UB 9
+#define SMOLMC_GX_CHUNK 36
+template <int NF>
+__device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t (&e)[SMOLMC_GX_UB], const unsigned char *gx,
+                                                      const uint32_t (&s8)[NF], const double (&dq)[NF]) {
+    constexpr int U = SMOLMC_GX_UB;
     double v[U][NF], pv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -346,27 +299,38 @@ __device__ __forceinline__ void field_sweep_gx_multi_batch(double *phi, const ui
     for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const bool fresh = g0 + u >= gdone; // wave-uniform
         double x = pv[u];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) x = fma(fresh ? dq[f] : 0.0, v[u][f], x);
+        for (int f = 0; f < NF; ++f) x = fma(dq[f], v[u][f], x);
         pp[64 * u] = x;
     }
 }
 template <int NF>
 __device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
                                                      int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
-    constexpr int U = NF <= 2 ? 6 : 4;
-    const int ngf = na >> 6;
+    constexpr int U = SMOLMC_GX_UB, NB = SMOLMC_GX_CHUNK / SMOLMC_GX_UB;
+    const int ngf = na >> 6; // full groups of 64 entries
     int g = 0;
-    if (ngf >= U) {
-        do {
-            const int g0 = min(g, ngf - U);
-            field_sweep_gx_multi_batch<U, NF>(phi, E8, gx, lane, g0, g, s8, dq);
-            g = g0 + U;
-        } while (g < ngf);
+    while (ngf - g >= U) {
+        const int nb = min(NB, (ngf - g) / U); // full batches of this chunk (uniform)
+        const uint32_t *pe = E8 + g * 64 + lane;
+        uint32_t e[NB][U];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[b][u] = pe[64 * min(b * U + u, nb * U - 1)]; // (clamped: reads only)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < nb) field_sweep_gx_groups<NF>(phi + (g + b * U) * 64 + lane, e[b], gx, s8, dq);
+        g += nb * U;
     }
-    for (; g < ngf; ++g) field_sweep_gx_multi_batch<1, NF>(phi, E8, gx, lane, g, g, s8, dq);
+    for (; g < ngf; ++g) { // fewer than a batch left: group by group
+        const uint32_t e = E8[g * 64 + lane];
+        double x = phi[g * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x = fma(dq[f], *(const double *)(gx + (size_t)(e + s8[f])), x);
+        phi[g * 64 + lane] = x;
+    }
     const int j = ngf * 64 + lane;
     if (j < na) { // ragged tail
         const uint32_t e = E8[j];
@@ -544,6 +508,7 @@ struct smolmc_handle {
     std::vector<double> bias_icpt; // SquareHyperplaneBias intercepts (zeros otherwise)
     std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
     int ew_gx_dims[3] = {0, 0, 0}, ew_gx_blocks = 0; // translation-compressed site kernel (0: none)
+    std::vector<uint8_t> site_ncodes; // species codes allowed on each site (occupancy validation)
 };
 
 static void free_samples(smolmc_handle *h);

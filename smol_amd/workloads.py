@@ -71,7 +71,9 @@ def neutral_rocksalt_occupancy(sc, first, count, seed=5):
 HEADLINE_T = 2500.0  # acceptance ~0.38 on the config-2 Hamiltonian (tuned once and frozen)
 # configs 3 and 5: temperature / chemical-potential scale (round 2 values; see tools/equil_sweep.py)
 CONFIG3_T, CONFIG3_MU = 3000.0, 0.5
-CONFIG5_T, CONFIG5_MU = (400.0, 2000.0), 0.5
+# (round 3: config 5's ladder moved from SURVEY's 400-2000 K, where the equilibrated walkers accept
+# 0.1 % of their steps, to 2500-12500 K: steady-state acceptance 0.17, profiles/r03_equil_sweep.jsonl)
+CONFIG5_T, CONFIG5_MU = (2500.0, 12500.0), 0.5
 CONFIG9_T, CONFIG9_PENALTY = 3000.0, 0.05
 
 

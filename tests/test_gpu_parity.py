@@ -344,6 +344,67 @@ def test_errors_surface_as_exceptions(monkeypatch):
             wl.set_state(np.zeros((2, 8), dtype=np.int32), None, 0.0)
 
 
+def test_table_and_occupancy_bounds_are_checked_at_the_boundary():
+    """SURVEY 5 (bounds on gather indices): the reference's compiled core runs with boundscheck=False
+    and reads garbage for a bad index; here every cluster-site / Ewald index is checked once at
+    smolmc_create and every occupancy code against the species of its site at set_state / eval."""
+    from smol_amd.engine import EngineError
+
+    c = load_case("rocksalt444_ewald")
+    N = c["sc"].num_sites
+    for key, msg in (("loc_idx", "local table"), ("full_idx", "full table")):
+        tab = tables_for("rocksalt444_ewald", MODES["int"])
+        tab._keep[key][7] = N + 5
+        with pytest.raises((EngineError, ValueError), match=msg):
+            _engine(tab, capi.make_config(1))
+    tab = tables_for("rocksalt444_ewald", MODES["int"])
+    tab._keep["ewald_inds"].flat[3] = tab.struct.ewald_dim
+    with pytest.raises((EngineError, ValueError), match="Ewald index"):
+        _engine(tab, capi.make_config(1))
+    tab = tables_for("rocksalt444_ewald", MODES["int"])
+    eng = _engine(tab, capi.make_config(1))
+    occ = np.zeros((1, N), dtype=np.int32)
+    occ[0, 2] = 3  # ternary cation site: codes 0..2
+    with pytest.raises(ValueError, match="occupancy code 3 out of range on site 2"):
+        eng.eval_full(occ)
+    with pytest.raises(ValueError, match="out of range"):
+        eng.set_state(occ, None, 500.0)
+
+
+def test_bounds_debug_build_runs_clean():
+    """libsmolmc_hip_bounds.so (make -C smol_amd/csrc bounds): the lean kernels with a trap at every
+    gather whose LDS address leaves the walker's occupancy.  A short run of every lean step type
+    must finish (a trap would surface as a HIP error) and equal the normal build."""
+    import os
+    import subprocess
+    import sys
+
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smol_amd", "libsmolmc_hip_bounds.so")
+    if not os.path.exists(lib):
+        pytest.skip("debug build not made (make -C smol_amd/csrc bounds)")
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from smol_amd import capi, workloads\n"
+        "from smol_amd.engine import Engine\n"
+        "wl = workloads.config2(count=64, dim=6)\n"
+        "out = []\n"
+        "for step in (capi.STEP_SWAP, capi.STEP_FLIP):\n"
+        "    eng = Engine(wl.tables, capi.make_config(64, capi.KERNEL_METROPOLIS, step))\n"
+        "    eng.set_state(wl.occupancy, wl.seeds, 1500.0)\n"
+        "    eng.run(700, sync=True)\n"
+        "    st = eng.get_state()\n"
+        "    out.append(int(st['occupancy'].astype(np.int64).sum() * 7 + st['n_accepted'].sum()))\n"
+        "print('CHECK', out)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for tag, env in (("normal", {}), ("bounds", {"SMOLMC_LIB": lib})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = [l for l in p.stdout.splitlines() if l.startswith("CHECK")][-1]
+    assert res["normal"] == res["bounds"]
+
+
 @pytest.mark.parametrize("kernel", ["metropolis", "wang-landau"])
 @pytest.mark.parametrize("offset,thin", [(0, 1), (5, 3), (63, 16), (15, 17), (1, 64), (40, 65)])
 def test_sample_rows_at_any_phase_of_the_random_batches(offset, thin, kernel, monkeypatch):
