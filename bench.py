@@ -314,31 +314,33 @@ def hbm_ce(rec):  # 56 algorithmic bytes per CE flip
                 note="CE flip, occupancy LDS-resident: nominal HBM fraction (56 B/flip)")
 
 
-def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None):
-    """transient (first `launches` launches after a warm-up launch) and, after `equil` more
-    untimed steps per walker, steady-state figures of one workload on this rank's walkers;
-    with `rex` every launch is followed by one exchange attempt of the global ladder."""
+def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None, transient_mc=None):
+    """transient (first `launches` launches of `transient_mc` steps after one warm-up launch of the
+    same length) and, after `equil` more untimed steps per walker, steady-state figures (launches of
+    `mc` steps) of one workload on this rank's walkers; with `rex` every launch is followed by one
+    exchange attempt of the global ladder."""
     from smol_amd import parallel
 
     eng = Engine(wl.tables, wl.make_config(device))
     eng.set_state(wl.occupancy, wl.seeds, wl.temperature)
 
-    def launch(n=1):
+    def launch(n=1, steps=None):
+        steps = mc if steps is None else steps
         if rex is None:
             for _ in range(n):
-                eng.run(mc)
+                eng.run(steps)
         else:
-            parallel.run_replica_exchange(eng, rex, n, mc)
+            parallel.run_replica_exchange(eng, rex, n, steps)
 
-    def measure():
-        launch(1)
+    def measure(mc=mc):
+        launch(1, mc)
         eng.sync()
         s0 = eng.get_state(occupancy=False)
         kms = []
 
         def body():
             for _ in range(launches):
-                launch(1)
+                launch(1, mc)
                 kms.append(eng.last_kernel_ms())
             eng.sync()
 
@@ -352,10 +354,14 @@ def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None):
                     flips_per_s=wl.flips_per_step * walkers * mc / (kms_sum / clock.world * 1e-3),
                     acceptance=acc / steps, timed_steps_per_replica=mc * launches)
 
-    first = measure()
+    keep = launches
+    if transient_mc:  # the transient figure of round 2: launches 2-4 from the random start
+        launches = 3
+    first = measure(transient_mc or mc)
+    launches = keep
     steady = None
     if equil:
-        done = (launches + 1) * mc
+        done = 4 * transient_mc if transient_mc else (launches + 1) * mc
         while done < equil:
             launch(10)
             done += 10 * mc
@@ -415,8 +421,17 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
                              "acceptance; the dense two-row formulation (58752 B/flip) is HBM-capped at "
                              "1.36e8 flips/s")
 
-        info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3])
+        # (the transient of round 2's bench: launches 2-11 of 2000 steps from the random start; config 3
+        # as specified has no mixed steady state -- its Ewald energy without the charged-cell term is
+        # concave in the net charge, unconstrained flips run to a pure composition -- so the steady
+        # figure is the cost of REJECTED proposals; config 9 below is the well-posed variant)
+        info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
+                                          transient_mc=2000)
         record(wl3, info, first, steady, ewald_roof, wl3.n_walkers, launches=10)
+        wl9 = workloads.config9()
+        info, first, steady = _engine_run(Engine, wl9, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
+                                          transient_mc=2000)
+        record(wl9, info, first, steady, ewald_roof, wl9.n_walkers, launches=10)
 
     # config 4: 1024 independent Wang-Landau walkers per rank; the window is centred on the
     # starting enthalpy, evaluated on the engine

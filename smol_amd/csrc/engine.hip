@@ -1959,17 +1959,50 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
             if (st[2 * f] >= h->N || (st[2 * f] >= 0 && (st[2 * f + 1] < 0 || st[2 * f + 1] > 255)))
                 return fail("replay step out of range");
     }
-    int *d_steps = nullptr;
+    // codes must exist on their sites (they index the delta tables)
+    for (size_t i = 0; i < n; ++i)
+        for (int f = 0; f < 2; ++f) {
+            const int32_t st = steps[i * 4 + 2 * f], cd = steps[i * 4 + 2 * f + 1];
+            if (st >= 0 && cd >= (int)h->site_ncodes[st]) return fail("replay step out of range (species code)");
+        }
+    // Lean handles replay on their own kernels (REPLAY instantiations of mc_lean_kernel,
+    // mc_lean_multi_kernel and mc_wl_kernel): Metropolis flips / swaps without bias, or Wang-Landau.  Everything
+    // else -- and SMOLMC_REPLAY_GENERAL for A/B runs -- takes the general kernel.
+    const bool lean_replay = h->lean && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP && !h->lp.bias_type &&
+                             nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_GENERAL") == nullptr;
+    int *d_steps = nullptr, *d_err = nullptr;
     double *d_u = nullptr, *d_H = nullptr;
     uint8_t *d_acc = nullptr;
     hipError_t e = hipMalloc((void **)&d_steps, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 16);
+    if (e == hipSuccess) e = hipMemset(d_err, 0, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&d_u, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_H, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_acc, n);
     if (e == hipSuccess) e = hipMemcpy(d_steps, steps, n * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_u, uniforms, n * 8, hipMemcpyHostToDevice);
     int rc = 0;
-    if (e == hipSuccess) {
+    if (e == hipSuccess && lean_replay) {
+        const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+        rc = wl_set_representation(h, wl && h->lp.wl.sum_mode);
+        LeanParams lp = h->lp;
+        memset(&lp.smp, 0, sizeof(lp.smp));
+        lp.steps = nsteps;
+        lp.rp_steps = d_steps; lp.rp_u = d_u; lp.rp_acc = d_acc; lp.rp_H = d_H; lp.rp_err = d_err;
+        if (!rc && h->lean_multi)
+            rc = h->lean_nslot == 2 ? smolmc_launch_multi_replay_2(h, lp)
+                                    : (h->lean_nslot == 4 ? smolmc_launch_multi_replay_4(h, lp) : smolmc_launch_multi_replay_8(h, lp));
+        else if (!rc)
+            rc = wl ? (h->lean_nslot == 2 ? smolmc_launch_wl_replay_2(h, lp) : smolmc_launch_wl_replay_4(h, lp))
+                    : (h->lean_nslot == 2 ? smolmc_launch_lean_replay_2(h, lp) : smolmc_launch_lean_replay_4(h, lp));
+        if (!rc) e = hipStreamSynchronize(h->stream);
+        int bad = 0;
+        if (!rc && e == hipSuccess) e = hipMemcpy(&bad, d_err, 4, hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess && bad)
+            rc = fail("replay step does not fit the handle's step type (a swap handle takes proper swaps: "
+                      "code1 == species at site2, code2 == species at site1; a flip handle single flips); "
+                      "the walkers have been advanced -- set the state again");
+    } else if (e == hipSuccess) {
         rc = wl_set_representation(h, false);
         KParams kp = h->kp;
         kp.steps_to_run = nsteps;
@@ -1979,10 +2012,11 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
         kp.rp_H = d_H;
         if (!rc) rc = launch_mc(h, kp, 1);
         if (!rc) e = hipStreamSynchronize(h->stream);
-        if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
-        if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);
     }
+    if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);
     hipFree(d_steps);
+    hipFree(d_err);
     hipFree(d_u);
     hipFree(d_H);
     hipFree(d_acc);

@@ -118,7 +118,7 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
         const uint32_t *E8 = Q->ew_E8;
         const uint32_t s8[1] = {Q->ew_S8[js]};
         const double d[1] = {dq};
-        field_sweep_gx_multi<1>(phi, E8, gx, lane, P.ew_nact, s8, d);
+        field_sweep_gx_multi<1, true>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         const double *g = P.ew_G + (size_t)s * P.ew_nact;
         field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
@@ -129,23 +129,28 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
 // the flips of an accepted TableFlip step (lane f of vsite / vdq: site and charge change of flip f):
 // with the translation-compressed kernel all of them in one pass over phi (up to four at a time),
 // else one sweep per flip
-__device__ __forceinline__ void field_apply_flips(const LeanParams &P, double *phi, int lane, int nfl, int vsite,
-                                                  double vdq) {
+// (inlined: out of line the kernel's register budget becomes the maximum over the call graph --
+// 256 VGPRs and scratch -- instead of shrinking)
+__device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl, int vsite, double vdq) {
     const LeanParamsKernarg Q = rare_params();
+
     const unsigned char *gx = (const unsigned char *)Q->ew_gx;
     auto site_of = [&](int f) { return (int)rdlane((uint32_t)vsite, f); };
     auto dq_of = [&](int f) {
         return __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), f), (int)rdlane((uint32_t)__double2loint(vdq), f));
     };
-    if (gx == nullptr) {
+    const int sb = Q->sbase, na = Q->ew_nact;
+    if (gx == nullptr) { // rows of the full site kernel, one sweep per flip
+        const double *G = Q->ew_G;
         for (int f = 0; f < nfl; ++f) {
             const double dqf = dq_of(f);
-            if (dqf != 0.0) field_apply(P, phi, lane, site_of(f), dqf);
+            if (dqf == 0.0) continue;
+            const double *g = G + (size_t)site_of(f) * na;
+            field_sweep<false>(phi, g, g, lane, na, dqf, 0.0);
         }
         return;
     }
     const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
-    const int sb = P.sbase, na = P.ew_nact;
     for (int f0 = 0; f0 < nfl; f0 += 4) {
         const int n = min(4, nfl - f0);
         uint32_t s8[4];
@@ -312,14 +317,20 @@ template <bool ABS> __device__ __forceinline__ void occ_st(uint8_t *occ, uint32_
 // (E = sum_k coef_k ct_k, so a proposal costs what it costs in interaction mode); the KF
 // correlation-function tables of the slot sit behind it in LDS and are read only on ACCEPTED
 // steps, at the table index the decision already computed, into KF accumulators per slot.
+// REPLAY: the proposals (site1, code1, site2, code2) and acceptance uniforms of every step come from
+// the host in the reference's draw order (smolmc_replay) instead of the engine's
+// Philox stream: the reference-order golden trajectories then drive this kernel's own evaluation --
+// index rows, gathers, delta tables, swap antisymmetry, float32 pre-test, potential field -- and
+// not only the general kernel's.  Separate instantiations (lean_replay_n*.hip).
 template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool WL, bool BIAS = false, bool SOLO = false,
-          int KF = 0, int OCC = 0>
+          int KF = 0, int OCC = 0, bool REPLAY = false>
 // OCC: waves per SIMD the register allocation is held to (0 = the compiler's choice, which is 4
 // for the headline instantiation at 113 VGPRs).  OCC = 6 (80 VGPRs, a few spills) is launched
 // when there are more walkers than 4 waves per SIMD can hold, see launch_lean_me.
 __global__ void __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
 __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     static_assert(KF == 0 || (!WL && !BIAS && !SOLO), "correlation-function tables: plain Metropolis layouts only");
+    static_assert(!REPLAY || (!WL && !BIAS && OCC == 0), "replay: plain Metropolis variants (Wang-Landau: mc_wl_kernel)");
     constexpr int NACC = KF ? KF : 1;
     // EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in
     // LDS.  A template parameter (not the runtime flag ew_field): both variants' pointers and code
@@ -490,11 +501,24 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // the NEXT step is always known one step ahead and is fetched while this step runs.
     int s1, a1;
     RowWords<NW> row1;
+    // replay: record i of this walker = (site1, code1, site2, code2), -1 = no flip; the site of an
+    // empty step is any valid one (its "flip" keeps the species)
+    uint32_t ridx = 0;
+    double lu_rp = 0.0;
+    int rp_bad = 0;
+    auto rp_site = [&](const uint32_t i) -> int {
+        const int v = uni(P.rp_steps[((size_t)r * (uint32_t)P.steps + i) * 4]);
+        return v >= 0 ? v : sbase;
+    };
     {
-        const unsigned long long sp = step - 1ull;
-        const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
-                                                            key0, key1).w[1]);
-        s1 = sbase + (int)__umulhi(w, nact);
+        if (REPLAY) {
+            s1 = rp_site(0u);
+        } else {
+            const unsigned long long sp = step - 1ull;
+            const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
+                                                                key0, key1).w[1]);
+            s1 = sbase + (int)__umulhi(w, nact);
+        }
         a1 = lean_swz(s1, swa, swm, swb);
         row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
     }
@@ -529,7 +553,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     while (steps_left != 0u) {
         // -------- random words (generated 16 steps at a time) --------
         const unsigned long long base = step & ~15ull;
-        if (base != batch_base) {
+        if (!REPLAY && base != batch_base) {
             batch_base = base;
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
@@ -592,8 +616,28 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); lph[0] += tn - lph_t; lph_t = tn; }
 #endif
-        const int s1n = (int)rdlane((uint32_t)nsite, l4);
-        const int a1n = (int)rdlane((uint32_t)naddr, l4);
+        int s1n, a1n;
+        int rq1 = 0, rq2 = -1, rq3 = 0; // replay: code1, site2, code2 of this step's record
+        bool rp_empty = false;
+        if (REPLAY) {
+            const int *rec = P.rp_steps + ((size_t)r * (uint32_t)P.steps + ridx) * 4;
+            const int q0 = uni(rec[0]);
+            rq1 = uni(rec[1]); rq2 = uni(rec[2]); rq3 = uni(rec[3]);
+            rp_empty = q0 < 0;
+            double u = uni_d(P.rp_u[(size_t)r * (uint32_t)P.steps + ridx]);
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing a number
+            lu_rp = log(u);
+            s1n = ridx + 1u < (uint32_t)P.steps ? rp_site(ridx + 1u) : s1;
+            a1n = lean_swz(s1n, swa, swm, swb);
+            if (FAST) { // the thresholds of the float32 pre-test, per step here (see the 64-step batches)
+                const double thr = lu_rp * inv_nbeta, eps = P.fast_eps + 1e-6 * fabs(thr);
+                thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
+                thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+            }
+        } else {
+            s1n = (int)rdlane((uint32_t)nsite, l4);
+            a1n = (int)rdlane((uint32_t)naddr, l4);
+        }
         // LDS address of site 1 as a VGPR, made once per step (the compiler would re-make the
         // SGPR -> VGPR move in every block that touches the site)
         uint32_t va1 = (uint32_t)a1;
@@ -602,7 +646,27 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         int nfl, s2, a2, n1, n2 = 0, o2 = 0; // (swap: s2 / a2 / o2 are set by every proposal outcome)
         if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         int fb = -1; // swap: lane of a first-round candidate hit (prefetched Ewald cross term)
-        if (STEP == SMOLMC_STEP_FLIP) {
+        if (REPLAY) {
+            // the recorded proposal.  A swap kernel evaluates swaps in their antisymmetric form
+            // (n2 == o1, o2 == n1 below): anything else in the record is flagged, not evaluated wrongly
+            if (STEP == SMOLMC_STEP_FLIP) {
+                nfl = rp_empty ? 0 : 1;
+                n1 = rp_empty ? o1 : rq1;
+                rp_bad |= (rq2 >= 0) ? 1 : 0;
+            } else if (!rp_empty && rq2 >= 0) {
+                nfl = 2;
+                s2 = rq2;
+                a2 = lean_swz(s2, swa, swm, swb);
+                o2 = uni((int)occ_ld<SOLO>(occ, (uint32_t)a2));
+                n2 = rq3;
+                n1 = rq1;
+                rp_bad |= (n2 != o1 || n1 != o2) ? 1 : 0;
+                n2 = o1; n1 = o2;
+            } else {
+                nfl = 0; s2 = s1; a2 = a1; o2 = o1; n2 = o1; n1 = o1;
+                rp_bad |= (!rp_empty || rq2 >= 0) ? 1 : 0;
+            }
+        } else if (STEP == SMOLMC_STEP_FLIP) {
             // Flip.propose_step (mcusher.py:154-170), default encoding 0..nc-1
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
             n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
@@ -817,8 +881,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             }
             if (HAS_MU) dH -= dMu;
             // -------- accept (metropolis.py:31-49) --------
-            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l64),
-                                               (int)rdlane((uint32_t)__double2loint(logu), l64));
+            const double lu = REPLAY ? lu_rp
+                                     : __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l64),
+                                                        (int)rdlane((uint32_t)__double2loint(logu), l64));
             // (the ballots make the wave-uniform decision visibly uniform to the compiler:
             // scalar branch, uniform counters in SGPRs)
             if (!WL) {
@@ -936,7 +1001,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         if (FAST && !BIAS) {
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
-            const unsigned long long bit = 1ull << l64;
+            const unsigned long long bit = 1ull << (REPLAY ? 0 : l64); // (replay: the thresholds are uniform)
             const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
             const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
             if (ca) on_accept();
@@ -960,6 +1025,20 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (REPLAY) { // accept flag and running enthalpy of every step (what smolmc_replay returns)
+            double lane_e = 0.0;
+            if (FAST) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) lane_e = fma(wgt[it], acc[it], lane_e);
+            }
+            const double Hnow = FAST ? H + (wave_sum_all(lane_e) - acc_mu) : H;
+            if (lane == 0) {
+                const size_t k = (size_t)r * (uint32_t)P.steps + ridx;
+                P.rp_acc[k] = (uint8_t)(nacc_add != nacc_before);
+                P.rp_H[k] = Hnow;
+            }
+            ridx++;
+        }
 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); lph[3] += tn - lph_t; lph_t = tn; }
@@ -1088,6 +1167,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         P.bias[r] += bias_acc;
         if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
     }
+    if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
     if (lane == 0) {
         if (!WL && HAS_EW) featp[P.Fce] += acc_ew;
         if (!WL && HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
@@ -1746,7 +1826,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
             if (dir >= 0) head_valid = false;
-            if (ew_field) field_apply_flips(P, phi, lane, nfl, vsite, vdq);
+            if (ew_field) field_apply_flips(phi, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;
@@ -1826,10 +1906,10 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 #undef key0
 #undef key1
 template <int NSLOT, int MM, int STEP, bool MU, int EW, bool WL, bool BIAS = false, bool SOLO = false, int KF = 0,
-          int OCC = 0>
+          int OCC = 0, bool REPLAY = false>
 static int launch_lean_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = SOLO ? (unsigned)h->R : (unsigned)((h->R + 3) / 4);
-    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF, OCC>;
+    auto kern = mc_lean_kernel<NSLOT, MM, STEP, MU, EW, WL, BIAS, SOLO, KF, OCC, REPLAY>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1927,4 +2007,38 @@ template <int NSLOT> static int launch_lean_nslot(smolmc_handle *h, const LeanPa
     if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
         return h->lean_mm == 2 ? launch_table_inst<NSLOT, 2>(h, lp) : launch_table_inst<NSLOT, 3>(h, lp);
     return h->lean_mm == 2 ? launch_lean_nm<NSLOT, 2>(h, lp) : launch_lean_nm<NSLOT, 3>(h, lp);
+}
+
+// replay variants (instantiated in lean_replay_n*.hip only): the handle's own layout (SOLO or four
+// walkers per workgroup), Ewald mode and mu row; correlation features with several functions per
+// orbit take the KF variant
+template <int NSLOT, int MM, int STEP, int KF>
+static int launch_lean_replay_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (ew) {
+        if (lp.ew_field)
+            return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false, false, false, KF, 0, true>(h, lp)
+                      : launch_lean_inst<NSLOT, MM, STEP, false, 2, false, false, false, KF, 0, true>(h, lp);
+        return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 1, false, false, false, KF, 0, true>(h, lp)
+                  : launch_lean_inst<NSLOT, MM, STEP, false, 1, false, false, false, KF, 0, true>(h, lp);
+    }
+    if constexpr (KF == 0) {
+        if (h->lean_solo)
+            return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, true, 0, 0, true>(h, lp)
+                      : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, true, 0, 0, true>(h, lp);
+    }
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, false, false, KF, 0, true>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, false, false, KF, 0, true>(h, lp);
+}
+template <int NSLOT> static int launch_lean_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    constexpr int K = SMOLMC_LEAN_MAX_KF;
+    if (h->lean_kf) {
+        if (h->lean_mm == 2)
+            return swap ? launch_lean_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP, K>(h, lp) : launch_lean_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP, K>(h, lp);
+        return swap ? launch_lean_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP, K>(h, lp) : launch_lean_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP, K>(h, lp);
+    }
+    if (h->lean_mm == 2)
+        return swap ? launch_lean_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP, 0>(h, lp) : launch_lean_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP, 0>(h, lp);
+    return swap ? launch_lean_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP, 0>(h, lp) : launch_lean_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP, 0>(h, lp);
 }

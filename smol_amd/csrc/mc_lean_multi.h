@@ -42,8 +42,11 @@ struct MultiRec { // slot record, 24 bytes
 // parameter: with the placement as a runtime flag the field reads are memory instructions "on some
 // paths only", which the compiler's s_waitcnt insertion cannot count (conservative waits at the
 // index-row fetches, see mc_lean.h).
-template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false>
+// REPLAY: proposals and uniforms from the host in the reference's draw order (see mc_lean_kernel;
+// instantiated in multi_replay_n*.hip).
+template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
+    static_assert(!REPLAY || !BIAS, "replay: unbiased variants");
     constexpr bool HAS_EW = EWM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -143,9 +146,18 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     };
 
     const uint32_t nsteps32 = (uint32_t)P.steps;
+    // replay: record i of this walker = (site1, code1, site2, code2), -1 = no flip (an empty step
+    // "flips" the first site of the first sublattice to its own species)
+    double lu_rp = 0.0;
+    int rp_bad = 0;
+    auto rp_site = [&](const uint32_t i) -> int {
+        const int v = uni(P.rp_steps[((size_t)r * nsteps32 + i) * 4]);
+        return v >= 0 ? v : P.m_sbase[0];
+    };
+    if (REPLAY && nsteps32) row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)rp_site(0u) * SITE_BYTES);
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
-        if (base != batch_base) {
+        if (!REPLAY && base != batch_base) {
             // site word of the batch's first step: W(base - 1, 0, 1)
             uint32_t carry;
             if (batch_base == base - 16) {
@@ -195,22 +207,67 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(1); // wave priority rises through the step (see mc_lean_kernel; no gain for ONE)
 #endif
-        const int s1 = (int)rdlane((uint32_t)vsite, l4), a1 = (int)rdlane((uint32_t)vaddr, l4);
-        const int sub1 = (int)rdlane((uint32_t)vsub, l4);
+        int s1, a1, sub1;
+        int rq1 = 0, rq2 = -1, rq3 = 0;
+        bool rp_empty = false;
+        if (REPLAY) {
+            const int *rec = P.rp_steps + ((size_t)r * nsteps32 + it_step) * 4;
+            const int q0 = uni(rec[0]);
+            rq1 = uni(rec[1]); rq2 = uni(rec[2]); rq3 = uni(rec[3]);
+            rp_empty = q0 < 0;
+            s1 = rp_empty ? P.m_sbase[0] : q0;
+            a1 = lean_swz(s1, swa, swm, swb);
+            sub1 = 0; // the active sublattice that holds the site
+            if (NS > 1 && s1 >= P.m_sbase[1] && s1 < P.m_sbase[1] + P.m_nact[1]) sub1 = 1;
+            if (NS > 2 && s1 >= P.m_sbase[2] && s1 < P.m_sbase[2] + P.m_nact[2]) sub1 = 2;
+            if (NS > 3 && s1 >= P.m_sbase[3] && s1 < P.m_sbase[3] + P.m_nact[3]) sub1 = 3;
+            rp_bad |= (s1 < sel4(P.m_sbase, sub1) || s1 >= sel4(P.m_sbase, sub1) + sel4(P.m_nact, sub1)) ? 1 : 0;
+            double u = uni_d(P.rp_u[(size_t)r * nsteps32 + it_step]);
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing a number
+            lu_rp = log(u);
+            if (FAST) {
+                const double thr = lu_rp / nbeta, eps = P.fast_eps + 1e-6 * fabs(thr);
+                thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
+                thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
+            }
+        } else {
+            s1 = (int)rdlane((uint32_t)vsite, l4);
+            a1 = (int)rdlane((uint32_t)vaddr, l4);
+            sub1 = (int)rdlane((uint32_t)vsub, l4);
+        }
         const int cls1 = sel4(P.m_cls, sub1);
         // prefetch the next step's row while this one runs (not across a batch boundary).  ONE:
         // issued after the gathers of flip 1, straight into row1 (no second register set, no
         // copy per step); with several classes the earlier issue is worth more than the copy.
         // (last step of a batch: the next site is not known yet -- its sublattice comes from the
         // next batch's words --, the own row is fetched once more instead and dropped)
-        const uint32_t nsite_pf = rdlane((uint32_t)vsite, l4 < 60 ? l4 + 4 : l4);
+        const uint32_t nsite_pf = REPLAY ? (uint32_t)(it_step + 1u < nsteps32 ? rp_site(it_step + 1u) : s1)
+                                         : rdlane((uint32_t)vsite, l4 < 60 ? l4 + 4 : l4);
         RowWords<NW> rown = row1;
         if (!ONE) rown = load_row<NW>(idx_rs, lane_voff, nsite_pf * SITE_BYTES);
 
         const int o1 = uni((int)occ[a1]);
         int nfl, s2, a2, n1, n2 = 0, o2 = 0, fb = -1; // (swap: s2 / a2 / o2 are set by every proposal outcome)
         if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
-        if (STEP == SMOLMC_STEP_FLIP) {
+        if (REPLAY) { // the recorded proposal
+            if (STEP == SMOLMC_STEP_FLIP) {
+                nfl = rp_empty ? 0 : 1;
+                n1 = rp_empty ? o1 : rq1;
+                rp_bad |= (rq2 >= 0) ? 1 : 0;
+            } else if (!rp_empty && rq2 >= 0) {
+                nfl = 2;
+                s2 = rq2;
+                a2 = lean_swz(s2, swa, swm, swb);
+                o2 = uni((int)occ[a2]);
+                n1 = rq1;
+                n2 = rq3;
+                // both sites of a swap lie on one sublattice (they share the slot records)
+                rp_bad |= (s2 < sel4(P.m_sbase, sub1) || s2 >= sel4(P.m_sbase, sub1) + sel4(P.m_nact, sub1)) ? 1 : 0;
+            } else {
+                nfl = 0; s2 = s1; a2 = a1; o2 = o1; n2 = o1; n1 = o1;
+                rp_bad |= (!rp_empty || rq2 >= 0) ? 1 : 0;
+            }
+        } else if (STEP == SMOLMC_STEP_FLIP) {
             const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(sel4(P.m_ncodes, sub1) - 1));
             n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
             nfl = 1;
@@ -366,7 +423,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         if (FAST) { // float32 pre-test (see mc_lean_kernel)
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
-            const unsigned long long bit = 1ull << l4;
+            const unsigned long long bit = 1ull << (REPLAY ? 0 : l4); // (replay: the thresholds are uniform)
             const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
             const bool cr = (__ballot(S > thr_hi) & bit) != 0ull;
             decided = ca | cr;
@@ -376,8 +433,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             dH = wave_sum_all(e);
             if (HAS_EW) dH += P.ew_coef * dEw;
             if (HAS_MU) dH -= dMu;
-            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
-                                               (int)rdlane((uint32_t)__double2loint(logu), l4));
+            const double lu = REPLAY ? lu_rp
+                                     : __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                                        (int)rdlane((uint32_t)__double2loint(logu), l4));
             const double exponent = nbeta * dH + 0.0 + dB; // metropolis.py:41-44
             accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         }
@@ -417,6 +475,16 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(0);
 #endif
+        if (REPLAY) { // accept flag and running enthalpy of every step (what smolmc_replay returns)
+            double lane_e = 0.0;
+            for (int i = lane; i < nrec; i += 64) lane_e = fma(s_rec[i].w, s_acc[i], lane_e);
+            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0));
+            if (lane == 0) {
+                const size_t k = (size_t)r * nsteps32 + it_step;
+                P.rp_acc[k] = (uint8_t)(nacc_add != nacc_before);
+                P.rp_H[k] = Hnow;
+            }
+        }
 
         if (--smp_countdown == 0) {
             const LeanParamsKernarg Q = rare_params(); // (sampling parameters re-read from the kernel arguments)
@@ -483,15 +551,16 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         P.nacc[r] += nacc_add;
         if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
     }
+    if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false, bool REPLAY = false>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
     // one site class with more than 256 clusters per site: slot records in registers
-    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8, BIAS>
-                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false, BIAS>;
+    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8, BIAS, REPLAY>
+                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false, BIAS, REPLAY>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -513,6 +582,21 @@ template <int NSLOT, int MM, int STEP, bool BIAS> static int launch_multi_me(smo
 template <int NSLOT, int MM, bool BIAS = false> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_multi_me<NSLOT, MM, SMOLMC_STEP_SWAP, BIAS>(h, lp);
     return launch_multi_me<NSLOT, MM, SMOLMC_STEP_FLIP, BIAS>(h, lp);
+}
+// replay variants (multi_replay_n*.hip)
+template <int NSLOT, int MM, int STEP> static int launch_multi_replay_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.m_mu != nullptr;
+    if (lp.ew_field == 1)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, false, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, false, true>(h, lp);
+    if (lp.ew_field == 2)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, false, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, false, true>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, false, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, false, true>(h, lp);
+}
+template <int NSLOT> static int launch_multi_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_multi_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
+    return swap ? launch_multi_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
 }
 template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
     return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2, true>(h, lp) : launch_multi_nm<NSLOT, 3, true>(h, lp);
@@ -1036,7 +1120,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         if (accepted) {
             vcnt += vu;
             if (dir >= 0) head_valid = false;
-            if (has_ew) field_apply_flips(P, phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
+            if (has_ew) field_apply_flips(phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             nacc_add++;

@@ -85,7 +85,8 @@ __device__ __noinline__ void wl_evict_row(double *grow, double *crow, int F, int
     }
 }
 
-template <int NSLOT, int MM, int STEP>
+// REPLAY: proposals and uniforms from the host in the reference's draw order (see mc_lean_kernel).
+template <int NSLOT, int MM, int STEP, bool REPLAY = false>
 __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -265,10 +266,21 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
 
     int s1, a1;
     RowWords<NW> row1;
+    uint32_t ridx = 0; // replay: record of this step
+    double lu_rp = 0.0;
+    int rp_bad = 0;
+    auto rp_site = [&](const uint32_t i) -> int {
+        const int v = uni(P.rp_steps[((size_t)r * (uint32_t)P.steps + i) * 4]);
+        return v >= 0 ? v : sbase;
+    };
     {
-        const unsigned long long sp = step - 1ull;
-        const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u, key0, key1).w[1]);
-        s1 = sbase + (int)__umulhi(w, nact);
+        if (REPLAY) {
+            s1 = rp_site(0u);
+        } else {
+            const unsigned long long sp = step - 1ull;
+            const uint32_t w = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u, key0, key1).w[1]);
+            s1 = sbase + (int)__umulhi(w, nact);
+        }
         a1 = lean_swz(s1, swa, swm, swb);
         row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s1 * SITE_BYTES);
     }
@@ -284,7 +296,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     while (steps_left != 0u) {
         // -------- random words (generated 16 steps at a time, see mc_lean_kernel) --------
         const unsigned long long base = step & ~15ull;
-        if (base != batch_base) {
+        if (!REPLAY && base != batch_base) {
             batch_base = base;
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), 0u, key0, key1);
@@ -317,8 +329,23 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
         do {
             __builtin_amdgcn_s_setprio(1);
             WL_PHASE(0)
-            const int s1n = (int)rdlane((uint32_t)nsite, l4);
-            const int a1n = (int)rdlane((uint32_t)naddr, l4);
+            int s1n, a1n;
+            int rq1 = 0, rq2 = -1, rq3 = 0;
+            bool rp_empty = false;
+            if (REPLAY) {
+                const int *rec = P.rp_steps + ((size_t)r * (uint32_t)P.steps + ridx) * 4;
+                const int q0 = uni(rec[0]);
+                rq1 = uni(rec[1]); rq2 = uni(rec[2]); rq3 = uni(rec[3]);
+                rp_empty = q0 < 0;
+                double u = uni_d(P.rp_u[(size_t)r * (uint32_t)P.steps + ridx]);
+                if (u != u) u = 0.0; // NaN: the reference accepted without drawing a number
+                lu_rp = log(u);
+                s1n = ridx + 1u < (uint32_t)P.steps ? rp_site(ridx + 1u) : s1;
+                a1n = lean_swz(s1n, swa, swm, swb);
+            } else {
+                s1n = (int)rdlane((uint32_t)nsite, l4);
+                a1n = (int)rdlane((uint32_t)naddr, l4);
+            }
             uint32_t va1 = (uint32_t)a1;
             asm volatile("" : "+v"(va1));
             const int o1 = uni((int)occ[va1]);
@@ -330,7 +357,23 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             const double win = *WL_LDS_F64P(rec0 - 24u + __umul24(widx1, 24u));
             int nfl, s2, a2, n1, n2 = 0, o2 = 0;
             if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
-            if (STEP == SMOLMC_STEP_FLIP) { // Flip.propose_step (mcusher.py:154-170)
+            if (REPLAY) { // the recorded proposal (a swap kernel takes proper swaps only)
+                if (STEP == SMOLMC_STEP_FLIP) {
+                    nfl = rp_empty ? 0 : 1;
+                    n1 = rp_empty ? o1 : rq1;
+                    rp_bad |= (rq2 >= 0) ? 1 : 0;
+                } else if (!rp_empty && rq2 >= 0) {
+                    nfl = 2;
+                    s2 = rq2;
+                    a2 = lean_swz(s2, swa, swm, swb);
+                    o2 = uni((int)occ[a2]);
+                    rp_bad |= (rq3 != o1 || rq1 != o2) ? 1 : 0;
+                    n2 = o1; n1 = o2;
+                } else {
+                    nfl = 0; s2 = s1; a2 = a1; o2 = o1; n2 = o1; n1 = o1;
+                    rp_bad |= (!rp_empty || rq2 >= 0) ? 1 : 0;
+                }
+            } else if (STEP == SMOLMC_STEP_FLIP) { // Flip.propose_step (mcusher.py:154-170)
                 const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), (uint32_t)(P.ncodes - 1));
                 n1 = (int)kk + ((int)kk >= o1 ? 1 : 0);
                 nfl = 1;
@@ -433,8 +476,9 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             __builtin_amdgcn_s_setprio(3);
             WL_PHASE(2)
             // -------- WangLandau._accept_step (wanglandau.py:186-202) --------
-            const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l64),
-                                               (int)rdlane((uint32_t)__double2loint(logu), l64));
+            const double lu = REPLAY ? lu_rp
+                                     : __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l64),
+                                                        (int)rdlane((uint32_t)__double2loint(logu), l64));
             int nb = b;
             bool accepted = false, decided = false;
             double dHa = 0.0; // what hoff gains when the step is accepted
@@ -531,6 +575,15 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             a1 = a1n;
             __builtin_amdgcn_s_setprio(0);
             WL_PHASE(4)
+            if (REPLAY) { // accept flag and running enthalpy of every step (what smolmc_replay returns)
+                const double Hnow = exact_enthalpy();
+                if (lane == 0) {
+                    const size_t k = (size_t)r * (uint32_t)P.steps + ridx;
+                    P.rp_acc[k] = (uint8_t)(nacc_add != nacc_before);
+                    P.rp_H[k] = Hnow;
+                }
+                ridx++;
+            }
             if (wl_rem_check == 0) {
                 const LeanParamsKernarg Q = rare_params();
                 wl_m = wl_flatness_check_rec(wl_rec, Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
@@ -608,6 +661,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
         P.wl.hist[(size_t)r * P.wl.L + i] = wl_rec[i].hist;
         P.wl.occur[(size_t)r * P.wl.L + i] = wl_rec[i].occur;
     }
+    if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
     const double Hend = exact_enthalpy();
     if (lane == 0) {
         P.wl.m[r] = wl_m;
@@ -622,10 +676,10 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
 #undef key0
 #undef key1
 
-template <int NSLOT, int MM, int STEP>
+template <int NSLOT, int MM, int STEP, bool REPLAY = false>
 static int launch_wl_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
-    auto kern = mc_wl_kernel<NSLOT, MM, STEP>;
+    auto kern = mc_wl_kernel<NSLOT, MM, STEP, REPLAY>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -640,4 +694,10 @@ template <int NSLOT> static int launch_wl_nslot(smolmc_handle *h, const LeanPara
     if (h->lean_mm == 2)
         return swap ? launch_wl_inst<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp) : launch_wl_inst<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
     return swap ? launch_wl_inst<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp) : launch_wl_inst<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
+}
+template <int NSLOT> static int launch_wl_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_wl_inst<NSLOT, 2, SMOLMC_STEP_SWAP, true>(h, lp) : launch_wl_inst<NSLOT, 2, SMOLMC_STEP_FLIP, true>(h, lp);
+    return swap ? launch_wl_inst<NSLOT, 3, SMOLMC_STEP_SWAP, true>(h, lp) : launch_wl_inst<NSLOT, 3, SMOLMC_STEP_FLIP, true>(h, lp);
 }

@@ -282,14 +282,12 @@ __device__ __forceinline__ void field_sweep(double *phi, const double *ga, const
 // flipped site sees the other flips of the step and not its own, no patching needed.)
 // The update of an accepted step is a chain of dependent memory round trips, ~1300 cycles each
 // (measured on config 5: 14 of them per accepted 3-flip step, 19 000 cycles): the E8 entries of up
-// to GX_CHUNK groups are therefore fetched in one go, then the gathers run in batches of GX_UB
-// groups, each one round trip (config 3 / 5, 27 groups: 1 + 3 instead of 6 / 14).
-#define SMOLMC_GX_UB 9
-#define SMOLMC_GX_CHUNK 36
-template <int NF>
-__device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t (&e)[SMOLMC_GX_UB], const unsigned char *gx,
-                                                      const uint32_t (&s8)[NF], const double (&dq)[NF]) {
-    constexpr int U = SMOLMC_GX_UB;
+// to 36 groups are therefore fetched in one go, then the gathers run in batches of 9 groups, each
+// one round trip (config 5, 27 groups: 1 + 3 round trips instead of 14).
+// A single flip (NF = 1) on a lattice of >= 27 groups takes all its gathers in one batch of 27.
+template <int NF, int U>
+__device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t (&e)[U], const unsigned char *gx,
+                                                      const uint32_t (&s8)[NF], const double (&dq)[NF], int first_fresh) {
     double v[U][NF], pv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -299,16 +297,18 @@ __device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t
     for (int u = 0; u < U; ++u) pv[u] = pp[64 * u];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+        // (groups below first_fresh were updated by an earlier batch -- the last batch of a sweep is
+        // shifted back so that it ends on the last full group -- and are rewritten unchanged)
+        const bool fresh = u >= first_fresh; // wave-uniform
         double x = pv[u];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) x = fma(dq[f], v[u][f], x);
+        for (int f = 0; f < NF; ++f) x = fma(fresh ? dq[f] : 0.0, v[u][f], x);
         pp[64 * u] = x;
     }
 }
-template <int NF>
-__device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
+template <int NF, int U, int NB>
+__device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
                                                      int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
-    constexpr int U = SMOLMC_GX_UB, NB = SMOLMC_GX_CHUNK / SMOLMC_GX_UB;
     const int ngf = na >> 6; // full groups of 64 entries
     int g = 0;
     while (ngf - g >= U) {
@@ -321,10 +321,21 @@ __device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t
             for (int u = 0; u < U; ++u) e[b][u] = pe[64 * min(b * U + u, nb * U - 1)]; // (clamped: reads only)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            if (b < nb) field_sweep_gx_groups<NF>(phi + (g + b * U) * 64 + lane, e[b], gx, s8, dq);
+            if (b < nb) field_sweep_gx_groups<NF, U>(phi + (g + b * U) * 64 + lane, e[b], gx, s8, dq, 0);
         g += nb * U;
     }
-    for (; g < ngf; ++g) { // fewer than a batch left: group by group
+    if (NF == 1 && g < ngf && ngf >= U) { // fewer than a batch left: one more batch, shifted back onto the end
+        // (single flips only: with several flips per step the extra unrolled batch costs the
+        // TableFlip kernels their registers -- 250 VGPRs, 128 SGPR spills)
+        const int g0 = ngf - U;
+        const uint32_t *pe = E8 + g0 * 64 + lane;
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
+        field_sweep_gx_groups<NF, U>(phi + g0 * 64 + lane, e, gx, s8, dq, g - g0);
+        g = ngf;
+    }
+    for (; g < ngf; ++g) { // (lattices of fewer than U groups) group by group
         const uint32_t e = E8[g * 64 + lane];
         double x = phi[g * 64 + lane];
 #pragma unroll
@@ -339,6 +350,14 @@ __device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t
         for (int f = 0; f < NF; ++f) x = fma(dq[f], *(const double *)(gx + (size_t)(e + s8[f])), x);
         phi[j] = x;
     }
+}
+// BIG: the 27-group batch for single flips (the flip kernels; the TableFlip kernels, whose steps
+// have several flips, do not carry that code)
+template <int NF, bool BIG = false>
+__device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
+                                                     int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
+    if (BIG && NF == 1 && (na >> 6) >= 27) field_sweep_gx_sized<NF, 27, 1>(phi, E8, gx, lane, na, s8, dq);
+    else field_sweep_gx_sized<NF, 9, 4>(phi, E8, gx, lane, na, s8, dq);
 }
 
 // ----------------------------------------------------------------------------
@@ -439,6 +458,12 @@ struct LeanParams {
     // read through rare_params() where an accepted flip needs them, never live across the step loop
     const double *ew_gx;
     const uint32_t *ew_E8, *ew_S8;
+    // replay (REPLAY instantiations only): host-provided proposals / uniforms, per-step outputs
+    const int *rp_steps;   // [R][steps][4]
+    const double *rp_u;    // [R][steps]
+    uint8_t *rp_acc;       // [R][steps]
+    double *rp_H;          // [R][steps]
+    int *rp_err;           // set when a record does not fit the kernel's step type
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -563,6 +588,13 @@ int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
 #define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
 int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_corr_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_wl_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_wl_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_replay_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_replay_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_wl_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_wl_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_bias_2(smolmc_handle *h, const LeanParams &lp);

@@ -74,7 +74,7 @@ CONFIG3_T, CONFIG3_MU = 3000.0, 0.5
 # (round 3: config 5's ladder moved from SURVEY's 400-2000 K, where the equilibrated walkers accept
 # 0.1 % of their steps, to 2500-12500 K: steady-state acceptance 0.17, profiles/r03_equil_sweep.jsonl)
 CONFIG5_T, CONFIG5_MU = (2500.0, 12500.0), 0.5
-CONFIG9_T, CONFIG9_PENALTY = 3000.0, 0.05
+CONFIG9_T, CONFIG9_PENALTY = 5000.0, 0.05  # steady-state acceptance 0.11 at 4000 K, 0.24 at 6000 K (profiles/r03_equil_sweep.jsonl)
 
 
 def config2(first=0, count=4096, dim=16, feature_mode=capi.FEATURES_INTERACTIONS, mc=10000):

@@ -49,40 +49,72 @@ def test_eval_full_and_delta_vs_reference_fixtures(name, mode):
                                        rtol=RTOL, atol=1e-8)
 
 
+REPLAY_KERNELS = pytest.mark.parametrize("replay_kernel", ["auto", "general-kernel"])
+
+
+def _replay_env(monkeypatch, replay_kernel):
+    """"auto": a lean handle replays on its own kernel (REPLAY instantiations of mc_lean_kernel /
+    mc_wl_kernel -- the kernels the BASELINE configurations run); "general-kernel": mc_kernel."""
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    if replay_kernel == "general-kernel":
+        monkeypatch.setenv("SMOLMC_REPLAY_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_REPLAY_GENERAL", raising=False)
+
+
 def _check_replay(eng, key, R=1):
     steps = np.tile(T[f"{key}_steps"][None], (R, 1, 1))
     us = np.tile(T[f"{key}_u"][None], (R, 1))
+    h_start = eng.get_state(occupancy=False)["enthalpy"].copy()
     acc, H = eng.replay(steps, us)
     st = eng.get_state()
     for r in range(R):
         assert np.array_equal(acc[r], T[f"{key}_accepted"])
         np.testing.assert_allclose(H[r], T[f"{key}_H"], rtol=RTOL, atol=ATOL)
+        if f"{key}_dH" in T.files:
+            # per-step enthalpy change of every ACCEPTED step (the running enthalpy moved by it),
+            # purely relative: north_star's 1e-10 where the change is not itself rounding noise
+            dH = np.diff(np.concatenate(([h_start[r]], H[r])))
+            want = T[f"{key}_dH"]
+            sel = T[f"{key}_accepted"].astype(bool) & (np.abs(want) > 1e-6)
+            assert sel.sum() > 10
+            rel = np.abs(dH[sel] - want[sel]) / np.abs(want[sel])
+            assert rel.max() < 1e-10, (key, rel.max())
         assert np.array_equal(st["occupancy"][r], T[f"{key}_occ_final"])
         np.testing.assert_allclose(st["features"][r], T[f"{key}_feat_final"], rtol=RTOL, atol=1e-8)
         assert st["n_accepted"][r] == T[f"{key}_accepted"].sum()
     return st
 
 
+@REPLAY_KERNELS
 @pytest.mark.parametrize("mode", ["int", "corr"])
-def test_replay_metropolis_swap_vs_reference_trajectory(mode):
+def test_replay_metropolis_swap_vs_reference_trajectory(mode, replay_kernel, monkeypatch):
+    _replay_env(monkeypatch, replay_kernel)
     tab = tables_for("fcc_prim666_triplets", MODES[mode])
     R = 5
     eng = _engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    assert eng.kernel_info().startswith("lean")
     eng.set_state(np.tile(T["B_occ0"], (R, 1)), temperature=T["B_T"][0])
     _check_replay(eng, f"B_swap_{mode}", R)
 
 
+@REPLAY_KERNELS
 @pytest.mark.parametrize("mode", ["int", "corr"])
-def test_replay_semigrand_flip_ewald_mu(mode):
+def test_replay_semigrand_flip_ewald_mu(mode, replay_kernel, monkeypatch):
+    _replay_env(monkeypatch, replay_kernel)
     tab = tables_for("rocksalt444_ewald", MODES[mode], mu_table=T["C_mu"])
     eng = _engine(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_FLIP))
+    assert eng.kernel_info().startswith("lean")
     eng.set_state(np.tile(T["C_occ0"], (2, 1)), temperature=T["C_T"][0])
     _check_replay(eng, f"C_flip_{mode}", 2)
 
 
-def test_replay_two_sublattices():
+@REPLAY_KERNELS
+def test_replay_two_sublattices(replay_kernel, monkeypatch):
+    _replay_env(monkeypatch, replay_kernel)
     tab = tables_for("rocksalt333_two_sublattices", MODES["int"])
     eng = _engine(tab, capi.make_config(2, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
+    assert eng.kernel_info().startswith("lean-multi")
     eng.set_state(np.tile(T["G_occ0"], (2, 1)), temperature=T["G_T"][0])
     _check_replay(eng, "G_swap_int", 2)
     tab = tables_for("rocksalt333_two_sublattices", MODES["corr"], mu_table=T["G_mu"])
@@ -113,15 +145,19 @@ def test_empty_swap_steps_on_gpu():
     assert np.array_equal(a["occupancy"][0], occ[0]) and a["n_accepted"][0] == 400
 
 
-def test_replay_swap_ewald():
+@REPLAY_KERNELS
+def test_replay_swap_ewald(replay_kernel, monkeypatch):
+    _replay_env(monkeypatch, replay_kernel)
     tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=T["C_mu"])
     eng = _engine(tab, capi.make_config(1, capi.KERNEL_METROPOLIS, capi.STEP_SWAP))
     eng.set_state(T["C_occ0"][None], temperature=T["C_T"][0])
     _check_replay(eng, "C_swap_int")
 
 
+@REPLAY_KERNELS
 @pytest.mark.parametrize("tag", ["B_wl", "B_wlflat"])
-def test_replay_wang_landau(tag):
+def test_replay_wang_landau(tag, replay_kernel, monkeypatch):
+    _replay_env(monkeypatch, replay_kernel)
     tab = tables_for("fcc_prim666_triplets", MODES["int"])
     w = T[f"{tag}_window"]
     cfg = capi.make_config(3, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=w[0],
@@ -352,15 +388,18 @@ def test_table_and_occupancy_bounds_are_checked_at_the_boundary():
 
     c = load_case("rocksalt444_ewald")
     N = c["sc"].num_sites
-    for key, msg in (("loc_idx", "local table"), ("full_idx", "full table")):
+    # (the flattened arrays may be views of the cached case: every corrupted entry is put back)
+    for key, pos, bad, msg in (("loc_idx", 7, N + 5, "local table"), ("full_idx", 7, N + 5, "full table"),
+                               ("ewald_inds", 3, None, "Ewald index")):
         tab = tables_for("rocksalt444_ewald", MODES["int"])
-        tab._keep[key][7] = N + 5
-        with pytest.raises((EngineError, ValueError), match=msg):
-            _engine(tab, capi.make_config(1))
-    tab = tables_for("rocksalt444_ewald", MODES["int"])
-    tab._keep["ewald_inds"].flat[3] = tab.struct.ewald_dim
-    with pytest.raises((EngineError, ValueError), match="Ewald index"):
-        _engine(tab, capi.make_config(1))
+        arr = tab._keep[key].reshape(-1)
+        old = int(arr[pos])
+        arr[pos] = tab.struct.ewald_dim if bad is None else bad
+        try:
+            with pytest.raises((EngineError, ValueError), match=msg):
+                _engine(tab, capi.make_config(1))
+        finally:
+            arr[pos] = old
     tab = tables_for("rocksalt444_ewald", MODES["int"])
     eng = _engine(tab, capi.make_config(1))
     occ = np.zeros((1, N), dtype=np.int32)
