@@ -108,6 +108,7 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
 // potential-field update after an accepted flip of site s by charge dq: every other
 // changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous); the own entry
 // is left as it was (phi excludes the self term): it is saved here and put back after the sweep.
+template <int FOOT = 2>
 __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
     const int js = s - P.sbase;
     const double keep = phi[js];
@@ -118,7 +119,7 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
         const uint32_t *E8 = Q->ew_E8;
         const uint32_t s8[1] = {Q->ew_S8[js]};
         const double d[1] = {dq};
-        field_sweep_gx_multi<1, true>(phi, E8, gx, lane, P.ew_nact, s8, d);
+        field_sweep_gx_multi<1, FOOT>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         const double *g = P.ew_G + (size_t)s * P.ew_nact;
         field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
@@ -131,6 +132,7 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
 // else one sweep per flip
 // (inlined: out of line the kernel's register budget becomes the maximum over the call graph --
 // 256 VGPRs and scratch -- instead of shrinking)
+template <int FOOT = 1>
 __device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl, int vsite, double vdq) {
     const LeanParamsKernarg Q = rare_params();
 
@@ -164,22 +166,23 @@ __device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl
         if (n == 1) {
             const uint32_t a[1] = {s8[0]};
             const double d[1] = {dq[0]};
-            field_sweep_gx_multi<1>(phi, E8, gx, lane, na, a, d);
+            field_sweep_gx_multi<1, FOOT>(phi, E8, gx, lane, na, a, d);
         } else if (n == 2) {
             const uint32_t a[2] = {s8[0], s8[1]};
             const double d[2] = {dq[0], dq[1]};
-            field_sweep_gx_multi<2>(phi, E8, gx, lane, na, a, d);
+            field_sweep_gx_multi<2, FOOT>(phi, E8, gx, lane, na, a, d);
         } else if (n == 3) {
             const uint32_t a[3] = {s8[0], s8[1], s8[2]};
             const double d[3] = {dq[0], dq[1], dq[2]};
-            field_sweep_gx_multi<3>(phi, E8, gx, lane, na, a, d);
+            field_sweep_gx_multi<3, FOOT>(phi, E8, gx, lane, na, a, d);
         } else {
-            field_sweep_gx_multi<4>(phi, E8, gx, lane, na, s8, dq);
+            field_sweep_gx_multi<4, FOOT>(phi, E8, gx, lane, na, s8, dq);
         }
     }
 }
 
 // both flips of a swap in one pass over phi (one read-modify-write per entry instead of two)
+template <int FOOT = 1>
 __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, int lane, int s1, double dq1,
                                              int s2, double dq2) {
     const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, i
         const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
         const uint32_t s8[2] = {S8[j1], S8[j2]};
         const double d[2] = {dq1, dq2};
-        field_sweep_gx_multi<2>(phi, E8, gx, lane, P.ew_nact, s8, d);
+        field_sweep_gx_multi<2, FOOT>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
     }
@@ -1356,6 +1359,12 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     const __amdgpu_buffer_rsrc_t idx_rs =
         __builtin_amdgcn_make_buffer_rsrc((void *)P.idx, 0, 0x7fffffff, 0x00020000);
     const uint32_t lane_voff = (uint32_t)lane * (ROW * 2u);
+    // (two kernel arguments every step needs, parked in vector registers: the kernel is short of
+    // SGPRs and the compiler otherwise re-reads them from the kernel-argument segment -- a scalar
+    // load and a full wait -- in the middle of every step)
+    uint32_t ew_na_v = has_ew ? (uint32_t)P.ew_nact : 0u;
+    double ew_coef_v = has_ew ? P.ew_coef : 0.0;
+    asm volatile("" : "+v"(ew_na_v), "+v"(ew_coef_v));
     // cached between accepted table steps: feasible directions at the current counts, their weight
     // sum, and (lane dir of vlp, bit dir of lp_valid) the log a-priori factor of direction dir
     bool head_valid = false;
@@ -1417,7 +1426,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             if (has_ew && ew_field) {
                 const int pi = lane >> 3, pj = lane & 7;
                 const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
-                if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)si * P.ew_nact + (sj - sbase)];
+                if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)((uint32_t)si * ew_na_v) + (uint32_t)(sj - sbase)];
             }
         };
 
@@ -1814,7 +1823,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         double dEw = 0.0;
         if (has_ew) {
             dEw = (ew_field ? 0.0 : wave_sum_all(ew_part)) + ew_uni;
-            dH += P.ew_coef * dEw;
+            dH += ew_coef_v * dEw;
         }
         if (has_mu) dH -= dMu;
         const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42

@@ -452,16 +452,16 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             if (HAS_EW) {
                 if (phi_lds) {
                     if (STEP == SMOLMC_STEP_SWAP) {
-                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
+                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2<1>(P, phi, lane, s1, dq1, s2, dq2);
                     } else if (dq1 != 0.0) {
-                        field_apply(P, phi, lane, s1, dq1);
+                        field_apply<1>(P, phi, lane, s1, dq1);
                     }
                 } else {
                     double *phi_g = P.ew_phi + (size_t)r * P.ew_nact;
                     if (STEP == SMOLMC_STEP_SWAP) {
-                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi_g, lane, s1, dq1, s2, dq2);
+                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2<0>(P, phi_g, lane, s1, dq1, s2, dq2);
                     } else if (dq1 != 0.0) {
-                        field_apply(P, phi_g, lane, s1, dq1);
+                        field_apply<0>(P, phi_g, lane, s1, dq1);
                     }
                 }
             }
@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         if (accepted) {
             vcnt += vu;
             if (dir >= 0) head_valid = false;
-            if (has_ew) field_apply_flips(phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
+            if (has_ew) field_apply_flips<0>(phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             nacc_add++;

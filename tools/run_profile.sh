@@ -3,7 +3,7 @@
 #   bash tools/run_profile.sh r02       (on the GPU box, from the repo root)
 # Outputs under gpurun_out/ (scratch); copy the summaries you want judged into profiles/.
 set -x
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -23,5 +23,5 @@ done
 cd $R
 python tools/rocpd_summary.py gpurun_out/ldspmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_lds_pmc.txt
 python tools/rocpd_summary.py gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_pmc.txt
-python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, 0, false, false, true" --replicas 4096 --mc 10000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
+python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, 0, false, false, true" --replicas 4096 --mc 125000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
 tail -c 600 gpurun_out/bench_${tag}.json

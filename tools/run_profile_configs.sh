@@ -3,7 +3,7 @@
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFGS=${CFGS:-"3 4 5 7"}
+CFGS=${CFGS:-"3 4 5 9"}
 cd /tmp
 for k in $CFGS; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/cprof_c$k -- python $R/tools/bench_configs.py --config $k > $R/gpurun_out/cprof_c$k.log 2>&1
