@@ -285,10 +285,12 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     const int nclasses = std::max<int>(1, (int)class_rep.size());
     size_t Cmax = 1;
     for (int s : class_rep) Cmax = std::max(Cmax, slots[s].size());
-    const int Cpad = (int)((Cmax + 63) / 64 * 64);
-    const int niter_max = Cpad / 64;
+    const int niter_max = (int)((Cmax + 63) / 64);
     h->nslot = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : (niter_max <= 8 ? 8 : 16));
     if (niter_max > 16) return fail("more than 1024 clusters per site are not supported yet");
+    // slot columns per class: the two-group kernels evaluate BOTH groups without a condition
+    // (mc_general.h), so the padding goes up to their full width (padded slots add 0.0)
+    const int Cpad = 64 * (h->nslot <= 2 ? h->nslot : niter_max);
     if (aliased)
         h->mm = need_mm <= 3 ? 3 : 6;
     else

@@ -2,6 +2,25 @@
 #pragma once
 #include "smolmc_common.h"
 
+// Kernel arguments that only some paths of the step loop need are re-read from the kernel-argument
+// segment where they are used (see rare_params in smolmc_common.h: held in SGPRs across the loop
+// they push the hot path into SGPR spills -- this kernel had 260-300 of them).  Valid in kernels
+// whose first argument is the KParams block.
+typedef const KParams __attribute__((address_space(4))) *KParamsKernarg;
+__device__ __forceinline__ KParamsKernarg gen_params() {
+    KParamsKernarg p = (KParamsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define PK (*gen_params())
+
+// what every step needs of the index table, hoisted once
+struct GenHot {
+    const void *idx;
+    int Cpad;
+    size_t row_stride; // Mmax * Cpad
+};
+
 struct Lds {
     const uint4 *descA;
     const uint4 *descB;
@@ -30,11 +49,11 @@ __device__ __forceinline__ int stride_of(const uint4 &a, int m) {
 //   PATCH: occupancy seen is the LDS state with site ps overridden to pc (second
 //          flip of a swap sees the first, processor/expansion.py:217-229).
 template <typename IdxT, int MM, bool GENERIC, bool PATCH>
-__device__ __forceinline__ double eval_slot(const KParams &P, const Lds &L, int cls, int c, int s,
+__device__ __forceinline__ double eval_slot(const GenHot &P, const Lds &L, int cls, int c, int s,
                                             int oldc, int newc, int ps, int pc, int &ind_i,
                                             int &ind_f) {
     const uint4 a = L.descA[cls * P.Cpad + c];
-    const IdxT *ip = (const IdxT *)P.idx + ((size_t)s * P.Mmax) * P.Cpad + c;
+    const IdxT *ip = (const IdxT *)P.idx + (size_t)s * P.row_stride + c;
     int x[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) x[m] = (int)ip[(size_t)m * P.Cpad];
@@ -64,7 +83,7 @@ __device__ __forceinline__ double eval_slot(const KParams &P, const Lds &L, int 
 
 // feature accumulation of one accepted slot (Metropolis: lane-private LDS cells)
 template <bool WL>
-__device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int cls, int c, int lane,
+__device__ __forceinline__ void accum_slot(const GenHot &P, const bool acc_by_slot, const Lds &L, int cls, int c, int lane,
                                            int ind_i, int ind_f) {
     const uint4 b = L.descB[cls * P.Cpad + c];
     const int K = (int)(b.z >> 16), feat = (int)(b.z & 0xffffu);
@@ -77,7 +96,7 @@ __device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int c
             __hip_atomic_fetch_add(&L.wl_cf[feat + k], fs * d, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
         } else {
-            double *cell = P.acc_by_slot ? L.acc + (size_t)cls * P.Cpad + c : L.acc + (size_t)(feat + k) * 64 + lane;
+            double *cell = acc_by_slot ? L.acc + (size_t)cls * P.Cpad + c : L.acc + (size_t)(feat + k) * 64 + lane;
             *cell = fma(fs, d, *cell);
         }
     }
@@ -86,8 +105,8 @@ __device__ __forceinline__ void accum_slot(const KParams &P, const Lds &L, int c
 // Ewald delta of one flip (ewald.pyx:38-58), wave-parallel over sites; returns the
 // lane-partial (caller reduces).  Reads ROWS of the transposed matrix, i.e. the same
 // entries M[i, add] / M[j, sub] the reference reads as columns.
-template <bool PATCH>
-__device__ __forceinline__ double ewald_partial(const KParams &P, const Lds &L, int lane, int s,
+template <bool PATCH, typename PT>
+__device__ __forceinline__ double ewald_partial(const PT &P, const Lds &L, int lane, int s,
                                                 int oldc, int newc, int ps, int pc) {
     const int W = P.ew_W;
     const int add = P.ew_inds[(size_t)s * W + newc];
@@ -113,8 +132,8 @@ __device__ __forceinline__ double ewald_partial(const KParams &P, const Lds &L, 
 //   sum_k [2 M[i_k, add] - 2 M[i_k, sub]]  (k != s, i_k = j_k)  + M[add,add] - M[sub,sub]
 //     = 2 (q_add - q_sub) * sum_{k != s} q(k, occ_k) G[s][k] + diag(add) - diag(sub)
 // One fully-used row of G (N x 8 B) streams per flip instead of two strided matrix rows.
-template <bool PATCH>
-__device__ __forceinline__ double ewald_compact_partial(const KParams &P, const Lds &L, int lane, int s,
+template <bool PATCH, typename PT>
+__device__ __forceinline__ double ewald_compact_partial(const PT &P, const Lds &L, int lane, int s,
                                                         int ps, int pc) {
     // sites with a single allowed species never change: their part of the sum is the
     // precomputed ew_frozen[s]; only the changeable sites are streamed
@@ -136,7 +155,8 @@ __device__ __forceinline__ double ewald_compact_partial(const KParams &P, const 
 // kernel): phi[j] += dq * G[s][j] for every other changeable site j; lane-strided, so each
 // address is always touched by the same lane (program order keeps later updates coherent; the
 // self-term patch after the sweep is one store of the same value from every lane).
-__device__ __forceinline__ void field_apply_global(const KParams &P, double *phi, int lane, int s, double dq) {
+template <typename PT>
+__device__ __forceinline__ void field_apply_global(const PT &P, double *phi, int lane, int s, double dq) {
     const double *g = P.ew_G + (size_t)s * P.ew_nact;
     const int js = s - P.ew_act_base;
     const double keep = phi[js]; // phi excludes the self term: put back after the sweep
@@ -145,7 +165,8 @@ __device__ __forceinline__ void field_apply_global(const KParams &P, double *phi
 }
 
 // both flips of a swap in one pass over phi
-__device__ __forceinline__ void field_apply_global2(const KParams &P, double *phi, int lane, int s1, double dq1,
+template <typename PT>
+__device__ __forceinline__ void field_apply_global2(const PT &P, double *phi, int lane, int s1, double dq1,
                                                     int s2, double dq2) {
     const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
     const int j1 = s1 - P.ew_act_base, j2 = s2 - P.ew_act_base;
@@ -162,8 +183,8 @@ __device__ __forceinline__ void field_apply_global2(const KParams &P, double *ph
 
 // Metropolis feature deltas accumulated since launch start, reduced over the wave:
 // calls emit(f, value) on lane 0 for every cluster-expansion feature f.
-template <typename F>
-__device__ __forceinline__ void reduce_feature_acc(const KParams &P, const Lds &L, int lane, F emit) {
+template <typename PT, typename F>
+__device__ __forceinline__ void reduce_feature_acc(const PT &P, const Lds &L, int lane, F emit) {
     if (P.acc_by_slot) {
         double *out = L.acc + (size_t)P.nclasses * P.Cpad; // [Fce] scratch
         for (int f = lane; f < P.Fce; f += 64) out[f] = 0.0;
@@ -269,17 +290,33 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
     uint32_t w_site_carry = 0;
     double logu_b = 0.0; // native mode: log(u) of the lane's step, computed per batch
     unsigned long long batch_base = ~0ull - 64ull;
-    long long smp_countdown = P.smp.every, smp_index = 0;
+    const long long smp_every = P.smp.every;
+    long long smp_countdown = smp_every, smp_index = 0;
+    // the few kernel arguments every step needs (everything else: PK, see gen_params)
+    GenHot hot;
+    hot.idx = P.idx;
+    hot.Cpad = P.Cpad;
+    hot.row_stride = (size_t)P.Mmax * P.Cpad;
+    const long long nsteps_run = P.steps_to_run;
+    const int nsub = P.nsub, step_type = P.step_type, nclasses = P.nclasses;
+    // (feature switches packed into one register)
+    const uint32_t gflags = (P.has_ewald ? 1u : 0u) | (P.has_mu ? 2u : 0u) | (P.acc_by_slot ? 4u : 0u) | ((uint32_t)P.bias_type << 3);
+#define has_ewald ((gflags & 1u) != 0u)
+#define has_mu ((gflags & 2u) != 0u)
+#define acc_by_slot ((gflags & 4u) != 0u)
+#define bias_type ((int)(gflags >> 3))
+    const int p0_0 = P.sub_ptr[0], sbase_0 = P.sub_base[0];
+    const uint32_t nact_0 = (uint32_t)(P.sub_ptr[1] - p0_0);
 
-    for (long long it_step = 0; it_step < P.steps_to_run; ++it_step, ++step) {
+    for (long long it_step = 0; it_step < nsteps_run; ++it_step, ++step) {
         // ================= proposal =========================================
         int nfl = 0, s1 = 0, n1 = 0, o1 = 0, s2 = 0, n2 = 0, o2 = 0;
         double u = 0.0, lu = 0.0;
         bool have_lu = false; // native mode supplies log(u) from the batch; replay takes it per step
         if (replay) {
-            const int *st = P.rp_steps + ((size_t)r * P.steps_to_run + it_step) * 4;
+            const int *st = PK.rp_steps + ((size_t)r * nsteps_run + it_step) * 4;
             int a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3];
-            u = P.rp_u[(size_t)r * P.steps_to_run + it_step];
+            u = PK.rp_u[(size_t)r * nsteps_run + it_step];
             if (u != u) u = 0.0; // NaN: the reference accepted without drawing
             a0 = uni(a0); a1 = uni(a1); a2 = uni(a2); a3 = uni(a3);
             u = uni_d(u);
@@ -313,28 +350,32 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             have_lu = true;
             // sublattice: MCUsher.get_random_sublattice (mcusher.py:146-148)
             int sl = 0;
-            if (P.nsub > 1) {
+            if (nsub > 1) {
                 const double x = (double)w_sub * (1.0 / 4294967296.0);
-                sl = P.nsub - 1;
-                for (int q = P.nsub - 2; q >= 0; --q)
-                    if (x < P.sub_cum[q]) sl = q;
+                sl = nsub - 1;
+                for (int q = nsub - 2; q >= 0; --q)
+                    if (x < PK.sub_cum[q]) sl = q;
             }
-            const int p0 = P.sub_ptr[sl];
-            const uint32_t nact = (uint32_t)(P.sub_ptr[sl + 1] - p0);
-            const int sbase = P.sub_base[sl];
+            int p0 = p0_0, sbase = sbase_0;
+            uint32_t nact = nact_0;
+            if (nsub > 1) {
+                p0 = PK.sub_ptr[sl];
+                nact = (uint32_t)(PK.sub_ptr[sl + 1] - p0);
+                sbase = PK.sub_base[sl];
+            }
             const uint32_t k1 = __umulhi(w_site, nact);
-            s1 = sbase >= 0 ? sbase + (int)k1 : P.sub_sites[p0 + k1];
+            s1 = sbase >= 0 ? sbase + (int)k1 : PK.sub_sites[p0 + k1];
             s1 = uni(s1);
             o1 = uni((int)L.occ[s1]);
-            if (P.step_type == SMOLMC_STEP_FLIP) {
+            if (step_type == SMOLMC_STEP_FLIP) {
                 // Flip.propose_step (mcusher.py:154-170)
-                const int c0 = P.sub_code_ptr[sl];
-                const uint32_t nc = (uint32_t)(P.sub_code_ptr[sl + 1] - c0);
+                const int c0 = PK.sub_code_ptr[sl];
+                const uint32_t nc = (uint32_t)(PK.sub_code_ptr[sl + 1] - c0);
                 const uint32_t kk = __umulhi(rdlane(W0, l4 + 1), nc - 1);
                 int code = -1;
                 uint32_t seen = 0;
                 for (uint32_t c = 0; c < nc; ++c) {
-                    int cc = P.sub_codes[c0 + c];
+                    int cc = PK.sub_codes[c0 + c];
                     if (cc == o1) continue;
                     if (seen == kk && code < 0) code = cc;
                     seen++;
@@ -353,7 +394,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
                     for (int j = 0; j < 4; ++j) {
                         if (found < 0) {
                             const uint32_t kc = __umulhi(ws[j], nact);
-                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            const int cs = sbase >= 0 ? sbase + (int)kc : PK.sub_sites[p0 + kc];
                             const bool hit = (int)L.occ[cs] != o1;
                             unsigned long long m = __ballot(hit) & (0xEull << l4);
                             if (m) found = (int)rdlane((uint32_t)cs, __ffsll((long long)m) - 1);
@@ -369,7 +410,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
 #pragma unroll
                         for (int j = 3; j >= 0; --j) {
                             const uint32_t kc = __umulhi(o.w[j], nact);
-                            const int cs = sbase >= 0 ? sbase + (int)kc : P.sub_sites[p0 + kc];
+                            const int cs = sbase >= 0 ? sbase + (int)kc : PK.sub_sites[p0 + kc];
                             if ((int)L.occ[cs] != o1) selsite = cs;
                         }
                         unsigned long long m = __ballot(selsite >= 0);
@@ -380,7 +421,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
                         if ((q & 63u) == 0) { // swap_options.size == 0 -> empty step (:197-199)
                             int any = 0;
                             for (uint32_t a = lane; a < nact; a += 64) {
-                                const int cs = sbase >= 0 ? sbase + (int)a : P.sub_sites[p0 + a];
+                                const int cs = sbase >= 0 ? sbase + (int)a : PK.sub_sites[p0 + a];
                                 any |= ((int)L.occ[cs] != o1);
                             }
                             if (__ballot(any) == 0ull) break;
@@ -402,111 +443,122 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         int cls1 = 0, cls2 = 0, nit1 = 0, nit2 = 0;
         double e = 0.0;
         if (nfl >= 1) {
-            cls1 = P.nclasses > 1 ? uni((int)L.site_class[s1]) : 0;
+            cls1 = nclasses > 1 ? uni((int)L.site_class[s1]) : 0;
             nit1 = cls1 == 255 ? 0 : uni(L.cls_niter[cls1]);
         }
+        // The two-group kernels evaluate both groups WITHOUT a condition per group: groups a class does
+        // not use have all-zero descriptors and index rows that point at the site itself (they add
+        // exactly 0.0), a site without clusters (class 255) borrows class 0 with weight zero.  With a
+        // branch per group the compiler drains its wait counters at every group and the loads of a
+        // step -- index entries, occupancy bytes, tensor entries: three dependent round trips per
+        // group -- run one group after the other.
+        constexpr bool ALL = NSLOT <= 2;
         if (nfl == 2) {
-            cls2 = P.nclasses > 1 ? uni((int)L.site_class[s2]) : 0;
+            cls2 = nclasses > 1 ? uni((int)L.site_class[s2]) : 0;
             nit2 = cls2 == 255 ? 0 : uni(L.cls_niter[cls2]);
+            const int c1e = cls1 == 255 ? 0 : cls1, c2e = cls2 == 255 ? 0 : cls2;
+            const double k1 = cls1 == 255 ? 0.0 : 1.0, k2 = cls2 == 255 ? 0.0 : 1.0;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
                 const int c = lane + 64 * it;
-                if (it < nit1)
-                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
-                                                             jf1[it]);
-                if (it < nit2)
-                    e += eval_slot<IdxT, MM, GENERIC, true>(P, L, cls2, c, s2, o2, n2, s1, n1, ii2[it],
-                                                            jf2[it]);
+                if (ALL || it < nit1)
+                    e += k1 * eval_slot<IdxT, MM, GENERIC, false>(hot, L, c1e, c, s1, o1, n1, 0, 0, ii1[it],
+                                                                  jf1[it]);
+                if (ALL || it < nit2)
+                    e += k2 * eval_slot<IdxT, MM, GENERIC, true>(hot, L, c2e, c, s2, o2, n2, s1, n1, ii2[it],
+                                                                 jf2[it]);
             }
         } else if (nfl == 1) {
+            const int c1e = cls1 == 255 ? 0 : cls1;
+            const double k1 = cls1 == 255 ? 0.0 : 1.0;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) {
                 const int c = lane + 64 * it;
-                if (it < nit1)
-                    e += eval_slot<IdxT, MM, GENERIC, false>(P, L, cls1, c, s1, o1, n1, 0, 0, ii1[it],
-                                                             jf1[it]);
+                if (ALL || it < nit1)
+                    e += k1 * eval_slot<IdxT, MM, GENERIC, false>(hot, L, c1e, c, s1, o1, n1, 0, 0, ii1[it],
+                                                                  jf1[it]);
             }
         }
         double dEw = 0.0, dMu = 0.0;
         double fdq1 = 0.0, fdq2 = 0.0; // potential-field mode: charge changes of the flips
-        if (P.has_ewald && nfl >= 1 && P.ew_field) {
+        if (has_ewald && nfl >= 1 && PK.ew_field) {
             // O(1) proposal from the walker's potential field (HBM copy, read past the L1 so
             // that the row updates of earlier accepted steps are seen)
-            double *phi = P.ew_phi + (size_t)r * P.ew_nact;
-            const int W = P.ew_W, ab = P.ew_act_base;
-            fdq1 = P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1];
+            double *phi = PK.ew_phi + (size_t)r * PK.ew_nact;
+            const int W = PK.ew_W, ab = PK.ew_act_base;
+            fdq1 = PK.ew_qs[(size_t)s1 * W + n1] - PK.ew_qs[(size_t)s1 * W + o1];
             const double p1 = __hip_atomic_load(&phi[s1 - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dEw = 2.0 * fdq1 * p1 + (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+            dEw = 2.0 * fdq1 * p1 + (PK.ew_dg[(size_t)s1 * W + n1] - PK.ew_dg[(size_t)s1 * W + o1]);
             if (nfl == 2) {
-                fdq2 = P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2];
+                fdq2 = PK.ew_qs[(size_t)s2 * W + n2] - PK.ew_qs[(size_t)s2 * W + o2];
                 const double p2 = __hip_atomic_load(&phi[s2 - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double cross = s2 != s1 ? P.ew_G[(size_t)s2 * P.ew_nact + (s1 - ab)] : 0.0;
+                const double cross = s2 != s1 ? PK.ew_G[(size_t)s2 * PK.ew_nact + (s1 - ab)] : 0.0;
                 dEw += 2.0 * fdq2 * (p2 + fdq1 * cross) +
-                       (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+                       (PK.ew_dg[(size_t)s2 * W + n2] - PK.ew_dg[(size_t)s2 * W + o2]);
             }
             dEw = uni_d(dEw);
-        } else if (P.has_ewald && nfl >= 1) {
-            if (P.ew_compact) {
-                const int W = P.ew_W;
-                const double s1sum = P.ew_frozen[s1] + wave_sum(ewald_compact_partial<false>(P, L, lane, s1, 0, 0));
-                dEw = 2.0 * (P.ew_qs[(size_t)s1 * W + n1] - P.ew_qs[(size_t)s1 * W + o1]) * s1sum +
-                      (P.ew_dg[(size_t)s1 * W + n1] - P.ew_dg[(size_t)s1 * W + o1]);
+        } else if (has_ewald && nfl >= 1) {
+            if (PK.ew_compact) {
+                const int W = PK.ew_W;
+                const double s1sum = PK.ew_frozen[s1] + wave_sum(ewald_compact_partial<false>(PK, L, lane, s1, 0, 0));
+                dEw = 2.0 * (PK.ew_qs[(size_t)s1 * W + n1] - PK.ew_qs[(size_t)s1 * W + o1]) * s1sum +
+                      (PK.ew_dg[(size_t)s1 * W + n1] - PK.ew_dg[(size_t)s1 * W + o1]);
                 if (nfl == 2) {
-                    const double s2sum = P.ew_frozen[s2] + wave_sum(ewald_compact_partial<true>(P, L, lane, s2, s1, n1));
-                    dEw += 2.0 * (P.ew_qs[(size_t)s2 * W + n2] - P.ew_qs[(size_t)s2 * W + o2]) * s2sum +
-                           (P.ew_dg[(size_t)s2 * W + n2] - P.ew_dg[(size_t)s2 * W + o2]);
+                    const double s2sum = PK.ew_frozen[s2] + wave_sum(ewald_compact_partial<true>(PK, L, lane, s2, s1, n1));
+                    dEw += 2.0 * (PK.ew_qs[(size_t)s2 * W + n2] - PK.ew_qs[(size_t)s2 * W + o2]) * s2sum +
+                           (PK.ew_dg[(size_t)s2 * W + n2] - PK.ew_dg[(size_t)s2 * W + o2]);
                 }
                 dEw = uni_d(dEw);
             } else {
-                double pe = ewald_partial<false>(P, L, lane, s1, o1, n1, 0, 0);
-                if (nfl == 2) pe += ewald_partial<true>(P, L, lane, s2, o2, n2, s1, n1);
+                double pe = ewald_partial<false>(PK, L, lane, s1, o1, n1, 0, 0);
+                if (nfl == 2) pe += ewald_partial<true>(PK, L, lane, s2, o2, n2, s1, n1);
                 dEw = wave_sum(pe);
             }
         }
-        if (P.has_mu && nfl >= 1) {
+        if (has_mu && nfl >= 1) {
             // delta chemical work against the ORIGINAL occupancy (ensemble.py:368-374)
-            dMu = P.mu[(size_t)s1 * P.mu_W + n1] - P.mu[(size_t)s1 * P.mu_W + o1];
+            dMu = PK.mu[(size_t)s1 * PK.mu_W + n1] - PK.mu[(size_t)s1 * PK.mu_W + o1];
             if (nfl == 2) {
                 const int orig2 = uni((int)L.occ[s2]);
-                dMu += P.mu[(size_t)s2 * P.mu_W + n2] - P.mu[(size_t)s2 * P.mu_W + orig2];
+                dMu += PK.mu[(size_t)s2 * PK.mu_W + n2] - PK.mu[(size_t)s2 * PK.mu_W + orig2];
             }
             dMu = uni_d(dMu);
         }
         double dH = wave_sum(e);
-        if (P.has_ewald) dH += P.ew_coef * dEw;
-        if (P.has_mu) dH -= dMu;
+        if (has_ewald) dH += PK.ew_coef * dEw;
+        if (has_mu) dH -= dMu;
         // MCBias.compute_bias_change against the ORIGINAL occupancy (kernel/base.py:307-311):
         // FugacityBias log-ratio per flipped site (bias.py:188-206); SquareChargeBias the
         // difference of -penalty * charge^2 (bias.py:75-93, :264-277) on the running charge
         double dB = 0.0, dQ = 0.0;
         int bias_orig2 = 0; // species of site 2 BEFORE the step (the second flip sees the first)
-        if (!WL && P.bias_type && nfl >= 1) {
-            const double *b1 = P.bias_tab + (size_t)s1 * P.bias_W;
+        if (!WL && bias_type && nfl >= 1) {
+            const double *b1 = PK.bias_tab + (size_t)s1 * PK.bias_W;
             const int orig2 = nfl == 2 ? uni((int)L.occ[s2]) : 0;
             bias_orig2 = orig2;
-            const double *b2 = P.bias_tab + (size_t)s2 * P.bias_W;
-            if (P.bias_type == SMOLMC_BIAS_FUGACITY) {
+            const double *b2 = PK.bias_tab + (size_t)s2 * PK.bias_W;
+            if (bias_type == SMOLMC_BIAS_FUGACITY) {
                 dB = log(b1[n1] / b1[o1]);
                 if (nfl == 2) dB += log(b2[n2] / b2[orig2]);
-            } else if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) {
+            } else if (bias_type == SMOLMC_BIAS_SQUARE_CHARGE) {
                 dQ = b1[n1] - b1[o1];
                 if (nfl == 2) dQ += b2[n2] - b2[orig2];
                 const double cn = charge + dQ;
-                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+                dB = -PK.bias_pen * (cn * cn) - (-PK.bias_pen * (charge * charge));
             } else {
                 // SquareHyperplaneBias (bias.py:290-366; compute_bias_change is the inherited
                 // recompute-and-subtract, :75-93, restated on the running A_r . n - b_r kept per
                 // walker in HBM: a rarely used term, not worth registers in this kernel)
                 double sq_new = 0.0, sq_old = 0.0;
-                for (int k = 0; k < P.bias_rows; ++k) {
-                    const size_t ro = (size_t)k * P.bias_row_stride;
+                for (int k = 0; k < PK.bias_rows; ++k) {
+                    const size_t ro = (size_t)k * PK.bias_row_stride;
                     double dq = b1[ro + n1] - b1[ro + o1];
                     if (nfl == 2) dq += b2[ro + n2] - b2[ro + orig2];
-                    const double c = ((volatile const double *)P.charge)[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k]; // (vector load: written by this wave)
+                    const double c = ((volatile const double *)PK.charge)[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k]; // (vector load: written by this wave)
                     sq_old += c * c;
                     sq_new += (c + dq) * (c + dq);
                 }
-                dB = -P.bias_pen * sq_new - (-P.bias_pen * sq_old);
+                dB = -PK.bias_pen * sq_new - (-PK.bias_pen * sq_old);
             }
             dB = uni_d(dB);
             dQ = uni_d(dQ);
@@ -521,11 +573,11 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         } else {
             // WangLandau._accept_step (wanglandau.py:186-202)
             const double new_h = H + dH;
-            if (new_h < P.wl_min || new_h >= P.wl_max) {
+            if (new_h < PK.wl_min || new_h >= PK.wl_max) {
                 accepted = false;
             } else {
-                const int b = (int)floordiv_exact(H - P.wl_min, P.wl_bin);
-                const int nb = (int)floordiv_exact(new_h - P.wl_min, P.wl_bin);
+                const int b = (int)floordiv_exact(H - PK.wl_min, PK.wl_bin);
+                const int nb = (int)floordiv_exact(new_h - PK.wl_min, PK.wl_bin);
                 const double exponent = L.wl_S[b] - L.wl_S[nb] + 0.0;
                 accepted = __ballot(exponent >= 0.0 ? true : (exponent > (have_lu ? lu : log(u)))) != 0ull;
             }
@@ -538,30 +590,30 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             if (nfl >= 1) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it)
-                    if (it < nit1) accum_slot<WL>(P, L, cls1, lane + 64 * it, lane, ii1[it], jf1[it]);
+                    if (it < nit1) accum_slot<WL>(hot, acc_by_slot != 0, L, cls1, lane + 64 * it, lane, ii1[it], jf1[it]);
             }
             if (nfl == 2) {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it)
-                    if (it < nit2) accum_slot<WL>(P, L, cls2, lane + 64 * it, lane, ii2[it], jf2[it]);
+                    if (it < nit2) accum_slot<WL>(hot, acc_by_slot != 0, L, cls2, lane + 64 * it, lane, ii2[it], jf2[it]);
             }
             if (nfl >= 1) L.occ[s1] = (uint8_t)n1; // every lane stores the same byte
             if (nfl == 2) L.occ[s2] = (uint8_t)n2;
             if (lane == 0) {
                 if (WL) {
-                    if (P.has_ewald) L.wl_cf[P.Fce] += dEw;
-                    if (P.has_mu) L.wl_cf[P.Fce + P.has_ewald] += dMu;
+                    if (has_ewald) L.wl_cf[PK.Fce] += dEw;
+                    if (has_mu) L.wl_cf[PK.Fce + has_ewald] += dMu;
                 }
             }
-            if (P.has_ewald && P.ew_field) {
-                double *phi = P.ew_phi + (size_t)r * P.ew_nact;
+            if (has_ewald && PK.ew_field) {
+                double *phi = PK.ew_phi + (size_t)r * PK.ew_nact;
                 // two flips: one pass over phi (the update is bound by HBM / Infinity-Cache traffic);
                 // a replayed step may flip the same site twice -> two passes keep the self-exclusion
                 if (nfl == 2 && s2 != s1) {
-                    if (fdq1 != 0.0 || fdq2 != 0.0) field_apply_global2(P, phi, lane, s1, fdq1, s2, fdq2);
+                    if (fdq1 != 0.0 || fdq2 != 0.0) field_apply_global2(PK, phi, lane, s1, fdq1, s2, fdq2);
                 } else {
-                    if (fdq1 != 0.0) field_apply_global(P, phi, lane, s1, fdq1);
-                    if (nfl == 2 && fdq2 != 0.0) field_apply_global(P, phi, lane, s2, fdq2);
+                    if (fdq1 != 0.0) field_apply_global(PK, phi, lane, s1, fdq1);
+                    if (nfl == 2 && fdq2 != 0.0) field_apply_global(PK, phi, lane, s2, fdq2);
                 }
             }
             acc_ew += dEw;
@@ -569,14 +621,14 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             H += dH;
             bias += dB;
             charge += dQ;
-            if (P.bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) {
-                const double *b1 = P.bias_tab + (size_t)s1 * P.bias_W, *b2 = P.bias_tab + (size_t)s2 * P.bias_W;
-                for (int k = 0; k < P.bias_rows; ++k) {
-                    const size_t ro = (size_t)k * P.bias_row_stride;
+            if (bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) {
+                const double *b1 = PK.bias_tab + (size_t)s1 * PK.bias_W, *b2 = PK.bias_tab + (size_t)s2 * PK.bias_W;
+                for (int k = 0; k < PK.bias_rows; ++k) {
+                    const size_t ro = (size_t)k * PK.bias_row_stride;
                     double dq = b1[ro + n1] - b1[ro + o1];
                     if (nfl == 2) dq += b2[ro + n2] - b2[ro + bias_orig2];
                     if (lane == 0) {
-                        volatile double *cq = (volatile double *)P.charge + (size_t)r * SMOLMC_MAX_BIAS_ROWS + k;
+                        volatile double *cq = (volatile double *)PK.charge + (size_t)r * SMOLMC_MAX_BIAS_ROWS + k;
                         *cq = *cq + dq;
                     }
                 }
@@ -587,75 +639,75 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
 
         if (WL) {
             // WangLandau._do_post_step (wanglandau.py:222-266)
-            const double bq = floordiv_exact(H - P.wl_min, P.wl_bin);
-            if (bq >= 0.0 && bq < (double)P.L) {
+            const double bq = floordiv_exact(H - PK.wl_min, PK.wl_bin);
+            if (bq >= 0.0 && bq < (double)PK.L) {
                 const int b = (int)bq;
                 wl_counter++;
-                const size_t cell = (size_t)r * P.L + b;
+                const size_t cell = (size_t)r * PK.L + b;
                 // lane 0 owns the occurrences counter (single-thread program order for
                 // its own global read-after-write); broadcast to the wave
                 long long total = 0;
-                if (lane == 0) total = P.wl_occur[cell];
+                if (lane == 0) total = PK.wl_occur[cell];
                 total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
                         (unsigned)uni((int)(total & 0xffffffffll));
-                if (lane < P.F) {
-                    double *mf = P.wl_meanf + cell * P.F + lane;
+                if (lane < PK.F) {
+                    double *mf = PK.wl_meanf + cell * PK.F + lane;
                     const double inv = 1.0 / (double)(total + 1);
                     *mf = inv * (L.wl_cf[lane] + (double)total * (*mf));
                 }
-                if (wl_counter % P.wl_update == 0) {
+                if (wl_counter % PK.wl_update == 0) {
                     if (lane == 0) {
                         L.wl_S[b] += wl_m;
                         L.wl_H[b] += 1;
-                        P.wl_occur[cell] = total + 1;
+                        PK.wl_occur[cell] = total + 1;
                     }
                 }
             }
-            if (wl_counter % P.wl_check == 0) {
+            if (wl_counter % PK.wl_check == 0) {
                 long cnt = 0;
                 double sum = 0;
-                for (int i = lane; i < P.L; i += 64)
+                for (int i = lane; i < PK.L; i += 64)
                     if (L.wl_S[i] > 0) { cnt++; sum += (double)L.wl_H[i]; }
                 const double tcnt = wave_sum((double)cnt), tsum = wave_sum(sum);
                 if (tcnt >= 2.0) {
-                    const double thr = P.wl_flat * (tsum / tcnt);
+                    const double thr = PK.wl_flat * (tsum / tcnt);
                     int bad = 0;
-                    for (int i = lane; i < P.L; i += 64)
+                    for (int i = lane; i < PK.L; i += 64)
                         if (L.wl_S[i] > 0 && !((double)L.wl_H[i] > thr)) bad = 1;
                     if (__ballot(bad) == 0ull) {
-                        for (int i = lane; i < P.L; i += 64) L.wl_H[i] = 0;
-                        wl_m = wl_m / P.wl_div;
+                        for (int i = lane; i < PK.L; i += 64) L.wl_H[i] = 0;
+                        wl_m = wl_m / PK.wl_div;
                     }
                 }
             }
         }
         if (replay && lane == 0) {
-            if (P.rp_acc) P.rp_acc[(size_t)r * P.steps_to_run + it_step] = (uint8_t)last_acc;
-            if (P.rp_H) P.rp_H[(size_t)r * P.steps_to_run + it_step] = H;
+            if (PK.rp_acc) PK.rp_acc[(size_t)r * nsteps_run + it_step] = (uint8_t)last_acc;
+            if (PK.rp_H) PK.rp_H[(size_t)r * nsteps_run + it_step] = H;
         }
-        if (P.smp.every && --smp_countdown == 0) { // record one thinned sample of this walker
-            smp_countdown = P.smp.every;
-            const size_t row = (size_t)smp_index * P.R + r;
+        if (smp_every && --smp_countdown == 0) { // record one thinned sample of this walker
+            smp_countdown = smp_every;
+            const size_t row = (size_t)smp_index * PK.R + r;
             smp_index++;
-            double *dstf = P.smp.feat + row * P.F;
-            const double *base = P.features + (size_t)r * P.F;
+            double *dstf = PK.smp.feat + row * PK.F;
+            const double *base = PK.features + (size_t)r * PK.F;
             if (WL) {
-                for (int i = lane; i < P.F; i += 64) dstf[i] = L.wl_cf[i];
+                for (int i = lane; i < PK.F; i += 64) dstf[i] = L.wl_cf[i];
             } else {
-                reduce_feature_acc(P, L, lane, [&](int f, double sm) { dstf[f] = base[f] + sm; });
+                reduce_feature_acc(PK, L, lane, [&](int f, double sm) { dstf[f] = base[f] + sm; });
                 if (lane == 0) {
-                    if (P.has_ewald) dstf[P.Fce] = base[P.Fce] + acc_ew;
-                    if (P.has_mu) dstf[P.Fce + P.has_ewald] = base[P.Fce + P.has_ewald] + acc_mu;
+                    if (has_ewald) dstf[PK.Fce] = base[PK.Fce] + acc_ew;
+                    if (has_mu) dstf[PK.Fce + has_ewald] = base[PK.Fce + has_ewald] + acc_mu;
                 }
             }
             if (lane == 0) {
-                P.smp.H[row] = H;
-                P.smp.acc[row] = (uint8_t)last_acc;
+                PK.smp.H[row] = H;
+                PK.smp.acc[row] = (uint8_t)last_acc;
             }
-            if (P.smp.occ) {
-                uint4 *dst = (uint4 *)(P.smp.occ + row * P.Npad);
+            if (PK.smp.occ) {
+                uint4 *dst = (uint4 *)(PK.smp.occ + row * PK.Npad);
                 const uint4 *src = (const uint4 *)L.occ;
-                for (int i = lane; i < P.Npad / 16; i += 64) dst[i] = src[i];
+                for (int i = lane; i < PK.Npad / 16; i += 64) dst[i] = src[i];
             }
         }
     }
@@ -680,8 +732,8 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
     } else {
         reduce_feature_acc(P, L, lane, [&](int f, double sm) { feat[f] += sm; });
         if (lane == 0) {
-            if (P.has_ewald) feat[P.Fce] += acc_ew;
-            if (P.has_mu) feat[P.Fce + P.has_ewald] += acc_mu;
+            if (has_ewald) feat[P.Fce] += acc_ew;
+            if (has_mu) feat[P.Fce + has_ewald] += acc_mu;
         }
     }
     if (lane == 0) {
@@ -689,11 +741,16 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         P.nsteps[r] = step;
         P.nacc[r] = nacc;
         P.last_acc[r] = (uint8_t)last_acc;
-        if (P.bias_type) P.bias[r] = bias;
-        if (P.bias_type == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
+        if (bias_type) P.bias[r] = bias;
+        if (bias_type == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
     }
 }
 
+
+#undef has_ewald
+#undef has_mu
+#undef acc_by_slot
+#undef bias_type
 
 // ---- kernel dispatch ----------------------------------------------------------
 template <typename IdxT, int NSLOT, int MM, bool GENERIC, bool WL>

@@ -132,7 +132,9 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
 // else one sweep per flip
 // (inlined: out of line the kernel's register budget becomes the maximum over the call graph --
 // 256 VGPRs and scratch -- instead of shrinking)
-template <int FOOT = 1>
+// (FEW: only the three- and four-flip sweeps are instantiated, shorter steps pad with zero charge
+// changes -- for kernels whose code size matters more than the sweep of their rarer steps)
+template <int FOOT = 1, bool FEW = false>
 __device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl, int vsite, double vdq) {
     const LeanParamsKernarg Q = rare_params();
 
@@ -163,7 +165,11 @@ __device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl
             s8[k] = S8[site_of(f) - sb];
             dq[k] = k < n ? dq_of(f) : 0.0;
         }
-        if (n == 1) {
+        if (FEW && n <= 3) {
+            const uint32_t a[3] = {s8[0], s8[1], s8[2]};
+            const double d[3] = {dq[0], dq[1], dq[2]};
+            field_sweep_gx_multi<3, FOOT>(phi, E8, gx, lane, na, a, d);
+        } else if (n == 1) {
             const uint32_t a[1] = {s8[0]};
             const double d[1] = {dq[0]};
             field_sweep_gx_multi<1, FOOT>(phi, E8, gx, lane, na, a, d);
@@ -1182,6 +1188,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 }
 
 
+// Philox out of line for the TableFlip kernel: its step loop is tens of KB of code (the instruction
+// cache is 64 KB per two CUs) and holds many calls, none of them on the per-step path.
+__device__ __noinline__ philox_out philox_call(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1) {
+    return philox4x32_10(c0, c1, c2, 0u, k0, k1);
+}
+
 // sum over species c of ln n_c! - ln (n_c + u_c)!  (mcusher.py:694-709) with lane c holding the
 // count n_c and its change u_c: every lane walks its own |u_c| table entries ln(k) (host libm; LDS
 // copy when it fits, else HBM) with the first four reads in flight together -- a scalar loop over
@@ -1223,7 +1235,7 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // A template parameter, not a runtime flag: the unused variants' pointers and code otherwise stay
 // live across the step loop (the kernel spills SGPRs as it is).
 template <int NSLOT, int MM, int EWM>
-__global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
+__global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
     constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1293,6 +1305,15 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
         return m;
     };
+    // lane c: the largest count change of species c in any direction.  Counts that stay at least
+    // that far from both limits make EVERY direction feasible -- the usual case away from the
+    // composition limits, where the feasibility mask and the weight sums then need no recomputation
+    int vmaxu = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vmaxu = max(vmaxu, vtf[i] < 0 ? -vtf[i] : vtf[i]);
+    auto all_feasible = [&](const int vc) -> bool {
+        return __ballot(lane < nc && (vc - vmaxu < 0 || vc + vmaxu > (int)nact)) == 0ull;
+    };
     // lane idx (< 2 tf_n): the enriched species of direction idx in the order the assignment draws
     // them (species ascending, u_c entries each; mcusher.py:627-631) as packed nibbles -- up to
     // SMOLMC_MAX_STEP_FLIPS = 8 of them
@@ -1303,6 +1324,18 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         for (int c = 0; c < P.ncodes; ++c) {
             const int u = sgn * s_tf[(lane >> 1) * P.ncodes + c];
             for (int z = 0; z < u && k < 8; ++z, ++k) venr |= (uint32_t)c << (4 * k);
+        }
+    }
+    // ... and the depleted species in the order the site scan wants them (species ascending, -u_c
+    // entries each), with their number (= the number of flips of the direction)
+    uint32_t vdep = 0;
+    int vncol = 0;
+    if (lane < 2 * P.tf_n) {
+        const int sgn = (lane & 1) ? -1 : 1;
+        for (int c = 0; c < P.ncodes; ++c) {
+            const int u = sgn * s_tf[(lane >> 1) * P.ncodes + c];
+            for (int z = 0; z < -u; ++z, ++vncol)
+                if (vncol < 8) vdep |= (uint32_t)c << (4 * vncol);
         }
     }
     const uint32_t lane4 = (uint32_t)(lane & 7) * 4u;
@@ -1350,7 +1383,6 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     // 32-bit loop state (the host splits launches at 2^30 steps): the kernel is short of SGPRs
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu, smp_index = 0; // (no sampling: never reaches zero)
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
-    double logu = 0.0;
     uint32_t batch_base = ~0u; // low word of the batch's first step: consecutive steps change it exactly when the batch changes
     uint32_t w_site_carry = 0;
     constexpr int ROW = NSLOT * MM;
@@ -1371,40 +1403,219 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
     unsigned feas_now = 0, lp_valid = 0;
     double sumw = 0.0, vlp = 0.0, vcum = 0.0;
     int last_feas = -1;
-    // Candidate block: the first 32 positions of the site-candidate stream c_t = W(step, 4 + t/4,
-    // t%4) of TWO steps, one candidate per lane (lane L: step (step & ~1) + (L >> 5), t = L & 31),
-    // from one Philox call per two steps.  A table step needs |u| <= 8 sites and nearly always
-    // finds them among its first 32 candidates: those steps skip the 256-candidate round (a Philox
-    // call, 4 gathers and 4 ballots per species) -- see the fast path below.
-    uint32_t cblk_base = ~0u;
-    int cb_site = 0, cb_addr = 0;
-
-#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
-    long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph2[2] = {0, 0};
-    long long ph_t = clock64();
-#endif
-    for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
+    // Proposal batch: the proposals of 64 consecutive steps computed at once, lane l <-> step
+    // (step & ~63) + l, all on the vector unit (the step-at-a-time proposal below is a chain of
+    // dependent scalar instructions -- ballot, find-first, readlane, compare -- of one wave:
+    // ~4000 cycles per step where the batch costs ~40 vector instructions per step).  A proposal
+    // is a function of the random words of its step, of the feasibility mask of the directions
+    // (species counts) and of the species at the sites its scan EXAMINES (site 1 and the
+    // candidates up to the partner for a swap; the site candidates up to the last pick for a
+    // table step).  Those sites are kept (16 x u16 per lane); after every accepted step the
+    // lanes that examined a changed site, and all lanes when the feasibility mask changed, are
+    // marked stale, and a stale step -- as every step the batch does not cover: more than four
+    // flips, more than 32 site candidates, no swap partner among the first 12 candidates --
+    // is proposed by the step-at-a-time code, which is the definition (oracle: propose_table_flip).
+    uint32_t q_base = ~0u;           // low word of the batch's first step
+    uint32_t q_meta = 0;             // bit 0 covered | bit 1 swap | bits 2-4 flips | bits 5-8 direction
+    uint32_t q_s01 = 0, q_s23 = 0;   // sites of the flips (u16 each)
+    uint32_t q_pack = 0;             // old species of flip f: nibble f; new species: nibble 4 + f
+    uint32_t q_w1 = 0;               // W(step, 0, 1): the site word of the NEXT step
+    uint32_t q_c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q_c[i] = 0xffffffffu;
+    double q_logu = 0.0;             // log of the acceptance uniform
+    unsigned long long q_stale = ~0ull;
+    auto compute_head = [&]() {
+        const LeanParamsKernarg Q = rare_params();
+        const int tfn = Q->tf_n, na = Q->nact;
+        feas_now = feasible(vcnt, tfn, na);
+        sumw = masked_sum(feas_now, tfn);
+        head_valid = true;
+        lp_valid = 0u;
+        // running sums of the feasible weights, lane idx <-> direction idx, added in the
+        // order choose_section_from_partition adds them: the per-step choice below is then
+        // one compare + ballot instead of a loop of readlanes and float64 adds
+        double c = 0.0;
+        last_feas = -1;
+        const int n2 = 2 * tfn;
+        for (int idx = 0; idx < n2; ++idx)
+            if ((feas_now >> idx) & 1u) {
+                c += weight_of(idx);
+                if (lane == idx) vcum = c;
+                last_feas = idx;
+            }
+    };
+    auto propose_batch = [&](const unsigned long long b0) { // b0: first step of the block
+        const LeanParamsKernarg Q = rare_params();
+        uint32_t carry; // lane 0's site word W(b0 - 1, 0, 1)
+        if (q_base == (uint32_t)b0 - 64u) {
+            carry = rdlane(q_w1, 63);
+        } else {
+            const unsigned long long sp = b0 - 1ull;
+            carry = (uint32_t)uni((int)philox_call((uint32_t)sp, (uint32_t)(sp >> 32), 0u, key0, key1).w[1]);
+        }
+        q_base = (uint32_t)b0;
+        q_stale = 0ull;
+        const unsigned long long st = b0 + (unsigned)lane;
+        const uint32_t c0 = (uint32_t)st, c1 = (uint32_t)(st >> 32);
+        const philox_out o0 = philox_call(c0, c1, 0u, key0, key1);
+        q_logu = log(philox_u53(o0.w[2], o0.w[3]));
+        q_w1 = o0.w[1];
+        uint32_t wsite = (uint32_t)__shfl((int)o0.w[1], (lane + 63) & 63);
+        wsite = lane == 0 ? carry : wsite;
+        q_meta = 0u;
+        if (!(sumw > 0.0)) return; // no feasible direction: every step a swap -- left to the step-at-a-time code
+        const bool is_swap = (double)o0.w[0] * (1.0 / 4294967296.0) < Q->tf_sw;
+        const philox_out o1 = philox_call(c0, c1, 1u, key0, key1);
+        const philox_out o2 = philox_call(c0, c1, 2u, key0, key1);
+        // direction, its species lists (choose_section_from_partition, math.py:870-893)
+        const double target = (double)o1.w[0] * (1.0 / 4294967296.0) * sumw;
+        int d = -1;
+        {
+            const int n2 = 2 * Q->tf_n;
+            for (int idx = 0; idx < n2; ++idx) {
+                const double c = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vcum), idx),
+                                                  (int)rdlane((uint32_t)__double2loint(vcum), idx));
+                if (((feas_now >> idx) & 1u) && d < 0 && target < c) d = idx;
+            }
+            if (d < 0) d = last_feas;
+        }
+        const uint32_t dep = (uint32_t)__shfl((int)vdep, d), enr = (uint32_t)__shfl((int)venr, d);
+        const int ncol = __shfl(vncol, d);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q_c[i] = 0xffffffffu;
+        uint32_t meta = 0u, pack = 0u;
+        int col0 = -1, col1 = -1, col2 = -1, col3 = -1;
+        if (is_swap) {
+            // Swap.propose_step (mcusher.py:176-200): the first 12 candidates c_t = W(step, 1 + t % 3, t / 3)
+            const philox_out o3 = philox_call(c0, c1, 3u, key0, key1);
+            const int s1 = sbase + (int)__umulhi(wsite, nact);
+            const int sp1 = (int)occ[lean_swz(s1, swa, swm, swb)];
+            q_c[0] = 0xffff0000u | (uint32_t)s1;
+            int found = -1, fo = 0;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const uint32_t w = (t % 3 == 0 ? o1 : t % 3 == 1 ? o2 : o3).w[t / 3];
+                const int cs = sbase + (int)__umulhi(w, nact);
+                const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                if (found < 0) {
+                    const int slot = 1 + t;
+                    q_c[slot >> 1] = (slot & 1) ? ((q_c[slot >> 1] & 0x0000ffffu) | ((uint32_t)cs << 16))
+                                                : ((q_c[slot >> 1] & 0xffff0000u) | (uint32_t)cs);
+                    if (v != sp1) { found = cs; fo = v; }
+                }
+            }
+            if (found >= 0) {
+                col0 = s1;
+                col1 = found;
+                pack = (uint32_t)sp1 | ((uint32_t)fo << 4) | ((uint32_t)fo << 16) | ((uint32_t)sp1 << 20);
+                meta = 1u | 2u | (2u << 2);
+            }
+        }
+        // table steps: the sites of the depleted species from the candidate stream
+        // c_t = W(step, 4 + t / 4, t % 4); one pass, the wanted species is that of the next pick
+        int k = 0;
+        bool scanning = !is_swap && ncol >= 1 && ncol <= 4;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (__ballot(scanning) != 0ull) {
+                const philox_out o = philox_call(c0, c1, 4u + (uint32_t)b, key0, key1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * b + j;
+                    const int cs = sbase + (int)__umulhi(o.w[j], nact);
+                    const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                    if (scanning) {
+                        q_c[t >> 1] = (t & 1) ? ((q_c[t >> 1] & 0x0000ffffu) | ((uint32_t)cs << 16))
+                                              : ((q_c[t >> 1] & 0xffff0000u) | (uint32_t)cs);
+                        const int want = (int)((dep >> (4 * k)) & 15u);
+                        const bool dup = cs == col0 || cs == col1 || cs == col2 || cs == col3;
+                        if (v == want && !dup) {
+                            col0 = k == 0 ? cs : col0;
+                            col1 = k == 1 ? cs : col1;
+                            col2 = k == 2 ? cs : col2;
+                            col3 = k == 3 ? cs : col3;
+                            pack |= (uint32_t)v << (4 * k);
+                            k++;
+                            scanning = k < ncol;
+                        }
+                    }
+                }
+            }
+        }
+        if (!is_swap && ncol >= 1 && ncol <= 4 && k == ncol) {
+            // the random assignment to the enriched species (mcusher.py:627-631): the k-th draw
+            // W(step, 2, k) takes the rr-th pick still available
+            uint32_t avail = (1u << ncol) - 1u, left = (uint32_t)ncol;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (kk < ncol) {
+                    const uint32_t rr = __umulhi(o2.w[kk], left);
+                    uint32_t m = avail;
+#pragma unroll
+                    for (int z = 0; z < 3; ++z) m = z < (int)rr ? (m & (m - 1u)) : m;
+                    const int pj = __ffs((int)m) - 1;
+                    avail &= ~(1u << pj);
+                    left--;
+                    pack |= ((enr >> (4 * kk)) & 15u) << (16 + 4 * pj);
+                }
+            meta = 1u | ((uint32_t)ncol << 2) | ((uint32_t)d << 5);
+        }
+        q_meta = meta;
+        q_s01 = ((uint32_t)col0 & 0xffffu) | ((uint32_t)col1 << 16);
+        q_s23 = ((uint32_t)col2 & 0xffffu) | ((uint32_t)col3 << 16);
+        q_pack = pack;
+    };
+    // the 16-step word batch of the step-at-a-time proposal (lane l = block l & 3 of step base + (l >> 2))
+    auto word_batch = [&]() {
         const unsigned long long base = step & ~15ull;
         if ((uint32_t)base != batch_base) {
             if (batch_base == (uint32_t)base - 16u) {
                 w_site_carry = rdlane(W1, 60);
             } else {
                 const unsigned long long sp = base - 1ull;
-                w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
-                                                                key0, key1).w[1]);
+                w_site_carry = (uint32_t)uni((int)philox_call((uint32_t)sp, (uint32_t)(sp >> 32), 0u, key0, key1).w[1]);
             }
             batch_base = (uint32_t)base;
             const unsigned long long st = base + (unsigned)(lane >> 2);
-            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3),
-                                               0u, key0, key1);
+            const philox_out o = philox_call((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), key0, key1);
             W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
-            logu = log(philox_u53(o.w[2], o.w[3]));
         }
+    };
+
+#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
+    long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_cov[3] = {0, 0, 0}, ph_bat = 0;
+    long long ph_t = clock64();
+#endif
+    for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
+        // feasibility mask, weight sums of the directions: recomputed (here only: one copy of the
+        // code) after the species counts changed; the batch's directions assume the old mask
+        if (__builtin_expect(!head_valid, 0)) {
+            const unsigned feas_old = feas_now;
+            compute_head();
+            if (feas_now != feas_old) q_stale = ~0ull;
+        }
+#ifdef SMOLMC_EXP_PHASES
+        const long long tb0 = clock64();
+#endif
+        if (__builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull); // (first step of a launch)
+        const int l6 = (int)(step & 63ull);
         const int l4 = (int)(step & 15ull) * 4;
+        const uint32_t q_m = rdlane(q_meta, l6);
+#ifdef SMOLMC_NO_TABLE_BATCH // A/B switch: every step through the step-at-a-time proposal
+        const bool covered = false;
+#else
+        const bool covered = (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
+#endif
+        const uint32_t a01 = rdlane(q_s01, l6), a23 = rdlane(q_s23, l6), pk = rdlane(q_pack, l6);
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
+                                           (int)rdlane((uint32_t)__double2loint(q_logu), l6));
+#ifdef SMOLMC_EXP_PHASES
+        ph_bat += clock64() - tb0;
+#endif
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; }
 #endif
-        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1); // wave priority rises through the step (see mc_lean_kernel)
 #endif
@@ -1432,30 +1643,78 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
+        // count changes (lane c: species c) of table direction d
+        auto set_direction = [&](const int d) {
+            const int usg = (d & 1) ? -1 : 1;
+            // column values of the chosen vector, lane-indexed (register array -> select chain)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vu = (i == (d >> 1)) ? vtf[i] : vu;
+            vu *= usg; // lane c: change of the count of species c
+        };
+        // compute_log_priori_factor (mcusher.py:656-711), cached per direction (lane d of vlp)
+        auto priori_of = [&](const int d) {
+            if (__builtin_expect(!((lp_valid >> d) & 1u), 0)) {
+                const LeanParamsKernarg Q = rare_params();
+                const int tfn = Q->tf_n, na = Q->nact, lnlen = Q->tf_ln_len;
+                const double tsw = Q->tf_sw;
+                const double *lng = Q->tf_ln;
+                // (all directions feasible now and after the step: the same sum, no mask to form)
+                const double sum_next = (feas_now == (1u << (2 * tfn)) - 1u && all_feasible(vcnt + vu))
+                                            ? sumw : masked_sum(feasible(vcnt + vu, tfn, na), tfn);
+                double lf = 0.0;
+                // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
+                // case away from the composition limits), no division / log needed
+                const double w_now = weight_of(d), w_back = weight_of(d ^ 1);
+                if (!(w_now == w_back && sum_next == sumw)) {
+                    const double p_now = (1.0 - tsw) * w_now / sumw;
+                    const double p_next = (1.0 - tsw) * w_back / sum_next;
+                    lf = log(p_next / p_now);
+                }
+                lf += table_log_count_ratio(lnlen ? s_ln : lng, vu, vcnt, nc);
+                lf = uni_d(lf);
+                if (lane == d) vlp = lf;
+                lp_valid |= 1u << d;
+            }
+            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), d),
+                                          (int)rdlane((uint32_t)__double2loint(vlp), d));
+        };
+        if (covered) {
+            // the batch's proposal of this step (see propose_batch)
+            nfl = (int)((q_m >> 2) & 7u);
+            vsite = lane == 0 ? (int)(a01 & 0xffffu) : lane == 1 ? (int)(a01 >> 16)
+                  : lane == 2 ? (int)(a23 & 0xffffu) : (int)(a23 >> 16);
+            vold = (int)((pk >> lane4) & 15u);
+            vnew = (int)(((pk >> 16) >> lane4) & 15u);
+            if (!(q_m & 2u)) {
+                dir = (int)((q_m >> 5) & 15u);
+                set_direction(dir);
+            }
+            {
+                // rows and Ewald cross terms as in fetch_rows, the sites being scalars here
+                const uint32_t s0 = a01 & 0xffffu, s1 = a01 >> 16, s2 = nfl > 2 ? a23 & 0xffffu : s0, s3 = nfl > 3 ? a23 >> 16 : s0;
+                rows[0] = load_row<NW>(idx_rs, lane_voff, s0 * SITE_BYTES);
+                rows[1] = load_row<NW>(idx_rs, lane_voff, s1 * SITE_BYTES);
+                rows[2] = load_row<NW>(idx_rs, lane_voff, s2 * SITE_BYTES);
+                rows[3] = load_row<NW>(idx_rs, lane_voff, s3 * SITE_BYTES);
+                if (has_ew && ew_field) {
+                    const int pi = lane >> 3, pj = lane & 7;
+                    const uint32_t si = pi == 1 ? s1 : pi == 2 ? s2 : s3, sj = pj == 0 ? s0 : pj == 1 ? s1 : s2;
+                    if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)(si * ew_na_v) + (sj - (uint32_t)sbase)];
+                }
+            }
+#ifdef SMOLMC_EXP_PHASES
+            ph_cov[0]++;
+#endif
+        } else {
+        word_batch();
+        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
+#ifdef SMOLMC_EXP_PHASES
+        if (q_m & 1u) ph_cov[1]++; else if (do_swap) ph_cov[2]++;
+#endif
         if (!do_swap) { // flip_weights_mask (math.py:832-867) at the current counts
             // the species counts only change on accepted table steps: the feasibility mask, its
             // weight sum and the a-priori factor of every direction are kept until then
-            if (!head_valid) {
-                const LeanParamsKernarg Q = rare_params();
-                const int tfn = Q->tf_n, na = Q->nact;
-                feas_now = feasible(vcnt, tfn, na);
-                sumw = masked_sum(feas_now, tfn);
-                head_valid = true;
-                lp_valid = 0u;
-                // running sums of the feasible weights, lane idx <-> direction idx, added in the
-                // order choose_section_from_partition adds them: the per-step choice below is then
-                // one compare + ballot instead of a loop of readlanes and float64 adds
-                double c = 0.0;
-                last_feas = -1;
-                const int n2 = 2 * tfn;
-                for (int idx = 0; idx < n2; ++idx)
-                    if ((feas_now >> idx) & 1u) {
-                        c += weight_of(idx);
-                        if (lane == idx) vcum = c;
-                        last_feas = idx;
-                    }
-            }
             if (!(sumw > 0.0)) do_swap = true;
         }
         if (do_swap) {
@@ -1479,8 +1738,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             }
             if (found < 0) {
                 for (uint32_t q = 0;; ++q) {
-                    const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
-                                                       4u + 64u * q + (uint32_t)lane, 0u, key0, key1);
+                    const philox_out o = philox_call((uint32_t)step, (uint32_t)(step >> 32),
+                                                       4u + 64u * q + (uint32_t)lane, key0, key1);
                     int selsite = -1, selv = 0;
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
@@ -1517,34 +1776,7 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 const uint32_t hit = (uint32_t)__ballot(target < vcum) & feas_now; // first feasible idx with target < running sum
                 dir = hit ? __ffs((int)hit) - 1 : last_feas;
             }
-            const int usg = (dir & 1) ? -1 : 1;
-            // column values of the chosen vector, lane-indexed (register array -> select chain)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
-            vu *= usg; // lane c: change of the count of species c
-            // compute_log_priori_factor (mcusher.py:656-711), cached per direction (lane dir of vlp)
-            if (!((lp_valid >> dir) & 1u)) {
-                const LeanParamsKernarg Q = rare_params();
-                const int tfn = Q->tf_n, na = Q->nact, lnlen = Q->tf_ln_len;
-                const double tsw = Q->tf_sw;
-                const double *lng = Q->tf_ln;
-                const double sum_next = masked_sum(feasible(vcnt + vu, tfn, na), tfn);
-                double lf = 0.0;
-                // equal weights and equal feasible sums: p_next / p_now is exactly 1 (the common
-                // case away from the composition limits), no division / log needed
-                const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
-                if (!(w_now == w_back && sum_next == sumw)) {
-                    const double p_now = (1.0 - tsw) * w_now / sumw;
-                    const double p_next = (1.0 - tsw) * w_back / sum_next;
-                    lf = log(p_next / p_now);
-                }
-                lf += table_log_count_ratio(lnlen ? s_ln : lng, vu, vcnt, nc);
-                lf = uni_d(lf);
-                if (lane == dir) vlp = lf;
-                lp_valid |= 1u << dir;
-            }
-            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
-                                          (int)rdlane((uint32_t)__double2loint(vlp), dir));
+            set_direction(dir);
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[1] += tn - ph_t; ph_t = tn; }
 #endif
@@ -1557,70 +1789,14 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
             uint32_t round = 0;
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
             bool have_round = false;
-            // ---- fast path: all picks among the first 16 candidates of the stream -------------
-            bool fast_done = false;
-#ifndef SMOLMC_NO_TABLE_FAST
-            {
-                if ((uint32_t)(step & ~1ull) != cblk_base) {
-                    cblk_base = (uint32_t)(step & ~1ull);
-                    const unsigned long long sl = (step & ~1ull) + (unsigned)(lane >> 5);
-                    const uint32_t t = (uint32_t)lane & 31u;
-                    const philox_out o = philox4x32_10((uint32_t)sl, (uint32_t)(sl >> 32), 4u + (t >> 2), 0u,
-                                                       key0, key1);
-                    const uint32_t wsel = (t & 3u) == 0u ? o.w[0] : (t & 3u) == 1u ? o.w[1]
-                                        : (t & 3u) == 2u ? o.w[2] : o.w[3];
-                    cb_site = sbase + (int)__umulhi(wsel, nact);
-                    cb_addr = lean_swz(cb_site, swa, swm, swb);
-                }
-#ifdef SMOLMC_EXP_PHASES
-                { const long long tn = clock64(); ph2[0] += tn - ph_t; ph_t = tn; }
-#endif
-                const int g32 = (int)(step & 1ull) * 32;      // first lane of this step's candidates
-                const int cvl = (int)occ[cb_addr];            // species of every lane's candidate
-                // Picks on the scalar unit: per depleted species one ballot gives the candidates of
-                // that species at or after the running stream position; each pick is the lowest
-                // set bit (s_ff1), its site one v_readlane, and it goes straight into lane ncol of
-                // the lane-indexed pick registers -- a table step picks 1 .. 8 sites,
-                // typically 3.  (The lane-parallel form of round 2 -- ranks by v_mbcnt, compaction
-                // through LDS, DPP duplicate check -- cost two LDS round trips and ~150
-                // instructions for the same three picks.)  A site the stream names twice (choice
-                // without replacement) or a block that runs out sends the step to the full scan.
-                uint32_t fpos = 0; // next stream position (kept across species)
-                bool ok = true;
-                uint32_t dep = (uint32_t)__ballot(vu < 0) & ((1u << nc) - 1u); // depleted species
-                while (dep != 0u && ok) {
-                    const int c = __ffs((int)dep) - 1;
-                    dep &= dep - 1u;
-                    int need = -(int)rdlane((uint32_t)vu, c);
-                    uint32_t m = (uint32_t)(__ballot(cvl == c) >> g32); // bit t: candidate t has species c
-                    m = fpos < 32u ? (m >> fpos) << fpos : 0u;
-                    if (__popc(m) < need || ncol + need > 8) { ok = false; break; }
-                    do {
-                        const int t = __ffs((int)m) - 1;
-                        m &= m - 1u;
-                        const int site = (int)rdlane((uint32_t)cb_site, g32 + t);
-                        if ((__ballot(vcol == site) & ((1ull << ncol) - 1ull)) != 0ull) { ok = false; break; }
-                        vcol = lane == ncol ? site : vcol; // (v_writelane needs its lane select in M0 here: a compare + select is as cheap)
-                        vcsp = lane == ncol ? c : vcsp;
-                        ncol++;
-                        fpos = (uint32_t)t + 1u;
-                    } while (--need > 0);
-                }
-#ifdef SMOLMC_EXP_PHASES
-                { const long long tn = clock64(); ph2[1] += tn - ph_t; ph_t = tn; }
-#endif
-                if (ok) fast_done = true;
-                else { vcol = 0; vcsp = 0; ncol = 0; } // block exhausted or repeated site: full scan
-            }
-#endif
-            for (int c = 0; c < nc && !fast_done; ++c) {
+            for (int c = 0; c < nc; ++c) {
                 int need = -(int)rdlane((uint32_t)vu, c);
                 unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
                 bool have_masks = false;
                 while (need > 0) {
                     if (!have_round) {
-                        const philox_out o = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
-                                                           4u + 64u * round + (uint32_t)lane, 0u, key0, key1);
+                        const philox_out o = philox_call((uint32_t)step, (uint32_t)(step >> 32),
+                                                           4u + 64u * round + (uint32_t)lane, key0, key1);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             cs[j] = sbase + (int)__umulhi(o.w[j], nact);
@@ -1696,6 +1872,8 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 vnew = (int)((newpack >> lane4) & 15u);
             }
         }
+        } // (step-at-a-time proposal)
+        if (dir >= 0) priori_of(dir);
 
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(2);
@@ -1801,18 +1979,13 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
                 if (has_mu) dMu += s_mu[nw] - s_mu[od];
             }
         };
-        if (TWO_PHASE) {
-            if (nfl == 3) two_phase(std::integral_constant<int, 3>{});
-            else if (nfl == 2) two_phase(std::integral_constant<int, 2>{});
-            else if (nfl >= 4) two_phase(std::integral_constant<int, 4>{});
-            else if (nfl == 1) two_phase(std::integral_constant<int, 1>{});
-        } else {
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-                if (f < nfl) eval_flip(f, rows[f]);
-        }
-        for (int f = 4; f < nfl; ++f)
-            eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
+        // (two instantiations: the code of the step loop competes for the instruction cache; steps of
+        // one flip or of more than three are evaluated flip by flip)
+        if (TWO_PHASE && nfl == 3) two_phase(std::integral_constant<int, 3>{});
+        else if (TWO_PHASE && nfl == 2) two_phase(std::integral_constant<int, 2>{});
+        else
+            for (int f = 0; f < nfl; ++f)
+                eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1827,15 +2000,34 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
         }
         if (has_mu) dH -= dMu;
         const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
-        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
-                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
         const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         if (accepted) {
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
-            vcnt += vu; // species counts follow the accepted table direction (0 for swaps)
-            if (dir >= 0) head_valid = false;
-            if (ew_field) field_apply_flips(phi, lane, nfl, vsite, vdq);
+            if (dir >= 0) {
+                // species counts follow the accepted table direction; the mask of the feasible
+                // directions is recomputed unless all were feasible and still are
+                const bool was_all = all_feasible(vcnt);
+                vcnt += vu;
+                lp_valid = 0u;
+                if (!(was_all && all_feasible(vcnt))) head_valid = false;
+            }
+            {
+                // batch lanes whose scan examined a site that has just changed are stale (all 32
+                // kept sites against every flipped site; unused slots hold 0xffff, no site)
+                uint32_t hit = 0u;
+                for (int f = 0; f < nfl; ++f) {
+                    const uint32_t sf = rdlane((uint32_t)vsite, f);
+                    const uint32_t pat = sf | (sf << 16);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t dd = q_c[i] ^ pat; // a zero half-word <=> that kept site is sf
+                        hit |= (dd - 0x00010001u) & ~dd & 0x80008000u;
+                    }
+                }
+                q_stale |= __ballot(hit != 0u);
+            }
+            if (ew_field) field_apply_flips<1, true>(phi, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;
@@ -1883,10 +2075,13 @@ __global__ void __launch_bounds__(256) mc_table_kernel(const LeanParams P) {
 
 #ifdef SMOLMC_EXP_PHASES
     if ((r == 0 || r == P.R / 2 || r == P.R - 1) && lane == 0)
-        printf("phases (cycles per step): skeleton %.0f | head %.0f | picks %.0f | assign/swap %.0f | eval %.0f | decide %.0f | picks: block %.0f, species loop %.0f\n",
+        printf("phases (cycles per step): skeleton %.0f | head %.0f | picks %.0f | assign/swap %.0f | eval %.0f | decide %.0f\n",
                (double)ph_acc[0] / (double)P.steps, (double)ph_acc[1] / (double)P.steps, (double)ph_acc[2] / (double)P.steps,
-               (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps, (double)ph_acc[5] / (double)P.steps,
-               (double)ph2[0] / (double)P.steps, (double)ph2[1] / (double)P.steps);
+               (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps, (double)ph_acc[5] / (double)P.steps);
+    if ((r == 0 || r == P.R / 2 || r == P.R - 1) && lane == 0)
+        printf("batch: covered %.3f of the steps, stale %.3f, swaps left out %.3f | batch %.0f cycles per step\n",
+               (double)ph_cov[0] / (double)P.steps, (double)ph_cov[1] / (double)P.steps, (double)ph_cov[2] / (double)P.steps,
+               (double)ph_bat / (double)P.steps);
 #endif
     if (ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];

@@ -27,8 +27,11 @@ def main():
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--temperature", type=float, default=0.0)
+    ap.add_argument("--ladder", default="", help="config 5: lowest,highest temperature of the exchange ladder")
     a = ap.parse_args()
     kw = {}
+    if a.ladder:
+        kw["t_lo"], kw["t_hi"] = (float(x) for x in a.ladder.split(","))
     if a.replicas:
         kw["count"] = a.replicas
     if a.dim:
