@@ -1584,7 +1584,7 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
     };
 
 #ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
-    long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_cov[3] = {0, 0, 0}, ph_bat = 0;
+    long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_cov[3] = {0, 0, 0}, ph_bat = 0, ph_prop[4] = {0, 0, 0, 0};
     long long ph_t = clock64();
 #endif
     for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
@@ -1789,7 +1789,44 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
             uint32_t round = 0;
             int cs[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
             bool have_round = false;
-            for (int c = 0; c < nc; ++c) {
+            // ---- first the 64 leading candidates of the stream, one per lane -------------------
+            // (one Philox call and one gather; per depleted species a ballot gives the candidates of
+            // that species at or after the running stream position, every pick is its lowest set
+            // bit.  A site the stream names twice or a stream that needs more than 64 candidates
+            // sends the step to the full scan below.)
+            bool fast_done = false;
+#ifndef SMOLMC_NO_TABLE_FAST
+            {
+                const philox_out o = philox_call((uint32_t)step, (uint32_t)(step >> 32), 4u + ((uint32_t)lane >> 2), key0, key1);
+                const uint32_t wsel = (lane & 3) == 0 ? o.w[0] : (lane & 3) == 1 ? o.w[1] : (lane & 3) == 2 ? o.w[2] : o.w[3];
+                const int cb_site = sbase + (int)__umulhi(wsel, nact);
+                const int cvl = (int)occ[lean_swz(cb_site, swa, swm, swb)];
+                uint32_t fpos = 0; // next stream position (kept across species)
+                bool ok = true;
+                uint32_t dep = (uint32_t)__ballot(vu < 0) & ((1u << nc) - 1u); // depleted species
+                while (dep != 0u && ok) {
+                    const int c = __ffs((int)dep) - 1;
+                    dep &= dep - 1u;
+                    int need = -(int)rdlane((uint32_t)vu, c);
+                    unsigned long long m = __ballot(cvl == c); // bit t: candidate t has species c
+                    m = fpos < 64u ? (m >> fpos) << fpos : 0ull;
+                    if (__popcll(m) < need || ncol + need > 8) { ok = false; break; }
+                    do {
+                        const int t = __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        const int site = (int)rdlane((uint32_t)cb_site, t);
+                        if ((__ballot(vcol == site) & ((1ull << ncol) - 1ull)) != 0ull) { ok = false; break; }
+                        vcol = lane == ncol ? site : vcol;
+                        vcsp = lane == ncol ? c : vcsp;
+                        ncol++;
+                        fpos = (uint32_t)t + 1u;
+                    } while (--need > 0);
+                }
+                if (ok) fast_done = true;
+                else { vcol = 0; vcsp = 0; ncol = 0; } // stream exhausted or repeated site: full scan
+            }
+#endif
+            for (int c = 0; c < nc && !fast_done; ++c) {
                 int need = -(int)rdlane((uint32_t)vu, c);
                 unsigned long long B[4] = {0ull, 0ull, 0ull, 0ull};
                 bool have_masks = false;
@@ -1873,7 +1910,13 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
             }
         }
         } // (step-at-a-time proposal)
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_prop[covered ? 0 : 1] += tn - ph_t; ph_prop[2] -= tn; }
+#endif
         if (dir >= 0) priori_of(dir);
+#ifdef SMOLMC_EXP_PHASES
+        ph_prop[2] += clock64();
+#endif
 
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(2);
@@ -2009,9 +2052,12 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
                 // directions is recomputed unless all were feasible and still are
                 const bool was_all = all_feasible(vcnt);
                 vcnt += vu;
+#ifndef SMOLMC_EXP_NOPRIORI // timing experiment only when defined (wrong results)
                 lp_valid = 0u;
+#endif
                 if (!(was_all && all_feasible(vcnt))) head_valid = false;
             }
+#ifndef SMOLMC_EXP_NOSTALE // timing experiment only when defined (wrong results)
             {
                 // batch lanes whose scan examined a site that has just changed are stale (all 32
                 // kept sites against every flipped site; unused slots hold 0xffff, no site)
@@ -2025,9 +2071,16 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
                         hit |= (dd - 0x00010001u) & ~dd & 0x80008000u;
                     }
                 }
+#ifdef SMOLMC_EXP_STALEIGN // timing experiment only when defined (wrong results): the marking is computed and dropped
+                if (__ballot(hit != 0u) == 0x123456789abcull) q_stale = ~0ull;
+#else
                 q_stale |= __ballot(hit != 0u);
+#endif
             }
+#endif
+#ifndef SMOLMC_EXP_NOFIELD // timing experiment only when defined (wrong results)
             if (ew_field) field_apply_flips<1, true>(phi, lane, nfl, vsite, vdq);
+#endif
             acc_mu += dMu;
             acc_ew += dEw;
             H += dH;
@@ -2082,6 +2135,10 @@ __global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
         printf("batch: covered %.3f of the steps, stale %.3f, swaps left out %.3f | batch %.0f cycles per step\n",
                (double)ph_cov[0] / (double)P.steps, (double)ph_cov[1] / (double)P.steps, (double)ph_cov[2] / (double)P.steps,
                (double)ph_bat / (double)P.steps);
+    if ((r == 0 || r == P.R / 2 || r == P.R - 1) && lane == 0)
+        printf("proposal: %.0f cycles per covered step, %.0f per step-at-a-time step; a-priori factor %.0f cycles per step\n",
+               (double)ph_prop[0] / (double)(ph_cov[0] ? ph_cov[0] : 1), (double)ph_prop[1] / (double)(P.steps - ph_cov[0] ? P.steps - ph_cov[0] : 1),
+               (double)ph_prop[2] / (double)P.steps);
 #endif
     if (ew_field)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
