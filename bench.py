@@ -410,16 +410,20 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
 
         def ewald_roof(rec):
             # potential-field formulation: a proposal reads O(1) LDS words; only an ACCEPTED flip
-            # updates the walker's field from one row of the site kernel (n_act doubles).  The
-            # 2-rows-per-proposal figure of SURVEY 8d does not describe this algorithm.
+            # updates the walker's field with n_act entries of the site kernel (gathered from the
+            # translation-compressed tables).  The 2-rows-per-proposal figure of SURVEY 8d does not
+            # describe this algorithm.
             row_bytes = wl3.sc.size * 8.0
             a = rec["flips_per_s"] * rec["acceptance"] * row_bytes / 1e9
             return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
                         l2_peak=L2_PEAK_GBS, acceptance=rec["acceptance"],
                         row_bytes_per_accepted_flip=row_bytes,
-                        note="accepted-flip row bytes (n_act*8 B each) over kernel time; depends on the "
-                             "acceptance; the dense two-row formulation (58752 B/flip) is HBM-capped at "
-                             "1.36e8 flips/s")
+                        note="site-kernel entries gathered per ACCEPTED flip (n_act*8 B each) over kernel time; "
+                             "since round 3 they come from the translation-compressed tables (95 KB, L2 "
+                             "resident: measured HBM fetch 22 MB per launch, profiles/r03_configs_pmc.txt), so "
+                             "this is an L2 / LDS rate, quoted against the HBM peak only for scale; it depends "
+                             "on the acceptance; the dense two-row formulation (58752 B/flip) is HBM-capped "
+                             "at 1.36e8 flips/s")
 
         # (the transient of round 2's bench: launches 2-11 of 2000 steps from the random start; config 3
         # as specified has no mixed steady state -- its Ewald energy without the charged-cell term is

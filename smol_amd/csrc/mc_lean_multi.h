@@ -130,6 +130,48 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     unsigned long long batch_base = ~0ull;
     RowWords<NW> row1;
 
+    // Pending field updates (field in HBM + translation-compressed site kernel): an accepted flip is
+    // not swept into phi at once but kept in a list of up to four (table offset S8[s], charge
+    // change); a proposal at site j adds sum_p dq_p G[s_p][j] -- one gather from the compressed
+    // tables by one lane per entry -- to the stored phi[j], and a full list goes into phi in ONE
+    // pass (field_sweep_gx_multi<4>): phi, the traffic that bounds these kernels on large cells, is
+    // read and written once per four accepted flips instead of once per flip / swap.  G[s][s] = 0
+    // in the tables, so an entry never corrects its own site.  (Replay keeps the immediate update.)
+    constexpr bool PEND = EWM == 2 && !REPLAY;
+    const unsigned char *gxp = PEND ? (const unsigned char *)P.ew_gx : nullptr;
+#ifdef SMOLMC_NO_EWALD_PENDING // A/B switch
+    const bool pend_on = false;
+#else
+    // (worth it from about 32 groups of 64 field entries on: LiNiO2 8^3, 16 groups, loses 15 %)
+    const bool pend_on = PEND && gxp != nullptr && P.ew_nact >= 2048;
+#endif
+    int npend = 0;
+    uint32_t vps8 = 0;  // lane l: table offset of entry l & 3
+    double vpdq = 0.0;  //         its charge change
+    uint32_t vE8s = 0, vE8c[4] = {0, 0, 0, 0}; // per batch: E8 of the lane's site / swap candidates
+    auto flush_pending = [&]() {
+        const LeanParamsKernarg Q = rare_params();
+        uint32_t s8[4];
+        double dq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s8[k] = rdlane(vps8, k < npend ? k : 0);
+            const double d = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vpdq), k),
+                                              (int)rdlane((uint32_t)__double2loint(vpdq), k));
+            dq[k] = k < npend ? d : 0.0;
+        }
+        // (flip kernels: small batches inside their 128-register budget, four waves per SIMD; the swap
+        // kernels run two waves per SIMD anyway and take batches of nine groups)
+        field_sweep_gx_multi<4, STEP == SMOLMC_STEP_SWAP ? 0 : -1>(P.ew_phi + (size_t)r * Q->ew_nact, Q->ew_E8, gxp, lane, Q->ew_nact, s8, dq);
+        npend = 0;
+    };
+    auto push_pending = [&](const int s, const double dq) {
+        const LeanParamsKernarg Q = rare_params();
+        const uint32_t s8 = Q->ew_S8[s - Q->ew_act_base];
+        if ((lane & 3) == npend) { vps8 = s8; vpdq = dq; }
+        npend++;
+    };
+
     MultiRec rcs[ONE ? NSLOT : 1];
     if (ONE) {
 #pragma unroll
@@ -196,6 +238,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
                 if (HAS_EW) vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (vsite - abase)];
             }
+            if (pend_on) {
+                const uint32_t *pE8 = rare_params()->ew_E8;
+                vE8s = pE8[vsite - abase];
+                if (STEP == SMOLMC_STEP_SWAP) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vE8c[j] = pE8[cand[j] - abase];
+                }
+            }
             // index row of the batch's first step (the other steps' rows are prefetched one step
             // ahead, see below).  Every step issues the same loads in the same order whatever
             // path it takes: a load that exists on some paths only makes the compiler's s_waitcnt
@@ -248,6 +298,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 
         const int o1 = uni((int)occ[a1]);
         int nfl, s2, a2, n1, n2 = 0, o2 = 0, fb = -1; // (swap: s2 / a2 / o2 are set by every proposal outcome)
+        uint32_t e8_2 = 0xffffffffu; // E8 of the swap partner when it came from the batch's candidates
         if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         if (REPLAY) { // the recorded proposal
             if (STEP == SMOLMC_STEP_FLIP) {
@@ -285,6 +336,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         s2 = (int)rdlane((uint32_t)cand[J], b);                                                    \
         a2 = (int)rdlane((uint32_t)canda[J], b);                                                   \
         o2 = (int)rdlane((uint32_t)v##J, b);                                                       \
+        if (PEND) e8_2 = rdlane(vE8c[J], b);                                                       \
         if (J == 0) fb = b;                                                                        \
     }
             SMOLMC_CAND_MASK(0)
@@ -350,6 +402,20 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 p2 = phi_lds ? phi[s2 - abase]
                              : __hip_atomic_load(&phi[s2 - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        double corr1 = 0.0, corr2 = 0.0; // what the pending flips add to the stored potentials
+        if (pend_on) {
+            const uint32_t e1 = rdlane(vE8s, l4);
+            uint32_t e2 = e1;
+            if (STEP == SMOLMC_STEP_SWAP) e2 = e8_2 != 0xffffffffu ? e8_2 : rare_params()->ew_E8[s2 - abase];
+            const bool act = lane < 8 && (lane & 3) < npend;
+            const uint32_t off = act ? ((lane & 4) ? e2 : e1) + vps8 : 0u;
+            const double g = *(const double *)(gxp + off);
+            double t = act ? vpdq * g : 0.0;
+            t = dpp_xor_add<0xB1>(t); // sums over the quads 0-3 (site 1) and 4-7 (site 2)
+            t = dpp_xor_add<0x4E>(t);
+            corr1 = __hiloint2double((int)rdlane((uint32_t)__double2hiint(t), 0), (int)rdlane((uint32_t)__double2loint(t), 0));
+            corr2 = __hiloint2double((int)rdlane((uint32_t)__double2hiint(t), 4), (int)rdlane((uint32_t)__double2loint(t), 4));
+        }
         RowWords<NW> row2 = row1;
         if (STEP == SMOLMC_STEP_SWAP) row2 = load_row<NW>(idx_rs, lane_voff, (uint32_t)s2 * SITE_BYTES);
 
@@ -373,7 +439,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         double ew_uni = 0.0, dq1 = 0.0, dq2 = 0.0;
         if (HAS_EW) {
             dq1 = s_q[sub1 * 8 + n1] - s_q[sub1 * 8 + o1];
-            ew_uni = 2.0 * dq1 * p1 + (s_dg[sub1 * 8 + n1] - s_dg[sub1 * 8 + o1]);
+            ew_uni = 2.0 * dq1 * (p1 + corr1) + (s_dg[sub1 * 8 + n1] - s_dg[sub1 * 8 + o1]);
         }
         if (STEP == SMOLMC_STEP_SWAP) {
             occ[a1] = (uint8_t)n1; // tentative: the second flip sees the first (expansion.py:217-229)
@@ -393,7 +459,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                     fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
                                                (int)rdlane((uint32_t)__double2loint(vGc), fb))
                             : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - abase)];
-                ew_uni += 2.0 * dq2 * (p2 + dq1 * cross) + (s_dg[sub1 * 8 + n2] - s_dg[sub1 * 8 + o2]);
+                ew_uni += 2.0 * dq2 * ((p2 + corr2) + dq1 * cross) + (s_dg[sub1 * 8 + n2] - s_dg[sub1 * 8 + o2]);
             }
         }
         double dMu = 0.0;
@@ -456,6 +522,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                     } else if (dq1 != 0.0) {
                         field_apply<1>(P, phi, lane, s1, dq1);
                     }
+                } else if (pend_on) {
+                    const int nnew = (dq1 != 0.0 ? 1 : 0) + ((STEP == SMOLMC_STEP_SWAP && dq2 != 0.0) ? 1 : 0);
+                    if (npend + nnew > 4) flush_pending();
+                    if (dq1 != 0.0) push_pending(s1, dq1);
+                    if (STEP == SMOLMC_STEP_SWAP && dq2 != 0.0) push_pending(s2, dq2);
                 } else {
                     double *phi_g = P.ew_phi + (size_t)r * P.ew_nact;
                     if (STEP == SMOLMC_STEP_SWAP) {
@@ -521,6 +592,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
 
     // ---- write back ---------------------------------------------------------------
+    if (pend_on && npend > 0) flush_pending(); // (phi in HBM is complete between launches)
     if (phi_lds)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     {

@@ -355,13 +355,15 @@ __device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t
 // one-sublattice flip kernels, whose occupancy is bound by the field in LDS anyway); 1: chunks of
 // four batches with the E entries fetched first; 0: plain batches of nine -- the multi-sublattice
 // kernels with the field in HBM live on their occupancy (LiNiO2 8^3 flips: 4.2e9 -> 2.7e9 steps/s
-// with the big batch's 233 VGPRs).
+// with the big batch's 233 VGPRs); -1: batches of four groups, for the four-flip sweep of the
+// pending-update list in those kernels.
 template <int NF, int FOOT = 1>
 __device__ __forceinline__ void field_sweep_gx_multi(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
                                                      int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
     if (FOOT == 2 && NF == 1 && (na >> 6) >= 27) field_sweep_gx_sized<NF, 27, 1>(phi, E8, gx, lane, na, s8, dq);
     else if (FOOT >= 1) field_sweep_gx_sized<NF, 9, 4>(phi, E8, gx, lane, na, s8, dq);
-    else field_sweep_gx_sized<NF, 9, 1>(phi, E8, gx, lane, na, s8, dq);
+    else if (FOOT == 0) field_sweep_gx_sized<NF, 9, 1>(phi, E8, gx, lane, na, s8, dq);
+    else field_sweep_gx_sized<NF, 4, 1>(phi, E8, gx, lane, na, s8, dq); // (-1: four flips at a time inside a 128-register budget)
 }
 
 // ----------------------------------------------------------------------------

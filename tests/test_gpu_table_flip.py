@@ -48,6 +48,37 @@ def test_table_flip_matches_oracle(kw):
     assert np.array_equal(n - n0, k[:, None] * FLIP_TABLE[0][None, :])
 
 
+@pytest.mark.parametrize("dim,ewald", [(3, True), (6, False), (6, True)], ids=["3^3+ewald", "6^3", "6^3+ewald"])
+def test_table_flip_proposal_batch_matches_oracle_over_many_blocks(dim, ewald):
+    """The kernel proposes 64 consecutive steps at once (lane = step) and re-proposes step by step
+    whatever an accepted step made stale (mc_lean.h, propose_batch); the oracle proposes one step
+    at a time.  Thousands of steps in launches that start and end inside the 64-step blocks, on a
+    small cell (the candidate stream names a site twice all the time: duplicate / fallback paths)
+    and a larger one, at a temperature where a quarter of the steps is accepted."""
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    sc, tab = _model(dim, coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=ewald)
+    R = 9
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    rng = np.random.default_rng(21)
+    occ = np.array([_neutral_occ(sc, (sc.size & 1) + 2 * (r % 3 + 1), rng) for r in range(R)])
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(4000)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ, seeds, 6000.0)
+    ora.set_state(occ, seeds, 6000.0)
+    for chunk in (1, 62, 3, 700, 129, 1105):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-7)
+    acc = a["n_accepted"].sum() / a["n_steps"].sum()
+    assert 0.02 < acc < 0.9
+    eng.close()
+
+
 def test_table_flip_detailed_balance_on_gpu():
     from smol_amd.engine import Engine
 
