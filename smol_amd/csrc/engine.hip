@@ -1309,6 +1309,21 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     lp.tf_ln_len = nact + 1;
                     h->lean_lds += (size_t)(nact + 1) * 8;
                 }
+                // Eight walkers per workgroup when two four-walker workgroups would share a CU
+                // anyway: waves w and w + 4 of a workgroup sit on the same SIMD, so that the
+                // launch order (update_walker_order) can pair a hot walker with a cold one there.
+                {
+                    const size_t per_wave = (size_t)lp.Nlds + 64 * 8 + 64 + (lp.ew_field ? (size_t)nact * 8 : 0);
+                    const size_t lds8 = h->lean_lds + 4 * per_wave;
+                    h->lean_wpb = 4;
+                    int cus = 0; // (fewer walkers than 8 per CU: four-walker workgroups spread over more CUs)
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+                    if (lds8 <= 160 * 1024 && h->lean_lds > 40 * 1024 && cfg->n_replicas % 8 == 0 &&
+                        (long)cfg->n_replicas >= 8L * cus && getenv("SMOLMC_TABLE_WPB4") == nullptr) {
+                        h->lean_wpb = 8;
+                        h->lean_lds_wpb8 = lds8;
+                    }
+                }
             }
         }
         h->lean = lean;
@@ -1573,6 +1588,7 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
     std::vector<double> beta;
     set_betas(h, temperature, beta);
     HIPCHK(hipMemcpy(h->d_beta, beta.data(), R * 8, hipMemcpyHostToDevice));
+    h->order_dirty = true;
     if (reset_aux) {
         std::vector<uint64_t> sd(R);
         for (size_t r = 0; r < R; ++r) sd[r] = seeds ? seeds[r] : (uint64_t)r;
@@ -1667,6 +1683,7 @@ extern "C" int smolmc_set_temperature(smolmc_handle *h, const double *temperatur
     set_betas(h, temperature, beta);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d_beta, beta.data(), (size_t)h->R * 8, hipMemcpyHostToDevice));
+    h->order_dirty = true;
     return 0;
 }
 
@@ -1811,8 +1828,69 @@ static int launch_mc(smolmc_handle *h, const KParams &kp, int replay) {
     }
 }
 
+// Launch-slot -> walker permutation for launches whose walkers differ in cost.  On an exchange ladder
+// a hot walker accepts several times as many steps as a cold one and an accepted TableFlip step
+// costs several rejected ones (field sweep, stale marking); a launch ends with its slowest SIMD,
+// and a SIMD hosts one wave of each of the two workgroups resident on its CU.  Slots are therefore
+// dealt so that the hottest walker shares its SIMD with the coldest, the second hottest with the
+// second coldest, ...: every SIMD gets about the same work.  mode 1 (SMOLMC_WALKER_ORDER, default):
+// the partner of a workgroup is the one half a grid later (workgroups are dealt round-robin over
+// the CUs, the second half of the grid lands on the CUs of the first); mode 2: the next workgroup;
+// 0: slot q runs walker q.  Ranks by beta ascending (hottest first), ties by walker index; built on
+// the host whenever the temperatures changed (one 8 B-per-walker read-back per exchange sweep).
+static int update_walker_order(smolmc_handle *h, LeanParams &lp) {
+    const char *env = getenv("SMOLMC_WALKER_ORDER"); // (read at every launch: tests switch it)
+    const int mode = env ? atoi(env) : 1;
+    if (mode != h->order_mode) h->order_dirty = true;
+    h->order_mode = mode;
+    lp.order = nullptr;
+    const int R = h->R, wpb = h->lean_wpb;
+    if (mode == 0 || h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP || h->lean_multi || R < 2 * wpb) return 0;
+    if (!h->d_order) {
+        HIPCHK(hipMalloc((void **)&h->d_order, (size_t)R * sizeof(int)));
+        h->allocs.push_back(h->d_order);
+        h->order_dirty = true;
+    }
+    if (h->order_dirty) {
+        std::vector<double> beta(R);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(beta.data(), h->d_beta, (size_t)R * 8, hipMemcpyDeviceToHost));
+        std::vector<int> by_rank(R), order(R);
+        for (int i = 0; i < R; ++i) by_rank[i] = i;
+        std::stable_sort(by_rank.begin(), by_rank.end(), [&](int a, int b) { return beta[a] < beta[b]; }); // hottest first
+        const int nb = (R + wpb - 1) / wpb;
+        for (int q = 0; q < R; ++q) {
+            int rho;
+            if (wpb == 8) {  // partner of wave w of a workgroup: wave w + 4 of the same workgroup (R % 8 == 0)
+                const int k = (q >> 3) * 4 + (q & 3);
+                rho = (q & 4) ? R - 1 - k : k;
+            } else if (mode == 1) { // partner of workgroup b: workgroup b + nb / 2
+                const int half = (nb / 2) * wpb;
+                rho = q < half ? q : (q < 2 * half ? R - 1 - (q - half) : q - half);
+            } else {         // partner of workgroup 2 p: workgroup 2 p + 1
+                const int b = q / wpb, w = q % wpb, k = (b >> 1) * wpb + w;
+                const bool paired = (b | 1) < nb;
+                rho = !paired ? (nb / 2) * wpb + w : ((b & 1) ? R - 1 - k : k);
+            }
+            order[q] = by_rank[rho];
+        }
+        { // (a permutation by construction; a slip here would run a walker twice and another not at all)
+            std::vector<char> seen(R, 0);
+            for (int q = 0; q < R; ++q) {
+                if (order[q] < 0 || order[q] >= R || seen[order[q]]) return fail("internal: walker order is not a permutation");
+                seen[order[q]] = 1;
+            }
+        }
+        HIPCHK(hipMemcpy(h->d_order, order.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice));
+        h->order_dirty = false;
+    }
+    lp.order = h->d_order;
+    return 0;
+}
+
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
+    TRY(update_walker_order(h, lp));
     if (h->lean_multi && lp.bias_type)
         return h->lean_nslot == 2 ? smolmc_launch_multi_bias_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_4(h, lp) : smolmc_launch_multi_bias_8(h, lp));
@@ -2115,5 +2193,6 @@ extern "C" int smolmc_import_temperature_dev(smolmc_handle *h, const double *src
                        h->d_beta, h->R, SMOLMC_KB);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->order_dirty = true;
     return 0;
 }

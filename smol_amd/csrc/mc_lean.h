@@ -1235,13 +1235,15 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // A template parameter, not a runtime flag: the unused variants' pointers and code otherwise stay
 // live across the step loop (the kernel spills SGPRs as it is).
 template <int NSLOT, int MM, int EWM>
-__global__ void __launch_bounds__(256, 2) mc_table_kernel(const LeanParams P) {
+__global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // (four or eight walkers per workgroup, two waves per SIMD)
     constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int r = uni(blockIdx.x * nwaves + wave);
+    // (launch slot -> walker: see update_walker_order, engine.hip)
+    const int slot = uni(blockIdx.x * nwaves + wave);
+    const int r = (P.order != nullptr && slot < P.R) ? uni(P.order[slot]) : slot;
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (ew_field ? (size_t)P.ew_nact * 8 : 0);
@@ -2205,13 +2207,14 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
 }
 template <int NSLOT, int MM, int EWM>
 static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
-    const unsigned grid = (unsigned)((h->R + 3) / 4);
+    const int wpb = h->lean_wpb;
+    const size_t lds = wpb == 8 ? h->lean_lds_wpb8 : h->lean_lds;
+    const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
     auto kern = mc_table_kernel<NSLOT, MM, EWM>;
-    if (h->lean_lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)h->lean_lds));
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds, h->stream, lp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -402,6 +402,9 @@ struct LeanSlot {
 };
 
 struct LeanParams {
+    // walker of launch slot q (= workgroup * waves + wave), or null: slot q runs walker q.  Set when
+    // the walkers' temperatures differ (an exchange ladder): see walker_order_kernel, engine.hip
+    const int *order;
     const uint16_t *idx;   // [N][64][NSLOT][MM]
     const uint32_t *idx32; // the same entries as 32-bit words (one-wave-per-workgroup layout)
     const double *dt;      // delta tables, all padded to a common [S*S][NTP] shape
@@ -499,6 +502,9 @@ struct DevBuf {
 struct smolmc_handle {
     smolmc_config cfg;
     int device = 0;
+    int *d_order = nullptr;    // launch-slot -> walker permutation (TableFlip kernels), see walker_order_kernel
+    bool order_dirty = true;   // temperatures changed since it was computed
+    int order_mode = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -520,6 +526,8 @@ struct smolmc_handle {
     bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
     bool lean_solo = false;             // mc_lean_kernel in its one-wave-per-workgroup layout
     int lean_occ = 0;                   // > 0: the solo instantiation held to this many waves per SIMD
+    int lean_wpb = 4;          // TableFlip kernel: walkers (waves) per workgroup -- 8 when one such workgroup fills a CU's LDS (see launch_table_ewm)
+    size_t lean_lds_wpb8 = 0;  // its dynamic LDS with 8 waves
     int lean_kf = 0;                    // > 0: correlation features with up to lean_kf functions per orbit
     std::vector<uint16_t> lean_idx_host; // lane-packed index rows (kept for the 32-bit copy)
     std::vector<int> site_class_host;   // site -> class (255 = no clusters)

@@ -79,6 +79,35 @@ def test_table_flip_proposal_batch_matches_oracle_over_many_blocks(dim, ewald):
     eng.close()
 
 
+def test_launch_order_of_a_ladder_does_not_change_any_walker(monkeypatch):
+    """On an exchange ladder the engine deals the walkers to launch slots hottest-with-coldest
+    (engine.hip, update_walker_order); which slot runs a walker must not matter."""
+    from smol_amd.engine import Engine
+
+    sc, tab = _model(6, coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=True)
+    R = 24
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    rng = np.random.default_rng(3)
+    occ = np.array([_neutral_occ(sc, 2 * (r % 3 + 1), rng) for r in range(R)])
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(77)
+    temps = rng.permutation(np.geomspace(1500.0, 9000.0, R))
+    states = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("SMOLMC_WALKER_ORDER", mode)
+        eng = Engine(tab, cfg)
+        eng.set_state(occ, seeds, temps)
+        eng.run(300)
+        eng.set_temperature(temps[::-1].copy())  # (a new ladder assignment: the order is rebuilt)
+        eng.run(300)
+        states.append(eng.get_state())
+        eng.close()
+    for s in states[1:]:
+        assert np.array_equal(s["occupancy"], states[0]["occupancy"])
+        assert np.array_equal(s["n_accepted"], states[0]["n_accepted"])
+        assert np.array_equal(s["enthalpy"], states[0]["enthalpy"])
+    assert states[0]["n_accepted"].sum() > 0
+
+
 def test_table_flip_detailed_balance_on_gpu():
     from smol_amd.engine import Engine
 
