@@ -463,6 +463,16 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
            per * world, launches=30, exchange_every_steps=wl5.mc_per_launch,
            exchange_acceptance_mean=float(rex.acceptance.mean()),
            exchange_path="collective (all-gather over %d ranks)" % world if world > 1 else "single rank (direct read-back)")
+    if world == 1:
+        # BASELINE's own ladder for config 5 (400-2000 K): equilibrated it accepts 0.1 % of its steps
+        # (why the default ladder above is hotter), so only the window rounds 1-2 quoted is timed
+        wl5c = workloads.config5(first=0, count=per, total=per, t_lo=400.0, t_hi=2000.0)
+        rexc = parallel.ReplicaExchange(wl5c.extras["ladder"], per, 0, 1, seed=11)
+        info, first, _ = _engine_run(Engine, wl5c, device, clock, 3, wl5c.mc_per_launch, rex=rexc)
+        record(wl5c, info, first, None,
+               lambda rec: dict(bound="issue", note="as config 5 above; launches 2-4 from the random start"),
+               per, launches=3, state="transient", exchange_every_steps=wl5c.mc_per_launch,
+               exchange_acceptance_mean=float(rexc.acceptance.mean()))
     return out
 
 
