@@ -804,15 +804,19 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     const double nbeta = -P.beta[r];
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0, nacc_before = 0;
-    const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);
+    const uint32_t key0_ = (uint32_t)P.seeds[r], key1_ = (uint32_t)(P.seeds[r] >> 32);
+    // (opaque at every Philox call: the twenty loop-invariant round keys otherwise live in SGPRs
+    // across the step loop, see mc_table_kernel)
+#define key0 opaque_u32(key0_)
+#define key1 opaque_u32(key1_)
     double acc_mu = 0.0, acc_ew = 0.0;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
-    uint32_t smp_countdown = (uint32_t)P.smp.every;
-    long long smp_index = 0;
+    uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
+    uint32_t smp_index = 0;
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
     double logu = 0.0;
-    unsigned long long batch_base = ~0ull;
+    uint32_t batch_base = ~0u; // low word of the batch's first step
     uint32_t w_site_carry = 0;
     constexpr int ROW = NSLOT * MM;
     constexpr int NW = ROW / 2;
@@ -830,22 +834,211 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     // its own sites; a step that finds all its picks among them skips the 256-candidate rounds.
     uint32_t cblk_base = ~0u, cb_word = 0u;
 
+    // ---- proposal batch (see mc_table_kernel: the proposals of 64 consecutive steps at once, lane
+    // l <-> step (step & ~63) + l, stale marking after accepted steps, the step-at-a-time code below
+    // as the definition and the fallback).  Here the picks of a direction run over the active
+    // sublattices in turn: lane idx (< 2 tf_n) holds, as nibbles in pick order, the (local) species
+    // and the sublattice of every depleted pick, and the same for the enriched entries in the
+    // order the assignment draws them; a candidate word maps to a site of the sublattice of the
+    // pick it is examined for.
+    uint32_t vdep_c = 0, vdep_s = 0, venr_c = 0, venr_s = 0;
+    int vncol = 0;
+    if (lane < 2 * P.tf_n) {
+        const int sgn = (lane & 1) ? -1 : 1;
+        int ne = 0, db = 0;
+        for (int sl = 0; sl < NS; ++sl) {
+            const int ncod = sel4(P.m_ncodes, sl);
+            for (int c = 0; c < ncod; ++c) {
+                const int u = sgn * s_tf[(lane >> 1) * D + db + c];
+                for (int z = 0; z < -u; ++z, ++vncol)
+                    if (vncol < 8) { vdep_c |= (uint32_t)c << (4 * vncol); vdep_s |= (uint32_t)sl << (4 * vncol); }
+                for (int z = 0; z < u; ++z, ++ne)
+                    if (ne < 8) { venr_c |= (uint32_t)c << (4 * ne); venr_s |= (uint32_t)sl << (4 * ne); }
+            }
+            db += ncod;
+        }
+    }
+    int vmaxu = 0; // lane d: the largest change of count dimension d in any direction
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vmaxu = max(vmaxu, vtf[i] < 0 ? -vtf[i] : vtf[i]);
+    auto all_feasible = [&](const int vc) -> bool {
+        return __ballot(lane < D && (vc - vmaxu < 0 || vc + vmaxu > dim_max)) == 0ull;
+    };
+    const uint32_t lane4 = (uint32_t)(lane & 7) * 4u;
+    uint32_t q_base = ~0u;           // low word of the batch's first step
+    uint32_t q_meta = 0;             // bit 0 covered | bit 1 swap | bits 2-4 flips | bits 5-8 direction
+    uint32_t q_s01 = 0, q_s23 = 0;   // sites of the flips (u16 each)
+    uint32_t q_pack = 0;             // old species of flip f: nibble f; new species: nibble 4 + f
+    uint32_t q_sub = 0;              // sublattice of flip f: nibble f
+    uint32_t q_w1 = 0;               // W(step, 0, 1): the site word of the NEXT step
+    uint32_t q_c[16];                // examined candidate sites (u16 each; 0xffff: none)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q_c[i] = 0xffffffffu;
+    unsigned long long q_stale = ~0ull;
+    auto compute_head = [&]() {
+        feas_now = feasible(vcnt);
+        sumw = masked_sum(feas_now);
+        head_valid = true;
+        lp_valid = 0u;
+        // running sums of the feasible weights, lane idx <-> direction idx (mc_table_kernel)
+        double c = 0.0;
+        last_feas = -1;
+        for (int idx = 0; idx < nf2; ++idx)
+            if ((feas_now >> idx) & 1u) {
+                c += weight_of(idx);
+                if (lane == idx) vcum = c;
+                last_feas = idx;
+            }
+    };
+    auto vsel4 = [&](const int a0, const int a1, const int a2, const int a3, const int k) -> int { // per-lane choice
+        return k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
+    };
+    auto propose_batch = [&](const unsigned long long b0) { // b0: first step of the block
+        const LeanParamsKernarg Q = rare_params();
+        const int sb0 = Q->m_sbase[0], sb1 = Q->m_sbase[1], sb2 = Q->m_sbase[2], sb3 = Q->m_sbase[3];
+        const int na0 = Q->m_nact[0], na1 = Q->m_nact[1], na2 = Q->m_nact[2], na3 = Q->m_nact[3];
+        uint32_t carry; // lane 0's site word W(b0 - 1, 0, 1)
+        if (q_base == (uint32_t)b0 - 64u) {
+            carry = rdlane(q_w1, 63);
+        } else {
+            const unsigned long long sp = b0 - 1ull;
+            carry = (uint32_t)uni((int)philox_call((uint32_t)sp, (uint32_t)(sp >> 32), 0u, key0, key1).w[1]);
+        }
+        q_base = (uint32_t)b0;
+        q_stale = 0ull;
+        const unsigned long long st = b0 + (unsigned)lane;
+        const uint32_t c0 = (uint32_t)st, c1 = (uint32_t)(st >> 32);
+        const philox_out o0 = philox_call(c0, c1, 0u, key0, key1);
+        q_w1 = o0.w[1];
+        uint32_t wsite = (uint32_t)__shfl((int)o0.w[1], (lane + 63) & 63);
+        wsite = lane == 0 ? carry : wsite;
+        q_meta = 0u;
+        if (!(sumw > 0.0)) return; // no feasible direction: every step a swap -- left to the step-at-a-time code
+        const bool is_swap = (double)o0.w[0] * (1.0 / 4294967296.0) < Q->tf_sw;
+        const philox_out o1 = philox_call(c0, c1, 1u, key0, key1);
+        const philox_out o2 = philox_call(c0, c1, 2u, key0, key1);
+        const double target = (double)o1.w[0] * (1.0 / 4294967296.0) * sumw;
+        int d = -1;
+        for (int idx = 0; idx < nf2; ++idx) {
+            const double c = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vcum), idx),
+                                              (int)rdlane((uint32_t)__double2loint(vcum), idx));
+            if (((feas_now >> idx) & 1u) && d < 0 && target < c) d = idx;
+        }
+        if (d < 0) d = last_feas;
+        const uint32_t dep_c = (uint32_t)__shfl((int)vdep_c, d), dep_s = (uint32_t)__shfl((int)vdep_s, d);
+        const uint32_t enr_c = (uint32_t)__shfl((int)venr_c, d), enr_s = (uint32_t)__shfl((int)venr_s, d);
+        const int ncol = __shfl(vncol, d);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q_c[i] = 0xffffffffu;
+        uint32_t meta = 0u, pack = 0u, subs = 0u;
+        int col0 = -1, col1 = -1, col2 = -1, col3 = -1;
+        if (is_swap) {
+            // Swap.propose_step inside the sublattice picked by W(step, 1, 1); the first 12
+            // candidates c_t = W(step, 1 + t % 3, t / 3)
+            const philox_out o3 = philox_call(c0, c1, 3u, key0, key1);
+            const int sl = sub_of(o1.w[1]);
+            const int sb = vsel4(sb0, sb1, sb2, sb3, sl);
+            const uint32_t na = (uint32_t)vsel4(na0, na1, na2, na3, sl);
+            const int s1 = sb + (int)__umulhi(wsite, na);
+            const int sp1 = (int)occ[lean_swz(s1, swa, swm, swb)];
+            q_c[0] = 0xffff0000u | (uint32_t)s1;
+            int found = -1, fo = 0;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const uint32_t w = (t % 3 == 0 ? o1 : t % 3 == 1 ? o2 : o3).w[t / 3];
+                const int cs = sb + (int)__umulhi(w, na);
+                const int v = (int)occ[lean_swz(cs, swa, swm, swb)];
+                if (found < 0) {
+                    const int slot = 1 + t;
+                    q_c[slot >> 1] = (slot & 1) ? ((q_c[slot >> 1] & 0x0000ffffu) | ((uint32_t)cs << 16))
+                                                : ((q_c[slot >> 1] & 0xffff0000u) | (uint32_t)cs);
+                    if (v != sp1) { found = cs; fo = v; }
+                }
+            }
+            if (found >= 0) {
+                col0 = s1;
+                col1 = found;
+                pack = (uint32_t)sp1 | ((uint32_t)fo << 4) | ((uint32_t)fo << 16) | ((uint32_t)sp1 << 20);
+                subs = (uint32_t)sl | ((uint32_t)sl << 4);
+                meta = 1u | 2u | (2u << 2);
+            }
+        }
+        // table steps: one pass over the candidate stream c_t = W(step, 4 + t / 4, t % 4); the next
+        // pick says which species is wanted and which sublattice maps the word to a site
+        int k = 0;
+        bool scanning = !is_swap && ncol >= 1 && ncol <= 4;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (__ballot(scanning) != 0ull) {
+                const philox_out o = philox_call(c0, c1, 4u + (uint32_t)b, key0, key1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * b + j;
+                    const int want = (int)((dep_c >> (4 * k)) & 15u), wsl = (int)((dep_s >> (4 * k)) & 15u);
+                    const int cs = vsel4(sb0, sb1, sb2, sb3, wsl) + (int)__umulhi(o.w[j], (uint32_t)vsel4(na0, na1, na2, na3, wsl));
+                    const int v = (int)occ[lean_swz(scanning ? cs : 0, swa, swm, swb)];
+                    if (scanning) {
+                        q_c[t >> 1] = (t & 1) ? ((q_c[t >> 1] & 0x0000ffffu) | ((uint32_t)cs << 16))
+                                              : ((q_c[t >> 1] & 0xffff0000u) | (uint32_t)cs);
+                        const bool dup = cs == col0 || cs == col1 || cs == col2 || cs == col3;
+                        if (v == want && !dup) {
+                            col0 = k == 0 ? cs : col0;
+                            col1 = k == 1 ? cs : col1;
+                            col2 = k == 2 ? cs : col2;
+                            col3 = k == 3 ? cs : col3;
+                            pack |= (uint32_t)v << (4 * k);
+                            subs |= (uint32_t)wsl << (4 * k);
+                            k++;
+                            scanning = k < ncol;
+                        }
+                    }
+                }
+            }
+        }
+        if (!is_swap && ncol >= 1 && ncol <= 4 && k == ncol) {
+            // the random assignment (mcusher.py:627-631), sublattice by sublattice: draw q takes the
+            // rr-th pick still available AMONG THE PICKS OF ITS SUBLATTICE
+            uint32_t avail = (1u << ncol) - 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < ncol) {
+                    const uint32_t esl = (enr_s >> (4 * q)) & 15u;
+                    uint32_t msl = 0u; // picks of that sublattice
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) msl |= (z < ncol && ((subs >> (4 * z)) & 15u) == esl) ? 1u << z : 0u;
+                    uint32_t m = avail & msl;
+                    const uint32_t rr = __umulhi(o2.w[q], (uint32_t)__popc(m));
+#pragma unroll
+                    for (int z = 0; z < 3; ++z) m = z < (int)rr ? (m & (m - 1u)) : m;
+                    const int pj = __ffs((int)m) - 1;
+                    avail &= ~(1u << pj);
+                    pack |= ((enr_c >> (4 * q)) & 15u) << (16 + 4 * pj);
+                }
+            meta = 1u | ((uint32_t)ncol << 2) | ((uint32_t)d << 5);
+        }
+        q_meta = meta;
+        q_s01 = ((uint32_t)col0 & 0xffffu) | ((uint32_t)col1 << 16);
+        q_s23 = ((uint32_t)col2 & 0xffffu) | ((uint32_t)col3 << 16);
+        q_pack = pack;
+        q_sub = subs;
+    };
+
 #ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
-    long long ph_acc[5] = {0, 0, 0, 0, 0};
+    long long ph_acc[5] = {0, 0, 0, 0, 0}, ph_cov = 0;
     long long ph_t = clock64();
 #endif
     const uint32_t nsteps32 = (uint32_t)P.steps;
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
-        if (base != batch_base) {
-            if (batch_base == base - 16) {
+        if ((uint32_t)base != batch_base) {
+            if (batch_base == (uint32_t)base - 16u) {
                 w_site_carry = rdlane(W1, 60);
             } else {
                 const unsigned long long sp = base - 1ull;
                 w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
                                                                 key0, key1).w[1]);
             }
-            batch_base = base;
+            batch_base = (uint32_t)base;
             const unsigned long long st = base + (unsigned)(lane >> 2);
             const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), 0u,
                                                key0, key1);
@@ -853,34 +1046,49 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             logu = log(philox_u53(o.w[2], o.w[3]));
         }
         const int l4 = (int)(step & 15ull) * 4;
-#ifdef SMOLMC_EXP_PHASES
-        { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; }
+        // feasibility mask / weight sums after the counts changed (one copy of the code); the batch's
+        // directions assume the mask they were chosen under
+        if (__builtin_expect(!head_valid, 0)) {
+            const unsigned feas_old = feas_now;
+            compute_head();
+            if (feas_now != feas_old) q_stale = ~0ull;
+        }
+        if (__builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull);
+        const int l6 = (int)(step & 63ull);
+        const uint32_t q_m = rdlane(q_meta, l6);
+#ifdef SMOLMC_NO_TABLE_BATCH // A/B switch: every step through the step-at-a-time proposal
+        const bool covered = false;
+#else
+        const bool covered = (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
 #endif
-        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
-
+#ifdef SMOLMC_EXP_PHASES
+        { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; if (covered) ph_cov++; }
+#endif
         // flips of this step, lane-indexed: lane f holds flip f (site, new / old code, sublattice)
         int vsite = 0, vnew = 0, vold = 0, vfsub = 0;
         int nfl = 0, dir = -1;
         bool fast_ok = false;
         int vu = 0; // table step: lane d holds the change of count dimension d
         double log_priori = 0.0;
+        if (covered) {
+            // the batch's proposal of this step (see propose_batch)
+            nfl = (int)((q_m >> 2) & 7u);
+            const uint32_t a01 = rdlane(q_s01, l6), a23 = rdlane(q_s23, l6), pk = rdlane(q_pack, l6), sb4 = rdlane(q_sub, l6);
+            vsite = lane == 0 ? (int)(a01 & 0xffffu) : lane == 1 ? (int)(a01 >> 16)
+                  : lane == 2 ? (int)(a23 & 0xffffu) : (int)(a23 >> 16);
+            vold = (int)((pk >> lane4) & 15u);
+            vnew = (int)(((pk >> 16) >> lane4) & 15u);
+            vfsub = (int)((sb4 >> lane4) & 15u);
+            if (!(q_m & 2u)) {
+                dir = (int)((q_m >> 5) & 15u);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
+                vu *= (dir & 1) ? -1 : 1;
+            }
+        } else {
+        const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
         if (!do_swap) {
-            if (!head_valid) { // (cached until the counts change: see mc_table_kernel)
-                feas_now = feasible(vcnt);
-                sumw = masked_sum(feas_now);
-                head_valid = true;
-                lp_valid = 0u;
-                // running sums of the feasible weights, lane idx <-> direction idx (mc_table_kernel)
-                double c = 0.0;
-                last_feas = -1;
-                for (int idx = 0; idx < nf2; ++idx)
-                    if ((feas_now >> idx) & 1u) {
-                        c += weight_of(idx);
-                        if (lane == idx) vcum = c;
-                        last_feas = idx;
-                    }
-            }
             if (!(sumw > 0.0)) do_swap = true;
         }
         if (do_swap) {
@@ -948,22 +1156,6 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 #pragma unroll
             for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
             vu *= (dir & 1) ? -1 : 1;
-            if (!((lp_valid >> dir) & 1u)) { // compute_log_priori_factor (mcusher.py:656-711), cached per direction
-                const double sum_next = masked_sum(feasible(vcnt + vu));
-                double lf = 0.0;
-                const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
-                if (!(w_now == w_back && sum_next == sumw)) {
-                    const double p_now = (1.0 - P.tf_sw) * w_now / sumw;
-                    const double p_next = (1.0 - P.tf_sw) * w_back / sum_next;
-                    lf = log(p_next / p_now);
-                }
-                lf += table_log_count_ratio(P.tf_ln, vu, vcnt, D);
-                lf = uni_d(lf);
-                if (lane == dir) vlp = lf;
-                lp_valid |= 1u << dir;
-            }
-            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
-                                          (int)rdlane((uint32_t)__double2loint(vlp), dir));
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[1] += tn - ph_t; ph_t = tn; }
 #endif
@@ -1108,6 +1300,27 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             done = !fast || fast_ok;
             } // (block attempt, then full scan)
         }
+        } // (step-at-a-time proposal)
+        if (dir >= 0) {
+            if (__builtin_expect(!((lp_valid >> dir) & 1u), 0)) { // compute_log_priori_factor (mcusher.py:656-711), cached per direction
+                // (all directions feasible now and after the step: the same weight sum, no mask to form)
+                const double sum_next = (feas_now == (1u << nf2) - 1u && all_feasible(vcnt + vu)) ? sumw : masked_sum(feasible(vcnt + vu));
+                double lf = 0.0;
+                const double w_now = weight_of(dir), w_back = weight_of(dir ^ 1);
+                if (!(w_now == w_back && sum_next == sumw)) {
+                    const double tsw = rare_params()->tf_sw;
+                    const double p_now = (1.0 - tsw) * w_now / sumw;
+                    const double p_next = (1.0 - tsw) * w_back / sum_next;
+                    lf = log(p_next / p_now);
+                }
+                lf += table_log_count_ratio(rare_params()->tf_ln, vu, vcnt, D);
+                lf = uni_d(lf);
+                if (lane == dir) vlp = lf;
+                lp_valid |= 1u << dir;
+            }
+            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
+                                          (int)rdlane((uint32_t)__double2loint(vlp), dir));
+        }
 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[2] += tn - ph_t; ph_t = tn; }
@@ -1190,8 +1403,27 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 }
             }
         if (accepted) {
-            vcnt += vu;
-            if (dir >= 0) head_valid = false;
+            if (dir >= 0) {
+                // the mask of the feasible directions is recomputed unless all were feasible and still are
+                const bool was_all = all_feasible(vcnt);
+                vcnt += vu;
+                lp_valid = 0u;
+                if (!(was_all && all_feasible(vcnt))) head_valid = false;
+            }
+            {
+                // batch lanes whose scan examined a site that has just changed are stale
+                uint32_t hit = 0u;
+                for (int f = 0; f < nfl; ++f) {
+                    const uint32_t sf = rdlane((uint32_t)vsite, f);
+                    const uint32_t pat = sf | (sf << 16);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t dd = q_c[i] ^ pat; // a zero half-word <=> that kept site is sf
+                        hit |= (dd - 0x00010001u) & ~dd & 0x80008000u;
+                    }
+                }
+                q_stale |= __ballot(hit != 0u);
+            }
             if (has_ew) field_apply_flips<0>(phi_lds ? phi : P.ew_phi + (size_t)r * P.ew_nact, lane, nfl, vsite, vdq);
             acc_mu += dMu;
             acc_ew += dEw;
@@ -1206,30 +1438,35 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[4] += tn - ph_t; ph_t = tn; }
 #endif
-        if (P.smp.every && --smp_countdown == 0) {
-            smp_countdown = (uint32_t)P.smp.every;
-            const size_t row = (size_t)smp_index * P.R + r;
+        if (--smp_countdown == 0) { // (sampling parameters: re-read from the kernel arguments, see rare_params)
+            const LeanParamsKernarg Q = rare_params();
+            smp_countdown = (uint32_t)Q->smp.every;
+            const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
             s_feat[lane] = 0.0;
             double lane_e = 0.0;
+            const LeanSlot *q_slots = Q->slots;
+            const int qF = Q->F, qFce = Q->Fce;
+            double *const q_feat = Q->smp.feat;
             for (int i = lane; i < nrec; i += 64) {
-                const LeanSlot sl = P.slots[i];
+                const LeanSlot sl = q_slots[i];
                 const double v = s_acc[i];
                 lane_e = fma(sl.w, v, lane_e);
                 if (sl.live && v != 0.0)
                     __hip_atomic_fetch_add(&s_feat[sl.feat], sl.fs * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-            if (lane < P.Fce) P.smp.feat[row * P.F + lane] = base_feat + s_feat[lane];
-            if (has_ew && lane == P.Fce) P.smp.feat[row * P.F + lane] = base_feat + acc_ew;
-            if (has_mu && lane == P.Fce + (has_ew ? 1 : 0)) P.smp.feat[row * P.F + lane] = base_feat + acc_mu;
-            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (has_ew ? P.ew_coef * acc_ew : 0.0));
+            if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
+            if (has_ew && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
+            if (has_mu && lane == qFce + (has_ew ? 1 : 0)) q_feat[row * qF + lane] = base_feat + acc_mu;
+            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (has_ew ? Q->ew_coef * acc_ew : 0.0));
             if (lane == 0) {
-                P.smp.H[row] = Hnow;
-                P.smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+                Q->smp.H[row] = Hnow;
+                Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
             }
-            if (P.smp.occ) {
-                uint32_t *dst = (uint32_t *)(P.smp.occ + row * P.Npad);
-                for (int i = lane; i < P.Npad / 4; i += 64)
+            if (Q->smp.occ) {
+                const int qNpad = Q->Npad;
+                uint32_t *dst = (uint32_t *)(Q->smp.occ + row * qNpad);
+                for (int i = lane; i < qNpad / 4; i += 64)
                     dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
             }
         }
@@ -1237,7 +1474,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 
 #ifdef SMOLMC_EXP_PHASES
     if (r == 0 && lane == 0)
-        printf("multi phases (cycles per step): skeleton %.0f | head %.0f | picks+assign/swap %.0f | eval %.0f | decide+update %.0f\n",
+        printf("multi phases (cycles per step): covered %.3f | skeleton %.0f | head %.0f | picks+assign/swap %.0f | eval %.0f | decide+update %.0f\n", (double)ph_cov / (double)P.steps,
                (double)ph_acc[0] / (double)P.steps, (double)ph_acc[1] / (double)P.steps, (double)ph_acc[2] / (double)P.steps,
                (double)ph_acc[3] / (double)P.steps, (double)ph_acc[4] / (double)P.steps);
 #endif
@@ -1269,6 +1506,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     }
 }
 
+#undef key0
+#undef key1
 template <int NSLOT, int MM> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
