@@ -1374,11 +1374,80 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             if (has_mu) dMu += s_mu[sl * 8 + nw] - s_mu[sl * 8 + od];
             occ[lean_swz(s, swa, swm, swb)] = (uint8_t)nw; // tentative (every lane, same byte)
         };
+        // Steps of two or three flips on the two-group kernels in two phases (see mc_table_kernel): (A)
+        // every flip's slot records, occupancy gathers, potential read and tentative write ISSUED back
+        // to back -- the LDS executes in order, flip f + 1 sees flip f --, (B) table reads and
+        // arithmetic; the deltas stay in registers until the decision (no pending cells in LDS).
+        constexpr int TPF = NSLOT <= 2 ? 3 : 0; // flips the two-phase form covers (four: 256 VGPRs and scratch)
+        double tpd[TPF ? TPF : 1][NSLOT];
+        int tpcls[TPF ? TPF : 1];
+        bool two_phased = false;
+        auto two_phase = [&](auto nflips) {
+            constexpr int NF = decltype(nflips)::value;
+            int fsite[NF], fnw[NF], fod[NF], fsl[NF];
+            uint32_t g[NF][NSLOT * MM];
+            MultiRec rc[NF][NSLOT];
+            double fpot[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-            if (f < nfl) eval_flip(f, rows[f]);
-        for (int f = 4; f < nfl; ++f)
-            eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
+            for (int f = 0; f < NF; ++f) {
+                fsite[f] = (int)rdlane((uint32_t)vsite, f);
+                fnw[f] = (int)rdlane((uint32_t)vnew, f);
+                fod[f] = (int)rdlane((uint32_t)vold, f);
+                fsl[f] = (int)rdlane((uint32_t)vfsub, f);
+                tpcls[f] = sel4(P.m_cls, fsl[f]);
+                const MultiRec *rec = s_rec + ((size_t)tpcls[f] * NSLOT) * 64 + lane;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) rc[f][it] = rec[it * 64];
+#pragma unroll
+                for (int q = 0; q < NSLOT * MM; ++q) g[f][q] = (uint32_t)occ[row_entry<NW>(rows[f], q)];
+                fpot[f] = !has_ew ? 0.0
+                          : (phi_lds ? phi[fsite[f] - abase]
+                                     : __hip_atomic_load(&phi[fsite[f] - abase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                occ[lean_swz(fsite[f], swa, swm, swb)] = (uint8_t)fnw[f]; // tentative (every lane, same byte)
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int nw = fnw[f], od = fod[f], sl = fsl[f];
+                const uint32_t pair = (uint32_t)od * snt8 + (uint32_t)nw * nt8;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    uint32_t a = rc[f][it].doff8;
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) a += __umul24(rc[f][it].st8[m], g[f][it * MM + m]);
+                    const double d = *(const double *)((const unsigned char *)s_dt + (a + pair));
+                    e = fma(rc[f][it].w, d, e);
+                    tpd[f][it] = d;
+                }
+                if (has_ew) {
+                    const double dq = s_q[sl * 8 + nw] - s_q[sl * 8 + od];
+                    double pot = fpot[f];
+#pragma unroll
+                    for (int m = 0; m < f; ++m) {
+                        const double dqm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vdq), m),
+                                                            (int)rdlane((uint32_t)__double2loint(vdq), m));
+                        const double gfm = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vG), 8 * f + m),
+                                                            (int)rdlane((uint32_t)__double2loint(vG), 8 * f + m));
+                        pot = fma(dqm, gfm, pot);
+                    }
+                    ew_uni += 2.0 * dq * pot + (s_dg[sl * 8 + nw] - s_dg[sl * 8 + od]);
+                    if (lane == f) vdq = dq;
+                }
+                if (has_mu) dMu += s_mu[sl * 8 + nw] - s_mu[sl * 8 + od];
+            }
+            two_phased = true;
+        };
+#ifndef SMOLMC_NO_MULTI_TWO_PHASE
+        if (TPF && nfl == 2) two_phase(std::integral_constant<int, 2>{});
+        else if (TPF && nfl == 3) two_phase(std::integral_constant<int, 3>{});
+        else
+#endif
+        {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (f < nfl) eval_flip(f, rows[f]);
+            for (int f = 4; f < nfl; ++f)
+                eval_flip(f, load_row<NW>(idx_rs, lane_voff, rdlane((uint32_t)vsite, f) * SITE_BYTES));
+        }
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[3] += tn - ph_t; ph_t = tn; }
 #endif
@@ -1402,6 +1471,15 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                     pend[it * 64] = 0.0;
                 }
             }
+        if (accepted && two_phased) { // feature deltas of the two-phase form: registers -> accumulator cells
+#pragma unroll
+            for (int f = 0; f < (TPF ? TPF : 1); ++f)
+                if (f < nfl) {
+                    double *cell = s_acc + ((size_t)tpcls[f] * NSLOT) * 64 + lane;
+#pragma unroll
+                    for (int it = 0; it < NSLOT; ++it) cell[it * 64] += tpd[f][it];
+                }
+        }
         if (accepted) {
             if (dir >= 0) {
                 // the mask of the feasible directions is recomputed unless all were feasible and still are
