@@ -815,7 +815,6 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
     uint32_t smp_index = 0;
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
-    double logu = 0.0;
     uint32_t batch_base = ~0u; // low word of the batch's first step
     uint32_t w_site_carry = 0;
     constexpr int ROW = NSLOT * MM;
@@ -871,6 +870,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     uint32_t q_pack = 0;             // old species of flip f: nibble f; new species: nibble 4 + f
     uint32_t q_sub = 0;              // sublattice of flip f: nibble f
     uint32_t q_w1 = 0;               // W(step, 0, 1): the site word of the NEXT step
+    double q_logu = 0.0;             // log of the acceptance uniform
     uint32_t q_c[16];                // examined candidate sites (u16 each; 0xffff: none)
 #pragma unroll
     for (int i = 0; i < 16; ++i) q_c[i] = 0xffffffffu;
@@ -909,6 +909,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         const unsigned long long st = b0 + (unsigned)lane;
         const uint32_t c0 = (uint32_t)st, c1 = (uint32_t)(st >> 32);
         const philox_out o0 = philox_call(c0, c1, 0u, key0, key1);
+        q_logu = log(philox_u53(o0.w[2], o0.w[3]));
         q_w1 = o0.w[1];
         uint32_t wsite = (uint32_t)__shfl((int)o0.w[1], (lane + 63) & 63);
         wsite = lane == 0 ? carry : wsite;
@@ -1029,22 +1030,22 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 #endif
     const uint32_t nsteps32 = (uint32_t)P.steps;
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
-        const unsigned long long base = step & ~15ull;
-        if ((uint32_t)base != batch_base) {
-            if (batch_base == (uint32_t)base - 16u) {
-                w_site_carry = rdlane(W1, 60);
-            } else {
-                const unsigned long long sp = base - 1ull;
-                w_site_carry = (uint32_t)uni((int)philox4x32_10((uint32_t)sp, (uint32_t)(sp >> 32), 0u, 0u,
-                                                                key0, key1).w[1]);
+        // the 16-step word batch of the step-at-a-time proposal (lane l = block l & 3 of step base + (l >> 2))
+        auto word_batch = [&]() {
+            const unsigned long long base = step & ~15ull;
+            if ((uint32_t)base != batch_base) {
+                if (batch_base == (uint32_t)base - 16u) {
+                    w_site_carry = rdlane(W1, 60);
+                } else {
+                    const unsigned long long sp = base - 1ull;
+                    w_site_carry = (uint32_t)uni((int)philox_call((uint32_t)sp, (uint32_t)(sp >> 32), 0u, key0, key1).w[1]);
+                }
+                batch_base = (uint32_t)base;
+                const unsigned long long st = base + (unsigned)(lane >> 2);
+                const philox_out o = philox_call((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), key0, key1);
+                W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
             }
-            batch_base = (uint32_t)base;
-            const unsigned long long st = base + (unsigned)(lane >> 2);
-            const philox_out o = philox4x32_10((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)(lane & 3), 0u,
-                                               key0, key1);
-            W0 = o.w[0]; W1 = o.w[1]; W2 = o.w[2]; W3 = o.w[3];
-            logu = log(philox_u53(o.w[2], o.w[3]));
-        }
+        };
         const int l4 = (int)(step & 15ull) * 4;
         // feasibility mask / weight sums after the counts changed (one copy of the code); the batch's
         // directions assume the mask they were chosen under
@@ -1086,6 +1087,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 vu *= (dir & 1) ? -1 : 1;
             }
         } else {
+        word_batch();
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
         bool do_swap = (double)rdlane(W0, l4) * (1.0 / 4294967296.0) < P.tf_sw;
         if (!do_swap) {
@@ -1456,8 +1458,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         if (has_ew) dH += P.ew_coef * dEw;
         if (has_mu) dH -= dMu;
         const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
-        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
-                                           (int)rdlane((uint32_t)__double2loint(logu), l4));
+        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
+                                           (int)rdlane((uint32_t)__double2loint(q_logu), l6));
         const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         nacc_before = nacc_add;
         // pending feature deltas of the touched classes: keep (accept) or drop (reject)
