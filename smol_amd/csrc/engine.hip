@@ -1278,7 +1278,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             if (lean && !wl && !t->has_ewald && !t->bias_type && !h->lean_kf && cfg->step_type != SMOLMC_STEP_TABLE_FLIP &&
                 getenv("SMOLMC_NO_SOLO") == nullptr) {
                 const size_t pw = ((size_t)lp.Nlds + 64 * 8 + 15) & ~(size_t)15;
-                const size_t solo_lds = pw + ((size_t)lp.dt_len + 24) * 8;
+                // (SMOLMC_EXP_F32TAB: room for the float32 shadow tables of the -DSMOLMC_EXP_F32TAB experiment build)
+                const size_t solo_lds = pw + ((size_t)lp.dt_len + 24) * 8 +
+                                        (getenv("SMOLMC_EXP_F32TAB") ? (((size_t)lp.dt_len * 4 + 15) & ~(size_t)15) : 0);
                 if (solo_lds * 16 <= 160 * 1024 - 16 * 256) {
                     std::vector<uint32_t> wide(h->lean_idx_host.begin(), h->lean_idx_host.end());
                     if (dev_upload(h, wide.data(), wide.size(), &lp.idx32)) return bail(1);

@@ -298,7 +298,9 @@ typedef __attribute__((address_space(3))) double lds_f64_t;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SMOLMC_LDS_U8(a) (*(lds_u8_t *)(a))
 #define SMOLMC_LDS_F64(a) (*(const lds_f64_t *)(a))
+#define SMOLMC_LDS_F32(a) (*(const __attribute__((address_space(3))) float *)(a))
 #else
+#define SMOLMC_LDS_F32(a) (*(const float *)(uintptr_t)(a))
 #define SMOLMC_LDS_U8(a) (*(uint8_t *)(uintptr_t)(a))
 #define SMOLMC_LDS_F64(a) (*(const double *)(uintptr_t)(a))
 #endif
@@ -368,6 +370,20 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64);     // Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+#ifdef SMOLMC_EXP_F32TAB
+    // EXPERIMENT (the round-2 review's "one bounded experiment" on the headline kernel): a float32
+    // shadow of the delta tables for the decision, float64 entries read on accepted steps only.
+    // Solo layout, swap steps, no Ewald / bias / correlation functions; the host adds the shadow's
+    // LDS when SMOLMC_EXP_F32TAB is set in the environment (engine.hip).
+    constexpr bool F32TAB = SOLO && STEP == SMOLMC_STEP_SWAP && !HAS_EW && !WL && !BIAS && KF == 0 && !REPLAY;
+    const uint32_t sh_off = dt_off + (uint32_t)(P.dt_len + 24) * 8u; // shadow entry of the double at LDS address a: sh_off + (a - dt_off) / 2
+    if (F32TAB) {
+        float *s_dt32 = (float *)(smem + sh_off);
+        for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt32[i] = (float)P.dt[i];
+    }
+#else
+    constexpr bool F32TAB = false;
+#endif
     if (HAS_MU && threadIdx.x < 8) s_mu[threadIdx.x] = threadIdx.x < P.ncodes ? P.mu_row[threadIdx.x] : 0.0;
     if (HAS_EW && ew_field && threadIdx.x < 8) {
         s_q[threadIdx.x] = P.ew_qrow[threadIdx.x];
@@ -586,7 +602,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     // accept <=> -beta dH > log u <=> dH < log(u) / -beta =: thr  (dH <= 0 always
                     // passes since thr >= 0); certain on either side of thr -+ eps
                     const double thr = logu * inv_nbeta; // (a rounding of the band centre: covered by eps)
-                    const double eps = P.fast_eps + 1e-6 * fabs(thr);
+                    const double eps = (F32TAB ? 2.0 : 1.0) * P.fast_eps + 1e-6 * fabs(thr); // (shadow tables: + sum|w| max|dt| 2^-23, a sixteenth of fast_eps)
                     thr_lo = P.fast_eps > 0.0 ? (float)(thr - eps) : -INFINITY;
                     thr_hi = P.fast_eps > 0.0 ? (float)(thr + eps) : INFINITY;
                 }
@@ -782,6 +798,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         constexpr bool DIFF = STEP == SMOLMC_STEP_SWAP;
 #endif
         double e = 0.0, d1[NSLOT], d2[NSLOT];
+#ifdef SMOLMC_EXP_F32TAB
+        float t1f[NSLOT], ef32 = 0.0f;
+#endif
         uint32_t dp[NSLOT];
         uint32_t ad1[NSLOT], ad2[NSLOT]; // KF: LDS addresses of the two decision reads
         {
@@ -792,7 +811,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 if (DIFF) a = dp[it] = doff8[it] + pair1;
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, bounded(row_addr<SOLO, NW>(row1, it * MM + m), (uint32_t)P.Nlds)));
-                if (DIFF) {
+                if (DIFF && F32TAB) {
+#ifdef SMOLMC_EXP_F32TAB
+                    ad1[it] = a;
+                    t1f[it] = SMOLMC_LDS_F32(sh_off + ((a - dt_off) >> 1));
+#endif
+                } else if (DIFF) {
                     d1[it] = SMOLMC_LDS_F64(a);
                     if (KF) ad1[it] = a;
                 } else {
@@ -831,7 +855,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 uint32_t a = DIFF ? dp[it] : doff8[it];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(st8[it][m], (uint32_t)occ_ld<SOLO>(occ, bounded(row_addr<SOLO, NW>(row2, it * MM + m), (uint32_t)P.Nlds)));
-                if (DIFF) {
+                if (DIFF && F32TAB) {
+#ifdef SMOLMC_EXP_F32TAB
+                    ad2[it] = a;
+                    ef32 = fmaf((float)wgt[it], t1f[it] - SMOLMC_LDS_F32(sh_off + ((a - dt_off) >> 1)), ef32);
+#endif
+                } else if (DIFF) {
                     d1[it] -= SMOLMC_LDS_F64(a); // D[(o2,n2)] = -D[(o1,n1)]: the step's delta of this slot
                     if (KF) ad2[it] = a;
                     e = fma(wgt[it], d1[it], e);
@@ -881,8 +910,21 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                 dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
             }
         }
+#ifdef SMOLMC_EXP_F32TAB
+        bool have_d1 = false;
+#endif
         // exact float64 decision (metropolis.py:31-49 / wanglandau.py:186-202)
         auto exact_decision = [&]() -> bool {
+#ifdef SMOLMC_EXP_F32TAB
+            if (F32TAB) { // the float64 deltas, now that they are needed
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) {
+                    d1[it] = SMOLMC_LDS_F64(ad1[it]) - SMOLMC_LDS_F64(ad2[it]);
+                    e = fma(wgt[it], d1[it], e);
+                }
+                have_d1 = true;
+            }
+#endif
             dH = LEAN_WAVE_SUM(e);
             if (HAS_EW) {
                 dEw = (ew_field ? 0.0 : LEAN_WAVE_SUM(ew_part)) + ew_uni;
@@ -920,10 +962,16 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
 #ifdef SMOLMC_NO_SELACC
         constexpr bool SELACC = false;
 #else
-        constexpr bool SELACC = DIFF && FAST && !BIAS; // (measured: no gain for the flip / Ewald variants)
+        constexpr bool SELACC = DIFF && FAST && !BIAS && !F32TAB; // (measured: no gain for the flip / Ewald variants)
 #endif
         uint32_t sel_hi = 0u; // high word of sel
         auto on_accept = [&]() {
+#ifdef SMOLMC_EXP_F32TAB
+            if (F32TAB && !have_d1) {
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it) d1[it] = SMOLMC_LDS_F64(ad1[it]) - SMOLMC_LDS_F64(ad2[it]);
+            }
+#endif
             if (KF) {
                 // the K correlation-function tables of each slot (global memory, L2-resident),
                 // read at the index the decision already computed: byte ad - doff8 inside table k
@@ -1008,7 +1056,11 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         __builtin_amdgcn_s_setprio(3);
 #endif
         if (FAST && !BIAS) {
+#ifdef SMOLMC_EXP_F32TAB
+            const float ef = F32TAB ? ((HAS_MU && lane == 0) ? ef32 - (float)dMu : ef32) : (float)((HAS_MU && lane == 0) ? e - dMu : e);
+#else
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
+#endif
             const float S = wave_sum_f32_uniform(ef);
             const unsigned long long bit = 1ull << (REPLAY ? 0 : l64); // (replay: the thresholds are uniform)
             const bool ca = (__ballot(S < thr_lo) & bit) != 0ull;
