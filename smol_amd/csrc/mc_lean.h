@@ -108,8 +108,10 @@ __device__ __forceinline__ double lean_ewald_partial(const LeanParams &P, const 
 // potential-field update after an accepted flip of site s by charge dq: every other
 // changeable site j gains dq * G[s][j] (G symmetric, row s is contiguous); the own entry
 // is left as it was (phi excludes the self term): it is saved here and put back after the sweep.
-template <int FOOT = 2>
-__device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
+// (PRE: the caller holds the E8 entries of the first 27 groups in registers, see field_sweep_gx_pre27)
+template <int FOOT = 2, bool PRE = false>
+__device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq,
+                                            const uint32_t (&e0)[27], const bool have_e0) {
     const int js = s - P.sbase;
     const double keep = phi[js];
     // (the compressed tables' pointers are re-read from the kernel arguments: see rare_params)
@@ -119,12 +121,19 @@ __device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, in
         const uint32_t *E8 = Q->ew_E8;
         const uint32_t s8[1] = {Q->ew_S8[js]};
         const double d[1] = {dq};
-        field_sweep_gx_multi<1, FOOT>(phi, E8, gx, lane, P.ew_nact, s8, d);
+        if (PRE && have_e0) field_sweep_gx_pre27(phi, E8, gx, lane, P.ew_nact, s8, d, e0);
+        else field_sweep_gx_multi<1, FOOT>(phi, E8, gx, lane, P.ew_nact, s8, d);
     } else {
         const double *g = P.ew_G + (size_t)s * P.ew_nact;
         field_sweep<false>(phi, g, g, lane, P.ew_nact, dq, 0.0);
     }
     phi[js] = keep; // (every lane stores the same value)
+}
+
+template <int FOOT = 2>
+__device__ __forceinline__ void field_apply(const LeanParams &P, double *phi, int lane, int s, double dq) {
+    const uint32_t none[27] = {};
+    field_apply<FOOT, false>(P, phi, lane, s, dq, none, false);
 }
 
 // the flips of an accepted TableFlip step (lane f of vsite / vdq: site and charge change of flip f):
@@ -407,6 +416,25 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
     __syncthreads();
     if (!live) return;
+
+    // single flips with the potential field and the compressed site kernel: the E8 entries of the
+    // first 27 groups of field entries, lane constants of the launch (field_sweep_gx_pre27)
+#ifdef SMOLMC_NO_EWALD_E8REG // A/B switch
+    constexpr bool EPRE = false;
+#else
+    constexpr bool EPRE = HAS_EW && STEP == SMOLMC_STEP_FLIP && !REPLAY;
+#endif
+    uint32_t ereg[27] = {};
+    bool epre_on = false;
+    if (EPRE) {
+        const LeanParamsKernarg Q = rare_params();
+        const uint32_t *E8 = Q->ew_E8;
+        epre_on = ew_field && Q->ew_gx != nullptr && (Q->ew_nact >> 6) >= 27;
+        if (epre_on) {
+#pragma unroll
+            for (int u = 0; u < 27; ++u) ereg[u] = E8[64 * u + lane];
+        }
+    }
 
     // per-lane slot constants (registers for the whole launch)
     uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
@@ -1023,7 +1051,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
                     if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
                 } else if (dq1 != 0.0) {
 #ifndef SMOLMC_EXP_NOFIELD // timing experiment only when defined (wrong results)
-                    field_apply(P, phi, lane, s1, dq1);
+                    field_apply<2, EPRE>(P, phi, lane, s1, dq1, ereg, epre_on);
 #endif
                 }
             }

@@ -308,9 +308,9 @@ __device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t
 }
 template <int NF, int U, int NB>
 __device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
-                                                     int na, const uint32_t (&s8)[NF], const double (&dq)[NF]) {
+                                                     int na, const uint32_t (&s8)[NF], const double (&dq)[NF], int gstart = 0) {
     const int ngf = na >> 6; // full groups of 64 entries
-    int g = 0;
+    int g = gstart;          // (groups below gstart: done by the caller, see field_sweep_gx_pre27)
     while (ngf - g >= U) {
         const int nb = min(NB, (ngf - g) / U); // full batches of this chunk (uniform)
         const uint32_t *pe = E8 + g * 64 + lane;
@@ -350,6 +350,15 @@ __device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t
         for (int f = 0; f < NF; ++f) x = fma(dq[f], *(const double *)(gx + (size_t)(e + s8[f])), x);
         phi[j] = x;
     }
+}
+// Single flip with the E8 entries of the first 27 groups already in registers: they are lane
+// constants of the launch (E8[64 u + lane]), and fetching them is the first of the three dependent
+// round trips of a sweep (E8 -> table entries -> phi).  The kernels that take the 27-group batch hold
+// 27 such registers inside the sweep anyway; kept across the step loop they cost nothing at the peak.
+__device__ __forceinline__ void field_sweep_gx_pre27(double *phi, const uint32_t *E8, const unsigned char *gx, int lane, int na,
+                                                     const uint32_t (&s8)[1], const double (&dq)[1], const uint32_t (&e0)[27]) {
+    field_sweep_gx_groups<1, 27>(phi + lane, e0, gx, s8, dq, 0);
+    if ((na >> 6) > 27 || (na & 63)) field_sweep_gx_sized<1, 27, 1>(phi, E8, gx, lane, na, s8, dq, 27);
 }
 // FOOT: register footprint the caller can afford.  2: the 27-group batch for single flips (the
 // one-sublattice flip kernels, whose occupancy is bound by the field in LDS anyway); 1: chunks of
