@@ -24,9 +24,17 @@ def _engine(tab, cfg):
     return Engine(tab, cfg)
 
 
+def _max_rel(a, b, floor):
+    """largest |a - b| / |b| over the entries with |b| > floor (north_star's bar is 1e-10 RELATIVE;
+    assert_allclose's atol would let a relative 1e-8 through on a value of 0.1)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    m = np.abs(b) > floor
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
+
+
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("mode", ["int", "corr"])
-def test_eval_full_and_delta_vs_reference_fixtures(name, mode):
+def test_eval_full_and_delta_vs_reference_fixtures(name, mode, record_property):
     c = load_case(name)
     g = c["gold"]
     tab = tables_for(name, MODES[mode])
@@ -38,6 +46,7 @@ def test_eval_full_and_delta_vs_reference_fixtures(name, mode):
     if c["ewald"] is not None:
         np.testing.assert_allclose(full[:, nce], g["full_ewald"], rtol=RTOL)
     nper = len(g["flips"]) // len(g["occ"])
+    worst = dict(full=0.0, delta=0.0, delta_ewald=0.0)
     for k, occ in enumerate(g["occ"]):
         rows = g["flips"][k * nper:(k + 1) * nper]
         d = eng.eval_delta(occ, rows)
@@ -47,6 +56,19 @@ def test_eval_full_and_delta_vs_reference_fixtures(name, mode):
         if c["ewald"] is not None:
             np.testing.assert_allclose(d[:, nce], g["delta_ewald"][k * nper:(k + 1) * nper],
                                        rtol=RTOL, atol=1e-8)
+        # the relative bar itself, wherever the reference value is not (nearly) zero
+        gd = g["delta_corr" if mode == "corr" else "delta_int"][k * nper:(k + 1) * nper]
+        worst["delta"] = max(worst["delta"], _max_rel(d[:, :nce], gd, 1e-6))
+        if c["ewald"] is not None:
+            ge = g["delta_ewald"][k * nper:(k + 1) * nper]
+            # (an Ewald delta is a sum over N sites of terms of order max|delta|: cancellation-free entries only)
+            worst["delta_ewald"] = max(worst["delta_ewald"], _max_rel(d[:, nce], ge, 1e-3 * float(np.abs(ge).max())))
+    worst["full"] = _max_rel(full[:, :nce], g["full_corr" if mode == "corr" else "full_int"], 1e-6)
+    print(f"max relative errors vs the reference core [{name}, {mode}]: " +
+          ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    for k, v in worst.items():
+        record_property(f"max_rel_{k}", v)
+        assert v < 1e-10, (k, v)
 
 
 REPLAY_KERNELS = pytest.mark.parametrize("replay_kernel", ["auto", "general-kernel"])
