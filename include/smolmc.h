@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 5
+#define SMOLMC_ABI_VERSION 6
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
@@ -54,6 +54,13 @@ extern "C" {
 #define SMOLMC_STEP_SWAP 1 /* Swap  mcusher.py:173 */
 #define SMOLMC_STEP_TABLE_FLIP 2 /* TableFlip mcusher.py:397 (charge-neutral semigrand) */
 #define SMOLMC_MAX_STEP_FLIPS 8  /* most single-site flips in one TableFlip step */
+/* One MC step as the ushers return it (a list of (site, code) tuples, mcusher.py:104-116), as a fixed
+ * record of SMOLMC_STEP_ROW int32: (site_0, code_0, ..., site_7, code_7), flips in the order the
+ * reference applies them (sequential-flip semantics, expansion.py:217-229); the record ends at the
+ * first site < 0 (-1 = no flip; an all -1 record is the empty step of mcusher.py:197-199). */
+#define SMOLMC_STEP_ROW (2 * SMOLMC_MAX_STEP_FLIPS)
+#define SMOLMC_MAX_FLIP_VECTORS 32 /* rows of flip_table (2 x that many directions) */
+#define SMOLMC_MAX_FLIP_DIMS 64    /* columns of flip_table: species over the active sublattices */
 
 /*
  * Read-only model tables.  Flattened, caller-owned equivalents of the
@@ -132,8 +139,8 @@ typedef struct smolmc_tables {
      * flip_table rows are flip vectors in "counts" format over the ACTIVE sublattices'
      * species, concatenated in sub_* order (the reference's dims of inactive sublattices
      * are always zero and are dropped); directions 2i / 2i+1 are +row i / -row i. */
-    int32_t n_flip_vectors;
-    const int32_t *flip_table;   /* [n_flip_vectors x sum(codes of active sublattices)] */
+    int32_t n_flip_vectors;      /* <= SMOLMC_MAX_FLIP_VECTORS */
+    const int32_t *flip_table;   /* [n_flip_vectors x sum(codes of active sublattices)], <= SMOLMC_MAX_FLIP_DIMS columns */
     const double *flip_weights;  /* [2 x n_flip_vectors] (mcusher.py:519-538) */
     double swap_weight;          /* probability of a canonical Swap instead (mcusher.py:540) */
 
@@ -227,8 +234,9 @@ int smolmc_set_wl(smolmc_handle *h, const double *entropy /*RxL*/, const int64_t
                   const double *mod_factor /*R*/);
 /* Step / accept counters of every walker.  n_steps is the walker's position in its random stream
  * (Philox counter) and, for Wang-Landau, the step counter the check period refers to
- * (WangLandau._steps_counter): with smolmc_set_state(reset_aux = 0) + these two calls a run resumes
- * bit-for-bit in another process.  NULL = leave as it is. */
+ * (WangLandau._steps_counter).  Resume in a fresh handle / process, bit for bit:
+ * smolmc_set_state(occ, seeds, T, reset_aux = 1) -- the seeds are only taken with reset_aux != 0 --
+ * then smolmc_set_counters and, for Wang-Landau, smolmc_set_wl.  NULL = leave as it is. */
 int smolmc_set_counters(smolmc_handle *h, const uint64_t *n_steps /*R*/, const uint64_t *n_accepted /*R*/);
 
 /* ---- the hot path -------------------------------------------------------- */
@@ -255,12 +263,26 @@ int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
  * < 256 by construction, smolmc_tables.n_codes). */
 int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double *features,
                           uint8_t *accepted, uint8_t *occupancy);
-/* Same loop driven by host-provided proposals ("replay mode"):
- * steps [R x nsteps x 4] = (site1, code1, site2, code2), -1 = no flip;
- * uniforms [R x nsteps] = the number rng.random() returned (NaN if not drawn).
- * accepted_out [R x nsteps] and enthalpy_out [R x nsteps] may be NULL. */
-int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,
-                  const double *uniforms, uint8_t *accepted_out, double *enthalpy_out);
+/* Same loop driven by host-provided proposals ("replay mode"): what
+ * StandardSingleStepMixin.single_step (kernel/base.py:145-166) does after mcusher.propose_step
+ * returned, with the numbers the reference's Generator produced.
+ *   steps       [R x nsteps x SMOLMC_STEP_ROW] step records (see SMOLMC_STEP_ROW); every site must be
+ *               a changeable site of an active sublattice and every code one of its species.
+ *   uniforms    [R x nsteps] the number rng.random() returned in _accept_step (NaN if not drawn:
+ *               the reference accepted without drawing, metropolis.py:46-48).
+ *   log_priori  [R x nsteps] or NULL: mcusher.compute_log_priori_factor(occupancy, step) added to the
+ *               exponent (metropolis.py:41-42, wanglandau.py:197-198).  NULL or a NaN entry: the
+ *               engine's own value -- 0 for Flip / Swap handles (mcusher.py:118-134); for TableFlip
+ *               handles TableFlip.compute_log_priori_factor (mcusher.py:656-711) evaluated on the
+ *               device from the step and the walker's species counts; a step that is neither a
+ *               canonical swap nor +-(a row of flip_table) fails like the reference's
+ *               ValueError("Step ... is not in flip table.", :673-674).
+ * Outputs (each may be NULL): accepted_out [R x nsteps]; enthalpy_out [R x nsteps] the walker's
+ * enthalpy AFTER the step; log_priori_out [R x nsteps] the a-priori factor that entered the
+ * exponent.  Bias terms (MCBias) and Wang-Landau state take part exactly as in smolmc_run. */
+int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps, const double *uniforms,
+                  const double *log_priori, uint8_t *accepted_out, double *enthalpy_out,
+                  double *log_priori_out);
 /* elapsed device time of the last smolmc_run / smolmc_replay launch in ms
  * (HIP events recorded on the launch stream) */
 int smolmc_last_kernel_ms(smolmc_handle *h, float *ms);
@@ -273,11 +295,11 @@ int smolmc_last_kernel_ms(smolmc_handle *h, float *ms);
 int smolmc_eval_full(smolmc_handle *h, const int32_t *occ /*nocc x N*/, int nocc,
                      double *features);
 /* Ensemble.compute_feature_vector_change (ensemble.py:353-376) for nstep steps of
- * up to 2 sequential flips each on ONE occupancy:
+ * up to SMOLMC_MAX_STEP_FLIPS sequential flips each on ONE occupancy:
  * delta_correlations_from_occupancies / delta_interactions_from_occupancies
  * (evaluator.pyx:211-317) x size with sequential-flip semantics
  * (expansion.py:217-229), delta_ewald_single_flip (ewald.pyx:9-59), mu table.
- * flips [nstep x 4] like smolmc_replay; dfeatures [nstep x F]. */
+ * flips [nstep x SMOLMC_STEP_ROW] step records like smolmc_replay; dfeatures [nstep x F]. */
 int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ /*N*/, const int32_t *flips,
                       int nstep, double *dfeatures);
 

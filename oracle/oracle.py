@@ -13,6 +13,7 @@ import subprocess
 import numpy as np
 
 from smol_amd.capi import smolmc_config, smolmc_tables
+from smol_amd.capi import step_rows as capi_step_rows
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -76,7 +77,9 @@ def lib():
         L.orc_compute_bias_change.restype = C.c_double
         L.orc_compute_bias_change.argtypes = [tp, i32p, i32p, C.c_int]
         L.orc_mc_run.argtypes = [C.c_void_p, C.c_int64]
-        L.orc_mc_replay.argtypes = [C.c_void_p, C.c_int64, i32p, f64p, u8p, f64p]
+        L.orc_mc_replay.argtypes = [C.c_void_p, C.c_int64, i32p, f64p, f64p, u8p, f64p, f64p]
+        L.orc_table_step_log_priori.restype = C.c_double
+        L.orc_table_step_log_priori.argtypes = [tp, i32p, i32p, C.c_int, C.POINTER(C.c_int)]
         L.orc_mc_propose.argtypes = [C.c_void_p, C.c_int, C.c_uint64, i32p, f64p]
         _LIB = L
     return _LIB
@@ -158,6 +161,16 @@ class OracleEvaluator:
         lib().orc_natural_parameters(self.t, _p(out, C.c_double))
         return out
 
+    def table_log_priori(self, occ, flips):
+        """TableFlip.compute_log_priori_factor (mcusher.py:656-711) of a step (sequence of (site, code))."""
+        fl = np.ascontiguousarray(np.asarray(flips, dtype=np.int32).reshape(-1, 2))
+        status = C.c_int(0)
+        v = lib().orc_table_step_log_priori(self.t, _p(self._occ(occ), C.c_int32), _p(fl, C.c_int32), len(fl),
+                                            C.byref(status))
+        if status.value:
+            raise ValueError("Step is not in flip table.")
+        return v
+
 
 class OracleMC:
     """Batched CPU walkers: the oracle twin of smol_amd's engine handle."""
@@ -195,17 +208,23 @@ class OracleMC:
     def run(self, nsteps):
         lib().orc_mc_run(self.h, int(nsteps))
 
-    def replay(self, steps, uniforms):
-        steps = np.ascontiguousarray(steps, dtype=np.int32)
-        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+    def replay(self, steps, uniforms, log_priori=None, with_priori=False):
+        """steps (R, n, 2k) int32 with k <= 8 flips per record (padded to SMOLMC_STEP_ROW with -1),
+        uniforms (R, n); log_priori (R, n) or None (see smolmc_replay)."""
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.R, -1)
         n = uniforms.shape[-1]
+        steps = capi_step_rows(steps, self.R, n)
+        lp = None if log_priori is None else np.ascontiguousarray(log_priori, dtype=np.float64).reshape(self.R, n)
         acc = np.zeros((self.R, n), dtype=np.uint8)
         H = np.zeros((self.R, n))
-        lib().orc_mc_replay(
-            self.h, n, _p(steps, C.c_int32), _p(uniforms, C.c_double), _p(acc, C.c_uint8),
-            _p(H, C.c_double),
+        lpo = np.zeros((self.R, n))
+        rc = lib().orc_mc_replay(
+            self.h, n, _p(steps, C.c_int32), _p(uniforms, C.c_double), _p(lp, C.c_double),
+            _p(acc, C.c_uint8), _p(H, C.c_double), _p(lpo, C.c_double),
         )
-        return acc.astype(bool), H
+        if rc:
+            raise ValueError("Step is not in flip table.")  # mcusher.py:673-674
+        return (acc.astype(bool), H, lpo) if with_priori else (acc.astype(bool), H)
 
     def get_state(self):
         occ = np.zeros((self.R, self.N), dtype=np.int32)

@@ -403,6 +403,9 @@ static const double ORC_KB = 8.617333262145e-5; /* smol/constants.py:4 */
 int orc_mc_create(const smolmc_tables *t, const smolmc_config *cfg, orc_mc **out) {
     if (t->bias_type && cfg->kernel_type == SMOLMC_KERNEL_WANGLANDAU)
         return 2; /* "Cannot apply bias to Wang-Landau simulation!" (wanglandau.py:127-128) */
+    if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP &&
+        (t->n_flip_vectors > SMOLMC_MAX_FLIP_VECTORS || t->sub_code_ptr[t->n_sublattices] > SMOLMC_MAX_FLIP_DIMS))
+        return 4;
     orc_mc *h = (orc_mc *)calloc(1, sizeof(orc_mc));
     if (!h) return 1;
     h->t = t;
@@ -675,8 +678,8 @@ static double table_masked_weights(const smolmc_tables *t, const int *n, double 
 static double table_log_priori(const smolmc_tables *t, const int *n, int idx, double sum_now,
                                const double *mw_now) {
     int d = (int)t->sub_code_ptr[t->n_sublattices];
-    int n_next[64];
-    double mw_next[128];
+    int n_next[SMOLMC_MAX_FLIP_DIMS];
+    double mw_next[2 * SMOLMC_MAX_FLIP_VECTORS];
     const int32_t *row = t->flip_table + (size_t)(idx / 2) * d;
     int sgn = (idx & 1) ? -1 : 1;
     for (int i = 0; i < d; ++i) n_next[i] = n[i] + sgn * row[i];
@@ -704,8 +707,8 @@ static int propose_table_flip(const orc_mc *h, const int32_t *occ, const rng_ctx
     uint32_t w1[4];
     rng_block(g, 1, w1);
     *log_priori = 0.0;
-    int n[64];
-    double mw[128];
+    int n[SMOLMC_MAX_FLIP_DIMS];
+    double mw[2 * SMOLMC_MAX_FLIP_VECTORS];
     double sumw = 0;
     int do_swap = (double)w0[0] * (1.0 / 4294967296.0) < t->swap_weight; /* mcusher.py:577-578 */
     if (!do_swap) {
@@ -899,26 +902,90 @@ int orc_mc_run(orc_mc *h, int64_t nsteps) {
     return 0;
 }
 
-/* replay mode: proposals + uniforms from the host (reference Generator order) */
+/* TableFlip.compute_log_priori_factor (mcusher.py:656-711) of an arbitrary step: _get_flip_id
+ * (:641-654) over delta_counts_from_step (occu_utils.py:131-168, a site may appear several times:
+ * the running occupancy is followed), then the factor at the counts of `occ`.  *status: 0 ok,
+ * 1 = step is not in the flip table (the reference raises ValueError, :673-674), 2 = a flip on an
+ * inactive site / impossible code (occu_utils.py:160-163). */
+double orc_table_step_log_priori(const smolmc_tables *t, const int32_t *occ, const int32_t *flips,
+                                 int nflips, int *status) {
+    int d = (int)t->sub_code_ptr[t->n_sublattices];
+    int dn[SMOLMC_MAX_FLIP_DIMS], n[SMOLMC_MAX_FLIP_DIMS];
+    double mw[2 * SMOLMC_MAX_FLIP_VECTORS];
+    *status = 0;
+    for (int i = 0; i < d; ++i) dn[i] = 0;
+    for (int f = 0; f < nflips; ++f) {
+        int site = flips[2 * f], code = flips[2 * f + 1];
+        int cur = occ[site];
+        for (int g = 0; g < f; ++g)
+            if (flips[2 * g] == site) cur = flips[2 * g + 1]; /* occu_now[site] = code */
+        int dim_ori = -1, dim_nex = -1;
+        for (int sl = 0; sl < t->n_sublattices; ++sl) {
+            int in_sl = 0;
+            for (int64_t a = t->sub_site_ptr[sl]; a < t->sub_site_ptr[sl + 1] && !in_sl; ++a)
+                in_sl = t->sub_active_sites[a] == site;
+            if (!in_sl) continue;
+            for (int64_t c = t->sub_code_ptr[sl]; c < t->sub_code_ptr[sl + 1]; ++c) {
+                if (t->sub_codes[c] == cur) dim_ori = (int)c;
+                if (t->sub_codes[c] == code) dim_nex = (int)c;
+            }
+        }
+        if (dim_ori < 0 || dim_nex < 0) { *status = 2; return 0.0; }
+        dn[dim_ori] -= 1;
+        dn[dim_nex] += 1;
+    }
+    int zero = 1;
+    for (int i = 0; i < d; ++i) zero &= dn[i] == 0;
+    if (zero) return 0.0; /* canonical swap: fid = -1 (:668-671) */
+    int idx = -1;
+    for (int v = 0; v < t->n_flip_vectors && idx < 0; ++v) {
+        const int32_t *row = t->flip_table + (size_t)v * d;
+        int eqp = 1, eqm = 1;
+        for (int i = 0; i < d; ++i) { eqp &= row[i] == dn[i]; eqm &= -row[i] == dn[i]; }
+        if (eqp) idx = 2 * v;
+        else if (eqm) idx = 2 * v + 1;
+    }
+    if (idx < 0) { *status = 1; return 0.0; }
+    table_counts(t, occ, n);
+    double sum = table_masked_weights(t, n, mw);
+    return table_log_priori(t, n, idx, sum, mw);
+}
+
+/* replay mode: proposals + uniforms from the host (reference Generator order); records of
+ * SMOLMC_STEP_ROW ints, log_priori as smolmc_replay documents it.  Returns 0, or 3 when a step of a
+ * TableFlip handle is not in the flip table / touches an inactive site. */
 int orc_mc_replay(orc_mc *h, int64_t nsteps, const int32_t *steps, const double *uniforms,
-                  uint8_t *accepted_out, double *enthalpy_out) {
-#pragma omp parallel for schedule(static)
+                  const double *log_priori, uint8_t *accepted_out, double *enthalpy_out,
+                  double *log_priori_out) {
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
     for (int r = 0; r < h->R; ++r) {
         double *dfeat = (double *)malloc(sizeof(double) * h->F);
-        for (int64_t k = 0; k < nsteps; ++k) {
-            const int32_t *st = steps + ((size_t)r * nsteps + k) * 4;
-            int nf = st[0] < 0 ? 0 : (st[2] < 0 ? 1 : 2);
+        for (int64_t k = 0; k < nsteps && !bad; ++k) {
+            const int32_t *st = steps + ((size_t)r * nsteps + k) * SMOLMC_STEP_ROW;
+            int nf = 0;
+            while (nf < SMOLMC_MAX_STEP_FLIPS && st[2 * nf] >= 0) nf++;
             double u = uniforms[(size_t)r * nsteps + k];
             if (isnan(u)) u = 0.0; /* not drawn by the reference => it accepted without a draw */
-            int a = do_step(h, r, st, nf, u, 0.0, dfeat);
+            double lp = log_priori ? log_priori[(size_t)r * nsteps + k] : NAN;
+            if (isnan(lp)) {
+                lp = 0.0;
+                if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) {
+                    int status = 0;
+                    lp = orc_table_step_log_priori(h->t, h->occ + (size_t)r * h->N, st, nf, &status);
+                    if (status) { bad |= 1; break; }
+                }
+            }
+            int a = do_step(h, r, st, nf, u, lp, dfeat);
             if (accepted_out) accepted_out[(size_t)r * nsteps + k] = (uint8_t)a;
             if (enthalpy_out)
                 enthalpy_out[(size_t)r * nsteps + k] =
                     h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU ? h->wl_cur_h[r] : h->enthalpy[r];
+            if (log_priori_out) log_priori_out[(size_t)r * nsteps + k] = lp;
         }
         free(dfeat);
     }
-    return 0;
+    return bad ? 3 : 0;
 }
 
 /* proposal only (for usher statistics tests, tests/test_moca/test_mcushers.py:124-196) */

@@ -23,6 +23,9 @@ STEP_FLIP = 0
 STEP_SWAP = 1
 STEP_TABLE_FLIP = 2
 BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE, BIAS_SQUARE_HYPERPLANE = 0, 1, 2, 3
+ABI_VERSION = 6
+MAX_STEP_FLIPS = 8              # SMOLMC_MAX_STEP_FLIPS
+STEP_ROW = 2 * MAX_STEP_FLIPS   # SMOLMC_STEP_ROW: int32 per step record (site, code) x 8, -1 = no flip
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -485,6 +488,33 @@ class TableSet:
                         q[inds[s, code]] = prim.charges[sc.site_b[s]][code]  # vacancies have no index
             return q
         return ewald_charges
+
+
+def step_rows(steps, *lead):
+    """Step records for smolmc_replay / smolmc_eval_delta: an int32 array (..., 2 k) of k <= 8
+    (site, code) pairs per step -- or a list of steps, each a list of (site, code) tuples as the
+    reference's ushers return them (mcusher.py:104-116) -- padded with -1 to SMOLMC_STEP_ROW."""
+    if isinstance(steps, (list, tuple)) and (len(steps) == 0 or isinstance(steps[0], (list, tuple))) and not (
+            len(steps) and len(steps[0]) and np.isscalar(steps[0][0])):
+        out = np.full((len(steps), STEP_ROW), -1, dtype=np.int32)
+        for i, st in enumerate(steps):
+            if len(st) > MAX_STEP_FLIPS:
+                raise ValueError(f"a step of {len(st)} flips exceeds SMOLMC_MAX_STEP_FLIPS = {MAX_STEP_FLIPS}")
+            for j, (site, code) in enumerate(st):
+                out[i, 2 * j], out[i, 2 * j + 1] = site, code
+        return out.reshape(*lead, STEP_ROW) if lead else out
+    a = np.asarray(steps)
+    if not np.issubdtype(a.dtype, np.integer):
+        raise ValueError("Buffer dtype mismatch for steps: expected int32")
+    w = a.shape[-1] if a.ndim else 0
+    if lead:
+        a = a.reshape(*lead, -1)
+        w = a.shape[-1]
+    if w == 0 or w % 2 or w > STEP_ROW:
+        raise ValueError(f"step records must hold 1..{MAX_STEP_FLIPS} (site, code) pairs")
+    out = np.full(a.shape[:-1] + (STEP_ROW,), -1, dtype=np.int32)
+    out[..., :w] = a
+    return np.ascontiguousarray(out)
 
 
 def make_config(

@@ -403,7 +403,7 @@ def model_arrays(model, coefs):
 
 
 def golden_case(core, name, prim, cutoffs, scmatrix, basis="sinusoid", with_ewald=False,
-                nocc=3, nflips=120, seed=0):
+                nocc=3, nflips=120, seed=0, write=True):
     from smol_amd import ewald as ewmod
     from smol_amd import synth
 
@@ -458,7 +458,8 @@ def golden_case(core, name, prim, cutoffs, scmatrix, basis="sinusoid", with_ewal
         out.update(full_ewald=np.array(few), delta_ewald=np.array(des),
                    delta_ewald_legacy=np.array(del_),
                    ewald_diag=np.diag(ew[1]).copy(), ewald_row0=ew[1][0].copy())
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    if write:  # (make_golden_v6.py rebuilds the same models without rewriting the fixtures)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "sites", sc.num_sites, "F", model.num_corr_functions, "flips", len(flips))
     return model, sc, coefs, proc, active
 

@@ -1,0 +1,603 @@
+#!/usr/bin/env python3
+"""Golden trajectories for ABI v6: TableFlip, the three MCBias terms, Wang-Landau with
+update_period > 1 -- every delta from the REFERENCE's compiled core, the control flow in the
+reference's own Generator (PCG64) call order.
+
+Run in the build container only (needs /root/reference, Cython, gcc, scipy):
+
+    python tests/golden/make_golden_v6.py
+
+What is the reference's own code here and what is restated
+----------------------------------------------------------
+* executed from /root/reference as it is: the compiled core (see make_golden.py) and
+  smol/moca/occu_utils.py (pure numpy; loaded by path -- `import smol.moca` needs pymatgen / monty,
+  absent from this image): get_dim_ids_table, occu_to_species_list, occu_to_counts,
+  delta_counts_from_step.
+* restated, with the reference's call order on the shared numpy Generator:
+    TableFlip.propose_step / _get_flip_id / compute_log_priori_factor   mcusher.py:553-711
+    flip_weights_mask / choose_section_from_partition                   utils/math.py:832-893
+    FugacityBias / SquareChargeBias / SquareHyperplaneBias              kernel/bias.py:96-366
+    Metropolis / WangLandau single_step                                 kernel/base.py:145-166,
+                                                                        metropolis.py:31-49,
+                                                                        wanglandau.py:186-266
+  One deviation, stated: TableFlip builds its canonical-swap helper as `Swap(self.sublattices)`
+  (mcusher.py:540) WITHOUT passing the kernel's Generator, so the reference draws swap proposals
+  from an unseeded Generator of its own; here that second Generator is seeded (seed + 7919) so that
+  the fixture is reproducible.  The kernel's Generator sees exactly the reference's calls.
+
+Output: tests/golden/trajectories_v6.npz (data only).
+"""
+
+import importlib.util
+import os
+import sys
+from math import log
+
+import numpy as np
+from scipy.special import gammaln
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+
+REF = mg.REF
+kB = mg.kB
+NUM_TOL = 1e-6  # smol/utils/math.py:24
+
+
+def load_ref_occu_utils():
+    spec = importlib.util.spec_from_file_location(
+        "ref_occu_utils", os.path.join(REF, "smol", "moca", "occu_utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+OU = load_ref_occu_utils()
+
+
+class Sublattice:
+    """The attributes of smol.moca.sublattice.Sublattice the ushers / biases read."""
+
+    def __init__(self, sites, species, charges, active=True):
+        self.sites = np.asarray(sites)
+        self.active_sites = self.sites.copy() if active else np.array([], dtype=int)
+        self.species = list(species)
+        self.charges = list(charges)
+        self.encoding = np.arange(len(species), dtype=int)
+        self.is_active = bool(active) and len(species) > 1
+
+
+def sublattices_of(sc):
+    prim = sc.model.prim
+    out = []
+    for b in range(prim.nb):
+        S = prim.nspecies[b]
+        q = [0.0] * S if prim.charges is None else [0.0 if c is None else float(c) for c in prim.charges[b]]
+        names = [f"X{i}" for i in range(S)] if prim.species is None else prim.species[b]
+        out.append(Sublattice(np.flatnonzero(sc.site_b == b), names, q, active=S > 1))
+    return out
+
+
+# ---- smol/utils/math.py:832-893 (monty import keeps the module itself from loading) -------
+def flip_weights_mask(flip_vectors, n, max_n=None):
+    flip_vectors = np.array(flip_vectors, dtype=int)
+    directions = np.concatenate([(u, -u) for u in flip_vectors], axis=0)
+    if max_n is None:
+        max_n = np.ones(len(n)) * np.inf
+    else:
+        max_n = np.array(max_n, dtype=int)
+    return ~(np.any(directions + n < 0, axis=-1) | np.any(directions + n > max_n, axis=-1))
+
+
+def choose_section_from_partition(probabilities, rng):
+    p = np.array(probabilities)
+    if np.allclose(p, 0):
+        p = np.ones(len(p))
+    if not np.all(p >= -NUM_TOL):
+        raise ValueError("Probabilities contain negative number.")
+    p = p / p.sum()
+    return int(round(rng.choice(len(p), p=p)))
+
+
+# ---- ushers -------------------------------------------------------------------------------
+class Usher:  # MCUsher (mcusher.py:36-148)
+    def __init__(self, sublattices, rng):
+        self.sublattices = sublattices
+        self.active_sublattices = [s for s in sublattices if s.is_active]
+        n = len(self.active_sublattices)
+        self._sublatt_probs = np.array(n * [1 / n])
+        self._rng = rng
+
+    def get_random_sublattice(self):
+        return self._rng.choice(self.active_sublattices, p=self._sublatt_probs)
+
+    def compute_log_priori_factor(self, occupancy, step):
+        return 0.0
+
+
+class Flip(Usher):  # mcusher.py:151-170
+    def propose_step(self, occupancy):
+        sublattice = self.get_random_sublattice()
+        site = self._rng.choice(sublattice.active_sites)
+        choices = set(sublattice.encoding) - {occupancy[site]}
+        return [(int(site), int(self._rng.choice(list(choices))))]
+
+
+class Swap(Usher):  # mcusher.py:173-200
+    def propose_step(self, occupancy):
+        sublattice = self.get_random_sublattice()
+        site1 = self._rng.choice(sublattice.active_sites)
+        species1 = occupancy[site1]
+        sublattice_occu = occupancy[sublattice.active_sites]
+        swap_options = sublattice.active_sites[sublattice_occu != species1]
+        if swap_options.size > 0:
+            site2 = self._rng.choice(swap_options)
+            return [(int(site1), int(occupancy[site2])), (int(site2), int(species1))]
+        return []
+
+
+class TableFlip(Usher):  # mcusher.py:397-711
+    def __init__(self, sublattices, rng, flip_table, A, b, swap_weight=0.1, flip_weights=None,
+                 swap_rng=None):
+        super().__init__(sublattices, rng)
+        self.bits = [sl.species for sl in sublattices]
+        self.dim_ids = OU.get_dim_ids_by_sublattice(self.bits)
+        self.max_n = [len(sl.active_sites) for sl in sublattices for _ in sl.species]
+        self.d = len(self.max_n)
+        self.flip_table = np.array(flip_table, dtype=int)
+        self.swap_weight = swap_weight
+        self.flip_weights = (np.ones(len(self.flip_table) * 2) if flip_weights is None
+                             else np.array(flip_weights, dtype=float))
+        # CompositionSpace._A / _b * supercell_size (space.py; charge balance + site numbers),
+        # given explicitly: only its use in propose_step:588-596 matters here
+        self._A, self._b = np.array(A), np.array(b)
+        self._swapper = Swap(sublattices, swap_rng)  # mcusher.py:540 (own Generator, see module doc)
+        self._dim_ids_table = OU.get_dim_ids_table(sublattices, active_only=True)
+        self._dim_ids_full = OU.get_dim_ids_table(sublattices, active_only=False)
+
+    def propose_step(self, occupancy):
+        rng = self._rng
+        if rng.random() < self.swap_weight:
+            return self._swapper.propose_step(occupancy)
+        species_list = OU.occu_to_species_list(occupancy, self.d, self._dim_ids_table)
+        species_n = [len(sites) for sites in species_list]
+        species_list_full = OU.occu_to_species_list(occupancy, self.d, self._dim_ids_full)
+        species_n_full = [len(sites) for sites in species_list_full]
+        if not np.allclose(self._A @ np.array(species_n_full), self._b):
+            mask = np.zeros(2 * len(self.flip_table), dtype=int)
+        else:
+            mask = flip_weights_mask(self.flip_table, species_n, self.max_n).astype(int)
+        masked_weights = self.flip_weights * mask
+        if np.any(masked_weights <= -NUM_TOL):
+            raise ValueError("negative weights")
+        if np.allclose(masked_weights, 0):
+            return self._swapper.propose_step(occupancy)
+        idx = choose_section_from_partition(masked_weights, rng=rng)
+        u = self.flip_table[idx // 2]
+        if idx % 2 == 1:
+            u = -1 * u
+        step = []
+        for sl_id, (sublatt, dim_ids) in enumerate(zip(self.sublattices, self.dim_ids)):
+            if not sublatt.is_active:
+                continue
+            site_ids = []
+            dim_ids = np.array(dim_ids, dtype=int)
+            u_sl = u[dim_ids]
+            dims_from = dim_ids[u_sl < 0]
+            dims_to = dim_ids[u_sl > 0]
+            codes_to = sublatt.encoding[u_sl > 0]
+            for d in dims_from:
+                site_ids.extend(rng.choice(species_list[d], size=-1 * u[d], replace=False).tolist())
+            for d, code in zip(dims_to, codes_to):
+                for site_id in rng.choice(site_ids, size=u[d], replace=False):
+                    step.append((int(site_id), int(code)))
+                    site_ids.remove(site_id)
+            assert len(site_ids) == 0
+        return step
+
+    def _get_flip_id(self, occupancy, step):
+        dn = OU.delta_counts_from_step(occupancy, step, self.d, self._dim_ids_table)
+        if np.allclose(dn, 0):
+            return -1, 0
+        for fid, v in enumerate(self.flip_table):
+            if np.allclose(v, dn):
+                return fid, 0
+            if np.allclose(-v, dn):
+                return fid, 1
+        return None, None
+
+    def compute_log_priori_factor(self, occupancy, step):
+        fid, direction = self._get_flip_id(occupancy, step)
+        if fid is None:
+            raise ValueError(f"Step {step} is not in flip table.")
+        if fid < 0:
+            return 0
+        u = (-2 * direction + 1) * self.flip_table[fid]
+        n_now = OU.occu_to_counts(occupancy, self.d, self._dim_ids_table)
+        mask_now = flip_weights_mask(self.flip_table, n_now, self.max_n).astype(int)
+        weights_now = self.flip_weights * mask_now
+        p_now = (1 - self.swap_weight) * weights_now[fid * 2 + direction] / weights_now.sum()
+        n_next = n_now + u
+        mask_next = flip_weights_mask(self.flip_table, n_next, self.max_n).astype(int)
+        weights_next = self.flip_weights * mask_next
+        p_next = ((1 - self.swap_weight) * weights_next[fid * 2 + (1 - direction)]
+                  / weights_next.sum())
+        log_factor = np.log(p_next / p_now)
+        dim_ids = np.arange(len(u), dtype=int)
+        dims_nonzero = dim_ids[~np.isclose(u, 0)]
+
+        def facln(n):
+            return gammaln(n + 1)
+
+        for dim in dims_nonzero:
+            log_factor += facln(n_now[dim]) - facln(n_next[dim])
+        return log_factor
+
+
+# ---- biases (kernel/bias.py) ----------------------------------------------------------------
+class MCBias:  # bias.py:24-93
+    def __init__(self, sublattices):
+        self.sublattices = sublattices
+        self.active_sublattices = [s for s in sublattices if s.is_active]
+
+    def compute_bias_change(self, occupancy, step):  # :75-93
+        occu_next = occupancy.copy()
+        for site, code in step:
+            occu_next[site] = code
+        return self.compute_bias(occu_next) - self.compute_bias(occupancy)
+
+
+class FugacityBias(MCBias):  # bias.py:96-237
+    def __init__(self, sublattices, fugacity_fractions):
+        super().__init__(sublattices)
+        num_cols = max(max(sl.encoding) for sl in sublattices) + 1
+        num_rows = sum(len(sl.sites) for sl in sublattices)
+        table = np.ones((num_rows, num_cols))
+        for fus, sublatt in zip(fugacity_fractions, self.active_sublattices):
+            ordered_fus = np.array(fus)  # in site-space order
+            table[sublatt.sites[:, None], sublatt.encoding] = ordered_fus[None, :]
+        self._fu_table = table
+
+    def compute_bias(self, occupancy):  # :174-186
+        return sum(log(self._fu_table[site, species]) for site, species in enumerate(occupancy))
+
+    def compute_bias_change(self, occupancy, step):  # :188-206
+        steps = {site: code for site, code in step}
+        return sum(log(self._fu_table[site, code] / self._fu_table[site, occupancy[site]])
+                   for site, code in steps.items())
+
+
+class SquareChargeBias(MCBias):  # bias.py:240-277
+    def __init__(self, sublattices, penalty=0.5):
+        super().__init__(sublattices)
+        self.penalty = penalty
+        num_cols = max(max(sl.encoding) for sl in sublattices) + 1
+        num_rows = sum(len(sl.sites) for sl in sublattices)
+        table = np.zeros((num_rows, num_cols))
+        for sublatt in sublattices:
+            cs = np.array(sublatt.charges)
+            table[sublatt.sites[:, None], sublatt.encoding] = cs[None, :]
+        self._c_table = table
+
+    def compute_bias(self, occupancy):  # :264-277
+        c = np.sum(self._c_table[np.arange(len(occupancy), dtype=int), occupancy])
+        return -self.penalty * c**2
+
+
+class SquareHyperplaneBias(MCBias):  # bias.py:280-366
+    def __init__(self, sublattices, hyperplane_normals, hyperplane_intercepts, penalty=0.5):
+        super().__init__(sublattices)
+        self.penalty = penalty
+        self._A = np.array(hyperplane_normals, dtype=int)
+        self._b = np.array(hyperplane_intercepts, dtype=int)
+        self._dim_ids_table = OU.get_dim_ids_table(sublattices)
+        self.d = sum(len(sl.species) for sl in sublattices)
+
+    def compute_bias(self, occupancy):  # :352-366
+        n = OU.occu_to_counts(occupancy, self.d, self._dim_ids_table)
+        return -self.penalty * np.sum((self._A @ n - self._b) ** 2)
+
+
+# ---- kernels ----------------------------------------------------------------------------------
+def _record(steps, k, st):
+    for j, (s, c) in enumerate(st):
+        steps[k, 2 * j], steps[k, 2 * j + 1] = s, c
+
+
+def run_metropolis(proc, mode, usher, rng, temperature, occ0, nsteps, bias=None):
+    """kernel/base.py:145-166,192-239,291-343 + metropolis.py:31-49 + sampler.py:195-207."""
+    nat = proc.natural_params(mode)
+    beta = 1.0 / (kB * temperature)
+
+    def single_step(occ):
+        st = usher.propose_step(occ)
+        dfe = proc.feature_change(occ, st, mode)
+        dh = np.array(np.dot(nat, dfe), dtype=np.float64)
+        db = np.array(bias.compute_bias_change(occ, st), dtype=np.float64) if bias is not None else None
+        lf = usher.compute_log_priori_factor(occ, st)
+        exponent = -beta * dh + lf
+        if bias is not None:
+            exponent += db
+        u = np.nan
+        if exponent >= 0:
+            a = True
+        else:
+            u = rng.random()
+            a = bool(exponent > log(u))
+        return st, dfe, float(dh), (0.0 if db is None else float(db)), float(lf), u, a
+
+    single_step(np.zeros(len(occ0), dtype=np.int32))  # constructor priming step (base.py:237-239)
+    occ = np.array(occ0, dtype=np.int32)
+    feats = proc.features(occ, mode)
+    enth = float(np.dot(nat, feats))
+    b = float(bias.compute_bias(occ)) if bias is not None else 0.0
+    steps = -np.ones((nsteps, 16), dtype=np.int32)
+    us = np.full(nsteps, np.nan)
+    acc = np.zeros(nsteps, dtype=bool)
+    H, dH, LP, B = np.zeros(nsteps), np.zeros(nsteps), np.zeros(nsteps), np.zeros(nsteps)
+    for k in range(nsteps):
+        st, dfe, dh, db, lf, u, a = single_step(occ)
+        _record(steps, k, st)
+        us[k], LP[k], dH[k] = u, lf, dh
+        if a:
+            for s, c in st:
+                occ[s] = c
+            feats = feats + dfe
+            enth = enth + dh
+            b = b + db
+        acc[k], H[k], B[k] = a, enth, b
+    out = dict(steps=steps, u=us, accepted=acc, dH=dH, H=H, log_priori=LP, occ_final=occ,
+               feat_final=feats)
+    if bias is not None:
+        out["bias"] = B
+    return out
+
+
+def run_wanglandau(proc, mode, usher, rng, window, occ0, nsteps, flatness=0.8, mod_factor=1.0,
+                   check_period=1000, update_period=1):
+    """wanglandau.py:107-300 with any usher (a-priori factor in the exponent, :196-198)."""
+    nat = proc.natural_params(mode)
+    emin, emax, bsz = window
+    levels = np.arange(emin, emax, bsz)
+    L, F = len(levels), len(nat)
+    entropy, hist = np.zeros(L), np.zeros(L, dtype=np.int64)
+    occur, meanf = np.zeros(L, dtype=np.int64), np.zeros((L, F))
+    m = mod_factor
+    # constructor priming step: current enthalpy is inf, the window test rejects (inf >= max):
+    # only the proposal's numbers are drawn
+    usher.propose_step(np.zeros(len(occ0), dtype=np.int32))
+    counter = 0
+    occ = np.array(occ0, dtype=np.int32)
+    cur_f = proc.features(occ, mode)
+    cur_h = float(np.dot(cur_f, nat))
+
+    def bin_id(e):
+        return int((e - emin) // bsz)
+
+    steps = -np.ones((nsteps, 16), dtype=np.int32)
+    us = np.full(nsteps, np.nan)
+    acc = np.zeros(nsteps, dtype=bool)
+    H, LP = np.zeros(nsteps), np.zeros(nsteps)
+    for k in range(nsteps):
+        st = usher.propose_step(occ)
+        _record(steps, k, st)
+        dfe = proc.feature_change(occ, st, mode)
+        dh = float(np.dot(nat, dfe))
+        b = bin_id(cur_h)
+        new_h = cur_h + dh
+        if new_h < emin or new_h >= emax:
+            a = False
+            LP[k] = np.nan  # never computed by the reference (:191-192)
+        else:
+            nb = bin_id(new_h)
+            lf = usher.compute_log_priori_factor(occ, st)
+            LP[k] = lf
+            exponent = entropy[b] - entropy[nb] + lf
+            if exponent >= 0:
+                a = True
+            else:
+                u = rng.random()
+                us[k] = u
+                a = bool(exponent > log(u))
+        if a:
+            for s, c in st:
+                occ[s] = c
+            cur_f = cur_f + dfe
+            cur_h = cur_h + dh
+        b = bin_id(cur_h)
+        if 0 <= b < L:
+            counter += 1
+            total = occur[b]
+            meanf[b, :] = 1 / (total + 1) * (cur_f + total * meanf[b, :])
+            if counter % update_period == 0:
+                entropy[b] += m
+                hist[b] += 1
+                occur[b] += 1
+        if counter % check_period == 0:
+            h = hist[entropy > 0]
+            if len(h) >= 2 and (h > flatness * h.mean()).all():
+                hist[:] = 0
+                m = m / 2.0
+        acc[k], H[k] = a, cur_h
+    return dict(steps=steps, u=us, accepted=acc, H=H, log_priori=LP, occ_final=occ,
+                entropy=entropy, histogram=hist, occurrences=occur, mean_features=meanf,
+                mod_factor=np.array([m]), feat_final=cur_f, levels=levels)
+
+
+# ---- models -----------------------------------------------------------------------------------
+def neutral_occ_C(sc, n_ti, rng):
+    """Li+/Mn3+/Ti4+ on P cation sites against P O2-: 2 n_Mn + 3 n_Ti = P."""
+    P = sc.size
+    n_mn = (P - 3 * n_ti) // 2
+    assert 2 * n_mn + 3 * n_ti == P
+    occ = np.zeros(sc.num_sites, dtype=np.int32)
+    perm = rng.permutation(P)
+    occ[perm[:n_mn]] = 1
+    occ[perm[n_mn:n_mn + n_ti]] = 2
+    return occ
+
+
+def neutral_occ_G(sc, n_ti, n_f, rng):
+    """cations Li+/Mn3+/Ti4+ (P sites), anions O2-/F- (P sites): n_Li + 3 n_Mn + 4 n_Ti = 2 P - n_F."""
+    P = sc.size
+    n_mn = (P - n_f - 3 * n_ti) // 2
+    assert 2 * n_mn + 3 * n_ti == P - n_f and n_mn >= 0
+    occ = np.zeros(sc.num_sites, dtype=np.int32)
+    cat = np.flatnonzero(sc.site_b == 0)
+    an = np.flatnonzero(sc.site_b == 1)
+    perm = rng.permutation(P)
+    occ[cat[perm[:n_mn]]] = 1
+    occ[cat[perm[n_mn:n_mn + n_ti]]] = 2
+    occ[an[rng.permutation(P)[:n_f]]] = 1
+    return occ
+
+
+def main():
+    from smol_amd import synth
+
+    core = mg.build_reference_core()
+    mB = mg.golden_case(core, "fcc_prim666_triplets", synth.fcc_prim(), {2: 6.0, 3: 5.0},
+                        [6, 6, 6], seed=2, write=False)
+    mC = mg.golden_case(core, "rocksalt444_ewald", synth.rocksalt_prim(), {2: 6.0, 3: 5.0},
+                        [4, 4, 4], with_ewald=True, seed=3, write=False)
+    mG = mg.golden_case(core, "rocksalt333_two_sublattices",
+                        synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 4.5, 3: 3.2},
+                        [3, 3, 3], with_ewald=True, seed=7, write=False)
+    traj = {}
+
+    def put(tag, r):
+        traj.update({f"{tag}_{k}": v for k, v in r.items()})
+
+    # ---- case C: one active sublattice (64 cations), flip table 3 Mn3+ <-> Li+ + 2 Ti4+ ----------
+    model, sc, coefs, proc, active = mC
+    subsC = sublattices_of(sc)
+    P = sc.size
+    tableC = np.array([[1, -3, 2, 0]])            # reference format: dims of ALL sublattices
+    A_C = np.array([[1, 3, 4, -2], [1, 1, 1, 0], [0, 0, 0, 1]])
+    b_C = np.array([0, P, P])
+    traj["TC_flip_table"] = tableC[:, :3]         # engine format: active sublattices only
+    traj["TC_swap_weight"] = np.array([0.2])
+    occ0 = neutral_occ_C(sc, 10, np.random.default_rng(31))
+    mu = np.zeros((sc.num_sites, 3))
+    mu[active] = [0.15, -0.1, 0.3]
+    traj["TC_occ0"], traj["TC_mu"], traj["TC_T"] = occ0, mu, np.array([4000.0])
+    proc.mu_table = mu
+    for mode, seed in (("int", 501), ("corr", 502)):
+        rng = np.random.default_rng(seed)
+        ush = TableFlip(subsC, rng, tableC, A_C, b_C, swap_weight=0.2,
+                        swap_rng=np.random.default_rng(seed + 7919))
+        put(f"TC_tf_{mode}", run_metropolis(proc, mode, ush, rng, 4000.0, occ0, 2500))
+    # unequal weights: the p_next / p_now part of the a-priori factor
+    rng = np.random.default_rng(503)
+    fw = np.array([1.0, 2.5])
+    ush = TableFlip(subsC, rng, tableC, A_C, b_C, swap_weight=0.2, flip_weights=fw,
+                    swap_rng=np.random.default_rng(503 + 7919))
+    put("TC_tfw_int", run_metropolis(proc, "int", ush, rng, 4000.0, occ0, 1500))
+    traj["TC_tfw_flip_weights"] = fw
+    # near the composition limit (n_Ti = 0: one direction infeasible, mask changes along the chain)
+    occ_lim = neutral_occ_C(sc, 0, np.random.default_rng(32))
+    rng = np.random.default_rng(504)
+    ush = TableFlip(subsC, rng, tableC, A_C, b_C, swap_weight=0.2,
+                    swap_rng=np.random.default_rng(504 + 7919))
+    put("TC_tflim_int", run_metropolis(proc, "int", ush, rng, 6000.0, occ_lim, 1200))
+    traj["TC_tflim_occ0"], traj["TC_tflim_T"] = occ_lim, np.array([6000.0])
+    # TableFlip + FugacityBias (any usher composes with any bias, kernel/base.py:229-235)
+    fus = [[0.2, 0.3, 0.5]]
+    rng = np.random.default_rng(505)
+    ush = TableFlip(subsC, rng, tableC, A_C, b_C, swap_weight=0.2,
+                    swap_rng=np.random.default_rng(505 + 7919))
+    bias = FugacityBias(subsC, fus)
+    put("TC_tffug_int", run_metropolis(proc, "int", ush, rng, 4000.0, occ0, 1500, bias=bias))
+    traj["TC_fug_table"] = bias._fu_table
+    # TableFlip + Wang-Landau
+    rng = np.random.default_rng(506)
+    ush = TableFlip(subsC, rng, tableC, A_C, b_C, swap_weight=0.2,
+                    swap_rng=np.random.default_rng(506 + 7919))
+    hs = traj["TC_tf_int_H"]
+    window = (float(hs.min() - 3.0), float(hs.max() + 3.0), 0.5)
+    put("TC_tfwl_int", run_wanglandau(proc, "int", ush, rng, window, occ0, 2500, check_period=100))
+    traj["TC_tfwl_window"], traj["TC_tfwl_check"] = np.array(window), np.array([100])
+    # biases with Flip steps (semigrand, mu + Ewald)
+    rng = np.random.default_rng(507)
+    bias = FugacityBias(subsC, fus)
+    put("BC_fug_flip_int", run_metropolis(proc, "int", Flip(subsC, rng), rng, 2500.0, occ0, 2000, bias=bias))
+    rng = np.random.default_rng(508)
+    bias = SquareChargeBias(subsC, penalty=0.05)
+    put("BC_sqc_flip_corr", run_metropolis(proc, "corr", Flip(subsC, rng), rng, 2500.0, occ0, 2000, bias=bias))
+    traj["BC_sqc_table"], traj["BC_sqc_penalty"] = bias._c_table, np.array([0.05])
+    traj["BC_T"] = np.array([2500.0])
+    proc.mu_table = None
+
+    # ---- case G: two active sublattices (27 cations + 27 anions), two flip vectors ------------------
+    model, sc, coefs, proc, active = mG
+    subsG = sublattices_of(sc)
+    P = sc.size
+    tableG = np.array([[1, -3, 2, 0, 0], [1, -1, 0, -2, 2]])
+    A_G = np.array([[1, 3, 4, -2, -1], [1, 1, 1, 0, 0], [0, 0, 0, 1, 1]])
+    b_G = np.array([0, P, P])
+    traj["TG_flip_table"] = tableG
+    traj["TG_swap_weight"] = np.array([0.15])
+    occ0 = neutral_occ_G(sc, 4, 5, np.random.default_rng(41))
+    mu = np.zeros((sc.num_sites, 3))
+    mu[sc.site_b == 0] = [0.2, -0.1, 0.05]
+    mu[sc.site_b == 1, :2] = [-0.3, 0.15]
+    traj["TG_occ0"], traj["TG_mu"], traj["TG_T"] = occ0, mu, np.array([5000.0])
+    proc.mu_table = mu
+    for mode, seed in (("int", 601), ("corr", 602)):
+        rng = np.random.default_rng(seed)
+        ush = TableFlip(subsG, rng, tableG, A_G, b_G, swap_weight=0.15,
+                        swap_rng=np.random.default_rng(seed + 7919))
+        put(f"TG_tf_{mode}", run_metropolis(proc, mode, ush, rng, 5000.0, occ0, 2500))
+    # a third, six-flip vector (the sum of the two): steps of 3, 3 and 6 flips in one chain
+    tableG6 = np.array([[1, -3, 2, 0, 0], [1, -1, 0, -2, 2], [2, -4, 2, -2, 2]])
+    rng = np.random.default_rng(606)
+    ush = TableFlip(subsG, rng, tableG6, A_G, b_G, swap_weight=0.15,
+                    swap_rng=np.random.default_rng(606 + 7919))
+    put("TG6_tf_int", run_metropolis(proc, "int", ush, rng, 5000.0, occ0, 2500))
+    traj["TG6_flip_table"] = tableG6
+    # SquareHyperplaneBias with Flip steps: charge plane + a composition plane (n_Li - n_Ti = 9)
+    A_h = np.array([[1, 3, 4, -2, -1], [1, 0, -1, 0, 0]])
+    b_h = np.array([0, 9])
+    rng = np.random.default_rng(603)
+    bias = SquareHyperplaneBias(subsG, A_h, b_h, penalty=0.02)
+    put("BG_hyp_flip_int", run_metropolis(proc, "int", Flip(subsG, rng), rng, 5000.0, occ0, 2000, bias=bias))
+    traj["BG_hyp_A"], traj["BG_hyp_b"], traj["BG_hyp_penalty"] = A_h, b_h, np.array([0.02])
+    traj["BG_hyp_dim_ids"] = OU.get_dim_ids_table(subsG)
+    rng = np.random.default_rng(604)
+    bias = SquareChargeBias(subsG, penalty=0.04)
+    put("BG_sqc_swap_int", run_metropolis(proc, "int", Swap(subsG, rng), rng, 5000.0, occ0, 1500, bias=bias))
+    traj["BG_sqc_table"], traj["BG_sqc_penalty"] = bias._c_table, np.array([0.04])
+    rng = np.random.default_rng(605)
+    fusG = [[0.2, 0.3, 0.5], [0.65, 0.35]]
+    bias = FugacityBias(subsG, fusG)
+    put("BG_fug_flip_corr", run_metropolis(proc, "corr", Flip(subsG, rng), rng, 5000.0, occ0, 2000, bias=bias))
+    traj["BG_fug_table"] = bias._fu_table
+    proc.mu_table = None
+
+    # ---- case B: Wang-Landau with update_period = 3 (wanglandau.py:241-245) -----------------------
+    model, sc, coefs, proc, active = mB
+    T0 = np.load(os.path.join(HERE, "trajectories.npz"))
+    occ0 = T0["B_occ0"]
+    subsB = sublattices_of(sc)
+    hs = T0["B_swap_int_H"]
+    rng = np.random.default_rng(701)
+    r0 = run_metropolis(proc, "int", Swap(subsB, rng), rng, 2000.0, occ0, 500)
+    hs = r0["H"]
+    window = (float(hs.min() - 1.0), float(hs.max() + 3.0), 2.0)  # coarse bins: the flatness branch fires
+    rng = np.random.default_rng(702)
+    put("B_wlup3", run_wanglandau(proc, "int", Swap(subsB, rng), rng, window, occ0, 4000,
+                                  check_period=60, update_period=3))
+    traj["B_wlup3_window"], traj["B_wlup3_check"], traj["B_wlup3_update"] = (
+        np.array(window), np.array([60]), np.array([3]))
+    np.savez_compressed(os.path.join(HERE, "trajectories_v6.npz"), **traj)
+    for k in sorted(traj):
+        if k.endswith("_accepted"):
+            print(k, "acceptance", traj[k].mean(), "steps", len(traj[k]))
+    print("trajectories_v6 written")
+
+
+if __name__ == "__main__":
+    main()
