@@ -73,21 +73,28 @@ __global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const
     }
 }
 
-// Ensemble.compute_feature_vector_change for one step (<= 2 sequential flips) per
+// Ensemble.compute_feature_vector_change for one step (<= SMOLMC_MAX_STEP_FLIPS sequential flips) per
 // wave, reference table layout and arithmetic chain p / ratio / J, x size
-// (evaluator.pyx:244-262, :302-315; expansion.py:217-231).
+// (evaluator.pyx:244-262, :302-315; expansion.py:217-231).  Flip f sees the flips before it: a site's
+// species is the code of the LAST earlier flip there, else the occupancy's.
 __global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const uint8_t *occ,
                                                         const int *flips, double *out_all) {
     const int lane = threadIdx.x;
-    const int *fl = flips + (size_t)blockIdx.x * 4;
+    const int *fl = flips + (size_t)blockIdx.x * SMOLMC_STEP_ROW;
     double *out = out_all + (size_t)blockIdx.x * T.F;
     for (int i = lane; i < T.F; i += 64) out[i] = 0.0;
     __syncthreads();
-    const int nfl = fl[0] < 0 ? 0 : (fl[2] < 0 ? 1 : 2);
+    int nfl = 0;
+    while (nfl < SMOLMC_MAX_STEP_FLIPS && fl[2 * nfl] >= 0) nfl++;
+    auto seen = [&](const int x, const int f) -> int { // species of site x as flip f sees it
+        int v = occ[x];
+        for (int g = 0; g < f; ++g)
+            if (fl[2 * g] == x) v = fl[2 * g + 1];
+        return v;
+    };
     double dew = 0, dmu = 0;
     for (int f = 0; f < nfl; ++f) {
         const int s = fl[2 * f], newc = fl[2 * f + 1];
-        const int ps = f == 1 ? fl[0] : -1, pc = f == 1 ? fl[1] : 0;
         for (long long rr = T.site_ptr[s]; rr < T.site_ptr[s + 1]; ++rr) {
             const int n = T.loc_orbit[rr];
             const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1, Nt = T.orb_tensor_len[n];
@@ -102,8 +109,7 @@ __global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const
                     int ind_i = 0, ind_f = 0;
                     for (int i = 0; i < I; ++i) {
                         const int x = ind[j * I + i];
-                        int v = occ[x];
-                        if (x == ps) v = pc;
+                        const int v = seen(x, f);
                         const int vf = (x == s) ? newc : v;
                         ind_i += st[i] * v;
                         ind_f += st[i] * vf;
@@ -119,14 +125,12 @@ __global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const
         }
         if (T.has_ewald) {
             // ewald.pyx:38-58
-            int oldc = occ[s];
-            if (s == ps) oldc = pc;
+            const int oldc = seen(s, f);
             const int W = T.ew_W;
             const int add = T.ew_inds[(size_t)s * W + newc], sub = T.ew_inds[(size_t)s * W + oldc];
             double o = 0;
             for (int k = lane; k < T.N; k += 64) {
-                int v = occ[k];
-                if (k == ps) v = pc;
+                const int v = seen(k, f);
                 const int vf = (k == s) ? newc : v;
                 const int i = T.ew_inds[(size_t)k * W + vf], j = T.ew_inds[(size_t)k * W + v];
                 if (i != -1 && add != -1)
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(64) eval_delta_kernel(const RefTables T, const
             }
             dew += wave_sum(o);
         }
-        if (T.has_mu)
+        if (T.has_mu) // against the ORIGINAL occupancy (ensemble.py:368-374)
             dmu += T.mu[(size_t)s * T.mu_W + newc] - T.mu[(size_t)s * T.mu_W + occ[s]];
     }
     __syncthreads();
@@ -210,9 +214,20 @@ static int num_ce_features(const smolmc_tables *t) {
 }
 
 // Build the MC-optimised tables (classes, slot descriptors, member index rows).
+// Models mc_kernel / the lean kernels cannot take (more than 1024 clusters per site, more than 255 site
+// classes, tensor strides beyond 16 bits, an occupancy that does not fit LDS) are not refused: the
+// handle notes why (general_reason) and every launch takes the universal kernel (mc_univ.h).
+static int no_general(smolmc_handle *h, const char *why) {
+    h->general_ok = false;
+    h->general_reason = why;
+    return 0;
+}
+
 static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     const int N = t->num_sites;
     const bool corr = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+    if ((size_t)h->Npad + 4096 > 160 * 1024) return no_general(h, "occupancy does not fit LDS");
+    if (getenv("SMOLMC_FORCE_UNIVERSAL")) return no_general(h, "SMOLMC_FORCE_UNIVERSAL");
     // does any local row contain a repeated site (aliased tiny supercells)?
     bool aliased = false;
     int maxI = 1;
@@ -230,7 +245,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     for (int o = 0; o < t->n_orb; ++o)
         for (int i = 0; i < t->orb_nsites[o]; ++i)
             if (t->tensor_indices[t->orb_stride_off[o] + i] > 65535)
-                return fail("tensor stride exceeds 16 bits");
+                return no_general(h, "tensor stride exceeds 16 bits");
     h->generic = aliased;
     const int need_mm = aliased ? maxI : std::max(1, maxI - 1);
 
@@ -276,7 +291,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         std::stable_sort(sl.begin(), sl.end(), [](const Slot &a, const Slot &b) { return a.nmem > b.nmem; });
         auto itc = class_of.find(sig);
         if (itc == class_of.end()) {
-            if (class_rep.size() >= 255) return fail("more than 255 site classes");
+            if (class_rep.size() >= 255) return no_general(h, "more than 255 site classes");
             itc = class_of.emplace(sig, (int)class_rep.size()).first;
             class_rep.push_back(s);
         }
@@ -287,7 +302,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     for (int s : class_rep) Cmax = std::max(Cmax, slots[s].size());
     const int niter_max = (int)((Cmax + 63) / 64);
     h->nslot = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : (niter_max <= 8 ? 8 : 16));
-    if (niter_max > 16) return fail("more than 1024 clusters per site are not supported yet");
+    if (niter_max > 16) return no_general(h, "more than 1024 clusters per site");
     // slot columns per class: the two-group kernels evaluate BOTH groups without a condition
     // (mc_general.h), so the padding goes up to their full width (padded slots add 0.0)
     const int Cpad = 64 * (h->nslot <= 2 ? h->nslot : niter_max);
@@ -372,7 +387,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             slot_fs[(size_t)c * Cpad + q] = scale;
         }
     }
-    if (xt.size() > 0xffffffffull) return fail("decision tensors too large");
+    if (xt.size() > 0xffffffffull) return no_general(h, "decision tensors too large");
 
     // member index rows [site][m][Cpad]; padded entries point at the site itself
     const size_t idx_n = (size_t)N * MM * Cpad;
@@ -982,12 +997,16 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     // species codes a site may carry: max_species by default, the largest sublattice code + 1 on
     // the sites of an active sublattice
     h->site_ncodes.assign((size_t)t->num_sites, (uint8_t)std::min(255, std::max(1, t->max_species)));
+    h->site_active.assign((size_t)t->num_sites, 0);
     for (int k = 0; k < t->n_sublattices; ++k) {
         int top = 0;
         for (int64_t c = t->sub_code_ptr[k]; c < t->sub_code_ptr[k + 1]; ++c) top = std::max(top, t->sub_codes[c]);
         for (int64_t i = t->sub_site_ptr[k]; i < t->sub_site_ptr[k + 1]; ++i) {
             const int st = t->sub_active_sites[i];
-            if (st >= 0 && st < t->num_sites) h->site_ncodes[st] = (uint8_t)std::min(255, top + 1);
+            if (st >= 0 && st < t->num_sites) {
+                h->site_ncodes[st] = (uint8_t)std::min(255, top + 1);
+                h->site_active[st] = 1;
+            }
         }
     }
     if (int rc = build_mc_tables(h, t)) return bail(rc);
@@ -1016,8 +1035,6 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         if (brows < 1 || brows > SMOLMC_MAX_BIAS_ROWS)
             return bail(fail("bias_rows must be in [1, SMOLMC_MAX_BIAS_ROWS]"));
         if (wl) return bail(fail("Cannot apply bias to Wang-Landau simulation!")); // wanglandau.py:127-128
-        if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP)
-            return bail(fail("bias terms are implemented for Flip / Swap steps"));
         if (!t->bias_table || t->bias_width < t->max_species)
             return bail(fail("bias_table must be [num_sites x >= max_species]"));
         if (t->bias_type != SMOLMC_BIAS_FUGACITY && !(t->bias_penalty > 0.0))
@@ -1134,8 +1151,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     h->waves_per_block = 4;
     while (h->waves_per_block > 1 && tb + pw * h->waves_per_block > 160 * 1024) h->waves_per_block /= 2;
     h->lds_bytes = tb + pw * h->waves_per_block;
-    if (h->lds_bytes > 160 * 1024)
-        return bail(fail("model does not fit the 160 KiB LDS budget (tables + one chain)"));
+    if (h->general_ok && h->lds_bytes > 160 * 1024)
+        no_general(h, "tables + one chain exceed the 160 KiB LDS budget of mc_kernel");
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
@@ -1165,6 +1182,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         }
         std::vector<double> bias_pair(64, 0.0);
         if (lean && t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) lean = false; // general kernel
+        // the table kernels are Metropolis kernels of at most 8 flip vectors: Wang-Landau TableFlip
+        // and larger tables take the universal kernel
+        if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP && (wl || t->n_flip_vectors > 8)) lean = false;
         // several correlation functions per orbit: plain Metropolis flip / swap variants only
         if (lean && h->lean_kf && (wl || t->bias_type || cfg->step_type == SMOLMC_STEP_TABLE_FLIP)) lean = false;
         if (lean && t->bias_type) {
@@ -1232,7 +1252,6 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     return bail(1);
                 lp.tf_n = t->n_flip_vectors;
                 lp.tf_sw = t->swap_weight;
-                if (t->n_flip_vectors > 8) return bail(fail("at most 8 flip vectors are supported"));
             }
             if (wl) {
                 lp.wl.L = h->L;
@@ -1490,17 +1509,68 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     (int)lean, (int)h->lean_tables, h->lean_nslot, h->lean_mm, h->lean_lds, t->has_ewald,
                     kp.ew_compact, h->lp.ew_field, nact, kp.ew_nact, kp.ew_act_base, sbase, h->nslot, h->mm,
                     h->lds_bytes);
+    }
+    // ---- universal kernel (mc_univ.h): parameter block of every handle; `univ` when nothing else serves
+    {
+        UParams &up = h->up;
+        memset(&up, 0, sizeof(up));
+        up.T = h->rt;
+        up.natural = h->d_natural;
+        up.wl = wl ? 1 : 0;
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
                 return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
                                  "smol/moca/composition/space.py:404-429)"));
-            if (!h->lean || wl)
-                return bail(fail("TableFlip is implemented for Metropolis models on the lean paths only "
-                                 "(interaction features, contiguous sublattices = site classes, <= 512 "
-                                 "clusters per site, uniform mu rows, factorising Ewald matrix)"));
             if (!(t->swap_weight >= 0.0 && t->swap_weight < 1.0))
                 return bail(fail("swap_weight must be in [0, 1)"));
+            const int ns = t->n_sublattices, d = (int)t->sub_code_ptr[ns];
+            if (t->n_flip_vectors > SMOLMC_MAX_FLIP_VECTORS || d > SMOLMC_MAX_FLIP_DIMS)
+                return bail(fail("flip table larger than SMOLMC_MAX_FLIP_VECTORS x SMOLMC_MAX_FLIP_DIMS"));
+            std::vector<int> dim_sub(d);
+            int max_nact = 0;
+            for (int k = 0; k < ns; ++k) {
+                for (int64_t c = t->sub_code_ptr[k]; c < t->sub_code_ptr[k + 1]; ++c) dim_sub[c] = k;
+                max_nact = std::max(max_nact, (int)(t->sub_site_ptr[k + 1] - t->sub_site_ptr[k]));
+            }
+            h->max_step_flips = 2;
+            for (int v = 0; v < t->n_flip_vectors; ++v) {
+                // species are exchanged inside a sublattice (mcusher.py:612-634: "Sub-lattices can not
+                // cross", assert len(site_ids) == 0), a step flips the sites of the depleted species
+                int total = 0;
+                for (int k = 0; k < ns; ++k) {
+                    int sum = 0, picks = 0;
+                    for (int64_t c = t->sub_code_ptr[k]; c < t->sub_code_ptr[k + 1]; ++c) {
+                        const int u = t->flip_table[(size_t)v * d + c];
+                        sum += u;
+                        picks += u < 0 ? -u : 0;
+                    }
+                    if (sum != 0) return bail(fail("flip vector does not conserve the sites of a sublattice"));
+                    total += picks;
+                }
+                if (total == 0) return bail(fail("flip vector without any flip"));
+                if (total > SMOLMC_MAX_STEP_FLIPS) return bail(fail("flip vector of more than SMOLMC_MAX_STEP_FLIPS flips"));
+                h->max_step_flips = std::max(h->max_step_flips, total);
+            }
+            for (int i = 0; i < 2 * t->n_flip_vectors; ++i)
+                if (!(t->flip_weights[i] >= 0.0)) return bail(fail("flip weights must be non-negative"));
+            std::vector<double> ln((size_t)max_nact + 2, 0.0);
+            for (int k = 1; k <= max_nact + 1; ++k) ln[k] = std::log((double)k);
+            if (dev_upload(h, t->flip_table, (size_t)t->n_flip_vectors * d, &up.tf_table) ||
+                dev_upload(h, t->flip_weights, (size_t)2 * t->n_flip_vectors, &up.tf_w) ||
+                dev_upload(h, ln.data(), ln.size(), &up.tf_ln) || dev_upload(h, dim_sub.data(), dim_sub.size(), &up.tf_dim_sub))
+                return bail(1);
+            up.tf_n = t->n_flip_vectors;
+            up.tf_d = d;
+            up.tf_sw = t->swap_weight;
         }
+        // per-wave LDS: step scratch (flips, counts, weights: 928 B) + the occupancy when it fits
+        const size_t scratch = 928, with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
+        up.occ_lds = with_occ <= 160 * 1024 - 256 && getenv("SMOLMC_UNIV_OCC_HBM") == nullptr;
+        up.lds_per_wave = (int)(up.occ_lds ? with_occ : scratch);
+        h->univ_wpb = 4;
+        while (h->univ_wpb > 1 && (size_t)up.lds_per_wave * h->univ_wpb > 64 * 1024) h->univ_wpb /= 2;
+        const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
+        h->univ = !h->lean && (table || !h->general_ok);
     }
     *out = h;
     return 0;
@@ -1698,7 +1768,10 @@ extern "C" int smolmc_sync(smolmc_handle *h) {
 
 extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     if (!h || !buf || n <= 0) return fail("null argument");
-    if (h->lean)
+    if (h->univ)
+        snprintf(buf, (size_t)n, "universal occ=%s field=%d lds=%zu (%s)", h->up.occ_lds ? "lds" : "hbm", h->kp.ew_field,
+                 (size_t)h->up.lds_per_wave * h->univ_wpb, h->general_ok ? "TableFlip outside the lean families" : h->general_reason.c_str());
+    else if (h->lean)
         snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu%s", h->lean_multi ? "lean-multi" : "lean",
                  h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds,
                  h->lean_solo ? (h->lean_occ ? " solo=1 occ=6" : " solo=1") : (h->lean_kf ? " kf=1" : ""));
@@ -1920,8 +1993,24 @@ static void free_samples(smolmc_handle *h) {
     h->smp_has_occ = false;
 }
 
+// parameter block of a universal-kernel launch: the handle's current KParams; on a lean handle (a
+// replay the lean kernels cannot take) the potential field is used exactly when the lean kernel
+// maintains it
+static UParams univ_block_of(smolmc_handle *h) {
+    UParams up = h->up;
+    up.K = h->kp;
+    if (h->lean && !h->lp.ew_field) up.K.ew_field = 0;
+    return up;
+}
+
 static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
     TRY(wl_set_representation(h, h->lean && h->lp.wl.sum_mode));
+    if (h->univ) {
+        UParams up = univ_block_of(h);
+        up.K.steps_to_run = nsteps;
+        up.K.smp = smp;
+        return smolmc_launch_univ(h, up, 0);
+    }
     if (h->lean) {
         // the lean kernels count steps in 32 bits: launches are split at 2^30 steps (on a
         // sample boundary when samples are being recorded)
@@ -2029,39 +2118,99 @@ extern "C" int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double 
     return get_samples_impl(h, enthalpy, features, accepted, nullptr, occupancy);
 }
 
-extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps,
-                             const double *uniforms, uint8_t *accepted_out, double *enthalpy_out) {
+// lean replay kernels that exist: Metropolis flips / swaps (plain, KF, with MCBias), multi-sublattice,
+// Wang-Landau; TableFlip handles have their own (smolmc_table_replay_available)
+static bool smolmc_lean_replay_takes(const smolmc_handle *h) {
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) return false;
+    if (h->lp.bias_type) return SMOLMC_HAVE_BIAS_REPLAY != 0;
+    return true;
+}
+static bool smolmc_table_replay_available() { return SMOLMC_HAVE_TABLE_REPLAY != 0; }
+static int smolmc_launch_lean_replay(smolmc_handle *h, const LeanParams &lp) {
+    const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+#if SMOLMC_HAVE_TABLE_REPLAY
+    if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) {
+        LeanParams q = lp;
+        TRY(update_walker_order(h, q));
+        if (h->lean_multi)
+            return h->lean_nslot == 2 ? smolmc_launch_multi_table_replay_2(h, q)
+                                      : (h->lean_nslot == 4 ? smolmc_launch_multi_table_replay_4(h, q) : smolmc_launch_multi_table_replay_8(h, q));
+        return h->lean_nslot == 2 ? smolmc_launch_table_replay_2(h, q) : smolmc_launch_table_replay_4(h, q);
+    }
+#endif
+#if SMOLMC_HAVE_BIAS_REPLAY
+    if (lp.bias_type && h->lean_multi)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_bias_replay_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_replay_4(h, lp) : smolmc_launch_multi_bias_replay_8(h, lp));
+    if (lp.bias_type) return h->lean_nslot == 2 ? smolmc_launch_lean_bias_replay_2(h, lp) : smolmc_launch_lean_bias_replay_4(h, lp);
+#endif
+    if (h->lean_multi)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_replay_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_replay_4(h, lp) : smolmc_launch_multi_replay_8(h, lp));
+    return wl ? (h->lean_nslot == 2 ? smolmc_launch_wl_replay_2(h, lp) : smolmc_launch_wl_replay_4(h, lp))
+              : (h->lean_nslot == 2 ? smolmc_launch_lean_replay_2(h, lp) : smolmc_launch_lean_replay_4(h, lp));
+}
+
+extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *steps, const double *uniforms,
+                             const double *log_priori, uint8_t *accepted_out, double *enthalpy_out,
+                             double *log_priori_out) {
     if (!h || !steps || !uniforms) return fail("null argument");
     if (nsteps <= 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     const size_t n = (size_t)h->R * nsteps;
+    // every flip: a changeable site of an active sublattice (the lean kernels index their tables
+    // relative to the active range; a code beyond the site's species would index past its tensors)
+    int max_flips = 0;
     for (size_t i = 0; i < n; ++i) {
-        const int32_t *st = steps + i * 4;
-        for (int f = 0; f < 2; ++f)
-            if (st[2 * f] >= h->N || (st[2 * f] >= 0 && (st[2 * f + 1] < 0 || st[2 * f + 1] > 255)))
-                return fail("replay step out of range");
-    }
-    // codes must exist on their sites (they index the delta tables)
-    for (size_t i = 0; i < n; ++i)
-        for (int f = 0; f < 2; ++f) {
-            const int32_t st = steps[i * 4 + 2 * f], cd = steps[i * 4 + 2 * f + 1];
-            if (st >= 0 && cd >= (int)h->site_ncodes[st]) return fail("replay step out of range (species code)");
+        const int32_t *st = steps + i * SMOLMC_STEP_ROW;
+        int nf = 0;
+        for (; nf < SMOLMC_MAX_STEP_FLIPS && st[2 * nf] >= 0; ++nf) {
+            const int32_t site = st[2 * nf], code = st[2 * nf + 1];
+            if (site >= h->N) return fail("replay step out of range");
+            if (!h->site_active[site]) return fail("replay step out of range: the site is not changeable (not on an active sublattice)");
+            if (code < 0 || code >= (int)h->site_ncodes[site]) return fail("replay step out of range (species code)");
         }
+        max_flips = std::max(max_flips, nf);
+    }
+    bool priori_given = false; // a factor the Flip / Swap kernels do not model
+    if (log_priori)
+        for (size_t i = 0; i < n && !priori_given; ++i) priori_given = log_priori[i] == log_priori[i] && log_priori[i] != 0.0;
+    const bool table = h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP;
     // Lean handles replay on their own kernels (REPLAY instantiations of mc_lean_kernel,
-    // mc_lean_multi_kernel and mc_wl_kernel): Metropolis flips / swaps without bias, or Wang-Landau.  Everything
-    // else -- and SMOLMC_REPLAY_GENERAL for A/B runs -- takes the general kernel.
-    const bool lean_replay = h->lean && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP && !h->lp.bias_type &&
-                             nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_GENERAL") == nullptr;
+    // mc_lean_multi_kernel, mc_wl_kernel, mc_table_kernel, mc_table_multi_kernel); steps those cannot
+    // take (more than two flips on a Flip / Swap handle, a given a-priori factor there), universal
+    // handles and SMOLMC_REPLAY_UNIVERSAL take the universal kernel; SMOLMC_REPLAY_GENERAL: mc_kernel.
+    const bool two_flip_ok = max_flips <= 2 && !priori_given && !table;
+    const bool want_general = getenv("SMOLMC_REPLAY_GENERAL") != nullptr && two_flip_ok && h->general_ok;
+    const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30);
+    const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&
+                             ((two_flip_ok && smolmc_lean_replay_takes(h)) || lean_table_replay);
+    const bool general_replay = !lean_replay && !h->univ && two_flip_ok && h->general_ok && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr;
     int *d_steps = nullptr, *d_err = nullptr;
-    double *d_u = nullptr, *d_H = nullptr;
+    double *d_u = nullptr, *d_H = nullptr, *d_lp = nullptr, *d_lpo = nullptr;
     uint8_t *d_acc = nullptr;
-    hipError_t e = hipMalloc((void **)&d_steps, n * 16);
+    // the two-flip kernels read records of four ints
+    std::vector<int32_t> packed;
+    const bool narrow = (lean_replay && !table) || general_replay;
+    if (narrow) {
+        packed.resize(n * 4);
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 4; ++k) packed[i * 4 + k] = steps[i * SMOLMC_STEP_ROW + k];
+    }
+    const size_t row_bytes = narrow ? 16 : SMOLMC_STEP_ROW * 4;
+    hipError_t e = hipMalloc((void **)&d_steps, n * row_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_err, 16);
     if (e == hipSuccess) e = hipMemset(d_err, 0, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&d_u, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_H, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_acc, n);
-    if (e == hipSuccess) e = hipMemcpy(d_steps, steps, n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lpo, n * 8);
+    if (e == hipSuccess) e = hipMemset(d_lpo, 0, n * 8);
+    if (e == hipSuccess && log_priori) {
+        e = hipMalloc((void **)&d_lp, n * 8);
+        if (e == hipSuccess) e = hipMemcpy(d_lp, log_priori, n * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(d_steps, narrow ? packed.data() : steps, n * row_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_u, uniforms, n * 8, hipMemcpyHostToDevice);
     int rc = 0;
     if (e == hipSuccess && lean_replay) {
@@ -2071,20 +2220,18 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
         memset(&lp.smp, 0, sizeof(lp.smp));
         lp.steps = nsteps;
         lp.rp_steps = d_steps; lp.rp_u = d_u; lp.rp_acc = d_acc; lp.rp_H = d_H; lp.rp_err = d_err;
-        if (!rc && h->lean_multi)
-            rc = h->lean_nslot == 2 ? smolmc_launch_multi_replay_2(h, lp)
-                                    : (h->lean_nslot == 4 ? smolmc_launch_multi_replay_4(h, lp) : smolmc_launch_multi_replay_8(h, lp));
-        else if (!rc)
-            rc = wl ? (h->lean_nslot == 2 ? smolmc_launch_wl_replay_2(h, lp) : smolmc_launch_wl_replay_4(h, lp))
-                    : (h->lean_nslot == 2 ? smolmc_launch_lean_replay_2(h, lp) : smolmc_launch_lean_replay_4(h, lp));
+        lp.rp_lp = d_lp; lp.rp_lp_out = d_lpo;
+        if (!rc) rc = smolmc_launch_lean_replay(h, lp);
         if (!rc) e = hipStreamSynchronize(h->stream);
         int bad = 0;
         if (!rc && e == hipSuccess) e = hipMemcpy(&bad, d_err, 4, hipMemcpyDeviceToHost);
         if (!rc && e == hipSuccess && bad)
-            rc = fail("replay step does not fit the handle's step type (a swap handle takes proper swaps: "
-                      "code1 == species at site2, code2 == species at site1; a flip handle single flips); "
-                      "the walkers have been advanced -- set the state again");
-    } else if (e == hipSuccess) {
+            rc = table ? fail("replay: Step is not in flip table (neither a canonical swap nor +-(a row of flip_table)); "
+                              "the walkers have been advanced -- set the state again")
+                       : fail("replay step does not fit the handle's step type (a swap handle takes proper swaps: "
+                              "code1 == species at site2, code2 == species at site1; a flip handle single flips); "
+                              "the walkers have been advanced -- set the state again");
+    } else if (e == hipSuccess && general_replay) {
         rc = wl_set_representation(h, false);
         KParams kp = h->kp;
         kp.steps_to_run = nsteps;
@@ -2094,14 +2241,31 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
         kp.rp_H = d_H;
         if (!rc) rc = launch_mc(h, kp, 1);
         if (!rc) e = hipStreamSynchronize(h->stream);
+    } else if (e == hipSuccess) {
+        rc = wl_set_representation(h, false);
+        UParams up = univ_block_of(h);
+        up.K.steps_to_run = nsteps;
+        memset(&up.K.smp, 0, sizeof(up.K.smp));
+        up.K.rp_steps = d_steps; up.K.rp_u = d_u; up.K.rp_acc = d_acc; up.K.rp_H = d_H;
+        up.rp_lp = d_lp; up.rp_lp_out = d_lpo; up.rp_err = d_err;
+        if (!rc) rc = smolmc_launch_univ(h, up, 1);
+        if (!rc) e = hipStreamSynchronize(h->stream);
+        int bad = 0;
+        if (!rc && e == hipSuccess) e = hipMemcpy(&bad, d_err, 4, hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess && bad)
+            rc = fail("replay: Step is not in flip table (neither a canonical swap nor +-(a row of flip_table)); "
+                      "the walkers have been advanced -- set the state again");
     }
     if (!rc && e == hipSuccess && accepted_out) e = hipMemcpy(accepted_out, d_acc, n, hipMemcpyDeviceToHost);
     if (!rc && e == hipSuccess && enthalpy_out) e = hipMemcpy(enthalpy_out, d_H, n * 8, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && log_priori_out) e = hipMemcpy(log_priori_out, d_lpo, n * 8, hipMemcpyDeviceToHost);
     hipFree(d_steps);
     hipFree(d_err);
     hipFree(d_u);
     hipFree(d_H);
     hipFree(d_acc);
+    hipFree(d_lpo);
+    if (d_lp) hipFree(d_lp);
     if (rc) return rc;
     if (e != hipSuccess) return fail(std::string("replay: ") + hipGetErrorString(e));
     return 0;
@@ -2151,17 +2315,18 @@ extern "C" int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ, const int
     if (nstep <= 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     for (int i = 0; i < nstep; ++i)
-        for (int f = 0; f < 2; ++f) {
-            const int s = flips[i * 4 + 2 * f], c = flips[i * 4 + 2 * f + 1];
-            if (s >= h->N || (s >= 0 && (c < 0 || c > 255))) return fail("flip out of range");
+        for (int f = 0; f < SMOLMC_MAX_STEP_FLIPS; ++f) {
+            const int s = flips[(size_t)i * SMOLMC_STEP_ROW + 2 * f], c = flips[(size_t)i * SMOLMC_STEP_ROW + 2 * f + 1];
+            if (s < 0) break;
+            if (s >= h->N || c < 0 || c >= (int)h->site_ncodes[s]) return fail("flip out of range");
         }
     TRY(ensure_eval_occ(h, 1));
     TRY(upload_occ(h, occ, 1, h->d_eval_occ));
     int *d_fl = nullptr;
     double *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_fl, (size_t)nstep * 16);
+    hipError_t e = hipMalloc((void **)&d_fl, (size_t)nstep * SMOLMC_STEP_ROW * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)nstep * h->F * 8);
-    if (e == hipSuccess) e = hipMemcpy(d_fl, flips, (size_t)nstep * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_fl, flips, (size_t)nstep * SMOLMC_STEP_ROW * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(eval_delta_kernel, dim3(nstep), dim3(64), 0, h->stream, h->rt, h->d_eval_occ,
                            d_fl, d_out);

@@ -482,6 +482,8 @@ struct LeanParams {
     uint8_t *rp_acc;       // [R][steps]
     double *rp_H;          // [R][steps]
     int *rp_err;           // set when a record does not fit the kernel's step type
+    const double *rp_lp;   // TableFlip replay: [R][steps] a-priori factors (NaN = derive) or null
+    double *rp_lp_out;     // [R][steps] the factor that entered the exponent (null: not recorded)
 };
 
 __device__ __forceinline__ int lean_swz(int s, int a, int m, int b) { return s ^ (((s >> a) & m) << b); }
@@ -502,6 +504,27 @@ struct RefTables { // device copies of the smolmc_tables arrays
     const double *mu;
 };
 
+
+// parameter block of the universal kernel (mc_univ.h)
+struct UParams {
+    KParams K;   // walker state, sublattices, Ewald / mu / bias tables, Wang-Landau state, replay, samples
+    RefTables T; // reference-layout tables (device copies of smolmc_tables)
+    const double *natural; // [F] natural parameters
+    // TableFlip
+    int tf_n, tf_d;          // flip vectors, dims (species over the active sublattices)
+    const int *tf_table;     // [tf_n][tf_d]
+    const double *tf_w;      // [2 tf_n]
+    double tf_sw;            // swap_weight
+    const double *tf_ln;     // ln(k), k = 0 .. largest sublattice (host libm, as the oracle's log)
+    const int *tf_dim_sub;   // [tf_d] sublattice of a dim
+    int occ_lds;             // occupancy staged in LDS (else read / written in HBM)
+    int lds_per_wave;
+    int wl;                  // Wang-Landau kernel
+    // replay extras
+    const double *rp_lp;     // [R][nsteps] a-priori factors (NaN = derive) or null
+    double *rp_lp_out;       // [R][nsteps] or null
+    int *rp_err;             // bit 0: step not in the flip table; bit 1: inactive site / impossible code
+};
 
 struct DevBuf {
     void *p = nullptr;
@@ -557,6 +580,14 @@ struct smolmc_handle {
     std::vector<double> ew_qs_host, ew_dg_host; // compact-Ewald per-(site, code) charge / diagonal
     int ew_gx_dims[3] = {0, 0, 0}, ew_gx_blocks = 0; // translation-compressed site kernel (0: none)
     std::vector<uint8_t> site_ncodes; // species codes allowed on each site (occupancy validation)
+    std::vector<uint8_t> site_active; // 1 on the sites of the active sublattices (replay validation)
+    // universal kernel (mc_univ.h): always available; `univ` = every launch of this handle takes it
+    UParams up;
+    bool univ = false;
+    bool general_ok = true;      // mc_kernel can run this model (else: why not)
+    std::string general_reason;
+    int univ_wpb = 4;
+    int max_step_flips = 2;      // most flips a native step of this handle makes (TableFlip: from the table)
 };
 
 static void free_samples(smolmc_handle *h);
@@ -601,12 +632,30 @@ __device__ __forceinline__ LeanParamsKernarg rare_params() {
     return p;
 }
 #endif
+int smolmc_launch_univ(smolmc_handle *h, const UParams &up, int replay);
 int smolmc_launch_general_2(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_4(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
+// replay instantiations of the TableFlip / biased lean kernels (0 while they are being brought up)
+#ifndef SMOLMC_HAVE_TABLE_REPLAY
+#define SMOLMC_HAVE_TABLE_REPLAY 0
+#endif
+#ifndef SMOLMC_HAVE_BIAS_REPLAY
+#define SMOLMC_HAVE_BIAS_REPLAY 0
+#endif
+int smolmc_launch_table_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_table_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_table_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_table_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_table_replay_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_bias_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_lean_bias_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_bias_replay_8(smolmc_handle *h, const LeanParams &lp);
 #define SMOLMC_WL_ROWS 32  // mc_wl_kernel: cached rows of per-bin feature sums per walker (LDS)
 #define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
 int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);

@@ -44,7 +44,7 @@ SYMBOLS = {
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
     "smolmc_get_samples": (C.c_int, [_HP, _f64p, _f64p, _u8p, _i32p]),
     "smolmc_get_samples_u8": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p]),
-    "smolmc_replay": (C.c_int, [_HP, C.c_int64, _i32p, _f64p, _u8p, _f64p]),
+    "smolmc_replay": (C.c_int, [_HP, C.c_int64, _i32p, _f64p, _f64p, _u8p, _f64p, _f64p]),
     "smolmc_last_kernel_ms": (C.c_int, [_HP, C.POINTER(C.c_float)]),
     "smolmc_eval_full": (C.c_int, [_HP, _i32p, C.c_int, _f64p]),
     "smolmc_eval_delta": (C.c_int, [_HP, _i32p, _i32p, C.c_int, _f64p]),
@@ -95,7 +95,7 @@ def load_library(path=None):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.smolmc_abi_version() != 5:
+    if lib.smolmc_abi_version() != capi.ABI_VERSION:
         raise RuntimeError("smolmc ABI version mismatch")
     if path is None:
         _LIB = lib
@@ -305,20 +305,24 @@ class Engine:
         self._chk(self._lib.smolmc_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    def replay(self, steps, uniforms):
-        """steps (R, n, 4) int32, uniforms (R, n) float64 -> (accepted (R,n) bool, H (R,n))."""
+    def replay(self, steps, uniforms, log_priori=None, with_priori=False):
+        """steps (R, n, 2k) int32 with k <= 8 (site, code) pairs per record (padded to
+        SMOLMC_STEP_ROW with -1), uniforms (R, n) float64, log_priori (R, n) or None (see
+        smolmc_replay) -> (accepted (R,n) bool, H (R,n)[, log_priori used (R,n)])."""
         uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.R, -1)
         n = uniforms.shape[1]
-        steps = np.ascontiguousarray(steps, dtype=np.int32).reshape(self.R, n, 4)
+        steps = capi.step_rows(steps, self.R, n)
+        lp = None if log_priori is None else np.ascontiguousarray(log_priori, dtype=np.float64).reshape(self.R, n)
         acc = np.zeros((self.R, n), dtype=np.uint8)
         H = np.zeros((self.R, n))
+        lpo = np.zeros((self.R, n)) if with_priori else None
         self._chk(
             self._lib.smolmc_replay(
-                self._h, n, _p(steps, C.c_int32), _p(uniforms, C.c_double), _p(acc, C.c_uint8),
-                _p(H, C.c_double),
+                self._h, n, _p(steps, C.c_int32), _p(uniforms, C.c_double), _p(lp, C.c_double),
+                _p(acc, C.c_uint8), _p(H, C.c_double), _p(lpo, C.c_double),
             )
         )
-        return acc.astype(bool), H
+        return (acc.astype(bool), H, lpo) if with_priori else (acc.astype(bool), H)
 
     # ---- evaluator level --------------------------------------------------------
     def eval_full(self, occupancies):
@@ -328,9 +332,13 @@ class Engine:
         return out
 
     def eval_delta(self, occupancy, steps):
-        """steps: (n, 4) int32 rows (site1, code1, site2, code2), -1 = absent."""
+        """steps: (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}), k <= 8, -1 = absent;
+        a single step may also be given as its list of (site, code) tuples."""
         occ = self._occ32(occupancy, (self.N,))
-        steps = np.ascontiguousarray(steps, dtype=np.int32).reshape(-1, 4)
+        a = np.asarray(steps, dtype=np.int32)
+        if a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 2):
+            a = a.reshape(1, -1)  # one step: flat record or (site, code) pairs
+        steps = capi.step_rows(a)
         out = np.zeros((len(steps), self.F))
         self._chk(
             self._lib.smolmc_eval_delta(

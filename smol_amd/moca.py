@@ -175,20 +175,17 @@ class Processor:
             types = {type(n) for n in occupancy}
             raise ValueError(f"occupancy contains {types}, but should be integers!")
         flips = list(flips)
-        if len(flips) > 2:
-            # sequential semantics (expansion.py:217-229): chain in pairs
+        if len(flips) > capi.MAX_STEP_FLIPS:
+            # sequential semantics (expansion.py:217-229): chain in records of eight flips
             total = 0.0
             occ = occupancy.copy()
-            for i in range(0, len(flips), 2):
-                chunk = flips[i:i + 2]
+            for i in range(0, len(flips), capi.MAX_STEP_FLIPS):
+                chunk = flips[i:i + capi.MAX_STEP_FLIPS]
                 total = total + self.compute_feature_vector_change(occ, chunk)
                 for s, c in chunk:
                     occ[s] = c
             return total
-        row = -np.ones(4, dtype=np.int32)
-        for j, (s, c) in enumerate(flips):
-            row[2 * j], row[2 * j + 1] = s, c
-        out = self._engine().eval_delta(occupancy, row[None, :])[0][self._feature_slice]
+        out = self._engine().eval_delta(occupancy, capi.step_rows([flips]))[0][self._feature_slice]
         return float(out[0]) if self._scalar_feature else out
 
     def compute_property(self, occupancy):
@@ -564,11 +561,8 @@ class Ensemble:
         return self._eval().eval_full(np.asarray(occupancy, dtype=np.int32)[None, :])[0]
 
     def compute_feature_vector_change(self, occupancy, step):
-        """ensemble.py:353-376 (steps of up to two flips)."""
-        row = -np.ones(4, dtype=np.int32)
-        for j, (s, c) in enumerate(step):
-            row[2 * j], row[2 * j + 1] = s, c
-        return self._eval().eval_delta(np.asarray(occupancy, dtype=np.int32), row[None, :])[0]
+        """ensemble.py:353-376 (steps of up to SMOLMC_MAX_STEP_FLIPS flips, e.g. TableFlip's)."""
+        return self._eval().eval_delta(np.asarray(occupancy, dtype=np.int32), capi.step_rows([list(step)]))[0]
 
 
 # --------------------------------------------------------------------------- #

@@ -1,0 +1,153 @@
+"""The universal kernel (mc_univ.h) -- the backstop for everything the specialised kernels decline --
+against the CPU oracle on the engine's own random stream (identical Philox words -> identical
+chains): every step type x kernel type x feature mode x bias the reference composes
+(kernel/base.py:192-239), occupancy in LDS and in HBM, models the other kernels cannot hold."""
+
+import numpy as np
+import pytest
+
+from smol_amd import capi
+from tests.cases import CASES, load_case, tables_for
+from tests.v6_cases import SPECS, T6, build
+
+pytestmark = pytest.mark.gpu
+MODES = {"int": capi.FEATURES_INTERACTIONS, "corr": capi.FEATURES_CORRELATIONS}
+
+
+def _pair(tab, cfg, occ, seeds, temp):
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ, seeds, temp)
+    ora.set_state(occ, seeds, temp)
+    return eng, ora
+
+
+def _same_chain(eng, ora, chunks, wl=False, bias=False):
+    for n in chunks:
+        eng.run(n)
+        ora.run(n)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        assert np.array_equal(a["accepted"], b["accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+        if bias:
+            np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=1e-10, atol=1e-9)
+        if wl:
+            x, y = eng.get_wl(), ora.get_wl()
+            assert np.array_equal(x["histogram"], y["histogram"])
+            assert np.array_equal(x["occurrences"], y["occurrences"])
+            np.testing.assert_allclose(x["entropy"], y["entropy"], rtol=0, atol=0)
+            np.testing.assert_allclose(x["mean_features"], y["mean_features"], rtol=1e-10, atol=1e-8)
+            np.testing.assert_allclose(x["mod_factor"], y["mod_factor"])
+    return a
+
+
+def _rand_occ(sc, rng, R):
+    nsp = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
+    return (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
+
+
+@pytest.mark.parametrize("occ_mem", ["lds", "hbm"])
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+@pytest.mark.parametrize("mode", ["int", "corr"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_flip_and_swap_chains_on_the_universal_kernel(name, mode, step, occ_mem, monkeypatch):
+    """Every golden model (pairs, triplets, ternary indicator basis on a skew cell, aliased 2x2x2,
+    vacancies, two active sublattices, Ewald): the universal kernel runs the oracle's chain."""
+    monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+    if occ_mem == "hbm":
+        monkeypatch.setenv("SMOLMC_UNIV_OCC_HBM", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_UNIV_OCC_HBM", raising=False)
+    c = load_case(name)
+    sc = c["sc"]
+    mu = None
+    if step == capi.STEP_FLIP:
+        mu = np.zeros((sc.num_sites, 3))
+        mu[:, :] = np.random.default_rng(5).uniform(-0.3, 0.3, 3)[None, :]
+    tab = tables_for(name, MODES[mode], mu_table=mu)
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    occ = _rand_occ(sc, np.random.default_rng(8), R)
+    eng, ora = _pair(tab, cfg, occ, np.arange(R, dtype=np.uint64) + np.uint64(50), 2500.0)
+    info = eng.kernel_info()
+    assert info.startswith("universal occ=" + occ_mem), info
+    a = _same_chain(eng, ora, (1, 7, 150))
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-8)
+    assert 0 < a["n_accepted"].sum()
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["TC_tf_int", "TC_tf_corr", "TC_tfw_int", "TC_tflim_int", "TC_tffug_int", "TC_tfwl_int",
+                                 "TG_tf_int", "TG_tf_corr", "TG6_tf_int"])
+@pytest.mark.parametrize("how", ["general-handle", "universal-handle", "hbm"])
+def test_table_flip_chains_on_the_universal_kernel(tag, how, monkeypatch):
+    """TableFlip outside the lean families (SMOLMC_FORCE_GENERAL: the reference's own TableFlip shapes
+    -- cation table, cation + anion table -- with correlation features, Wang-Landau, a bias term) on
+    the native stream: same chain as the oracle."""
+    for k in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL", "SMOLMC_UNIV_OCC_HBM"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv({"general-handle": "SMOLMC_FORCE_GENERAL", "universal-handle": "SMOLMC_FORCE_UNIVERSAL",
+                        "hbm": "SMOLMC_FORCE_UNIVERSAL"}[how], "1")
+    if how == "hbm":
+        monkeypatch.setenv("SMOLMC_UNIV_OCC_HBM", "1")
+    R = 4
+    tab, cfg, occ0, temp = build(tag, n_replicas=R)
+    sp = SPECS[tag]
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (R, 1)), np.arange(R, dtype=np.uint64) + np.uint64(900), temp)
+    assert eng.kernel_info().startswith("universal"), eng.kernel_info()
+    a = _same_chain(eng, ora, (1, 5, 64, 300), wl="wl" in sp, bias="bias" in sp)
+    acc = a["n_accepted"].sum() / a["n_steps"].sum()
+    assert 0.01 < acc < 0.99
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["BC_fug_flip_int", "BC_sqc_flip_corr", "BG_hyp_flip_int", "BG_sqc_swap_int", "BG_fug_flip_corr"])
+def test_biased_chains_on_the_universal_kernel(tag, monkeypatch):
+    monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+    R = 4
+    tab, cfg, occ0, temp = build(tag, n_replicas=R)
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (R, 1)), np.arange(R, dtype=np.uint64) + np.uint64(77), temp)
+    _same_chain(eng, ora, (1, 9, 400), bias=True)
+    eng.close()
+
+
+@pytest.mark.parametrize("update_period", [1, 3])
+def test_wang_landau_on_the_universal_kernel(update_period, monkeypatch):
+    monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+    tab, cfg, occ0, _ = build("B_wlup3", n_replicas=3)
+    cfg.wl_update_period = update_period
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (3, 1)), [4, 5, 6], 0.0)
+    _same_chain(eng, ora, (1, 59, 61, 500), wl=True)
+    assert (eng.get_wl()["mod_factor"] < 1.0).any()  # the flatness branch fired
+    eng.close()
+
+
+def test_wang_landau_update_period_on_the_general_kernel(monkeypatch):
+    """update_period > 1 forces mc_kernel (engine.hip lean eligibility): native stream vs the oracle."""
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    tab, cfg, occ0, _ = build("B_wlup3", n_replicas=3)
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (3, 1)), [4, 5, 6], 0.0)
+    assert eng.kernel_info().startswith("general"), eng.kernel_info()
+    _same_chain(eng, ora, (1, 59, 61, 500), wl=True)
+    eng.close()
+
+
+def test_device_side_sampling_on_the_universal_kernel(monkeypatch):
+    monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+    R = 3
+    tab, cfg, occ0, temp = build("TG_tf_int", n_replicas=R)
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (R, 1)), [1, 2, 3], temp)
+    smp = eng.run_sampled(6, 25)
+    for i in range(6):
+        ora.run(25)
+        b = ora.get_state()
+        assert np.array_equal(smp["occupancy"][i], b["occupancy"])
+        assert np.array_equal(smp["accepted"][i], b["accepted"])
+        np.testing.assert_allclose(smp["enthalpy"][i], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(smp["features"][i], b["features"], rtol=1e-10, atol=1e-8)
+    eng.close()

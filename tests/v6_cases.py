@@ -111,4 +111,4 @@ def check_wl(mc, tag):
     assert np.array_equal(wl["histogram"][0], g("histogram"))
     assert np.array_equal(wl["occurrences"][0], g("occurrences"))
     np.testing.assert_allclose(wl["mean_features"][0], g("mean_features"), rtol=1e-10, atol=1e-9)
-    np.testing.assert_allclose(wl["mod_factor"], g("mod_factor"))
+    np.testing.assert_allclose(wl["mod_factor"][0], g("mod_factor")[0])
