@@ -2186,6 +2186,9 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&
                              ((two_flip_ok && smolmc_lean_replay_takes(h)) || lean_table_replay);
     const bool general_replay = !lean_replay && !h->univ && two_flip_ok && h->general_ok && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr;
+    if (getenv("SMOLMC_DEBUG"))
+        fprintf(stderr, "[smolmc] replay path=%s max_flips=%d priori_given=%d\n",
+                lean_replay ? (table ? "lean-table" : "lean") : (general_replay ? "general" : "universal"), max_flips, (int)priori_given);
     int *d_steps = nullptr, *d_err = nullptr;
     double *d_u = nullptr, *d_H = nullptr, *d_lp = nullptr, *d_lpo = nullptr;
     uint8_t *d_acc = nullptr;

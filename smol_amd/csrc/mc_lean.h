@@ -350,7 +350,7 @@ template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool WL, bool BIAS 
 __global__ void __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
 __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     static_assert(KF == 0 || (!WL && !BIAS && !SOLO), "correlation-function tables: plain Metropolis layouts only");
-    static_assert(!REPLAY || (!WL && !BIAS && OCC == 0), "replay: plain Metropolis variants (Wang-Landau: mc_wl_kernel)");
+    static_assert(!REPLAY || (!WL && OCC == 0), "replay: Metropolis variants (Wang-Landau: mc_wl_kernel)");
     constexpr int NACC = KF ? KF : 1;
     // EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in
     // LDS.  A template parameter (not the runtime flag ew_field): both variants' pointers and code
@@ -1314,7 +1314,12 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // EWM: 0 = no Ewald term, 1 = compact Ewald with per-proposal row sums, 2 = potential field in LDS.
 // A template parameter, not a runtime flag: the unused variants' pointers and code otherwise stay
 // live across the step loop (the kernel spills SGPRs as it is).
-template <int NSLOT, int MM, int EWM>
+// REPLAY: the steps come from the host as records of SMOLMC_STEP_ROW ints (smolmc_replay: the
+// reference's own proposals in its Generator's order); the kernel derives the table direction of a
+// record from its count changes (_get_flip_id, mcusher.py:641-654), evaluates the a-priori factor with
+// the code of the native path (or takes the given one) and reports accept flag, enthalpy and factor
+// per step.
+template <int NSLOT, int MM, int EWM, bool REPLAY = false>
 __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // (four or eight walkers per workgroup, two waves per SIMD)
     constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1680,18 +1685,18 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #ifdef SMOLMC_EXP_PHASES
         const long long tb0 = clock64();
 #endif
-        if (__builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull); // (first step of a launch)
+        if (!REPLAY && __builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull); // (first step of a launch)
         const int l6 = (int)(step & 63ull);
         const int l4 = (int)(step & 15ull) * 4;
         const uint32_t q_m = rdlane(q_meta, l6);
 #ifdef SMOLMC_NO_TABLE_BATCH // A/B switch: every step through the step-at-a-time proposal
         const bool covered = false;
 #else
-        const bool covered = (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
+        const bool covered = !REPLAY && (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
 #endif
         const uint32_t a01 = rdlane(q_s01, l6), a23 = rdlane(q_s23, l6), pk = rdlane(q_pack, l6);
-        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
-                                           (int)rdlane((uint32_t)__double2loint(q_logu), l6));
+        double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
+                                     (int)rdlane((uint32_t)__double2loint(q_logu), l6));
 #ifdef SMOLMC_EXP_PHASES
         ph_bat += clock64() - tb0;
 #endif
@@ -1787,6 +1792,39 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #ifdef SMOLMC_EXP_PHASES
             ph_cov[0]++;
 #endif
+        } else if (REPLAY) {
+            // the recorded step: lane f <-> flip f
+            const LeanParamsKernarg Q = rare_params();
+            const size_t krec = (size_t)r * (uint32_t)Q->steps + ((uint32_t)Q->steps - steps_left);
+            const int *rec = Q->rp_steps + krec * SMOLMC_STEP_ROW;
+            const int v = lane < SMOLMC_STEP_ROW ? rec[lane] : -1;
+            while (nfl < SMOLMC_MAX_STEP_FLIPS && (int)rdlane((uint32_t)v, 2 * nfl) >= 0) nfl++;
+            const int ra = __shfl(v, 2 * (lane & 7)), rb = __shfl(v, 2 * (lane & 7) + 1); // (uniform control flow)
+            vsite = lane < nfl ? ra : sbase;
+            vnew = lane < nfl ? rb : 0;
+            // sites of the active sublattice, distinct inside a step (what the usher returns, mcusher.py:612-634)
+            bool bad = lane < nfl && (vsite < sbase || vsite >= sbase + (int)nact || vnew < 0 || vnew >= nc);
+            for (int f = 0; f < nfl; ++f) bad |= lane < nfl && lane != f && vsite == (int)rdlane((uint32_t)vsite, f);
+            int rbad = __ballot(bad) != 0ull ? 2 : 0;
+            if (rbad) { nfl = 0; vsite = sbase; vnew = 0; }
+            vold = lane < nfl ? (int)occ[lean_swz(vsite, swa, swm, swb)] : 0;
+            for (int f = 0; f < nfl; ++f)
+                vu += (lane == (int)rdlane((uint32_t)vnew, f)) - (lane == (int)rdlane((uint32_t)vold, f));
+            if (__ballot(lane < nc && vu != 0) != 0ull) { // _get_flip_id (mcusher.py:641-654)
+                const int tfn = Q->tf_n;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < tfn && dir < 0) {
+                        if (__ballot(lane < nc && vtf[i] != vu) == 0ull) dir = 2 * i;
+                        else if (__ballot(lane < nc && -vtf[i] != vu) == 0ull) dir = 2 * i + 1;
+                    }
+                if (dir < 0) { rbad |= 1; nfl = 0; vu = 0; } // "Step ... is not in flip table." (:673-674)
+            }
+            if (rbad && lane == 0) atomicOr(Q->rp_err, rbad);
+            double u = uni_d(Q->rp_u[krec]);
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing
+            lu = log(u);
+            fetch_rows();
         } else {
         word_batch();
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
@@ -1995,7 +2033,13 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_prop[covered ? 0 : 1] += tn - ph_t; ph_prop[2] -= tn; }
 #endif
-        if (dir >= 0) priori_of(dir);
+        if (REPLAY) {
+            const LeanParamsKernarg Q = rare_params();
+            const size_t krec = (size_t)r * (uint32_t)Q->steps + ((uint32_t)Q->steps - steps_left);
+            const double given = Q->rp_lp ? uni_d(Q->rp_lp[krec]) : __builtin_nan("");
+            if (given == given) log_priori = nfl ? given : 0.0;
+            else if (dir >= 0) priori_of(dir);
+        } else if (dir >= 0) priori_of(dir);
 #ifdef SMOLMC_EXP_PHASES
         ph_prop[2] += clock64();
 #endif
@@ -2140,7 +2184,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 if (!(was_all && all_feasible(vcnt))) head_valid = false;
             }
 #ifndef SMOLMC_EXP_NOSTALE // timing experiment only when defined (wrong results)
-            {
+            if (!REPLAY) {
                 // batch lanes whose scan examined a site that has just changed are stale (all 32
                 // kept sites against every flipped site; unused slots hold 0xffff, no site)
                 uint32_t hit = 0u;
@@ -2179,6 +2223,13 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (REPLAY && lane == 0) { // what smolmc_replay returns per step
+            const LeanParamsKernarg Q = rare_params();
+            const size_t krec = (size_t)r * (uint32_t)Q->steps + ((uint32_t)Q->steps - steps_left);
+            Q->rp_acc[krec] = (uint8_t)last_acc;
+            Q->rp_H[krec] = H;
+            if (Q->rp_lp_out) Q->rp_lp_out[krec] = log_priori;
+        }
 
         if (--smp_countdown == 0) {
             const LeanParamsKernarg Q = rare_params(); // (sampling parameters: see rare_params)
@@ -2285,12 +2336,12 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
     return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
-template <int NSLOT, int MM, int EWM>
+template <int NSLOT, int MM, int EWM, bool REPLAY = false>
 static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
     const int wpb = h->lean_wpb;
     const size_t lds = wpb == 8 ? h->lean_lds_wpb8 : h->lean_lds;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = mc_table_kernel<NSLOT, MM, EWM>;
+    auto kern = mc_table_kernel<NSLOT, MM, EWM, REPLAY>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -2302,10 +2353,14 @@ static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
 }
 
 
-template <int NSLOT, int MM>
+template <int NSLOT, int MM, bool REPLAY = false>
 static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
-    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0>(h, lp);
-    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2>(h, lp) : launch_table_ewm<NSLOT, MM, 1>(h, lp);
+    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0, REPLAY>(h, lp);
+    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2, REPLAY>(h, lp) : launch_table_ewm<NSLOT, MM, 1, REPLAY>(h, lp);
+}
+// (instantiated in table_replay_n*.hip only)
+template <int NSLOT> static int launch_table_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_inst<NSLOT, 2, true>(h, lp) : launch_table_inst<NSLOT, 3, true>(h, lp);
 }
 
 // biased Metropolis variants (instantiated in lean_bias_n*.hip only)
@@ -2325,6 +2380,25 @@ template <int NSLOT> static int launch_lean_bias_nslot(smolmc_handle *h, const L
                     : launch_lean_bias_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
     return swap ? launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp)
                 : launch_lean_bias_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
+}
+
+// biased replay variants (instantiated in lean_bias_replay_n*.hip only)
+template <int NSLOT, int MM, int STEP>
+static int launch_lean_bias_replay_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr;
+    if (ew)
+        return mu ? (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, true, 2, false, true, false, 0, 0, true>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, true, 1, false, true, false, 0, 0, true>(h, lp))
+                  : (lp.ew_field ? launch_lean_inst<NSLOT, MM, STEP, false, 2, false, true, false, 0, 0, true>(h, lp) : launch_lean_inst<NSLOT, MM, STEP, false, 1, false, true, false, 0, 0, true>(h, lp));
+    return mu ? launch_lean_inst<NSLOT, MM, STEP, true, 0, false, true, false, 0, 0, true>(h, lp)
+              : launch_lean_inst<NSLOT, MM, STEP, false, 0, false, true, false, 0, 0, true>(h, lp);
+}
+template <int NSLOT> static int launch_lean_bias_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_lean_bias_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp)
+                    : launch_lean_bias_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
+    return swap ? launch_lean_bias_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp)
+                : launch_lean_bias_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
 }
 
 // correlation features with several functions per orbit (instantiated in lean_corr_n*.hip only)

@@ -46,7 +46,6 @@ struct MultiRec { // slot record, 24 bytes
 // instantiated in multi_replay_n*.hip).
 template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
-    static_assert(!REPLAY || !BIAS, "replay: unbiased variants");
     constexpr bool HAS_EW = EWM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -670,6 +669,21 @@ template <int NSLOT> static int launch_multi_replay_nslot(smolmc_handle *h, cons
         return swap ? launch_multi_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
     return swap ? launch_multi_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
 }
+// biased replay variants (multi_bias_replay_n*.hip)
+template <int NSLOT, int MM, int STEP> static int launch_multi_bias_replay_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.m_mu != nullptr;
+    if (lp.ew_field == 1)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, true, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, true, true>(h, lp);
+    if (lp.ew_field == 2)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, true, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, true, true>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, true, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, true, true>(h, lp);
+}
+template <int NSLOT> static int launch_multi_bias_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_multi_bias_replay_me<NSLOT, 2, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_bias_replay_me<NSLOT, 2, SMOLMC_STEP_FLIP>(h, lp);
+    return swap ? launch_multi_bias_replay_me<NSLOT, 3, SMOLMC_STEP_SWAP>(h, lp) : launch_multi_bias_replay_me<NSLOT, 3, SMOLMC_STEP_FLIP>(h, lp);
+}
 template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
     return h->lean_mm == 2 ? launch_multi_nm<NSLOT, 2, true>(h, lp) : launch_multi_nm<NSLOT, 3, true>(h, lp);
 }
@@ -686,7 +700,8 @@ template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const 
 // ONE candidate stream, exactly as the oracle does.
 // ----------------------------------------------------------------------------
 // EWM: 0 = no Ewald term, 1 = potential field in LDS, 2 = in HBM (compile time, see mc_lean_multi_kernel)
-template <int NSLOT, int MM, int EWM>
+// REPLAY: host-provided step records (see mc_table_kernel)
+template <int NSLOT, int MM, int EWM, bool REPLAY = false>
 __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -801,6 +816,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     };
 
     double H = P.enthalpy[r];
+    double H_rp = H; // replay: running enthalpy reported per step
     const double nbeta = -P.beta[r];
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0, nacc_before = 0;
@@ -1054,14 +1070,15 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             compute_head();
             if (feas_now != feas_old) q_stale = ~0ull;
         }
-        if (__builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull);
+        if (!REPLAY && __builtin_expect((uint32_t)(step & ~63ull) != q_base, 0)) propose_batch(step & ~63ull);
         const int l6 = (int)(step & 63ull);
         const uint32_t q_m = rdlane(q_meta, l6);
 #ifdef SMOLMC_NO_TABLE_BATCH // A/B switch: every step through the step-at-a-time proposal
         const bool covered = false;
 #else
-        const bool covered = (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
+        const bool covered = !REPLAY && (q_m & 1u) != 0u && ((q_stale >> l6) & 1ull) == 0ull;
 #endif
+        double lu_rp = 0.0; // replay: log of the recorded uniform
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[0] += tn - ph_t; ph_t = tn; if (covered) ph_cov++; }
 #endif
@@ -1086,6 +1103,50 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 for (int i = 0; i < 8; ++i) vu = (i == (dir >> 1)) ? vtf[i] : vu;
                 vu *= (dir & 1) ? -1 : 1;
             }
+        } else if (REPLAY) {
+            // the recorded step: lane f <-> flip f (see mc_table_kernel)
+            const LeanParamsKernarg Q = rare_params();
+            const size_t krec = (size_t)r * nsteps32 + it_step;
+            const int *rec = Q->rp_steps + krec * SMOLMC_STEP_ROW;
+            const int v = lane < SMOLMC_STEP_ROW ? rec[lane] : -1;
+            while (nfl < SMOLMC_MAX_STEP_FLIPS && (int)rdlane((uint32_t)v, 2 * nfl) >= 0) nfl++;
+            const int ra = __shfl(v, 2 * (lane & 7)), rb = __shfl(v, 2 * (lane & 7) + 1); // (uniform control flow)
+            vsite = lane < nfl ? ra : sel4(P.m_sbase, 0);
+            vnew = lane < nfl ? rb : 0;
+            // sublattice of every flip, its dimension base; sites distinct inside a step
+            int fsub = -1, fbase = 0;
+            {
+                int b = 0;
+                for (int k = 0; k < NS; ++k) {
+                    const int sb = sel4(P.m_sbase, k), na = sel4(P.m_nact, k), nck = sel4(P.m_ncodes, k);
+                    if (vsite >= sb && vsite < sb + na) { fsub = k; fbase = b; if (vnew < 0 || vnew >= nck) fsub = -1; }
+                    b += nck;
+                }
+            }
+            bool bad = lane < nfl && fsub < 0;
+            for (int f = 0; f < nfl; ++f) bad |= lane < nfl && lane != f && vsite == (int)rdlane((uint32_t)vsite, f);
+            int rbad = __ballot(bad) != 0ull ? 2 : 0;
+            if (rbad) { nfl = 0; vsite = sel4(P.m_sbase, 0); vnew = 0; fsub = 0; fbase = 0; }
+            vfsub = lane < nfl ? fsub : 0;
+            vold = lane < nfl ? (int)occ[lean_swz(vsite, swa, swm, swb)] : 0;
+            for (int f = 0; f < nfl; ++f) {
+                const int fb = (int)rdlane((uint32_t)fbase, f);
+                vu += (lane == fb + (int)rdlane((uint32_t)vnew, f)) - (lane == fb + (int)rdlane((uint32_t)vold, f));
+            }
+            if (__ballot(lane < D && vu != 0) != 0ull) { // _get_flip_id (mcusher.py:641-654)
+                const int tfn = Q->tf_n;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < tfn && dir < 0) {
+                        if (__ballot(lane < D && vtf[i] != vu) == 0ull) dir = 2 * i;
+                        else if (__ballot(lane < D && -vtf[i] != vu) == 0ull) dir = 2 * i + 1;
+                    }
+                if (dir < 0) { rbad |= 1; nfl = 0; vu = 0; } // "Step ... is not in flip table." (:673-674)
+            }
+            if (rbad && lane == 0) atomicOr(Q->rp_err, rbad);
+            double u = uni_d(Q->rp_u[krec]);
+            if (u != u) u = 0.0; // NaN: the reference accepted without drawing
+            lu_rp = log(u);
         } else {
         word_batch();
         const uint32_t w_site = l4 == 0 ? w_site_carry : rdlane(W1, l4 - 4);
@@ -1323,6 +1384,11 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), dir),
                                           (int)rdlane((uint32_t)__double2loint(vlp), dir));
         }
+        if (REPLAY) { // a given a-priori factor replaces the kernel's own
+            const LeanParamsKernarg Q = rare_params();
+            const double given = Q->rp_lp ? uni_d(Q->rp_lp[(size_t)r * nsteps32 + it_step]) : __builtin_nan("");
+            if (given == given) log_priori = nfl ? given : 0.0;
+        }
 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[2] += tn - ph_t; ph_t = tn; }
@@ -1458,10 +1524,21 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         if (has_ew) dH += P.ew_coef * dEw;
         if (has_mu) dH -= dMu;
         const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
-        const double lu = __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
-                                           (int)rdlane((uint32_t)__double2loint(q_logu), l6));
+        const double lu = REPLAY ? lu_rp
+                                 : __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
+                                                    (int)rdlane((uint32_t)__double2loint(q_logu), l6));
         const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         nacc_before = nacc_add;
+        if (REPLAY) { // what smolmc_replay returns per step (the enthalpy follows the accepted changes)
+            if (accepted) H_rp += dH;
+            if (lane == 0) {
+                const LeanParamsKernarg Q = rare_params();
+                const size_t krec = (size_t)r * nsteps32 + it_step;
+                Q->rp_acc[krec] = (uint8_t)(accepted ? 1 : 0);
+                Q->rp_H[krec] = H_rp;
+                if (Q->rp_lp_out) Q->rp_lp_out[krec] = log_priori;
+            }
+        }
         // pending feature deltas of the touched classes: keep (accept) or drop (reject)
         for (int cls = 0; cls < NC; ++cls)
             if ((cmask >> cls) & 1u) {
@@ -1490,7 +1567,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 lp_valid = 0u;
                 if (!(was_all && all_feasible(vcnt))) head_valid = false;
             }
-            {
+            if (!REPLAY) {
                 // batch lanes whose scan examined a site that has just changed are stale
                 uint32_t hit = 0u;
                 for (int f = 0; f < nfl; ++f) {
@@ -1588,11 +1665,11 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 
 #undef key0
 #undef key1
-template <int NSLOT, int MM> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, bool REPLAY = false> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1>
-                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2> : mc_table_multi_kernel<NSLOT, MM, 0>);
+    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1, REPLAY>
+                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2, REPLAY> : mc_table_multi_kernel<NSLOT, MM, 0, REPLAY>);
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -1604,6 +1681,10 @@ template <int NSLOT, int MM> static int launch_table_multi_inst(smolmc_handle *h
     return 0;
 }
 
+// (instantiated in multi_table_replay_n*.hip only)
+template <int NSLOT> static int launch_table_multi_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2, true>(h, lp) : launch_table_multi_inst<NSLOT, 3, true>(h, lp);
+}
 template <int NSLOT> static int launch_multi_nslot(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
         return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2>(h, lp) : launch_table_multi_inst<NSLOT, 3>(h, lp);

@@ -1,0 +1,4 @@
+// mc_table_multi_kernel replay instantiations for NSLOT = 8
+#include "mc_lean_multi.h"
+
+int smolmc_launch_multi_table_replay_8(smolmc_handle *h, const LeanParams &lp) { return launch_table_multi_replay_nslot<8>(h, lp); }

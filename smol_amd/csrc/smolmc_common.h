@@ -639,12 +639,12 @@ int smolmc_launch_general_8(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_general_16(smolmc_handle *h, const KParams &kp, int replay);
 int smolmc_launch_lean_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
-// replay instantiations of the TableFlip / biased lean kernels (0 while they are being brought up)
+// replay instantiations of the TableFlip / biased lean kernels (0: those replays take the universal / general kernel)
 #ifndef SMOLMC_HAVE_TABLE_REPLAY
-#define SMOLMC_HAVE_TABLE_REPLAY 0
+#define SMOLMC_HAVE_TABLE_REPLAY 1
 #endif
 #ifndef SMOLMC_HAVE_BIAS_REPLAY
-#define SMOLMC_HAVE_BIAS_REPLAY 0
+#define SMOLMC_HAVE_BIAS_REPLAY 1
 #endif
 int smolmc_launch_table_replay_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_table_replay_4(smolmc_handle *h, const LeanParams &lp);

@@ -1,0 +1,4 @@
+// mc_table_kernel replay instantiations (host-provided step records, smolmc_replay) for NSLOT = 4
+#include "mc_lean.h"
+
+int smolmc_launch_table_replay_4(smolmc_handle *h, const LeanParams &lp) { return launch_table_replay_nslot<4>(h, lp); }

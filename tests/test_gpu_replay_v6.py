@@ -36,6 +36,7 @@ def _env(monkeypatch, kernel):
 
 def _replay(tag, kernel, monkeypatch, derive):
     _env(monkeypatch, kernel)
+    monkeypatch.setenv("SMOLMC_DEBUG", "1")  # the engine names the replay path on stderr
     R = 3
     tab, cfg, occ0, temp = build(tag, n_replicas=R)
     eng = _engine(tab, cfg)
@@ -54,15 +55,28 @@ def _replay(tag, kernel, monkeypatch, derive):
     return info
 
 
+# kernel family the handle of a trajectory gets by default, and the replay path that goes with it
+LEAN_TABLE = {"TC_tf_int", "TC_tfw_int", "TC_tflim_int", "TG_tf_int", "TG6_tf_int"}
+LEAN_PLAIN = {"BC_fug_flip_int", "BG_sqc_swap_int"}  # (lean / lean-multi with an MCBias term)
+
+
 @pytest.mark.parametrize("kernel", ["auto", "universal", "general", "universal-handle", "general-handle"])
 @pytest.mark.parametrize("tag", sorted(SPECS))
-def test_reference_trajectories_replay(tag, kernel, monkeypatch):
+def test_reference_trajectories_replay(tag, kernel, monkeypatch, capfd):
     info = _replay(tag, kernel, monkeypatch, derive=SPECS[tag]["step"] == "table")
+    err = capfd.readouterr().err
+    path = [ln.split("path=")[1].split()[0] for ln in err.splitlines() if "replay path=" in ln][-1]
     sp = SPECS[tag]
     if kernel == "universal-handle" or (kernel == "general-handle" and sp["step"] == "table"):
-        assert info.startswith("universal"), info
-    if kernel == "auto" and sp["step"] == "table" and sp["mode"] == "int" and "wl" not in sp and "bias" not in sp:
-        assert info.startswith("lean"), info  # the TableFlip kernels of config 5
+        assert info.startswith("universal") and path == "universal", (info, path)
+    if kernel == "universal":
+        assert path == "universal"
+    if kernel in ("general", "general-handle") and sp["step"] != "table":
+        assert path == "general", (info, path)
+    if kernel == "auto" and tag in LEAN_TABLE:
+        assert info.startswith("lean") and path == "lean-table", (info, path)  # the TableFlip kernels of config 5
+    if kernel == "auto" and tag in LEAN_PLAIN:
+        assert info.startswith("lean") and path == "lean", (info, path)
 
 
 @pytest.mark.parametrize("kernel", ["auto", "universal"])
