@@ -151,3 +151,49 @@ def test_device_side_sampling_on_the_universal_kernel(monkeypatch):
         np.testing.assert_allclose(smp["enthalpy"][i], b["enthalpy"], rtol=1e-10, atol=1e-8)
         np.testing.assert_allclose(smp["features"][i], b["features"], rtol=1e-10, atol=1e-8)
     eng.close()
+
+
+def test_more_than_1024_clusters_per_site(monkeypatch):
+    """1429 clusters per site (pairs <= 7 A, triplets <= 6.5 A on FCC): beyond the 16 slot groups of
+    mc_kernel -- the reference has no such limit (processor/expansion.py:120-163); the universal
+    kernel walks the reference's own per-site tables."""
+    from smol_amd import synth
+
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 7.0, 3: 6.5})
+    sc = synth.build_supercell(model, [7, 7, 7])
+    assert sum(rows.shape[0] for _, rows, _ in sc.local_tables()[0]) > 1024
+    coefs = synth.random_coefs(model, seed=3)
+    R = 3
+    occ = (np.random.default_rng(1).random((R, sc.num_sites)) < 0.4).astype(np.int32)
+    for mode, step in (("int", capi.STEP_SWAP), ("corr", capi.STEP_FLIP)):
+        tab = capi.TableSet.from_synth(sc, coefs, feature_mode=MODES[mode])
+        eng, ora = _pair(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, step), occ, [7, 8, 9], 1500.0)
+        assert "more than 1024 clusters per site" in eng.kernel_info(), eng.kernel_info()
+        a = _same_chain(eng, ora, (1, 40, 160))
+        np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-7)
+        assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+        eng.close()
+
+
+def test_occupancy_beyond_lds_runs_from_hbm(monkeypatch):
+    """A 64^3 binary FCC cell (262 144 sites): the occupancy of one walker exceeds a workgroup's
+    LDS, the universal kernel keeps it in HBM (one byte per site, L2-resident) -- three walkers
+    against the oracle."""
+    from smol_amd import synth
+
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    monkeypatch.delenv("SMOLMC_UNIV_OCC_HBM", raising=False)
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 3.0})
+    sc = synth.build_supercell(model, [64, 64, 64])
+    assert sc.num_sites == 262144
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=4))
+    R = 3
+    occ = (np.random.default_rng(2).random((R, sc.num_sites)) < 0.5).astype(np.int32)
+    eng, ora = _pair(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP), occ, [1, 2, 3], 900.0)
+    info = eng.kernel_info()
+    assert info.startswith("universal occ=hbm") and "does not fit LDS" in info, info
+    a = _same_chain(eng, ora, (1, 64, 400))
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    assert np.array_equal(a["occupancy"].sum(axis=1), occ.sum(axis=1))  # canonical
+    eng.close()
