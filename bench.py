@@ -307,6 +307,15 @@ class _Clock:
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.red_dev)
         return parallel.global_sums(t).cpu().numpy()
 
+    def max(self, values):
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.red_dev)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
 
 def hbm_ce(rec):  # 56 algorithmic bytes per CE flip
     a = rec["flips_per_s"] * ALGO_BYTES_PER_FLIP / 1e9
@@ -462,6 +471,7 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
                                                 "exchange step, mc_steps_per_s_kernel_only from the HIP events"),
            per * world, launches=30, exchange_every_steps=wl5.mc_per_launch,
            exchange_acceptance_mean=float(rex.acceptance.mean()),
+           exchange_latency_ms_per_sweep=float(clock.max([rex.exchange_seconds / max(rex.exchange_timed, 1) * 1e3])[0]),
            exchange_path="collective (all-gather over %d ranks)" % world if world > 1 else "single rank (direct read-back)")
     if world == 1:
         # BASELINE's own ladder for config 5 (400-2000 K): equilibrated it accepts 0.1 % of its steps
@@ -568,6 +578,7 @@ def main():
     ap.add_argument("--features", choices=("interactions", "correlations"), default="interactions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 4096-walkers-in-total measurement on N > 1 ranks")
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--oversubscribe", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -617,6 +628,21 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # how many ranks actually take part in the collectives: an all-reduce of ones over the backend the
+    # job runs on; the job refuses to report a number when that is not --gpus
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(ones.item())))
+        collective_backend = ("nccl (RCCL %s over xGMI)" % ".".join(str(v) for v in torch.cuda.nccl.version())
+                              if backend == "nccl" else "gloo (host-staged; --oversubscribe)")
+    else:
+        rccl_ranks, collective_backend = 1, "none (single rank: no process group, no collective on the path)"
+    if rccl_ranks != args.gpus:
+        sys.stderr.write(f"bench.py: {rccl_ranks} ranks took part in the all-reduce, --gpus {args.gpus}\n")
+        raise SystemExit(4)
+
     from smol_amd import capi, parallel, workloads
     from smol_amd.engine import Engine
 
@@ -630,7 +656,6 @@ def main():
     wl = workloads.config2(first, R, feature_mode=mode, mc=args.mc_per_step)
     eng = Engine(wl.tables, wl.make_config(device))
     eng.set_state(wl.occupancy, wl.seeds, wl.temperature)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -664,6 +689,36 @@ def main():
     )
     # global averages: the only collective on this path (RCCL all-reduce)
     stats = parallel.global_sums(stats).cpu().numpy()
+    kms_lo = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
+    kms_hi = kms_lo.clone()
+    if world > 1:
+        dist.all_reduce(kms_lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(kms_hi, op=dist.ReduceOp.MAX)
+    # north_star's "at 4096 replicas" next to the weak figure: 4096 walkers IN TOTAL, 4096 / N per GPU,
+    # the same number of launches (one rank: the headline measurement is that figure already)
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        eng.close()
+        f2, R2 = parallel.shard(N_REPLICAS, rank, world)
+        wl2 = workloads.config2(f2, R2, feature_mode=mode, mc=args.mc_per_step)
+        eng = Engine(wl2.tables, wl2.make_config(device))
+        eng.set_state(wl2.occupancy, wl2.seeds, wl2.temperature)
+        for _ in range(min(args.warmup, 2)):
+            eng.run(args.mc_per_step)
+        eng.sync()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.run(args.mc_per_step)
+        eng.sync()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        tt = torch.tensor([dt2], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt2 = float(tt.item())
+        strong = {"replicas_total": N_REPLICAS, "replicas_per_gpu": R2, "ms_per_step": dt2 / args.steps * 1e3,
+                  "value": 2.0 * args.steps * args.mc_per_step * N_REPLICAS / dt2, "unit": "attempted flips/s",
+                  "scaling": "strong"}
 
     if rank == 0:
         n_walk = stats[3]
@@ -735,6 +790,13 @@ def main():
             "acceptance_ratio": stats[0] / (args.steps * args.mc_per_step * n_walk),
             "mean_enthalpy_per_site_eV": stats[1] / n_walk / wl.sc.num_sites,
             "kernel_ms_mean_over_ranks": stats[4] / world,
+            "kernel_ms_min_over_ranks": float(kms_lo.item()),
+            "kernel_ms_max_over_ranks": float(kms_hi.item()),
+            "rccl_ranks": rccl_ranks,
+            "collective_backend": collective_backend,
+            "strong_scaling_4096_total": strong if strong is not None else (
+                {"replicas_total": int(n_walk), "value": value, "unit": "attempted flips/s", "scaling": "strong",
+                 "note": "one rank: identical to the headline measurement"} if world == 1 and R == N_REPLICAS else None),
             "roofline": roof,
         }
         assert int(n_walk) == total_walkers

@@ -174,7 +174,8 @@ typedef struct smolmc_config {
     /* Wang-Landau parameters (kernel/wanglandau.py:26-39) */
     double wl_min_enthalpy, wl_max_enthalpy, wl_bin_size;
     double wl_flatness, wl_mod_factor, wl_mod_divisor; /* mod_update = m / divisor */
-    int64_t wl_check_period, wl_update_period;
+    int64_t wl_check_period, wl_update_period; /* check period 0: no device-side flatness check (the
+                                                * caller checks and applies its own mod_update callable) */
 } smolmc_config;
 
 typedef struct smolmc_handle smolmc_handle;

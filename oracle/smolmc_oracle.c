@@ -846,7 +846,7 @@ static int do_step(orc_mc *h, int r, const int32_t *flips, int nflips, double u,
                 h->wl_occur[r * L + b] += 1;
             }
         }
-        if (h->wl_counter[r] % h->cfg.wl_check_period == 0) { /* :253-264 */
+        if (h->cfg.wl_check_period != 0 && h->wl_counter[r] % h->cfg.wl_check_period == 0) { /* :253-264; 0 = no check (smolmc.h) */
             const double *S = h->wl_entropy + r * L;
             int64_t *H = h->wl_hist + r * L;
             long cnt = 0;

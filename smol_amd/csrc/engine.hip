@@ -677,13 +677,18 @@ static int validate_tables(const smolmc_tables *t) {
         if (t->orb_stride_off[o] != nstr) return fail("orb_stride_off does not follow the orbit sizes");
         nstr += t->orb_nsites[o];
         // the largest flat tensor index a cluster of this orbit can form must lie inside the tensor
-        long long reach = 0;
+        // (strides of a row-major tensor over the site spaces of the cluster, orbit.py:268-275: member m
+        // has orb_tensor_len / stride_0 species for m = 0 and stride_{m-1} / stride_m after that; the
+        // largest flat index sum_m (species_m - 1) stride_m is then orb_tensor_len - 1)
+        long long prev = t->orb_tensor_len[o], reach = 0;
         for (int m = 0; m < t->orb_nsites[o]; ++m) {
             const int st = t->tensor_indices[t->orb_stride_off[o] + m];
             if (st <= 0) return fail("tensor stride must be positive");
-            reach = std::max<long long>(reach, st);
+            if (st > prev || prev % st != 0) return fail("tensor strides do not describe a row-major tensor");
+            reach += (prev / st - 1) * st;
+            prev = st;
         }
-        if (reach > t->orb_tensor_len[o]) return fail("tensor stride larger than its tensor");
+        if (reach >= t->orb_tensor_len[o]) return fail("tensor strides reach beyond their tensor");
         const int64_t a = t->full_off[o], b = t->full_off[o + 1];
         if (b < a || (b - a) % t->orb_nsites[o] != 0) return fail("full_off does not describe whole cluster rows");
         for (int64_t i = a; i < b; ++i)
@@ -1009,6 +1014,24 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             }
         }
     }
+    // ... and on every other site the width of its site space as the cluster tensors see it: member m of
+    // an orbit's rows has prev_stride / stride species (see validate_tables); a code beyond that would
+    // index past the tensors
+    {
+        std::vector<int> seen((size_t)t->num_sites, 0);
+        for (int o = 0; o < t->n_orb; ++o) {
+            const int I = t->orb_nsites[o];
+            const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
+            for (int64_t i = t->full_off[o]; i < t->full_off[o + 1]; ++i) {
+                const int m = (int)((i - t->full_off[o]) % I);
+                const int width = (int)((m == 0 ? t->orb_tensor_len[o] : st[m - 1]) / st[m]);
+                const int site = t->full_idx[i];
+                seen[site] = seen[site] ? std::min(seen[site], width) : width;
+            }
+        }
+        for (int s = 0; s < t->num_sites; ++s)
+            if (!h->site_active[s] && seen[s]) h->site_ncodes[s] = (uint8_t)std::min<int>(h->site_ncodes[s], std::min(255, seen[s]));
+    }
     if (int rc = build_mc_tables(h, t)) return bail(rc);
     if (int rc = build_ref_tables(h, t)) return bail(rc);
     kp.N = h->N;
@@ -1122,7 +1145,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         kp.wl_div = cfg->wl_mod_divisor;
         kp.wl_check = cfg->wl_check_period;
         kp.wl_update = cfg->wl_update_period;
-        if (kp.wl_check <= 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
+        // (check period 0: the flatness check is the caller's -- a host-side mod_update callable,
+        // wanglandau.py:100-105 -- and no kernel runs its own)
+        if (kp.wl_check < 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
         if (h->F > 64) return bail(fail("Wang-Landau supports at most 64 features"));
         if (dev_alloc(h, R * h->L, &kp.wl_entropy) || dev_alloc(h, R * h->L, &kp.wl_hist) ||
             dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F + 64, &kp.wl_meanf) || // (+64: the lean kernel's all-lane atomic, see mc_lean.h)

@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
                     }
                 }
             }
-            if (wl_counter % PK.wl_check == 0) {
+            if (PK.wl_check != 0 && wl_counter % PK.wl_check == 0) { // (check period 0: no device-side check)
                 long cnt = 0;
                 double sum = 0;
                 for (int i = lane; i < PK.L; i += 64)

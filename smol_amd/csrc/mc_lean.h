@@ -507,7 +507,7 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     long long wl_counter = WL ? P.wl.counter[r] : 0;
     // counter modulo the check period, carried instead of recomputed (a 64-bit
     // modulo by a runtime divisor every step costs more than the step's arithmetic)
-    long long wl_rem_check = WL ? wl_counter % P.wl.check : 0;
+    long long wl_rem_check = WL ? (P.wl.check ? wl_counter % P.wl.check : 1) : 0; // (check period 0: never reaches it)
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0; // accepted steps of this launch (32-bit counter; < 2^31 steps per launch)
     const uint32_t key0 = (uint32_t)P.seeds[r], key1 = (uint32_t)(P.seeds[r] >> 32);

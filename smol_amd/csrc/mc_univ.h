@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // lane 0's entropy update before the next step's reads
             }
-            if (wl_counter % P.wl_check == 0) {
+            if (P.wl_check != 0 && wl_counter % P.wl_check == 0) { // (check period 0: no device-side check)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 long cnt = 0;
                 double sum = 0;

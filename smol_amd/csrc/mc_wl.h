@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     const long long wl_counter0 = P.wl.counter[r];
     // counter modulo the check period (the host refuses periods >= 2^31)
     const uint32_t wl_check = (uint32_t)P.wl.check;
-    uint32_t wl_rem_check = (uint32_t)uni((int)(wl_counter0 % P.wl.check));
+    // (check period 0 = no device-side check: the remainder starts at 1 and cannot wrap to 0 inside a launch of < 2^30 steps)
+    uint32_t wl_rem_check = wl_check ? (uint32_t)uni((int)(wl_counter0 % P.wl.check)) : 1u;
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0, nacc_before = 0;
     const uint32_t key0_ = (uint32_t)P.seeds[r], key1_ = (uint32_t)(P.seeds[r] >> 32);

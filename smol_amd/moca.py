@@ -1328,13 +1328,13 @@ class Sampler:
                 tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty,
                                 intercepts=getattr(k0.bias, "intercepts", None))
             if isinstance(k0, WangLandau):
-                # (a callable mod_update: flatness checks on the host, the device's own period is
-                # set out of reach)
+                # (a callable mod_update: flatness checks on the host, check period 0 switches the
+                # device's own check off)
                 cfg = capi.make_config(
                     len(self._kernels), capi.KERNEL_WANGLANDAU, STEP_TYPES[k0.step_type], self._device,
                     min_enthalpy=k0._window[0], max_enthalpy=k0._window[1], bin_size=k0._window[2],
                     flatness=k0.flatness, mod_factor=k0._m0, mod_update=k0._mod_divisor,
-                    check_period=(1 << 31) - 1 if k0._mod_callable is not None else k0.check_period,
+                    check_period=0 if k0._mod_callable is not None else k0.check_period,
                     update_period=k0.update_period,
                 )
             else:
@@ -1497,8 +1497,9 @@ class Sampler:
         return ck
 
     def restore_aux(self, checkpoint):
-        """Put a checkpoint of ``aux_checkpoint`` back: occupancies (continuation: the aux state is
-        not reset), counters and the Wang-Landau arrays."""
+        """Put a checkpoint of ``aux_checkpoint`` back in a (possibly fresh) engine handle: occupancies
+        and seeds with ``reset_aux=True`` -- the seeds only travel with a reset, smolmc.h -- then the
+        checkpoint's counters and Wang-Landau arrays on top of the reset state."""
         eng = self._get_engine()
         seeds = np.array([k.seed64 for k in self._kernels], dtype=np.uint64)
         eng.set_state(self._local_occupancies(checkpoint["occupancy"]), seeds, self._temperatures(), reset_aux=True)

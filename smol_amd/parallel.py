@@ -115,6 +115,8 @@ class ReplicaExchange:
         self.seed = int(seed)
         self.rung_of = np.arange(self.n)  # walker -> rung
         self.calls = 0
+        self.exchange_seconds = 0.0  # host wall time spent in exchange steps (run_replica_exchange), walkers idle
+        self.exchange_timed = 0
         self.attempted = np.zeros(self.n - 1, dtype=np.int64)
         self.accepted = np.zeros(self.n - 1, dtype=np.int64)
 
@@ -207,9 +209,14 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         buf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
         tbuf = torch.empty(rex.per_rank, dtype=torch.float64, device=dev)
+    import time
+
     engine.set_temperature(rex.local_temperatures())
     for _ in range(n_exchanges):
         engine.run(steps_between)
+        if hasattr(engine, "sync"):
+            engine.sync()  # (the exchange needs the launch's enthalpies anyway; timed from here: its own latency)
+        t_ex = time.perf_counter()
         if on_device:
             engine.export_enthalpy(buf.data_ptr())
             new_t = rex.exchange(buf, force_collective=True)
@@ -222,4 +229,6 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
         else:
             rex.decide(engine.get_enthalpy())
             engine.set_temperature(rex.local_temperatures())
+        rex.exchange_seconds += time.perf_counter() - t_ex
+        rex.exchange_timed += 1
     return rex

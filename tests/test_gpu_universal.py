@@ -197,3 +197,27 @@ def test_occupancy_beyond_lds_runs_from_hbm(monkeypatch):
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
     assert np.array_equal(a["occupancy"].sum(axis=1), occ.sum(axis=1))  # canonical
     eng.close()
+
+
+def test_more_than_eight_flip_vectors(monkeypatch):
+    """Nine flip vectors (integer combinations of the two basis vectors of the cation + anion table,
+    up to eight flips per step): beyond the eight vector registers of the lean TableFlip kernels --
+    the reference takes any table (mcusher.py:397-551); oracle and universal kernel agree."""
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    from tests.cases import load_case
+
+    v1, v2 = np.array([1, -3, 2, 0, 0]), np.array([1, -1, 0, -2, 2])
+    table = np.array([v1, v2, v1 + v2, 2 * v1, v1 - v2, 2 * v2, 2 * v1 - v2, v1 - 2 * v2, 2 * v1 - 2 * v2])
+    assert len(table) == 9 and max(int(-r[r < 0].sum()) for r in table) == 8
+    c = load_case("rocksalt333_two_sublattices")
+    weights = np.linspace(0.5, 2.0, 18)
+    tab = capi.TableSet.from_synth(c["sc"], c["coefs"], ewald=c["ewald"], ewald_coef=0.1, mu_table=T6["TG_mu"],
+                                   flip_table=table, flip_weights=weights, swap_weight=0.15)
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    eng, ora = _pair(tab, cfg, np.tile(T6["TG_occ0"], (R, 1)), np.arange(R, dtype=np.uint64) + np.uint64(31), 6000.0)
+    assert eng.kernel_info().startswith("universal"), eng.kernel_info()
+    a = _same_chain(eng, ora, (1, 30, 500))
+    assert 0.01 < a["n_accepted"].sum() / a["n_steps"].sum() < 0.99
+    eng.close()
