@@ -105,26 +105,52 @@ __device__ __forceinline__ void accum_slot(const GenHot &P, const bool acc_by_sl
 // Ewald delta of one flip (ewald.pyx:38-58), wave-parallel over sites; returns the
 // lane-partial (caller reduces).  Reads ROWS of the transposed matrix, i.e. the same
 // entries M[i, add] / M[j, sub] the reference reads as columns.
+// The sum is a streaming gather -- per site one LDS byte (species), one index-table entry (L2) and one
+// entry of each of the two rows (HBM: the matrix of BASELINE config 3 is 382 MB) -- i.e. a chain of
+// three dependent loads per site.  Site by site that chain is all a wave does (measured, round 4:
+// 2650 cycles per site and lane, 1.9 TB/s of HBM fetch at two waves per SIMD); here U = 8 sites per
+// lane are in flight together: their species, then their eight index entries, then their sixteen
+// row entries are issued back to back, one exposed latency per stage and batch.
+// Every site k != s keeps its index (i == j) and that index is neither `add` nor `sub` (those belong
+// to site s), so its term is 2 (M[i, add] - M[i, sub]); site s itself contributes the diagonal
+// entries M[add, add] - M[sub, sub] (ewald.pyx:46-57 with i == add, j == sub).
 template <bool PATCH, typename PT>
 __device__ __forceinline__ double ewald_partial(const PT &P, const Lds &L, int lane, int s,
                                                 int oldc, int newc, int ps, int pc) {
-    const int W = P.ew_W;
-    const int add = P.ew_inds[(size_t)s * W + newc];
-    const int sub = P.ew_inds[(size_t)s * W + oldc];
+    constexpr int U = 8;
+    const int W = P.ew_W, N = P.N;
+    const int *inds = P.ew_inds;
+    const int add = inds[(size_t)s * W + newc];
+    const int sub = inds[(size_t)s * W + oldc];
     const double *radd = P.ew_Mt + (size_t)(add < 0 ? 0 : add) * P.ew_M;
     const double *rsub = P.ew_Mt + (size_t)(sub < 0 ? 0 : sub) * P.ew_M;
+    const double fa = add < 0 ? 0.0 : 2.0, fs = sub < 0 ? 0.0 : 2.0;
     double out = 0;
-    for (int k = lane; k < P.N; k += 64) {
-        int v = L.occ[k];
-        if (PATCH) v = (k == ps) ? pc : v;
-        int vf = (k == s) ? newc : v;
-        int i = P.ew_inds[(size_t)k * W + vf];
-        int j = (k == s) ? P.ew_inds[(size_t)k * W + v] : i;
-        double o = 0;
-        if (i != -1 && add != -1) o += (i != add ? 2.0 : 1.0) * radd[i];
-        if (j != -1 && sub != -1) o -= (j != sub ? 2.0 : 1.0) * rsub[j];
-        out += o;
+    for (int k0 = lane; k0 < N; k0 += 64 * U) {
+        int kk[U], ii[U];
+        double va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kk[u] = min(k0 + 64 * u, N - 1); // (clamped: loads only; masked below)
+            int v = L.occ[kk[u]];
+            if (PATCH) v = (kk[u] == ps) ? pc : v;
+            ii[u] = (int)((uint32_t)kk[u] * (uint32_t)W + (uint32_t)v);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ii[u] = inds[ii[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = ii[u] < 0 ? 0 : ii[u];
+            va[u] = radd[i];
+            vb[u] = rsub[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = k0 + 64 * u < N && kk[u] != s && ii[u] >= 0;
+            out += live ? fa * va[u] - fs * vb[u] : 0.0;
+        }
     }
+    if (lane == 0) out += (add < 0 ? 0.0 : radd[add]) - (sub < 0 ? 0.0 : rsub[sub]);
     return out;
 }
 

@@ -579,15 +579,16 @@ def test_device_side_sampling_equals_stepwise(name, mode, step, mukind, general,
     assert smp2["occupancy"] is None and smp2["enthalpy"].shape == (2, R)
 
 
+@pytest.mark.parametrize("case", ["rocksalt444_ewald", "rocksalt333_vacancy_ewald"])
 @pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP])
-def test_compact_ewald_matches_dense_rows_and_oracle(step, monkeypatch):
+def test_compact_ewald_matches_dense_rows_and_oracle(step, case, monkeypatch):
     """The factorised Ewald delta (site kernel G, enabled when ewald_charges are given and
     the matrix is of product form) against the dense two-row form of ewald.pyx:38-58 and
     the CPU oracle: same accept decisions, enthalpies to 1e-10."""
     from oracle import oracle as orc
 
-    c = load_case("rocksalt444_ewald")
-    tab = tables_for("rocksalt444_ewald", MODES["int"], mu_table=_mu("mu3", c))
+    c = load_case(case)  # (the vacancy case: Ewald index -1 entries in the batched dense gather)
+    tab = tables_for(case, MODES["int"], mu_table=_mu("mu3", c))
     assert tab.struct.ewald_charges  # charges travel with the synthetic tables
     R = 5
     cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
