@@ -1182,8 +1182,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
         bool lean = h->lean_tables && h->F <= 64 &&
-                    (!wl || (!t->has_ewald && !t->has_mu && cfg->wl_update_period == 1 && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
-                             getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr)) &&
+                    (!wl || (cfg->wl_update_period == 1 && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
+                             getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr && (getenv("SMOLMC_WL_PLAIN_ONLY") == nullptr || (!t->has_ewald && !t->has_mu)))) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
                     h->lean_nslot <= 4 && getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
@@ -1316,6 +1316,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     h->lean_lds = with_field;
                 }
             }
+            // Wang-Landau with the Ewald term: mc_wl_kernel takes it from the field in LDS only
+            // (also what the round-2 kernel SMOLMC_WL_V2 cannot do: no Ewald, no mu)
+            if (lean && wl && t->has_ewald && !lp.ew_field) lean = false;
+            if (lean && wl && (t->has_ewald || t->has_mu) && getenv("SMOLMC_WL_V2") != nullptr) lean = false;
             // one wave per workgroup (occupancy at LDS address 0, 32-bit index rows, a private
             // copy of the tables): Metropolis flips / swaps without Ewald term or bias, when 16
             // such workgroups still fit a CU

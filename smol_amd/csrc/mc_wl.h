@@ -86,15 +86,23 @@ __device__ __noinline__ void wl_evict_row(double *grow, double *crow, int F, int
 }
 
 // REPLAY: proposals and uniforms from the host in the reference's draw order (see mc_lean_kernel).
-template <int NSLOT, int MM, int STEP, bool REPLAY = false>
+// HAS_MU: semigrand Wang-Landau -- one chemical-potential row on the active sublattice; the chemical
+// work joins the enthalpy (ensemble.py:368-374) and is a feature of its own, carried as a uniform
+// scalar beside the per-slot accumulators (its run-integrated sum goes to the bin rows like theirs).
+// EWF: Ewald term from the walker's potential field in LDS: O(1) per proposal, one field
+// sweep per accepted step; these steps take the exact float64 decision (the Ewald delta is of the
+// order of eV and would have to be carried through the float32 error bound).
+template <int NSLOT, int MM, int STEP, bool REPLAY = false, bool HAS_MU = false, bool EWF = false>
 __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
     const int r = uni(blockIdx.x * nwaves + wave);
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (size_t)P.wl.L * 24 + (size_t)WL_ROWS * P.F * 8;
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (size_t)P.wl.L * 24 + (size_t)WL_ROWS * P.F * 8 +
+                            (EWF ? (size_t)P.ew_nact * 8 : 0);
     double *s_dt = (double *)smem;
+    double *s_mu = s_dt + P.dt_len, *s_q = s_mu + 8, *s_dg = s_mu + 16; // [8] each: mu / charge / diagonal term per code
     unsigned char *wbase = (unsigned char *)(s_dt + P.dt_len + 24) + (size_t)wave * per_wave;
     uint8_t *occ = wbase; // indexed by SWIZZLED site address
     double *s_cell = (double *)(wbase + P.Nlds); // 64 doubles: shadow copies of a run's feature sums
@@ -104,8 +112,14 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     WlBin *wl_rec = (WlBin *)(s_cell + 64) + 1;
     const uint32_t rec0 = (uint32_t)(uintptr_t)wl_rec; // LDS byte address of bin 0's record
     double *s_rows = (double *)(wl_rec + P.wl.L + 1);   // cached rows of per-bin feature sums [WL_ROWS][F]
+    double *phi = s_rows + (size_t)WL_ROWS * P.F;       // EWF: Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
+    if (threadIdx.x < 8) {
+        s_mu[threadIdx.x] = (HAS_MU && threadIdx.x < P.ncodes) ? P.mu_row[threadIdx.x] : 0.0;
+        s_q[threadIdx.x] = EWF ? P.ew_qrow[threadIdx.x] : 0.0;
+        s_dg[threadIdx.x] = EWF ? P.ew_dgrow[threadIdx.x] : 0.0;
+    }
     const bool live = r < P.R;
     if (live) {
         const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
@@ -122,9 +136,16 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             g.S = 0.0; g.hist = 0; g.occur = 0;
         }
         for (int i = lane; i < WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
+        if (EWF)
+            for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
     }
     __syncthreads();
     if (!live) return;
+    // uniform feature scalars: accepted chemical work / Ewald energy since the launch started, and their
+    // sums over the steps of the current run (what the per-slot acc / run are for the cluster features)
+    double acc_mu = 0.0, acc_ew = 0.0, run_mu = 0.0, run_ew = 0.0;
+    const int f_ew = P.Fce, f_mu = P.Fce + (EWF ? 1 : 0);
+    const double ew_coef = EWF ? P.ew_coef : 0.0;
 
     // per-lane slot constants (registers for the whole launch)
     uint32_t doff8[NSLOT], st8[NSLOT][MM], sfeat[NSLOT];
@@ -250,6 +271,12 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             __hip_atomic_fetch_add(&s_cell[scell[it]], sfs[it] * run[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             run[it] = 0.0;
         }
+        if ((HAS_MU || EWF) && lane == 0) { // (copy 0 of the scalar features' cells)
+            if (EWF) __hip_atomic_fetch_add(&s_cell[f_ew], run_ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (HAS_MU) __hip_atomic_fetch_add(&s_cell[f_mu], run_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        run_mu = 0.0;
+        run_ew = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) pend_c[k] = s_cell[wl_rd[k]];
         if (zero_lane) s_cell[lane] = 0.0;
@@ -258,11 +285,26 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
         run_n = 0;
         pend_bin = bin_of_run;
     };
-    auto exact_enthalpy = [&]() -> double { // H0 + sum over lanes and slots of w * acc
+    auto exact_enthalpy = [&]() -> double { // H0 + sum over lanes and slots of w * acc (+ Ewald, - chemical work)
         double le = 0.0;
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) le = fma(wgt[it], acc[it], le);
-        return H0 + wave_sum_all(le);
+        return H0 + (wave_sum_all(le) + ew_coef * acc_ew - acc_mu);
+    };
+    // current features through the (zero) shadow cells: f0 + sum over lanes and slots of fs * acc, + the scalars
+    auto current_features = [&]() -> double {
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it)
+            __hip_atomic_fetch_add(&s_cell[scell[it]], sfs[it] * acc[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if ((HAS_MU || EWF) && lane == 0) {
+            if (EWF) __hip_atomic_fetch_add(&s_cell[f_ew], acc_ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (HAS_MU) __hip_atomic_fetch_add(&s_cell[f_mu], acc_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        double fcur = f0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fcur += s_cell[wl_rd[k]];
+        if (zero_lane) s_cell[lane] = 0.0;
+        return fcur;
     };
 
     int s1, a1;
@@ -441,6 +483,23 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 n1 = o2;
             }
             (void)nfl;
+            // chemical work and Ewald delta of the proposal (uniform; ensemble.py:368-374, ewald.pyx:38-58
+            // through the potential field: flip 2 of a swap sees flip 1 through the cross term G[s2][s1])
+            double dMu = 0.0, dEw = 0.0, dq1 = 0.0, dq2 = 0.0;
+            if (HAS_MU && nfl >= 1) {
+                dMu = s_mu[n1] - s_mu[o1];
+                if (STEP == SMOLMC_STEP_SWAP && nfl == 2) dMu += s_mu[n2] - s_mu[o2];
+            }
+            if (EWF && nfl >= 1) {
+                dq1 = s_q[n1] - s_q[o1];
+                dEw = 2.0 * dq1 * phi[s1 - sbase] + (s_dg[n1] - s_dg[o1]);
+                if (STEP == SMOLMC_STEP_SWAP && nfl == 2) {
+                    dq2 = s_q[n2] - s_q[o2];
+                    const double cross = s2 != s1 ? P.ew_G[(size_t)s2 * P.ew_nact + (s1 - sbase)] : 0.0;
+                    dEw += 2.0 * dq2 * (phi[s2 - sbase] + dq1 * cross) + (s_dg[n2] - s_dg[o2]);
+                }
+                dEw = uni_d(dEw);
+            }
             __builtin_amdgcn_s_setprio(2);
             WL_PHASE(1)
             RowWords<NW> row2 = row1;
@@ -493,8 +552,8 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 nb = min(max(nb, 0), Lm1);
             }
 #endif
-            if (!force_exact && !decided) {
-                const float S32 = wave_sum_f32_uniform((float)e);
+            if (!EWF && !force_exact && !decided) {
+                const float S32 = wave_sum_f32_uniform((float)((HAS_MU && lane == 0) ? e - dMu : e));
                 dHa = (double)S32;
                 // proposed enthalpy in bins from the window start; the bin is certain when the
                 // fractional part is further from 0 and 1 than the tolerance (and the value inside
@@ -518,7 +577,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 }
             }
             if (!decided) { // exact: float64 delta, exact current enthalpy, exact floor division
-                const double dH = wave_sum_all(e);
+                const double dH = wave_sum_all(e) + ew_coef * dEw - dMu;
                 const double Hx = exact_enthalpy();
                 const double new_h = Hx + dH;
                 hoff = Hx - vmin;
@@ -540,6 +599,15 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 if (STEP == SMOLMC_STEP_FLIP) occ[va1] = (uint8_t)n1;
                 if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
                 sel_hi = 0x3ff00000u;
+                acc_mu += dMu;
+                acc_ew += dEw;
+                if (EWF) {
+                    if (STEP == SMOLMC_STEP_SWAP) {
+                        if (dq1 != 0.0 || dq2 != 0.0) field_apply2(P, phi, lane, s1, dq1, s2, dq2);
+                    } else if (dq1 != 0.0) {
+                        field_apply<1>(P, phi, lane, s1, dq1);
+                    }
+                }
                 hoff += dHa;
                 xb32 = (float)(hoff * inv_bin);
                 if (++since_sync >= resync_after) force_exact = true;
@@ -559,6 +627,8 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                     acc[it] = fma(sel, d1[it], acc[it]);
                     run[it] += acc[it];
                 }
+                if (HAS_MU) run_mu += acc_mu;
+                if (EWF) run_ew += acc_ew;
                 nacc_add += sh >> 29;
             }
             run_n++;
@@ -603,14 +673,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             smp_index++;
             // a pending flush owns pend_c (its cells were already zeroed): hand it over first
             pend_commit();
-            // current features = f0 + sum over lanes and slots of fs * acc, through the (zero) cells
-#pragma unroll
-            for (int it = 0; it < NSLOT; ++it)
-                __hip_atomic_fetch_add(&s_cell[scell[it]], sfs[it] * acc[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            double fcur = f0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) fcur += s_cell[wl_rd[k]];
-            if (zero_lane) s_cell[lane] = 0.0;
+            const double fcur = current_features();
             if (lane < qF) q_feat[row * qF + lane] = fcur;
             const double Hnow = exact_enthalpy();
             if (lane == 0) {
@@ -649,14 +712,11 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
     {
-#pragma unroll
-        for (int it = 0; it < NSLOT; ++it)
-            __hip_atomic_fetch_add(&s_cell[scell[it]], sfs[it] * acc[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        double fcur = f0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) fcur += s_cell[wl_rd[k]];
+        const double fcur = current_features();
         if (lane < P.F) featp[lane] = fcur;
     }
+    if (EWF)
+        for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     for (int i = lane; i < P.wl.L; i += 64) {
         P.wl.entropy[(size_t)r * P.wl.L + i] = wl_rec[i].S;
         P.wl.hist[(size_t)r * P.wl.L + i] = wl_rec[i].hist;
@@ -677,10 +737,10 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
 #undef key0
 #undef key1
 
-template <int NSLOT, int MM, int STEP, bool REPLAY = false>
-static int launch_wl_inst(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, int STEP, bool REPLAY, bool MU, bool EW>
+static int launch_wl_kern(smolmc_handle *h, const LeanParams &lp) {
     const unsigned grid = (unsigned)((h->R + 3) / 4);
-    auto kern = mc_wl_kernel<NSLOT, MM, STEP, REPLAY>;
+    auto kern = mc_wl_kernel<NSLOT, MM, STEP, REPLAY, MU, EW>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -689,6 +749,12 @@ static int launch_wl_inst(smolmc_handle *h, const LeanParams &lp) {
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return 0;
+}
+template <int NSLOT, int MM, int STEP, bool REPLAY = false>
+static int launch_wl_inst(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.mu_row != nullptr, ew = lp.ew_G != nullptr; // (Ewald: only with the field in LDS, engine.hip)
+    if (ew) return mu ? launch_wl_kern<NSLOT, MM, STEP, REPLAY, true, true>(h, lp) : launch_wl_kern<NSLOT, MM, STEP, REPLAY, false, true>(h, lp);
+    return mu ? launch_wl_kern<NSLOT, MM, STEP, REPLAY, true, false>(h, lp) : launch_wl_kern<NSLOT, MM, STEP, REPLAY, false, false>(h, lp);
 }
 template <int NSLOT> static int launch_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
     const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;

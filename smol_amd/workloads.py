@@ -227,5 +227,21 @@ def config9(first=0, count=2048, dim=12, mc=2000, temperature=None, penalty=None
         neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777), temperature, 1, mc)
 
 
+def config10(first=0, count=1024, dim=12, mc=2000, h0=None):
+    """(not in BASELINE.json) semigrand Wang-Landau with the Ewald term: the config-3 model (ternary
+    rocksalt dim^3, triplet CE + Ewald + mu, single flips) under the Wang-Landau kernel, window
+    centred on the starting enthalpy ``h0`` (evaluated by the caller on the engine, as for config 4).
+    The model class mc_wl_kernel took over from mc_kernel in round 4."""
+    model, sc, ew = _rocksalt(dim)
+    mu = _mu_rows(sc, CONFIG3_MU)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu)
+    kw = dict(kernel=capi.KERNEL_WANGLANDAU, step=capi.STEP_FLIP)
+    if h0 is not None:
+        kw.update(min_enthalpy=h0 - 400.37, max_enthalpy=h0 + 239.63, bin_size=1.25, flatness=0.8, check_period=1000)
+    return Workload(
+        10, f"config10: config-3 model (ternary rocksalt {dim}^3, triplet CE + Ewald + mu), Wang-Landau flips, 512 bins",
+        sc, tab, kw, neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777), 0.0, 1, mc)
+
+
 BUILDERS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: config6, 7: config7,
-            8: config8, 9: config9}
+            8: config8, 9: config9, 10: config10}

@@ -32,9 +32,9 @@ def test_random_shapes_match_oracle(shape, step, kernel):
     sc = synth.build_supercell(model, scm)
     rng = np.random.default_rng(100 + shape)
     is_ionic = prim.nb > 1
-    ew = ewald.supercell_ewald(sc) if is_ionic and kernel == "metropolis" else None
+    ew = ewald.supercell_ewald(sc) if is_ionic else None  # (Wang-Landau too: mc_wl_kernel with the field in LDS)
     mu = None
-    if step == capi.STEP_FLIP and kernel == "metropolis":
+    if step == capi.STEP_FLIP:  # semigrand, Metropolis and Wang-Landau
         nsp_max = max(prim.nspecies)
         mu = np.zeros((sc.num_sites, nsp_max))
         act = np.array([prim.nspecies[b] for b in sc.site_b]) > 1
@@ -69,7 +69,11 @@ def test_random_shapes_match_oracle(shape, step, kernel):
     if kernel == "wang-landau":
         wa, wb = eng.get_wl(), ora.get_wl()
         assert np.array_equal(wa["histogram"], wb["histogram"])
+        assert np.array_equal(wa["occurrences"], wb["occurrences"])
         np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-8)
+        if shape != 2:  # (the skew cell of shape 2 is aliased: mc_kernel)
+            assert eng.kernel_info().startswith("lean"), eng.kernel_info()
 
 
 @pytest.mark.parametrize("scm", [[9, 9, 9], [10, 10, 10], [8, 8, 12], [6, 6, 5]],

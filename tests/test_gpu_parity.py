@@ -755,7 +755,9 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
-    ("rocksalt444_ewald", "int", capi.STEP_SWAP, None, "wang-landau", "general"),     # WL + Ewald
+    ("rocksalt444_ewald", "int", capi.STEP_SWAP, None, "wang-landau", "lean"),        # WL + Ewald: field in LDS (round 4)
+    ("rocksalt444_ewald", "int", capi.STEP_FLIP, "mu3", "wang-landau", "lean"),       # semigrand WL + Ewald
+    ("fcc_prim666_triplets", "int", capi.STEP_FLIP, "mu2", "wang-landau", "lean"),    # semigrand WL
 ])
 def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, expected, monkeypatch):
     """DESIGN.md section 4 dispatch rules, asserted through smolmc_kernel_info: the parity tests

@@ -39,11 +39,11 @@ def main():
     if a.mc:
         kw["mc"] = a.mc
     wl = workloads.BUILDERS[a.config](**kw)
-    if a.config == 4:  # the window is centred on the starting enthalpy, evaluated on the engine
+    if a.config in (4, 10):  # the window is centred on the starting enthalpy, evaluated on the engine
         probe = Engine(wl.tables, capi.make_config(1))
         h0 = float(probe.natural_parameters @ probe.eval_full(wl.occupancy[:1])[0])
         probe.close()
-        wl = workloads.config4(h0=h0, **kw)
+        wl = workloads.BUILDERS[a.config](h0=h0, **kw)
     eng = Engine(wl.tables, wl.make_config())
     T = a.temperature if a.temperature > 0 else wl.temperature
     eng.set_state(wl.occupancy, wl.seeds, T)
