@@ -1546,6 +1546,44 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         up.T = h->rt;
         up.natural = h->d_natural;
         up.wl = wl ? 1 : 0;
+        {
+            const bool cm = t->feature_mode == SMOLMC_FEATURES_CORRELATIONS;
+            const int64_t nloc = t->site_ptr[t->num_sites];
+            std::vector<URec> recs((size_t)std::max<int64_t>(nloc, 1));
+            memset(recs.data(), 0, recs.size() * sizeof(URec));
+            for (int64_t r = 0; r < nloc; ++r) {
+                const int o = t->loc_orbit[r];
+                URec &u = recs[(size_t)r];
+                u.I = t->orb_nsites[o];
+                u.K = cm ? t->orb_nfunc[o] : 1;
+                u.Nt = t->orb_tensor_len[o];
+                u.J = t->loc_nrows[r];
+                for (int m = 0; m < u.I; ++m) u.st[m] = t->tensor_indices[t->orb_stride_off[o] + m];
+                u.feat = cm ? t->orb_bit_id[o] : t->orb_id[o];
+                u.idx_off = t->loc_off[r];
+                u.t_off = cm ? t->orb_ctensor_off[o] : t->orb_itensor_off[o];
+                u.scale = (double)t->size / t->loc_ratio[r] / (double)t->loc_nrows[r];
+                u.ratio = t->loc_ratio[r];
+            }
+            if (dev_upload(h, recs.data(), recs.size(), &up.recs)) return bail(1);
+            std::vector<long long> row_ptr((size_t)t->num_sites + 1, 0), row_off;
+            std::vector<int> row_rec;
+            for (int s = 0; s < t->num_sites; ++s) {
+                for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1]; ++r) {
+                    const int I = t->orb_nsites[t->loc_orbit[r]];
+                    for (int j = 0; j < t->loc_nrows[r]; ++j) {
+                        row_rec.push_back((int)r);
+                        row_off.push_back((long long)t->loc_off[r] + (long long)j * I);
+                    }
+                }
+                row_ptr[(size_t)s + 1] = (long long)row_rec.size();
+            }
+            if (nloc > 0x7fffffffll) return bail(fail("more than 2^31 local records"));
+            if (dev_upload(h, row_ptr.data(), row_ptr.size(), &up.row_ptr) ||
+                dev_upload(h, row_rec.data(), row_rec.size(), &up.row_rec) ||
+                dev_upload(h, row_off.data(), row_off.size(), &up.row_off))
+                return bail(1);
+        }
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
                 return bail(fail("TableFlip needs a flip table (CompositionSpace.flip_table, "
@@ -1593,7 +1631,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             up.tf_sw = t->swap_weight;
         }
         // per-wave LDS: step scratch (flips, counts, weights: 928 B) + the occupancy when it fits
-        const size_t scratch = 928, with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
+        // (+ the step's feature deltas, one cell per cluster feature, while that stays small)
+        up.dfeat_cells = (h->Fce <= 1024 && getenv("SMOLMC_UNIV_TWO_PASS") == nullptr) ? (h->Fce + 1) / 2 * 2 : 0;
+        const size_t scratch = 928 + (size_t)up.dfeat_cells * 8, with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
         up.occ_lds = with_occ <= 160 * 1024 - 256 && getenv("SMOLMC_UNIV_OCC_HBM") == nullptr;
         up.lds_per_wave = (int)(up.occ_lds ? with_occ : scratch);
         h->univ_wpb = 4;

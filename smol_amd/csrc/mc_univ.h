@@ -41,34 +41,62 @@ __device__ __forceinline__ philox_out univ_block(unsigned long long step, uint32
 }
 
 // lane-partial enthalpy change of ONE flip at site s (old -> new) against the current occupancy:
-// sum over the local records of s, their cluster rows (lanes) and correlation functions of
-// natural[feature] * (t[ind_f] - t[ind_i]) * size / ratio / J
+// sum over the cluster rows of s and their correlation functions of
+// natural[feature] * (t[ind_f] - t[ind_i]) * size / ratio / J.
+// The rows of ALL local records of the site are dealt to the lanes (row table built at create), two
+// groups of 64 in flight: a row costs a chain of dependent round trips (row -> record descriptor ->
+// member sites -> species -> tensor entries), and record by record that chain was all a wave did
+// (round 4: 50 us per step on config 2).
+// dF (or null): LDS cells of the step's feature deltas; every row adds scale * (t_k[ind_f] - t_k[ind_i])
+// to the cell of its feature (committed to the walker's features when the step is accepted).
 template <bool OL>
-__device__ __forceinline__ double univ_flip_partial(const RefTables &T, const double *natural, const uint8_t *occ, int lane,
-                                                    int s, int newc) {
+__device__ __forceinline__ double univ_flip_partial(const UParams &U, const uint8_t *occ, int lane, int s, int newc, double *dF) {
+    const RefTables &T = U.T;
     double e = 0.0;
-    const long long r0 = T.site_ptr[s], r1 = T.site_ptr[s + 1];
-    for (long long rr = r0; rr < r1; ++rr) {
-        const int n = T.loc_orbit[rr];
-        const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1, Nt = T.orb_tensor_len[n];
-        const int *st = T.tensor_indices + T.orb_stride_off[n];
-        const int *ind = T.loc_idx + T.loc_off[rr];
-        const int J = T.loc_nrows[rr];
-        const double scale = (double)T.P / T.loc_ratio[rr] / (double)J;
-        const double *t0 = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] : T.interaction_tensors + T.orb_itensor_off[n];
-        const double *nat = natural + (T.corr_mode ? T.orb_bit_id[n] : T.orb_id[n]);
-        for (int j = lane; j < J; j += 64) {
+    const long long q0 = U.row_ptr[s], q1 = U.row_ptr[s + 1];
+    const double *tens = T.corr_mode ? T.corr_tensors : T.interaction_tensors;
+    constexpr int G = 2;
+    for (long long qb = q0; qb < q1; qb += 64 * G) {
+        int rec[G];
+        long long off[G];
+        bool live[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long long q = qb + 64 * g + lane;
+            live[g] = q < q1;
+            const long long qq = live[g] ? q : q1 - 1; // (clamped: loads only)
+            rec[g] = U.row_rec[qq];
+            off[g] = U.row_off[qq];
+        }
+        URec R[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) R[g] = U.recs[rec[g]];
+        int x[G][SMOLMC_MAX_CLUSTER_SITES];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < SMOLMC_MAX_CLUSTER_SITES; ++i) x[g][i] = i < R[g].I ? T.loc_idx[off[g] + i] : s;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
             int ind_i = 0, ind_f = 0;
-            for (int i = 0; i < I; ++i) {
-                const int x = ind[j * I + i];
-                const int v = uocc_ld<OL>(occ, x);
-                const int vf = (x == s) ? newc : v;
-                ind_i += st[i] * v;
-                ind_f += st[i] * vf;
-            }
+#pragma unroll
+            for (int i = 0; i < SMOLMC_MAX_CLUSTER_SITES; ++i)
+                if (i < R[g].I) {
+                    const int v = uocc_ld<OL>(occ, x[g][i]);
+                    const int vf = (x[g][i] == s) ? newc : v;
+                    ind_i += R[g].st[i] * v;
+                    ind_f += R[g].st[i] * vf;
+                }
+            const double *t0 = tens + R[g].t_off;
+            const double *nat = U.natural + R[g].feat;
             double p = 0.0;
-            for (int k = 0; k < K; ++k) p = fma(nat[k], t0[(size_t)k * Nt + ind_f] - t0[(size_t)k * Nt + ind_i], p);
-            e = fma(scale, p, e);
+            for (int k = 0; k < R[g].K; ++k) {
+                const double d = t0[(size_t)k * R[g].Nt + ind_f] - t0[(size_t)k * R[g].Nt + ind_i];
+                p = fma(nat[k], d, p);
+                if (dF != nullptr && live[g] && d != 0.0)
+                    __hip_atomic_fetch_add(&dF[R[g].feat + k], R[g].scale * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            e = fma(live[g] ? R[g].scale : 0.0, p, e);
         }
     }
     return e;
@@ -77,33 +105,32 @@ __device__ __forceinline__ double univ_flip_partial(const RefTables &T, const do
 // feature deltas of ONE accepted flip, added to feat[] (wave-reduced per (record, function): the
 // reference's p / ratio / J, x size)
 template <bool OL>
-__device__ __forceinline__ void univ_flip_features(const RefTables &T, const uint8_t *occ, int lane, int s, int newc,
+__device__ __forceinline__ void univ_flip_features(const UParams &U, const uint8_t *occ, int lane, int s, int newc,
                                                    double *feat) {
+    const RefTables &T = U.T;
     const long long r0 = T.site_ptr[s], r1 = T.site_ptr[s + 1];
+    const double *tens = T.corr_mode ? T.corr_tensors : T.interaction_tensors;
     for (long long rr = r0; rr < r1; ++rr) {
-        const int n = T.loc_orbit[rr];
-        const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1, Nt = T.orb_tensor_len[n];
-        const int *st = T.tensor_indices + T.orb_stride_off[n];
-        const int *ind = T.loc_idx + T.loc_off[rr];
-        const int J = T.loc_nrows[rr];
-        const double *t0 = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] : T.interaction_tensors + T.orb_itensor_off[n];
-        const int o = T.corr_mode ? T.orb_bit_id[n] : T.orb_id[n];
-        for (int k = 0; k < K; ++k) {
-            const double *t = t0 + (size_t)k * Nt;
+        const URec R = U.recs[rr];
+        const int *ind = T.loc_idx + R.idx_off;
+        for (int k = 0; k < R.K; ++k) {
+            const double *t = tens + R.t_off + (size_t)k * R.Nt;
             double p = 0.0;
-            for (int j = lane; j < J; j += 64) {
+            for (int j = lane; j < R.J; j += 64) {
                 int ind_i = 0, ind_f = 0;
-                for (int i = 0; i < I; ++i) {
-                    const int x = ind[j * I + i];
-                    const int v = uocc_ld<OL>(occ, x);
-                    const int vf = (x == s) ? newc : v;
-                    ind_i += st[i] * v;
-                    ind_f += st[i] * vf;
-                }
+#pragma unroll
+                for (int i = 0; i < SMOLMC_MAX_CLUSTER_SITES; ++i)
+                    if (i < R.I) {
+                        const int x = ind[j * R.I + i];
+                        const int v = uocc_ld<OL>(occ, x);
+                        const int vf = (x == s) ? newc : v;
+                        ind_i += R.st[i] * v;
+                        ind_f += R.st[i] * vf;
+                    }
                 p += t[ind_f] - t[ind_i];
             }
             p = wave_sum(p);
-            if (lane == 0) feat[o + k] += p / T.loc_ratio[rr] / (double)J * (double)T.P;
+            if (lane == 0) unsafeAtomicAdd(&feat[R.feat + k], p / R.ratio / (double)R.J * (double)T.P); // (no return value: nobody waits)
         }
     }
 }
@@ -160,7 +187,9 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
     int *s_cnt = fl_orig + 8;            // [64] species counts over the active sites ("counts" format)
     int *s_col = s_cnt + 64;             // [8] sites collected for one sublattice
     double *s_mw = (double *)(s_col + 8); // [64] masked direction weights
-    uint8_t *occ = OL ? (uint8_t *)(s_mw + 64) : P.occ + (size_t)r * P.Npad;
+    double *s_dF = U.dfeat_cells ? s_mw + 64 : nullptr; // [dfeat_cells] feature deltas of the step in flight
+    uint8_t *occ = OL ? (uint8_t *)(s_mw + 64 + U.dfeat_cells) : P.occ + (size_t)r * P.Npad;
+    for (int i = lane; i < U.dfeat_cells; i += 64) s_dF[i] = 0.0;
     if (OL) {
         const uint4 *src = (const uint4 *)(P.occ + (size_t)r * P.Npad);
         for (int i = lane; i < P.Npad / 16; i += 64) ((uint4 *)occ)[i] = src[i];
@@ -481,13 +510,13 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
         // ================= pass 1: enthalpy change, flips applied tentatively ==============
         double e = 0.0, ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
         for (int f = 0; f < nfl; ++f) {
-            const int s = fl_site[f], newc = fl_new[f];
-            const int oldc = uocc_ld<OL>(occ, s);
+            const int s = uni(fl_site[f]), newc = uni(fl_new[f]);
+            const int oldc = uni(uocc_ld<OL>(occ, s));
             int orig = oldc;
             for (int g = f - 1; g >= 0; --g)
                 if (fl_site[g] == s) orig = fl_orig[g];
             if (lane == 0) { fl_old[f] = oldc; fl_orig[f] = orig; }
-            e += univ_flip_partial<OL>(T, U.natural, occ, lane, s, newc);
+            e += univ_flip_partial<OL>(U, occ, lane, s, newc, s_dF);
             if (has_ewald) {
                 if (P.ew_field) {
                     // O(1) from the walker's potential field + the cross terms of the earlier flips
@@ -524,7 +553,7 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
         if (has_mu) { dMu = uni_d(dMu); dH -= dMu; }
         // MCBias.compute_bias_change (kernel/base.py:307-311; orc_compute_bias_change): the last flip of a
         // site counts, against the species before the step
-        double dB = 0.0, dq_row[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
+        double dB = 0.0, dq_row[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0}, qrow_now[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
         if (bias_type && nfl) {
             const int W = P.bias_W;
             if (bias_type == SMOLMC_BIAS_FUGACITY) {
@@ -537,7 +566,9 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
                 }
             } else {
                 double sq_new = 0.0, sq_old = 0.0;
-                for (int k = 0; k < P.bias_rows; ++k) {
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) { // (constant indices: dq_row stays in registers)
+                    if (k >= P.bias_rows) continue;
                     const double *tab = P.bias_tab + (size_t)k * P.bias_row_stride;
                     const double c = __hip_atomic_load(&qrow[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     double cn = c;
@@ -549,6 +580,7 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
                         cn += tab[(size_t)s * W + fl_new[f]] - tab[(size_t)s * W + fl_orig[f]];
                     }
                     dq_row[k] = cn - c;
+                    qrow_now[k] = c;
                     sq_old += c * c;
                     sq_new += cn * cn;
                 }
@@ -579,15 +611,24 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
 
         // ================= update ==========================================================
         if (accepted && nfl) {
-            // pass 2: feature deltas flip by flip against the occupancy each flip saw
-            for (int f = nfl - 1; f >= 0; --f) uocc_st<OL>(occ, fl_site[f], fl_old[f], lane);
-            for (int f = 0; f < nfl; ++f) {
-                univ_flip_features<OL>(T, occ, lane, fl_site[f], fl_new[f], feat);
-                uocc_st<OL>(occ, fl_site[f], fl_new[f], lane);
+            if (s_dF != nullptr) {
+                // the cells filled by the enthalpy pass join the walker's features
+                for (int i = lane; i < Fce; i += 64) {
+                    const double v = s_dF[i];
+                    if (v != 0.0) unsafeAtomicAdd(&feat[i], v);
+                    s_dF[i] = 0.0;
+                }
+            } else {
+                // pass 2: feature deltas flip by flip against the occupancy each flip saw
+                for (int f = nfl - 1; f >= 0; --f) uocc_st<OL>(occ, fl_site[f], fl_old[f], lane);
+                for (int f = 0; f < nfl; ++f) {
+                    univ_flip_features<OL>(U, occ, lane, uni(fl_site[f]), uni(fl_new[f]), feat);
+                    uocc_st<OL>(occ, fl_site[f], fl_new[f], lane);
+                }
             }
             if (lane == 0) {
-                if (has_ewald) feat[Fce] += dEw;
-                if (has_mu) feat[Fce + (has_ewald ? 1 : 0)] += dMu;
+                if (has_ewald) unsafeAtomicAdd(&feat[Fce], dEw);
+                if (has_mu) unsafeAtomicAdd(&feat[Fce + (has_ewald ? 1 : 0)], dMu);
             }
             if (has_ewald && P.ew_field) {
                 const KParams *Q = &P;
@@ -605,14 +646,21 @@ __global__ void __launch_bounds__(256) mc_univ_kernel(const UParams U, const int
             }
             H += dH;
             bias += dB;
-            if (bias_type && bias_type != SMOLMC_BIAS_FUGACITY && lane == 0)
-                for (int k = 0; k < P.bias_rows; ++k) qrow[k] += dq_row[k];
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // lane 0's feature / charge stores before the wave reads them
+            if (bias_type && bias_type != SMOLMC_BIAS_FUGACITY && lane == 0) {
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                    if (k < P.bias_rows) __hip_atomic_store(&qrow[k], qrow_now[k] + dq_row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // lane 0's feature atomics / charge stores have reached L2 before the wave reads them there (the
+            // readers load past the L1): a wait, no cache maintenance
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             nacc++;
         } else if (accepted) {
             nacc++; // the empty step is accepted (metropolis.py:46)
         } else {
             for (int f = nfl - 1; f >= 0; --f) uocc_st<OL>(occ, fl_site[f], fl_old[f], lane);
+            if (s_dF != nullptr && nfl)
+                for (int i = lane; i < Fce; i += 64) s_dF[i] = 0.0;
         }
         last_acc = accepted ? 1 : 0;
 

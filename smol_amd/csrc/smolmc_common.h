@@ -505,11 +505,29 @@ struct RefTables { // device copies of the smolmc_tables arrays
 };
 
 
+// one local record (site, orbit) of the reference's LocalEvalData (processor/expansion.py:24-36) packed
+// for the universal kernel: everything a wave needs of it in one uniform 96-byte load instead of a
+// dozen dependent loads from the flattened smolmc_tables arrays
+struct URec {
+    int32_t I, K, Nt, J;  // sites per cluster, functions (1 in interaction mode), tensor length, rows
+    int32_t st[6];        // tensor strides of the members
+    int32_t feat, pad;    // first feature index (bit_id / orbit id)
+    int64_t idx_off;      // offset of the rows in loc_idx
+    int64_t t_off;        // offset of the tensor(s) in corr_tensors / interaction_tensors
+    double scale;         // size / ratio / J
+    double ratio;         // cluster_ratio (the feature pass divides like the reference: p / ratio / J)
+};
+
 // parameter block of the universal kernel (mc_univ.h)
 struct UParams {
     KParams K;   // walker state, sublattices, Ewald / mu / bias tables, Wang-Landau state, replay, samples
     RefTables T; // reference-layout tables (device copies of smolmc_tables)
     const double *natural; // [F] natural parameters
+    const URec *recs;      // [n_loc] packed local records, indexed like loc_orbit
+    // the cluster rows of every site flattened over its records (lane <-> row in the enthalpy pass):
+    const long long *row_ptr; // [N+1] rows of site s: row_ptr[s] .. row_ptr[s+1]
+    const int *row_rec;       // [nrows] local record of the row
+    const long long *row_off; // [nrows] offset of the row's first member in loc_idx
     // TableFlip
     int tf_n, tf_d;          // flip vectors, dims (species over the active sublattices)
     const int *tf_table;     // [tf_n][tf_d]
@@ -518,6 +536,8 @@ struct UParams {
     const double *tf_ln;     // ln(k), k = 0 .. largest sublattice (host libm, as the oracle's log)
     const int *tf_dim_sub;   // [tf_d] sublattice of a dim
     int occ_lds;             // occupancy staged in LDS (else read / written in HBM)
+    int dfeat_cells;         // > 0: per-wave LDS cells [dfeat_cells] take the step's feature deltas in the enthalpy
+                             // pass (committed on acceptance); 0: features come from a second pass over the flips
     int lds_per_wave;
     int wl;                  // Wang-Landau kernel
     // replay extras
