@@ -317,6 +317,29 @@ class _Clock:
         return t.cpu().numpy()
 
 
+def issue_roof(key, note):
+    """Roofline of a configuration whose kernel is bound on-chip: the VALU-issue and LDS-issue
+    fractions of its rocprofv3 PMC passes (profiles/pmc_constants.json, entry `key`, written by
+    tools/run_profile_configs.sh on the build whose source digest it carries) and the HBM bytes per
+    launch the same passes counted.  No modelled byte rate: these kernels keep their working set in
+    LDS / L2."""
+    def roof(rec):
+        from smol_amd.engine import source_digest
+
+        pmc = pmc_constants().get(key, {})
+        out = dict(bound="issue", unit="fraction of issue cycles", note=note,
+                   pmc_source=pmc.get("source", "no PMC pass for this configuration"),
+                   pmc_stale=bool(pmc) and pmc.get("csrc_sha256") != source_digest())
+        for k in ("valu_issue_frac", "lds_issue_frac", "valu_per_step", "salu_per_step", "lds_per_step", "vmem_per_step",
+                  "wave_cycles_per_step", "waves_per_simd", "lds_bank_conflict_per_step", "hbm_bytes_per_launch"):
+            if k in pmc:
+                out[k] = pmc[k]
+        if "valu_issue_frac" in pmc:
+            out["achieved"], out["peak"], out["frac"] = pmc["valu_issue_frac"], 1.0, pmc["valu_issue_frac"]
+        return out
+    return roof
+
+
 def hbm_ce(rec):  # SURVEY 8d: 56 algorithmic bytes per CE flip
     a = rec["flips_per_s"] * ALGO_BYTES_PER_FLIP / 1e9
     return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
@@ -417,22 +440,11 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
 
         wl3 = workloads.config3()
 
-        def ewald_roof(rec):
-            # potential-field formulation: a proposal reads O(1) LDS words; only an ACCEPTED flip
-            # updates the walker's field with n_act entries of the site kernel (gathered from the
-            # translation-compressed tables).  The 2-rows-per-proposal figure of SURVEY 8d does not
-            # describe this algorithm.
-            row_bytes = wl3.sc.size * 8.0
-            a = rec["flips_per_s"] * rec["acceptance"] * row_bytes / 1e9
-            return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
-                        l2_peak=L2_PEAK_GBS, acceptance=rec["acceptance"],
-                        row_bytes_per_accepted_flip=row_bytes,
-                        note="site-kernel entries gathered per ACCEPTED flip (n_act*8 B each) over kernel time; "
-                             "since round 3 they come from the translation-compressed tables (95 KB, L2 "
-                             "resident: measured HBM fetch 22 MB per launch, profiles/r03_configs_pmc.txt), so "
-                             "this is an L2 / LDS rate, quoted against the HBM peak only for scale; it depends "
-                             "on the acceptance; the dense two-row formulation (58752 B/flip) is HBM-capped "
-                             "at 1.36e8 flips/s")
+        ewald_note = ("potential-field formulation: a proposal reads O(1) LDS words, an ACCEPTED flip sweeps the walker's "
+                      "field (n_act gathers from the translation-compressed tables, 95 KB, L2 resident, + n_act LDS "
+                      "read-modify-writes); bound by the issue rate of one wave's LDS / address instructions, not by "
+                      "HBM (measured fetch 22 MB per launch); the dense two-row formulation of SURVEY 8d (58752 B/flip) is the "
+                      "SMOLMC_DENSE_EWALD path: pmc entry config3_dense_ewald")
 
         # (the transient of round 2's bench: launches 2-11 of 2000 steps from the random start; config 3
         # as specified has no mixed steady state -- its Ewald energy without the charged-cell term is
@@ -440,11 +452,37 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
         # figure is the cost of REJECTED proposals; config 9 below is the well-posed variant)
         info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
-        record(wl3, info, first, steady, ewald_roof, wl3.n_walkers, launches=10)
+        record(wl3, info, first, steady, issue_roof("config3", ewald_note), wl3.n_walkers, launches=10)
         wl9 = workloads.config9()
         info, first, steady = _engine_run(Engine, wl9, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
-        record(wl9, info, first, steady, ewald_roof, wl9.n_walkers, launches=10)
+        record(wl9, info, first, steady, issue_roof("config9", ewald_note), wl9.n_walkers, launches=10)
+
+    if world == 1:
+        # config 3 on the LITERAL formulation of ewald.pyx:38-58 (two rows of the 382 MB matrix gathered per
+        # proposal; what a matrix that does not factorise takes): the one HBM-bound kernel of the engine
+        os.environ["SMOLMC_DENSE_EWALD"] = "1"
+        try:
+            wl3d = workloads.config3(mc=500)
+            info, first, _ = _engine_run(Engine, wl3d, device, clock, 5, 500)
+        finally:
+            del os.environ["SMOLMC_DENSE_EWALD"]
+        A_EW = 2.0 * wl3d.sc.num_sites * 8.0 + wl3d.sc.num_sites  # 58 752 B per flip at N = 3456
+
+        def dense_roof(rec):
+            from smol_amd.engine import source_digest
+
+            pmc = pmc_constants().get("config3_dense_ewald", {})
+            a = rec["flips_per_s"] * A_EW / 1e9
+            return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
+                        algorithmic_bytes_per_flip=A_EW, traffic=pmc.get("hbm_bytes_per_launch"),
+                        traffic_unit="bytes per launch of 2048 x 500 flips (rocprofv3 FETCH_SIZE + WRITE_SIZE passes)",
+                        pmc_source=pmc.get("source", "none"),
+                        pmc_stale=bool(pmc) and pmc.get("csrc_sha256") != source_digest(),
+                        note="dense Ewald rows (SMOLMC_DENSE_EWALD): streaming gather, eight sites per lane in flight")
+
+        wl3d.name = "config3 with the dense Ewald rows (ewald.pyx:38-58 literally)"
+        record(wl3d, info, first, None, dense_roof, wl3d.n_walkers, launches=5)
 
     # config 4: 1024 independent Wang-Landau walkers per rank; the window is centred on the
     # starting enthalpy, evaluated on the engine
@@ -454,8 +492,10 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
     probe.close()
     wl4 = workloads.config4(first=rank * 1024, h0=h0)
     info, first, _ = _engine_run(Engine, wl4, device, clock, 5, 50_000)
-    record(wl4, info, first, None, hbm_ce, wl4.n_walkers * world, launches=5,
-           sharding="independent walkers, no collective")
+    record(wl4, info, first, None,
+           issue_roof("config4", "one wave per SIMD at 1024 walkers: the step is its chain of dependent instructions "
+                                 "(DESIGN.md section 5); occupancy and Wang-Landau state LDS-resident"),
+           wl4.n_walkers * world, launches=5, sharding="independent walkers, no collective")
 
     # config 5: TableFlip + ONE replica-exchange ladder over all ranks' walkers; every launch is
     # followed by an exchange attempt (one rank: decisions from a direct read-back; N ranks: RCCL
@@ -466,9 +506,9 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
     info, first, steady = _engine_run(Engine, wl5, device, clock, 30, wl5.mc_per_launch,
                                       equil=EQUIL_STEPS[5], rex=rex)
     record(wl5, info, first, steady,
-           lambda rec: dict(bound="issue", note="TableFlip proposal is instruction-issue bound (DESIGN.md §5); no "
-                                                "byte roofline applies; mc_steps_per_s is wall time including the "
-                                                "exchange step, mc_steps_per_s_kernel_only from the HIP events"),
+           issue_roof("config5", "TableFlip step (three flips + proposal + a-priori factor) at two waves per SIMD: "
+                                 "instruction-issue / latency bound (DESIGN.md section 5); mc_steps_per_s is wall time "
+                                 "including the exchange step, mc_steps_per_s_kernel_only from the HIP events"),
            per * world, launches=30, exchange_every_steps=wl5.mc_per_launch,
            exchange_acceptance_mean=float(rex.acceptance.mean()),
            exchange_latency_ms_per_sweep=float(clock.max([rex.exchange_seconds / max(rex.exchange_timed, 1) * 1e3])[0]),
@@ -480,7 +520,7 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
         rexc = parallel.ReplicaExchange(wl5c.extras["ladder"], per, 0, 1, seed=11)
         info, first, _ = _engine_run(Engine, wl5c, device, clock, 3, wl5c.mc_per_launch, rex=rexc)
         record(wl5c, info, first, None,
-               lambda rec: dict(bound="issue", note="as config 5 above; launches 2-4 from the random start"),
+               issue_roof("config5", "as config 5 above (PMC passes of the hot ladder); launches 2-4 from the random start"),
                per, launches=3, state="transient", exchange_every_steps=wl5c.mc_per_launch,
                exchange_acceptance_mean=float(rexc.acceptance.mean()))
     return out

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--mc", type=int, default=10000)
     ap.add_argument("--source", default="profiles/")
     ap.add_argument("--merge", default=None, help="existing json to update")
+    ap.add_argument("--key", default=None, help='entry name (default "<replicas>x<mc>"; other configurations: "config3" ...)')
+    ap.add_argument("--waves-per-simd", type=float, default=0.0, help="resident waves per SIMD (default replicas / 1024)")
     a = ap.parse_args()
     tot = {}
     for p in a.paths:
@@ -46,7 +48,7 @@ def main():
                     tot[ctr] = (float(val), int(n))
     if not tot:
         raise SystemExit("no counters for kernel " + a.kernel)
-    waves_per_simd = max(1, a.replicas // 1024)
+    waves_per_simd = a.waves_per_simd if a.waves_per_simd > 0 else max(1, a.replicas // 1024)
 
     def per_step(c):
         v, n = tot[c]
@@ -70,6 +72,10 @@ def main():
         busy = 4.0 * per_step("SQ_ACTIVE_INST_VALU") * waves_per_simd
         rec["valu_busy_cycles_per_step_per_simd"] = round(busy, 1)
         rec["valu_issue_frac"] = round(busy / (4.0 * per_step("SQ_WAVE_CYCLES")), 4)
+    if "SQ_ACTIVE_INST_LDS" in tot and "SQ_WAVE_CYCLES" in tot:
+        # LDS-instruction issue cycles of the waves of a SIMD over the cycles of a step (the share of the
+        # step during which the SIMD has an LDS instruction in its pipe)
+        rec["lds_issue_frac"] = round(per_step("SQ_ACTIVE_INST_LDS") * waves_per_simd / per_step("SQ_WAVE_CYCLES"), 4)
     if "SQ_LDS_BANK_CONFLICT" in tot:
         rec["lds_bank_conflict_per_step"] = round(per_step("SQ_LDS_BANK_CONFLICT"), 1)
     if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
@@ -77,7 +83,8 @@ def main():
         rec["write_bytes_per_launch"] = per_launch("WRITE_SIZE") * 1024.0
         rec["hbm_bytes_per_launch"] = rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
     out = json.load(open(a.merge)) if a.merge and os.path.exists(a.merge) else {}
-    out[f"{a.replicas}x{a.mc}"] = rec
+    rec["replicas"], rec["mc_steps_per_launch"] = a.replicas, a.mc
+    out[a.key or f"{a.replicas}x{a.mc}"] = rec
     print(json.dumps(out, indent=1))
 
 
