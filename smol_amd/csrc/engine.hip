@@ -1145,6 +1145,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         kp.wl_div = cfg->wl_mod_divisor;
         kp.wl_check = cfg->wl_check_period;
         kp.wl_update = cfg->wl_update_period;
+        kp.wl_sum_mode = (cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
         // (check period 0: the flatness check is the caller's -- a host-side mod_update callable,
         // wanglandau.py:100-105 -- and no kernel runs its own)
         if (kp.wl_check < 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
@@ -1163,7 +1164,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     tb = (tb + 15) / 16 * 16;
     size_t pw = (size_t)h->Npad;
     if (wl)
-        pw += (size_t)h->L * 16 + (size_t)h->F * 8;
+        pw += (size_t)h->L * 24 + (size_t)h->F * 8;
     else {
         const size_t by_feat = (size_t)h->Fce * 64 * 8;
         const size_t by_slot = ((size_t)kp.nclasses * kp.Cpad + h->Fce) * 8;
@@ -2073,7 +2074,9 @@ static UParams univ_block_of(smolmc_handle *h) {
 }
 
 static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
-    TRY(wl_set_representation(h, h->lean && h->lp.wl.sum_mode));
+    // (per-bin feature statistics as sums for the lean Wang-Landau kernel and for mc_kernel with
+    // update_period 1, as running means for the universal kernel)
+    TRY(wl_set_representation(h, h->univ ? false : (h->lean ? h->lp.wl.sum_mode != 0 : h->kp.wl_sum_mode != 0)));
     if (h->univ) {
         UParams up = univ_block_of(h);
         up.K.steps_to_run = nsteps;
@@ -2304,7 +2307,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
                               "code1 == species at site2, code2 == species at site1; a flip handle single flips); "
                               "the walkers have been advanced -- set the state again");
     } else if (e == hipSuccess && general_replay) {
-        rc = wl_set_representation(h, false);
+        rc = wl_set_representation(h, h->kp.wl_sum_mode != 0);
         KParams kp = h->kp;
         kp.steps_to_run = nsteps;
         kp.rp_steps = d_steps;

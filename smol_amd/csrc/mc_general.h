@@ -33,6 +33,7 @@ struct Lds {
     double *acc;    // this wave's feature accumulators [Fce][64]  (Metropolis)
     double *wl_S;   // WL: entropy [L]
     long long *wl_H; // WL: histogram [L]
+    long long *wl_O; // WL: occurrences [L]
     double *wl_cf;  // WL: current features [F]
 };
 
@@ -267,10 +268,11 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
     unsigned char *wp = smem + P.lds_tables + (size_t)wave * P.lds_per_wave;
     L.occ = wp;
     wp += P.Npad;
-    L.acc = nullptr; L.wl_S = nullptr; L.wl_H = nullptr; L.wl_cf = nullptr;
+    L.acc = nullptr; L.wl_S = nullptr; L.wl_H = nullptr; L.wl_O = nullptr; L.wl_cf = nullptr;
     if (WL) {
         L.wl_S = (double *)wp;        wp += (size_t)P.L * 8;
         L.wl_H = (long long *)wp;     wp += (size_t)P.L * 8;
+        L.wl_O = (long long *)wp;     wp += (size_t)P.L * 8;
         L.wl_cf = (double *)wp;
     } else {
         L.acc = (double *)wp;
@@ -286,6 +288,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
             for (int i = lane; i < P.L; i += 64) {
                 L.wl_S[i] = P.wl_entropy[(size_t)r * P.L + i];
                 L.wl_H[i] = P.wl_hist[(size_t)r * P.L + i];
+                L.wl_O[i] = P.wl_occur[(size_t)r * P.L + i];
             }
             for (int i = lane; i < P.F; i += 64) L.wl_cf[i] = P.features[(size_t)r * P.F + i];
         } else {
@@ -670,22 +673,25 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
                 const int b = (int)bq;
                 wl_counter++;
                 const size_t cell = (size_t)r * PK.L + b;
-                // lane 0 owns the occurrences counter (single-thread program order for
-                // its own global read-after-write); broadcast to the wave
-                long long total = 0;
-                if (lane == 0) total = PK.wl_occur[cell];
-                total = ((long long)(unsigned)uni((int)(total >> 32)) << 32) |
-                        (unsigned)uni((int)(total & 0xffffffffll));
+                // occurrences live in LDS beside entropy and histogram (a global counter cost a dependent
+                // load on every step); the per-bin feature statistics are running SUMS when update_period
+                // is 1 (wl_sum_mode: mean = sum / occurrences, converted when read) -- one atomic without
+                // return value per feature -- else the reference's running mean (wanglandau.py:235-239)
+                const long long total = L.wl_O[b];
                 if (lane < PK.F) {
                     double *mf = PK.wl_meanf + cell * PK.F + lane;
-                    const double inv = 1.0 / (double)(total + 1);
-                    *mf = inv * (L.wl_cf[lane] + (double)total * (*mf));
+                    if (PK.wl_sum_mode) {
+                        unsafeAtomicAdd(mf, L.wl_cf[lane]);
+                    } else {
+                        const double inv = 1.0 / (double)(total + 1);
+                        *mf = inv * (L.wl_cf[lane] + (double)total * (*mf));
+                    }
                 }
                 if (wl_counter % PK.wl_update == 0) {
                     if (lane == 0) {
                         L.wl_S[b] += wl_m;
                         L.wl_H[b] += 1;
-                        PK.wl_occur[cell] = total + 1;
+                        L.wl_O[b] = total + 1;
                     }
                 }
             }
@@ -749,6 +755,7 @@ __global__ void __launch_bounds__(256, (NSLOT <= 4 ? 4 : 2)) mc_kernel(const KPa
         for (int i = lane; i < P.L; i += 64) {
             P.wl_entropy[(size_t)r * P.L + i] = L.wl_S[i];
             P.wl_hist[(size_t)r * P.L + i] = L.wl_H[i];
+            P.wl_occur[(size_t)r * P.L + i] = L.wl_O[i];
         }
         for (int i = lane; i < P.F; i += 64) feat[i] = L.wl_cf[i];
         if (lane == 0) {

@@ -141,6 +141,9 @@ struct KParams {
     double *wl_meanf;             // [R][L][F]
     double *wl_m;                 // [R]
     long long *wl_counter;        // [R]
+    int wl_sum_mode;              // mc_kernel with update_period == 1: wl_meanf holds running SUMS (mean = sum /
+                                  // occurrences, formed when read): one fire-and-forget atomic per feature and
+                                  // step instead of a read-modify-write round trip on the step's path
     // Metropolis feature accumulators in LDS: acc_by_slot = 0 -> [Fce][64] cells (feature, lane);
     // 1 -> [nclasses][Cpad] cells (class, slot) + [Fce] scratch, used in interaction mode when
     // that is smaller (models with many orbits)

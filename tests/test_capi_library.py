@@ -95,3 +95,18 @@ def test_tableset_validation_errors():
         capi.TableSet(sc.num_sites, sc.size, m.num_orbits, m.num_corr_functions, tuple(bad2),
                       tuple(sc.full_indices), sc.local_tables(), None, coefs,
                       capi.FEATURES_CORRELATIONS, subs)
+
+
+def test_step_records_pad_to_the_abi_row():
+    """capi.step_rows: the ushers' lists of (site, code) tuples / narrow int arrays -> SMOLMC_STEP_ROW records."""
+    assert capi.STEP_ROW == 16 and capi.MAX_STEP_FLIPS == 8
+    r = capi.step_rows([[(1, 2), (3, 4), (5, 6)], []])
+    assert r.shape == (2, 16) and r.dtype == np.int32
+    assert r[0, :6].tolist() == [1, 2, 3, 4, 5, 6] and (r[0, 6:] == -1).all() and (r[1] == -1).all()
+    narrow = np.array([[[7, 1, -1, -1]], [[8, 0, 9, 1]]], dtype=np.int32)  # (R, n, 4): the pre-v6 layout
+    w = capi.step_rows(narrow, 2, 1)
+    assert w.shape == (2, 1, 16) and w[1, 0, :4].tolist() == [8, 0, 9, 1] and (w[..., 4:] == -1).all()
+    with pytest.raises(ValueError):
+        capi.step_rows([[(0, 0)] * 9])
+    with pytest.raises(ValueError):
+        capi.step_rows(np.zeros((3, 5), dtype=np.int32))

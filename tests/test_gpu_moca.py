@@ -361,3 +361,76 @@ def test_wang_landau_resumes_in_a_fresh_engine(fcc):
         assert np.array_equal(wa[k], wb[k]), k
     np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-12, atol=1e-10)
     np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-12, atol=1e-9)
+
+
+def _neutral(sc, n_ti, rng):
+    P = sc.size
+    n_mn = (P - 3 * n_ti) // 2
+    occ = np.zeros(sc.num_sites, dtype=np.int32)
+    perm = rng.permutation(P)
+    occ[perm[:n_mn]] = 1
+    occ[perm[n_mn:n_mn + n_ti]] = 2
+    return occ
+
+
+def test_any_usher_with_any_kernel_through_the_sampler(rocksalt):
+    """kernel/base.py:192-239 composes any usher with any kernel and bias: TableFlip under
+    Wang-Landau and TableFlip with a FugacityBias through the smol-shaped Sampler (both refused
+    before round 4; the universal kernel runs them).  Trace rows == recomputed features, the
+    composition stays on the charge-neutral line, Wang-Landau never leaves its window."""
+    model, sc, coefs = rocksalt
+    comp = moca.CompositeProcessor(sc)
+    comp.add_processor(moca.ClusterExpansionProcessor(sc, coefs))
+    comp.add_processor(moca.EwaldProcessor(sc, coefficient=0.1))
+    ens = moca.Ensemble(comp, chemical_potentials={"Li+": 0.1, "Mn3+": -0.2, "Ti4+": 0.05})
+    rng = np.random.default_rng(3)
+    occ = np.array([_neutral(sc, 3, rng), _neutral(sc, 5, rng)])
+    table = [[1, -3, 2, 0]]  # 3 Mn3+ <-> Li+ + 2 Ti4+ (the O2- column is always zero)
+    h0 = np.array([ens.natural_parameters @ ens.compute_feature_vector(o) for o in occ])
+    wl = moca.Sampler.from_ensemble(ens, float(h0.min()) - 30.3, float(h0.max()) + 30.1, 0.5, kernel_type="Wang-Landau",
+                                    step_type="table-flip", nwalkers=2, seeds=[5, 6], flip_table=table,
+                                    swap_weight=0.2, check_period=100)
+    wl.run(3000, occ, thin_by=500)
+    assert wl._engine.kernel_info().startswith("universal")
+    c = wl.samples
+    occs, feats, enth = c.get_occupancies(flat=False), c.get_feature_vectors(flat=False), c.get_enthalpies(flat=False)
+    assert np.all((enth >= h0.min() - 30.3) & (enth < h0.max() + 30.1))
+    for w in range(2):
+        np.testing.assert_allclose(feats[-1, w], ens.compute_feature_vector(occs[-1, w]), rtol=1e-10, atol=1e-8)
+        n = np.bincount(occs[-1, w][: sc.size], minlength=3)
+        assert n[0] + 3 * n[1] + 4 * n[2] == 2 * sc.size  # charge neutral against the O2- sublattice
+    assert (c.get_trace_value("entropy", flat=False)[-1] > 0).sum() >= 2
+    assert len(np.unique(occs[:, 0], axis=0)) > 1
+
+    fug = moca.Sampler.from_ensemble(ens, temperature=4000.0, step_type="table-flip", nwalkers=2, seeds=[7, 8],
+                                     flip_table=table, swap_weight=0.2, bias_type="fugacity",
+                                     bias_kwargs={"fugacity_fractions": [{"Li+": 0.2, "Mn3+": 0.3, "Ti4+": 0.5}]})
+    fug.run(2000, occ, thin_by=500)
+    assert fug._engine.kernel_info().startswith("universal")
+    c = fug.samples
+    b = c.get_trace_value("bias", flat=False)
+    bias = fug.mckernels[0].bias
+    occs = c.get_occupancies(flat=False)
+    for i in range(len(occs)):
+        np.testing.assert_allclose(b[i, :, 0], [bias.compute_bias(o) for o in occs[i]], rtol=1e-10, atol=1e-9)
+    assert c.sampling_efficiency() > 0.0
+
+
+def test_processor_change_of_a_whole_table_step(rocksalt):
+    """Processor.compute_feature_vector_change with more than two flips: one smolmc_eval_delta
+    record (ABI v6) instead of a chain of pairs -- equal to the difference of full vectors."""
+    model, sc, coefs = rocksalt
+    comp = moca.CompositeProcessor(sc)
+    comp.add_processor(moca.ClusterExpansionProcessor(sc, coefs))
+    comp.add_processor(moca.EwaldProcessor(sc, coefficient=0.3))
+    rng = np.random.default_rng(9)
+    occ, nsp = _rand_occ(rng, sc)
+    for nflips in (3, 5, 8, 11):
+        sites = rng.choice(sc.size, nflips, replace=False)
+        flips = [(int(s), int((occ[s] + 1) % 3)) for s in sites]
+        new = occ.copy()
+        for s, cde in flips:
+            new[s] = cde
+        d = comp.compute_feature_vector_change(occ, flips)
+        np.testing.assert_allclose(d, comp.compute_feature_vector(new) - comp.compute_feature_vector(occ),
+                                   rtol=1e-9, atol=1e-8)

@@ -25,3 +25,5 @@ python tools/rocpd_summary.py gpurun_out/ldspmc_${tag}_* 2>&1 | grep -v "not a d
 python tools/rocpd_summary.py gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_* 2>&1 | grep -v "not a database\|\.log" > gpurun_out/${tag}_headline_pmc.txt
 python tools/pmc_to_json.py --kernel "mc_lean_kernel<2, 2, 1, false, 0, false, false, true" --replicas 4096 --mc 125000 --source profiles/${tag}_headline_pmc.txt gpurun_out/pmc_${tag}_* > gpurun_out/pmc_constants_${tag}.json
 tail -c 600 gpurun_out/bench_${tag}.json
+# the raw rocpd databases are scratch (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_*/ gpurun_out/ldspmc_${tag}_*/

@@ -35,3 +35,4 @@ for k in $CFGS; do
      --source profiles/${tag}_configs_pmc.txt --merge gpurun_out/pmc_constants_${tag}_all.json gpurun_out/cpmc_${tag}_c${k}_* > gpurun_out/pmc_tmp.json \
      && mv gpurun_out/pmc_tmp.json gpurun_out/pmc_constants_${tag}_all.json
 done > gpurun_out/${tag}_configs_pmc.txt 2>&1
+rm -rf gpurun_out/cprof_${tag}_c*/ gpurun_out/cpmc_${tag}_c*/
