@@ -675,8 +675,14 @@ def main():
         ones = torch.ones(1, dtype=torch.float64, device=red_dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         rccl_ranks = int(round(float(ones.item())))
-        collective_backend = ("nccl (RCCL %s over xGMI)" % ".".join(str(v) for v in torch.cuda.nccl.version())
-                              if backend == "nccl" else "gloo (host-staged; --oversubscribe)")
+        if backend == "nccl":
+            try:  # (the version is decoration: it must never cost the run)
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = "?"
+            collective_backend = "nccl (RCCL %s over xGMI)" % ver
+        else:
+            collective_backend = "gloo (host-staged; --oversubscribe)"
     else:
         rccl_ranks, collective_backend = 1, "none (single rank: no process group, no collective on the path)"
     if rccl_ranks != args.gpus:
