@@ -1149,7 +1149,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         // (check period 0: the flatness check is the caller's -- a host-side mod_update callable,
         // wanglandau.py:100-105 -- and no kernel runs its own)
         if (kp.wl_check < 0 || kp.wl_update <= 0) return bail(fail("WL periods must be positive"));
-        if (h->F > 64) return bail(fail("Wang-Landau supports at most 64 features"));
+        // (the lane-indexed feature bookkeeping of mc_kernel / mc_wl_kernel holds 64 features; more -- the
+        // reference has no limit, wanglandau.py:117-118 -- take the universal kernel)
+        if (h->F > 64 && h->general_ok) no_general(h, "Wang-Landau with more than 64 features");
         if (dev_alloc(h, R * h->L, &kp.wl_entropy) || dev_alloc(h, R * h->L, &kp.wl_hist) ||
             dev_alloc(h, R * h->L, &kp.wl_occur) || dev_alloc(h, R * h->L * h->F + 64, &kp.wl_meanf) || // (+64: the lean kernel's all-lane atomic, see mc_lean.h)
             dev_alloc(h, R, &kp.wl_m) || dev_alloc(h, R, &kp.wl_counter))

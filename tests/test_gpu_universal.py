@@ -221,3 +221,28 @@ def test_more_than_eight_flip_vectors(monkeypatch):
     a = _same_chain(eng, ora, (1, 30, 500))
     assert 0.01 < a["n_accepted"].sum() / a["n_steps"].sum() < 0.99
     eng.close()
+
+
+def test_wang_landau_with_more_than_64_features(monkeypatch):
+    """A five-species FCC model in correlation mode has 65 correlation functions: beyond the 64
+    lane-indexed features of the Wang-Landau bookkeeping in mc_kernel / mc_wl_kernel (refused before
+    round 4; the reference has no limit, wanglandau.py:117-118)."""
+    from smol_amd import synth
+
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    model = synth.build_cluster_model(synth.fcc_prim(nspecies=5), {2: 6.0, 3: 3.0})
+    assert model.num_corr_functions > 64
+    sc = synth.build_supercell(model, [4, 4, 4])
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=6), feature_mode=capi.FEATURES_CORRELATIONS)
+    R = 3
+    occ = (np.random.default_rng(5).random((R, sc.num_sites)) * 5).astype(np.int32)
+    from oracle import oracle as orc
+
+    ev = orc.OracleEvaluator(tab)
+    h = np.array([ev.natural_parameters() @ ev.feature_vector(o) for o in occ])
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_FLIP, min_enthalpy=float(h.min()) - 20.37,
+                           max_enthalpy=float(h.max()) + 20.11, bin_size=0.5, check_period=80)
+    eng, ora = _pair(tab, cfg, occ, [11, 12, 13], 0.0)
+    assert "more than 64 features" in eng.kernel_info(), eng.kernel_info()
+    _same_chain(eng, ora, (1, 79, 2, 400), wl=True)
+    eng.close()
