@@ -42,13 +42,14 @@ def _replay(tag, kernel, monkeypatch, derive):
     eng = _engine(tab, cfg)
     info = eng.kernel_info()
     eng.set_state(np.tile(occ0, (R, 1)), temperature=temp)
+    h0 = float(eng.get_state(occupancy=False)["enthalpy"][0])
     steps = np.tile(T6[f"{tag}_steps"][None], (R, 1, 1))
     us = np.tile(T6[f"{tag}_u"][None], (R, 1))
     lp = None if derive else np.tile(T6[f"{tag}_log_priori"][None], (R, 1))
     acc, H, lpo = eng.replay(steps, us, log_priori=lp, with_priori=True)
     for r in range(R):
         assert np.array_equal(acc[r], acc[0]) and np.array_equal(H[r], H[0])
-    check_replay(eng, tag, acc[0], H[0], lp_out=lpo[0] if SPECS[tag]["step"] == "table" else None)
+    check_replay(eng, tag, acc[0], H[0], lp_out=lpo[0] if SPECS[tag]["step"] == "table" else None, h0=h0)
     if "wl" in SPECS[tag]:
         check_wl(eng, tag)
     eng.close()

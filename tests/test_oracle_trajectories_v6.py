@@ -18,9 +18,10 @@ def test_replay_with_the_reference_priori_factor(tag):
     tab, cfg, occ0, temp = build(tag)
     mc = orc.OracleMC(tab, cfg)
     mc.set_state(occ0[None], [0], temp)
+    h0 = float(mc.get_state()["enthalpy"][0])
     lp = T6[f"{tag}_log_priori"][None]
     acc, H = mc.replay(T6[f"{tag}_steps"][None], T6[f"{tag}_u"][None], log_priori=lp)
-    check_replay(mc, tag, acc[0], H[0])
+    check_replay(mc, tag, acc[0], H[0], h0=h0)
     if "wl" in SPECS[tag]:
         check_wl(mc, tag)
 

@@ -84,12 +84,23 @@ def build(tag, n_replicas=1):
     return tab, cfg, occ0, temp
 
 
-def check_replay(mc, tag, acc, H, lp_out=None, rtol=1e-10):
+def check_replay(mc, tag, acc, H, lp_out=None, rtol=1e-10, h0=None):
     """Accept flags, final occupancy, counters: bit-exact; enthalpies / features / bias: 1e-10
     relative (north_star's tolerance) with the absolute floor of the stored doubles' rounding."""
     g = lambda k: T6[f"{tag}_{k}"]  # noqa: E731
     assert np.array_equal(acc, g("accepted")), f"{tag}: first differing step {np.flatnonzero(acc != g('accepted'))[:5]}"
     np.testing.assert_allclose(H, g("H"), rtol=rtol, atol=1e-9)
+    if f"{tag}_dH" in T6:
+        # the enthalpy change of every ACCEPTED step, 1e-10 relative (north_star) -- read off the running
+        # enthalpies, so with the rounding of the two stored doubles it is the difference of as the floor
+        a = g("accepted").astype(bool)
+        h_prev = np.concatenate(([h0 if h0 is not None else np.nan], H[:-1]))
+        dH, want = (H - h_prev)[a], g("dH")[a]
+        ok = ~np.isnan(dH)
+        err = np.abs(dH[ok] - want[ok])
+        bound = 1e-10 * np.abs(want[ok]) + 8 * np.finfo(float).eps * np.abs(H[a][ok])
+        assert (err <= bound).all(), (tag, float((err / np.maximum(np.abs(want[ok]), 1e-300)).max()))
+        assert a.sum() > 10
     st = mc.get_state()
     assert np.array_equal(st["occupancy"][0], g("occ_final"))
     np.testing.assert_allclose(st["features"][0], g("feat_final"), rtol=rtol, atol=1e-8)
