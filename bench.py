@@ -569,9 +569,13 @@ def dry_run(args, rank, world):
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64)
     stats = torch.tensor([0.0, 0.0, 0.0, float(count)], dtype=torch.float64)
+    ones = torch.ones(1, dtype=torch.float64)  # the same rank census the GPU path takes
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    if int(round(float(ones.item()))) != args.gpus:
+        raise SystemExit(4)
     # configs 4 / 5 as N-rank workloads
     clock = _Clock(world, "cpu", gpu=False)
     per4, per5, sweeps = 1024, 2048, 6
@@ -589,6 +593,7 @@ def dry_run(args, rank, world):
             "metric": METRIC, "value": None, "unit": "attempted flips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
             "scaling": args.scaling, "dry_run": True, "walkers_total": int(stats[3].item()),
+            "rccl_ranks": int(round(float(ones.item()))), "collective_backend": "gloo (dry run, no GPU)" if world > 1 else "none (single rank)",
             "walkers_rank0": [first, count],
             "other_configs": [
                 {"config": "config4 (dry run)", "n_gpus": world, "replicas": int(w4), "wall_s": t4,

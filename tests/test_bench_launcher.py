@@ -27,6 +27,7 @@ def test_self_spawn_dry_run_weak_and_strong():
     rec = _line(out)
     assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["walkers_total"] == 8192 and rec["walkers_rank0"] == [0, 4096]
+    assert rec["rccl_ranks"] == 2 and rec["collective_backend"].startswith("gloo")  # the rank census of the bench line
     # configs 4 and 5 as N-rank workloads: independent shards / one ladder over all ranks with the
     # exchange (host-staged all-gather here) inside the timed region
     c4, c5 = rec["other_configs"]
