@@ -678,7 +678,7 @@ static double table_masked_weights(const smolmc_tables *t, const int *n, double 
 static double table_log_priori(const smolmc_tables *t, const int *n, int idx, double sum_now,
                                const double *mw_now) {
     int d = (int)t->sub_code_ptr[t->n_sublattices];
-    int n_next[SMOLMC_MAX_FLIP_DIMS];
+    int n_next[SMOLMC_MAX_FLIP_DIMS] = {0};
     double mw_next[2 * SMOLMC_MAX_FLIP_VECTORS];
     const int32_t *row = t->flip_table + (size_t)(idx / 2) * d;
     int sgn = (idx & 1) ? -1 : 1;
