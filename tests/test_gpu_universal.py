@@ -246,3 +246,63 @@ def test_wang_landau_with_more_than_64_features(monkeypatch):
     assert "more than 64 features" in eng.kernel_info(), eng.kernel_info()
     _same_chain(eng, ora, (1, 79, 2, 400), wl=True)
     eng.close()
+
+
+@pytest.mark.parametrize("bias", [None, "fug", "sqc", "hyp"])
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_replayed_records_of_arbitrary_flips(mode, bias, monkeypatch):
+    """Records of one to eight flips drawn at random -- several sublattices in one step, the SAME site
+    flipped more than once (what a MultiStep usher returns, mcusher.py:288-304) -- replayed on a Flip
+    handle (the universal kernel takes them) against the oracle: sequential-flip semantics of the
+    features (expansion.py:217-229), mu against the occupancy before the step (ensemble.py:368-374),
+    'the last flip of a site counts' for the bias terms (bias.py:75-93, 188-206)."""
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    c = load_case("rocksalt333_two_sublattices")
+    sc = c["sc"]
+    tab = capi.TableSet.from_synth(sc, c["coefs"], feature_mode=MODES[mode], ewald=c["ewald"], ewald_coef=0.1,
+                                   mu_table=T6["TG_mu"])
+    if bias == "fug":
+        tab.set_bias(capi.BIAS_FUGACITY, T6["BG_fug_table"])
+    elif bias == "sqc":
+        tab.set_bias(capi.BIAS_SQUARE_CHARGE, T6["BG_sqc_table"], 0.04)
+    elif bias == "hyp":
+        from tests.v6_cases import _hyperplane_tables
+
+        tab.set_bias(capi.BIAS_SQUARE_HYPERPLANE, _hyperplane_tables(T6["BG_hyp_A"], T6["BG_hyp_dim_ids"]), 0.02,
+                     intercepts=T6["BG_hyp_b"].astype(float))
+    R, n = 4, 300
+    rng = np.random.default_rng(17)
+    nsp = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
+    occ = (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
+    steps = -np.ones((R, n, 16), dtype=np.int32)
+    for r in range(R):
+        for k in range(n):
+            nf = int(rng.integers(0, 9))
+            sites = rng.integers(0, sc.num_sites, nf)
+            if nf >= 3 and rng.random() < 0.5:
+                sites[-1] = sites[0]  # a site flipped twice in one step
+            for j, s in enumerate(sites):
+                steps[r, k, 2 * j], steps[r, k, 2 * j + 1] = s, rng.integers(0, nsp[s])
+    us = rng.random((R, n))
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, np.arange(R, dtype=np.uint64), 3000.0)
+    a_acc, a_H = eng.replay(steps, us)
+    b_acc, b_H = ora.replay(steps, us)
+    assert np.array_equal(a_acc, b_acc)
+    np.testing.assert_allclose(a_H, b_H, rtol=1e-10, atol=1e-8)
+    a, b = eng.get_state(), ora.get_state()
+    assert np.array_equal(a["occupancy"], b["occupancy"])
+    np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    if bias:
+        np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=1e-10, atol=1e-9)
+    assert 0.05 < a_acc.mean() < 0.95
+    # a one-step chain of the same records on the native kernels afterwards: the handle is still consistent
+    eng.run(50)
+    ora.run(50)
+    assert np.array_equal(eng.get_state()["occupancy"], ora.get_state()["occupancy"])
+    eng.close()
