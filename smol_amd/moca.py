@@ -68,6 +68,34 @@ class Trace(SimpleNamespace):
         return self.__dict__.copy()
 
 
+class StepTrace(Trace):
+    """Trace of one attempted step: the walker's values plus ``delta_trace``, the changes the step
+    made to them (smol/moca/trace.py:46-90); ``names`` / ``items`` skip the inner trace."""
+
+    def __init__(self, /, **kwargs):
+        super().__init__(**kwargs)
+        self.__dict__["delta_trace"] = Trace()
+
+    @property
+    def names(self):
+        return tuple(n for n in self.__dict__ if n != "delta_trace")
+
+    def items(self):
+        for name, value in self.__dict__.items():
+            if name != "delta_trace":
+                yield name, value
+
+    def __setattr__(self, name, value):
+        if name == "delta_trace":
+            raise ValueError("Attribute name 'delta_trace' is reserved.")
+        super().__setattr__(name, value)
+
+    def as_dict(self):
+        d = self.__dict__.copy()
+        d["delta_trace"] = d["delta_trace"].as_dict()
+        return d
+
+
 class Sublattice:
     """Sites sharing one site space (smol/moca/sublattice.py:23-107)."""
 
@@ -97,6 +125,57 @@ class Sublattice:
     def reset_restricted_sites(self):
         if len(self.species) > 1:
             self.active_sites = self.sites.copy()
+
+    def _code_of(self, sp):
+        if isinstance(sp, (int, np.integer)):
+            code = int(sp)
+            if code not in self.encoding:
+                raise ValueError(f"code {code} is not in this sublattice's encoding {self.encoding}")
+            return code
+        return int(self.encoding[self.species.index(sp)])
+
+    def split_by_species(self, occu, species_in_partitions):
+        """Split into one sublattice per partition of this one's species, by what occupies each
+        site in ``occu`` (smol/moca/sublattice.py:109-186): partition p gets the sites holding
+        one of its species (given as species or as codes), keeps those codes as its encoding, and a
+        single-species partition is restricted (inactive).  Sites are listed code by code in
+        ascending code order, as the reference lists them."""
+        occu = np.asarray(occu)
+        out = []
+        for partition in species_in_partitions:
+            codes = sorted(self._code_of(sp) for sp in partition)
+            where = [int(np.where(self.encoding == c)[0][0]) for c in codes]
+            sites = np.concatenate([self.sites[occu[self.sites] == c] for c in codes] + [np.zeros(0, np.int64)])
+            actives = np.concatenate([self.active_sites[occu[self.active_sites] == c] for c in codes]
+                                     + [np.zeros(0, np.int64)])
+            part = Sublattice([self.species[i] for i in where], sites, [self.charges[i] for i in where])
+            part.sites = sites.astype(np.int64)
+            part.active_sites = actives.astype(np.int64)
+            part.encoding = np.array(codes, dtype=np.int32)
+            if len(codes) == 1:
+                part.restrict_sites(part.sites)
+            out.append(part)
+        return out
+
+    def __eq__(self, other):
+        """Same species, encoding and sites (restrictions are not compared, sublattice.py:188-199)."""
+        return (isinstance(other, Sublattice) and self.species == other.species
+                and np.array_equal(self.encoding, other.encoding) and np.array_equal(self.sites, other.sites))
+
+    __hash__ = None
+
+    def as_dict(self):
+        """JSON-able record (sublattice.py:201-217)."""
+        return dict(species=list(self.species), charges=list(self.charges), sites=self.sites.tolist(),
+                    encoding=self.encoding.tolist(), active_sites=self.active_sites.tolist())
+
+    @classmethod
+    def from_dict(cls, d):
+        sub = cls(d["species"], d["sites"], d.get("charges"))
+        sub.sites = np.array(d["sites"], dtype=np.int64)
+        sub.encoding = np.array(d["encoding"], dtype=np.int32)
+        sub.active_sites = np.array(d["active_sites"], dtype=np.int64)
+        return sub
 
 
 # --------------------------------------------------------------------------- #
@@ -489,6 +568,17 @@ class Ensemble:
         for s in self._sublattices:
             s.reset_restricted_sites()
 
+    def split_sublattice_by_species(self, sublattice_id, occu, species_in_partitions):
+        """Replace sublattice ``sublattice_id`` by its split by occupying species
+        (ensemble.py:288-321), e.g. Li/vacancy, transition metals and O of one site space as
+        sublattices that swaps cannot mix.  The chemical potentials are rebuilt for the species that
+        remain on active sublattices."""
+        splits = self._sublattices[sublattice_id].split_by_species(occu, species_in_partitions)
+        self._sublattices = (list(self._sublattices[:sublattice_id]) + splits
+                             + list(self._sublattices[sublattice_id + 1:]))
+        if self._chemical_potentials is not None:
+            self.chemical_potentials = {sp: self._chemical_potentials[sp] for sp in self.species}
+
     def composition_space(self, charge_balanced=True, other_constraints=None, optimize_basis=False,
                           table_ergodic=False):
         """CompositionSpace over ALL sublattices of this ensemble, sizes reduced by their gcd,
@@ -549,7 +639,8 @@ class Ensemble:
         # content key: a different restriction of the same size, or a new mu table that reuses
         # the id() of a freed one, must rebuild the handle
         key = (None if self._mu_table is None else self._mu_table.tobytes(),
-               tuple(np.asarray(s.active_sites).tobytes() for s in self._sublattices))
+               tuple(np.asarray(s.active_sites).tobytes() + b"|" + np.asarray(s.encoding).tobytes()
+                     for s in self._sublattices))
         if getattr(self, "_eval_key", None) != key:
             self._eval_tables = self.make_tables()
             self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
@@ -777,6 +868,72 @@ class MCKernel:
     def seed64(self):
         return np.uint64(int(self._seed) & 0xFFFFFFFFFFFFFFFF)
 
+    # -- single-kernel stepping (kernel/base.py:100-166,287-289,345-366) -----------------
+    # The reference steps ONE chain on the host through these; here they drive a one-walker
+    # engine handle owned by the kernel (same kernels, same random stream as walker 0 of a
+    # Sampler seeded with this kernel's seed).  An interface for tests, notebooks and custom
+    # drivers -- a launch per step -- not the sampling path (Sampler.run).
+    _owner = None  # (sampler, local walker) once a Sampler took this kernel
+
+    def _solo(self):
+        if getattr(self, "_solo_sampler", None) is None:
+            container = Sampler._container_for(self._ensemble, self, 1)
+            container.metadata["walker_range"] = (0, 1, 1)
+            self._solo_sampler = Sampler([self], container, device=getattr(self, "device", 0), _bind=False)
+        return self._solo_sampler
+
+    def _walker_trace(self, tr, w=0):
+        return StepTrace(**{k: (np.asarray(v[w]).astype(np.int32) if k == "occupancy" else np.asarray(v[w]))
+                        for k, v in tr.items()})
+
+    def set_aux_state(self, occupancy, *args, **kwargs):
+        """Load ``occupancy`` as this kernel's chain state: features, enthalpy, bias, Ewald field,
+        species counts and (Wang-Landau) the current bin are recomputed from it on the device; the
+        random stream, counters and Wang-Landau arrays carry on (kernel/base.py:287-289,
+        wanglandau.py:290-300)."""
+        self._solo()._load_state(np.asarray(occupancy))
+
+    def compute_initial_trace(self, occupancy):
+        """Trace of ``occupancy`` before any step (kernel/base.py:345-366)."""
+        solo = self._solo()
+        solo._load_state(np.asarray(occupancy))
+        tr = self._walker_trace(solo._current_trace(solo._get_engine()))
+        tr.accepted = np.array([True], dtype=bool)
+        return tr
+
+    def single_step(self, occupancy):
+        """Attempt one MC step from ``occupancy`` (kernel/base.py:145-166): the step is proposed,
+        priced and accepted / rejected on the device; ``occupancy`` is updated in place when the step
+        is accepted and the trace carries ``delta_trace`` (features, enthalpy, bias changes of the
+        PROPOSED step when accepted, zero otherwise -- the rejected proposal never leaves the GPU)."""
+        solo = self._solo()
+        eng = solo._get_engine()
+        occupancy_in = occupancy
+        solo._load_state(np.asarray(occupancy))
+        before = solo._current_trace(eng)
+        eng.run(1)
+        tr = self._walker_trace(solo._current_trace(eng))
+        delta = tr.delta_trace
+        delta.features = tr.features - before.features[0]
+        delta.enthalpy = np.array(tr.enthalpy[0] - before.enthalpy[0, 0], dtype=np.float64)
+        if self._bias is not None:
+            delta.bias = np.array(tr.bias[0] - before.bias[0, 0], dtype=np.float64)
+        if isinstance(occupancy_in, np.ndarray):
+            occupancy_in[:] = tr.occupancy
+            tr.occupancy = occupancy_in
+        self._last_trace = tr
+        return tr
+
+    @property
+    def trace(self):
+        """Trace of the last ``single_step`` / of this kernel's walker in its Sampler."""
+        if getattr(self, "_last_trace", None) is not None:
+            return self._last_trace
+        if self._owner is not None:
+            sampler, w = self._owner
+            return self._walker_trace(sampler._current_trace(sampler._get_engine()), w)
+        raise AttributeError("no step has been taken with this kernel yet")
+
 
 class Metropolis(MCKernel):
     """Metropolis-Hastings kernel (smol/moca/kernel/metropolis.py:52-100)."""
@@ -842,6 +999,42 @@ class WangLandau(MCKernel):
     @property
     def bin_size(self):
         return self._window[2]
+
+    # -- state of this kernel's walker (wanglandau.py:150-173), read from the device -------
+    def _wl_row(self):
+        if self._owner is not None:
+            sampler, w = self._owner
+        else:
+            sampler, w = self._solo(), 0
+        wl = sampler._get_engine().get_wl()
+        return {k: v[w] for k, v in wl.items()}
+
+    @property
+    def levels(self):
+        """Visited enthalpy levels."""
+        return self._levels[self._wl_row()["entropy"] > 0]
+
+    @property
+    def entropy(self):
+        """log(dos) on visited levels."""
+        S = self._wl_row()["entropy"]
+        return S[S > 0]
+
+    @property
+    def dos(self):
+        """Density of states on visited levels."""
+        S = self.entropy
+        return np.exp(S - S.min())
+
+    @property
+    def histogram(self):
+        """Histogram on visited levels."""
+        row = self._wl_row()
+        return row["histogram"][row["entropy"] > 0]
+
+    @property
+    def mod_factor(self):
+        return float(self._wl_row()["mod_factor"])
 
 
 KERNELS = {"metropolis": Metropolis, "wanglandau": WangLandau, "wang-landau": WangLandau,
@@ -1056,6 +1249,31 @@ class SampleContainer:
         np.savez_compressed(path, nsamples=self.num_samples, total_mc_steps=self._total_steps,
                             **{f"trace/{k}": v for k, v in self._all().items()})
 
+    def as_dict(self):
+        """JSON-able record of the samples (container.py:525-547): every traced value as nested
+        lists with its dtype, the counters and the sampling metadata.  The ensemble itself is a set
+        of flattened tables here, not a serialisable object: ``from_dict`` takes it as an argument."""
+        return {
+            "@class": self.__class__.__name__,
+            "nsamples": self.num_samples,
+            "total_mc_steps": self._total_steps,
+            "metadata": _jsonable(self.metadata),
+            "sublattices": [sub.as_dict() for sub in self.sublattices],
+            "natural_parameters": np.asarray(self.natural_parameters).tolist(),
+            "trace": {k: {"dtype": str(v.dtype), "data": v.tolist()} for k, v in self._all().items()},
+        }
+
+    @classmethod
+    def from_dict(cls, d, ensemble):
+        """Container of ``as_dict``'s record on ``ensemble`` (container.py:549-575)."""
+        arrays = {k: np.array(v["data"], dtype=np.dtype(v["dtype"])) for k, v in d["trace"].items()}
+        n = int(d["nsamples"])
+        c = cls(ensemble, Trace(**{k: v[:0] for k, v in arrays.items()}), d.get("metadata"))
+        if n:
+            c.append_block({k: v[:n] for k, v in arrays.items()}, 0)
+        c._total_steps = int(d["total_mc_steps"])
+        return c
+
     # Streaming backend: a directory of part-NNNNNN.npz files + manifest.json.  It stands in for the
     # HDF5 file of the reference (container.py:420-437 flush_to_backend, :439-504 get_backend; h5py is
     # not available here): every flush writes the samples held in memory as the next part and drops
@@ -1200,8 +1418,12 @@ class Sampler:
     indexed by GLOBAL walker, so walker g runs the same chain whatever the world size;
     ``global_statistics`` all-reduces the running sums over ranks (RCCL), the only collective."""
 
-    def __init__(self, kernels, container, engine=None, walker_range=None, device=0, world_size=1):
+    def __init__(self, kernels, container, engine=None, walker_range=None, device=0, world_size=1,
+                 _bind=True):
         self._kernels = kernels
+        if _bind:  # kernel-level accessors (WangLandau.dos, MCKernel.trace) read this sampler's engine
+            for w, k in enumerate(kernels):
+                k._owner = (self, w)
         self._container = container
         self._container.metadata["kernels"] = [k.spec for k in kernels]
         self._engine = engine
@@ -1233,7 +1455,15 @@ class Sampler:
         local_seeds = [None] * count if seeds is None else list(seeds[first:first + count])
         kernels = [mckernel_factory(kernel_type, ensemble, step_type, *args, seed=s, **kwargs)
                    for s in local_seeds]
-        k0 = kernels[0]
+        container = cls._container_for(ensemble, kernels[0], count)
+        container.metadata["walker_range"] = (first, count, nwalkers)
+        if device is None:
+            device = parallel.local_device(rank)
+        return cls(kernels, container, walker_range=(first, count), device=device, world_size=world_size)
+
+    @staticmethod
+    def _container_for(ensemble, k0, count):
+        """Empty SampleContainer with the trace schema of kernel ``k0`` for ``count`` walkers."""
         F = len(ensemble.natural_parameters)
         # occupancies are STORED as the device ring's bytes (a quarter of the int32 the reference
         # keeps) and handed out as int32 by the container's getters
@@ -1250,11 +1480,7 @@ class Sampler:
                               entropy=((L,), np.float64), cumulative_mean_features=((L, F), np.float64),
                               mod_factor=((1,), np.float64))
         schema = Trace(**{k: np.empty((0, count) + shp, dtype=dt) for k, (shp, dt) in per_walker.items()})
-        container = SampleContainer(ensemble, schema, ensemble.thermo_boundaries)
-        container.metadata["walker_range"] = (first, count, nwalkers)
-        if device is None:
-            device = parallel.local_device(rank)
-        return cls(kernels, container, walker_range=(first, count), device=device, world_size=world_size)
+        return SampleContainer(ensemble, schema, ensemble.thermo_boundaries)
 
     # -- accessors -----------------------------------------------------------------
     mckernels = property(lambda self: self._kernels)
@@ -1305,6 +1531,7 @@ class Sampler:
         h.update(b"mu" if mu is None else np.ascontiguousarray(mu).tobytes())
         for sub in ens.sublattices:
             h.update(np.ascontiguousarray(sub.active_sites, dtype=np.int64).tobytes() + b"|")
+            h.update(np.ascontiguousarray(sub.encoding, dtype=np.int64).tobytes() + b"/")
         if k0.bias is not None:
             h.update(np.ascontiguousarray(k0.bias._table).tobytes())
             h.update(repr((k0.bias.bias_type, k0.bias.penalty)).encode())

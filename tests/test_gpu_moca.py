@@ -435,3 +435,113 @@ def test_processor_change_of_a_whole_table_step(rocksalt):
         d = comp.compute_feature_vector_change(occ, flips)
         np.testing.assert_allclose(d, comp.compute_feature_vector(new) - comp.compute_feature_vector(occ),
                                    rtol=1e-9, atol=1e-8)
+
+
+def test_kernel_single_step_walks_the_sampler_chain(fcc):
+    """MCKernel.single_step / compute_initial_trace / set_aux_state / trace (kernel/base.py:145-166,
+    287-289,345-366; tests/test_moca/test_kernel.py test_single_step): a kernel stepped one step at
+    a time is walker 0 of a Sampler with the same seed -- same occupancies after every step -- the
+    occupancy is updated in place exactly when the step is accepted, and delta_trace holds the
+    change of the traced values."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    ens.chemical_potentials = {"A0": 0.05, "A1": -0.05}
+    occu0 = _rand_occ(np.random.default_rng(21), sc)[0]
+    kernel = moca.Metropolis(ens, "flip", 900.0, seed=77)
+    tr0 = kernel.compute_initial_trace(occu0)
+    assert tr0.accepted.tolist() == [True] and tr0.enthalpy.shape == (1,)
+    np.testing.assert_allclose(tr0.features, ens.compute_feature_vector(occu0), rtol=1e-12, atol=1e-10)
+    sampler = moca.Sampler.from_ensemble(ens, temperature=900.0, step_type="flip", nwalkers=1, seeds=[77])
+    sampler.run(60, occu0[None], thin_by=1)
+    ref = sampler.samples.get_occupancies(flat=False)[:, 0]
+    acc = sampler.samples.get_trace_value("accepted", flat=False)[:, 0, 0]
+    occu = occu0.copy()
+    n_acc = 0
+    for i in range(60):
+        prev = occu.copy()
+        feats = ens.compute_feature_vector(prev)
+        tr = kernel.single_step(occu)
+        assert tr.occupancy is occu and np.array_equal(occu, ref[i])
+        assert bool(tr.accepted[0]) == bool(acc[i]) == (not np.array_equal(prev, occu))
+        n_acc += bool(tr.accepted[0])
+        np.testing.assert_allclose(tr.delta_trace.features, ens.compute_feature_vector(occu) - feats,
+                                   rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(tr.delta_trace.enthalpy, ens.natural_parameters @ tr.delta_trace.features,
+                                   rtol=1e-9, atol=1e-9)
+        assert tr.temperature.tolist() == [900.0]
+    assert 0 < n_acc < 60 and kernel.trace is tr
+    assert "delta_trace" not in tr.names
+    # a kernel owned by a sampler reports its walker's trace
+    k = sampler.mckernels[0]
+    np.testing.assert_array_equal(k.trace.occupancy, ref[-1])
+
+
+def test_wang_landau_kernel_accessors(fcc):
+    """WangLandau.levels / entropy / dos / histogram / mod_factor (wanglandau.py:150-173) of a
+    kernel inside a Sampler are its walker's rows of the device state, on visited levels only."""
+    model, sc, coefs = fcc
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs)
+    occu = _rand_occ(np.random.default_rng(5), sc)[0]
+    h0 = float(ens.natural_parameters @ ens.compute_feature_vector(occu))
+    sampler = moca.Sampler.from_ensemble(ens, h0 - 8.0, h0 + 8.0, 0.5, kernel_type="Wang-Landau", nwalkers=2,
+                                         seeds=[1, 2], check_period=200, flatness=0.2)
+    sampler.run(3000, np.vstack([occu, occu]), thin_by=1500)
+    c = sampler.samples
+    ent = c.get_trace_value("entropy", flat=False)[-1]
+    hist = c.get_trace_value("histogram", flat=False)[-1]
+    m = c.get_trace_value("mod_factor", flat=False)[-1]
+    all_levels = np.arange(h0 - 8.0, h0 + 8.0, 0.5)
+    for w, k in enumerate(sampler.mckernels):
+        seen = ent[w] > 0
+        assert seen.sum() >= 2
+        np.testing.assert_array_equal(k.entropy, ent[w][seen])
+        np.testing.assert_array_equal(k.histogram, hist[w][seen])
+        np.testing.assert_allclose(k.levels, all_levels[seen])
+        np.testing.assert_allclose(k.dos, np.exp(ent[w][seen] - ent[w][seen].min()))
+        assert k.mod_factor == m[w, 0] and k.dos.min() == 1.0
+    # a lone kernel stepped by hand keeps its own Wang-Landau state
+    k = moca.WangLandau(ens, "flip", h0 - 8.0, h0 + 8.0, 0.5, seed=9, check_period=50)
+    o = occu.copy()
+    for _ in range(40):
+        tr = k.single_step(o)
+    assert tr.histogram.sum() == 40 and k.histogram.sum() == 40 and len(k.levels) == len(k.dos) >= 1
+    np.testing.assert_allclose(tr.features, ens.compute_feature_vector(o), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("step", ["swap", "flip"])
+def test_split_sublattice_sampling_matches_the_oracle(rocksalt, step):
+    """Ensemble.split_sublattice_by_species (ensemble.py:288-321): after splitting the cation
+    sublattice into {Li+, Ti4+} and {Mn3+} by occupancy, steps only mix Li+ and Ti4+ (codes 0 and 2:
+    an encoding with a gap), the Mn3+ sites never change, and the GPU chain equals the oracle's."""
+    from oracle import oracle as orc
+
+    model, sc, coefs = rocksalt
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, processor_type="expansion")
+    cation = next(i for i, s in enumerate(ens.sublattices) if len(s.species) == 3)
+    sub = ens.sublattices[cation]
+    rng = np.random.default_rng(31)
+    nw = 3
+    occ = np.zeros((nw, sc.num_sites), dtype=np.int32)
+    occ[:, sub.sites] = rng.integers(0, 3, len(sub.sites))[None]  # same partition for every walker
+    for w in range(1, nw):  # ... but the Li/Ti arrangement differs
+        mix = sub.sites[occ[0, sub.sites] != 1]
+        occ[w, mix] = rng.permutation(occ[0, mix])
+    if step == "flip":
+        ens.chemical_potentials = {sp: 0.02 * i for i, sp in enumerate(ens.species)}
+    ens.split_sublattice_by_species(cation, occ[0], [[0, 2], [1]])
+    assert [s.encoding.tolist() for s in ens.sublattices[cation:cation + 2]] == [[0, 2], [1]]
+    seeds = [3, 4, 5]
+    sampler = moca.Sampler.from_ensemble(ens, temperature=2500.0, step_type=step, nwalkers=nw, seeds=seeds)
+    sampler.run(400, occ, thin_by=100)
+    occs = sampler.samples.get_occupancies(flat=False)
+    mn = sub.sites[occ[0, sub.sites] == 1]
+    assert np.all(occs[:, :, mn] == 1) and np.all(np.isin(occs[:, :, ens.sublattices[cation].sites], [0, 2]))
+    assert len(np.unique(occs[:, 0], axis=0)) > 1
+    ora = orc.OracleMC(ens.make_tables(), capi.make_config(nw, step_type=moca.STEP_TYPES[step]))
+    ora.set_state(occ, np.array(seeds, dtype=np.uint64), 2500.0)
+    for i in range(4):
+        ora.run(100)
+        st = ora.get_state()
+        assert np.array_equal(occs[i], st["occupancy"])
+        np.testing.assert_allclose(sampler.samples.get_enthalpies(flat=False)[i, :, 0], st["enthalpy"],
+                                   rtol=1e-10, atol=1e-9)

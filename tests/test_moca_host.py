@@ -254,3 +254,86 @@ def test_streamed_run_keeps_the_final_sample(tmp_path, monkeypatch):
         assert (s.samples.get_occupancies(flat=False)[0] == (nsamples - 1) % 2).all()
         back = moca.SampleContainer.from_stream(str(tmp_path / f"s{nsamples}"), ens)
         assert back.num_samples == nsamples
+
+
+def test_step_trace_keeps_delta_trace_apart():  # smol/moca/trace.py:46-90
+    t = moca.StepTrace(a=np.zeros(2))
+    t.delta_trace.a = np.ones(2)
+    assert t.names == ("a",) and [k for k, _ in t.items()] == ["a"]
+    with pytest.raises(ValueError, match="reserved"):
+        t.delta_trace = moca.Trace()
+    d = t.as_dict()
+    np.testing.assert_array_equal(d["delta_trace"]["a"], [1.0, 1.0])
+
+
+def _rocksalt_ensemble():
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 6.0})
+    sc = synth.build_supercell(model, [2, 2, 2])
+    return sc, moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=2))
+
+
+def test_split_sublattice_by_species():
+    """sublattice.py:109-186 / ensemble.py:288-321 (tests/test_moca/test_sublattice.py
+    test_split, test_ensemble.py test_split_ensemble): sites go to the partition of the species
+    they hold, codes are kept, a single-species partition is restricted, chemical potentials
+    are rebuilt for the species still active."""
+    sc, ens = _rocksalt_ensemble()
+    cation = next(i for i, s in enumerate(ens.sublattices) if len(s.species) == 3)
+    sub = ens.sublattices[cation]
+    rng = np.random.default_rng(0)
+    occu = np.zeros(ens.num_sites, dtype=np.int32)
+    occu[sub.sites] = rng.integers(0, 3, len(sub.sites))
+    ens.restrict_sites(sub.sites[:2])
+    before = len(ens.sublattices)
+    names = sub.species
+    parts = sub.split_by_species(occu, [[names[0], names[2]], [names[1]]])
+    by_code = sub.split_by_species(occu, [[0, 2], [1]])
+    for a, b in zip(parts, by_code):
+        assert a == b and np.array_equal(a.active_sites, b.active_sites)
+    p0, p1 = parts
+    assert p0.species == (names[0], names[2]) and p0.encoding.tolist() == [0, 2]
+    assert p1.species == (names[1],) and p1.encoding.tolist() == [1] and not p1.is_active
+    assert sorted(np.concatenate([p0.sites, p1.sites])) == sorted(sub.sites)
+    assert np.all(np.isin(occu[p0.sites], [0, 2])) and np.all(occu[p1.sites] == 1)
+    # code by code in ascending code order, restricted sites carried over
+    n0 = int((occu[sub.sites] == 0).sum())
+    assert np.all(occu[p0.sites[:n0]] == 0) and np.all(occu[p0.sites[n0:]] == 2)
+    assert not np.isin(sub.sites[:2], np.concatenate([p0.active_sites, p1.active_sites])).any()
+    with pytest.raises(ValueError):
+        sub.split_by_species(occu, [[0, 7]])
+
+    ens.reset_restricted_sites()
+    ens.chemical_potentials = {sp: 0.1 * i for i, sp in enumerate(ens.species)}
+    ens.split_sublattice_by_species(cation, occu, [[names[0], names[2]], [names[1]]])
+    assert len(ens.sublattices) == before + 1
+    assert names[1] not in ens.species and set(ens.chemical_potentials) == set(ens.species)
+    # the table keeps the columns of the codes (ensemble.py:90-99)
+    p0 = ens.sublattices[cation]
+    np.testing.assert_allclose(ens._mu_table[p0.sites[0], [0, 2]],
+                               [ens.chemical_potentials[names[0]], ens.chemical_potentials[names[2]]])
+    assert np.all(ens._mu_table[ens.sublattices[cation + 1].sites] == 0.0)
+    d = p0.as_dict()
+    q = moca.Sublattice.from_dict(d)
+    assert q == p0 and np.array_equal(q.active_sites, p0.active_sites)
+
+
+def test_sample_container_dict_roundtrip(ensemble):
+    import json
+
+    s = moca.Sampler.from_ensemble(ensemble, temperature=500, nwalkers=2)
+    c = s.samples
+    rng = np.random.default_rng(1)
+    F = len(ensemble.natural_parameters)
+    for i in range(3):
+        c.save_sampled_trace(moca.Trace(
+            occupancy=rng.integers(0, 2, (2, ensemble.num_sites)).astype(np.int32),
+            features=rng.random((2, F)), enthalpy=rng.random((2, 1)),
+            temperature=np.full((2, 1), 500.0), accepted=np.array([[True], [False]])), thinned_by=4)
+    d = json.loads(json.dumps(c.as_dict()))  # container.py:525-575
+    e = moca.SampleContainer.from_dict(d, ensemble)
+    assert e.num_samples == 3 and e.total_mc_steps == 12 and e.traced_values == c.traced_values
+    for name in c.traced_values:
+        a, b = c.get_trace_value(name, flat=False), e.get_trace_value(name, flat=False)
+        assert a.dtype == b.dtype
+        np.testing.assert_array_equal(a, b)
+    assert e.metadata["kernels"][0]["kernel"] == "Metropolis"
