@@ -188,6 +188,16 @@ def default_species(prim):
     return names
 
 
+def _eval_device():
+    """HIP device of the one-walker evaluation handles: this rank's GPU under a one-process-per-GPU
+    launcher (LOCAL_RANK), else device 0."""
+    if "LOCAL_RANK" not in os.environ:
+        return 0
+    from . import parallel
+
+    return parallel.local_device(int(os.environ["LOCAL_RANK"]))
+
+
 class Processor:
     """Base of the GPU-backed processors (smol/moca/processor/base.py:26)."""
 
@@ -230,7 +240,7 @@ class Processor:
     def _engine(self):
         if self._eval_engine is None:
             self._eval_tables = self._make_tables()
-            self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
+            self._eval_engine = Engine(self._eval_tables, capi.make_config(1, device=_eval_device()))
         return self._eval_engine
 
     _feature_slice = slice(None)
@@ -643,7 +653,7 @@ class Ensemble:
                      for s in self._sublattices))
         if getattr(self, "_eval_key", None) != key:
             self._eval_tables = self.make_tables()
-            self._eval_engine = Engine(self._eval_tables, capi.make_config(1))
+            self._eval_engine = Engine(self._eval_tables, capi.make_config(1, device=_eval_device()))
             self._eval_key = key
         return self._eval_engine
 
@@ -879,7 +889,7 @@ class MCKernel:
         if getattr(self, "_solo_sampler", None) is None:
             container = Sampler._container_for(self._ensemble, self, 1)
             container.metadata["walker_range"] = (0, 1, 1)
-            self._solo_sampler = Sampler([self], container, device=getattr(self, "device", 0), _bind=False)
+            self._solo_sampler = Sampler([self], container, device=_eval_device(), _bind=False)
         return self._solo_sampler
 
     def _walker_trace(self, tr, w=0):
