@@ -6,10 +6,11 @@ dispatch overrides (auto / SMOLMC_FORCE_GENERAL / SMOLMC_FORCE_UNIVERSAL), each 
 engine and on the CPU oracle with the same Philox streams: occupancies, accept counters and
 Wang-Landau histograms bit-equal, enthalpies / features / bias / entropies to 1e-10.
 
-    python tools/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean] [--out gpurun_out/fuzz.jsonl]
+    python tests/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean] [--out gpurun_out/fuzz.jsonl]
 
-Not part of the test suite (cases are random and the run is time-boxed); a failing case prints the
-seed that reproduces it:  python tools/fuzz_campaign.py --only <case seed>."""
+The campaign itself is time-boxed and not collected by pytest (tests/test_gpu_fuzz_campaign.py runs a
+fixed handful of its cases); the oracle is the checker here, as everywhere under tests/.  A failing case
+prints the seed that reproduces it:  python tests/fuzz_campaign.py --only <case seed>."""
 import argparse
 import json
 import os
