@@ -319,8 +319,24 @@ class Processor:
                 groups[key] = (names[b], [sites], prim.charges[b])
         return [Sublattice(sp, np.concatenate(st), q) for sp, st, q in groups.values()]
 
+    @property
+    def allowed_species(self):
+        """Species names of every site's site space, in code order (processor/base.py:104-107)."""
+        prim = self.supercell.model.prim
+        names = getattr(prim, "species", None) or default_species(prim)
+        return [list(names[b]) for b in self.supercell.site_b]
+
     def encode_occupancy(self, occupancy):
-        return np.array(occupancy, dtype=np.int32)
+        """Species names (or codes already) -> int32 codes (processor/base.py:228-237)."""
+        allowed = self.allowed_species
+        if len(occupancy) != len(allowed):
+            raise ValueError(f"occupancy has {len(occupancy)} entries, the supercell {len(allowed)} sites")
+        return np.array([sp if isinstance(sp, (int, np.integer)) else species.index(sp)
+                         for species, sp in zip(allowed, occupancy)], dtype=np.int32)
+
+    def decode_occupancy(self, encoded_occupancy):
+        """int codes -> species names (processor/base.py:239-243)."""
+        return [species[int(i)] for i, species in zip(encoded_occupancy, self.allowed_species)]
 
 
 class ClusterExpansionProcessor(Processor):
@@ -476,6 +492,10 @@ class Ensemble:
         build's own tables: ``supercell`` is a smol_amd.synth.SupercellTables and
         ``coefficients`` the expansion coefficients (num_corr_functions long).  When
         ``ewald_coefficient`` is given an EwaldProcessor is composed in."""
+        if hasattr(supercell, "subspace") and hasattr(supercell, "ce_coefs"):
+            # the reference's own call shape: (cluster_expansion, supercell_matrix) with an expansion
+            # loaded from smol's serialization (smol_amd.mson.load_mson)
+            return cls.from_mson(supercell, coefficients, processor_type=processor_type, **kwargs)
         model = supercell.model
         if processor_type == "decomposition":
             ce = ClusterDecompositionProcessor(supercell, model.cluster_interaction_tensors(coefficients))
@@ -828,10 +848,15 @@ class MCKernel:
     valid_bias = ("FugacityBias", "SquareChargeBias", "SquareHyperplaneBias")
 
     def __init__(self, ensemble, step_type, *args, seed=None, bias_type=None, bias_kwargs=None, **kwargs):
-        if step_type not in STEP_TYPES:
+        # any spelling the reference's class_name_from_str accepts (class_utils.py:10-34):
+        # "TableFlip", "Table-Flip", "table-flip", "Flip", "swap", ...
+        key = str(step_type).lower().replace("-", "").replace("_", "")
+        key = "table-flip" if key == "tableflip" else key
+        if key not in STEP_TYPES:
             raise ValueError(
-                f"{step_type} is not a valid MCUsher for this kernel (supported: {sorted(STEP_TYPES)})."
+                f"{step_type} is not a valid MCUsher for this kernel (supported: Flip, Swap, TableFlip)."
             )
+        step_type = key
         self._ensemble = ensemble
         self.natural_params = ensemble.natural_parameters
         self.step_type = step_type
@@ -1258,6 +1283,16 @@ class SampleContainer:
         nsamples / total_mc_steps, like the HDF5 'trace' group."""
         np.savez_compressed(path, nsamples=self.num_samples, total_mc_steps=self._total_steps,
                             **{f"trace/{k}": v for k, v in self._all().items()})
+
+    def to_hdf5(self, file_path):
+        """container.py:615: HDF5 needs h5py, which this build does not depend on -- the same content
+        goes to ``to_npz`` (one file) or to the streaming directory of ``get_backend``."""
+        raise NotImplementedError("HDF5 output needs h5py; use to_npz(path) / from_npz, or Sampler.run(..., "
+                                  "stream_chunk=n, stream_file=directory) and SampleContainer.from_stream")
+
+    @classmethod
+    def from_hdf5(cls, file_path, swmr_mode=False, ensemble=None):
+        raise NotImplementedError("HDF5 input needs h5py; use from_npz(path, ensemble) or from_stream(directory, ensemble)")
 
     def as_dict(self):
         """JSON-able record of the samples (container.py:525-547): every traced value as nested

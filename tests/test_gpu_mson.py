@@ -126,6 +126,10 @@ def test_smol_shaped_api_on_the_imported_model(lno):
     every sample stays charge neutral and its trace rows equal a from-scratch evaluation."""
     ce, _ = lno
     ens = moca.Ensemble.from_mson(ce, np.diag([4, 4, 4]))
+    # the reference's call shape, Ensemble.from_cluster_expansion(expansion, supercell_matrix) (ensemble.py:133-217)
+    same = moca.Ensemble.from_cluster_expansion(ce, np.diag([4, 4, 4]))
+    np.testing.assert_array_equal(same.natural_parameters, ens.natural_parameters)
+    assert [s.species for s in same.sublattices] == [s.species for s in ens.sublattices]
     assert [s.species for s in ens.sublattices] == [("Li+", "Vacancy"), ("Ni3+", "Ni4+"), ("O2-",)]
     assert len(ens.natural_parameters) == 12  # 11 orbit interactions + Ewald
     nw = 8

@@ -337,3 +337,47 @@ def test_sample_container_dict_roundtrip(ensemble):
         assert a.dtype == b.dtype
         np.testing.assert_array_equal(a, b)
     assert e.metadata["kernels"][0]["kernel"] == "Metropolis"
+
+
+def test_names_accept_the_reference_spellings(ensemble):
+    """class_name_from_str (smol/utils/class_utils.py:10-34): camel caps, hyphens, any capitalisation,
+    for step types (mcusher.py:714-731), kernels (kernel/__init__.py:35-56) and biases (bias.py:355-372)."""
+    for name in ("Swap", "swap", "SWAP"):
+        assert moca.Metropolis(ensemble, name, 500.0).step_type == "swap"
+    for name in ("Flip", "flip"):
+        assert moca.Metropolis(ensemble, name, 500.0).step_type == "flip"
+    for name in ("TableFlip", "Table-Flip", "table-flip", "tableflip"):
+        k = moca.Metropolis(ensemble, name, 500.0, flip_table=[[1, -1]])
+        assert k.step_type == "table-flip"
+    with pytest.raises(ValueError, match="not a valid MCUsher"):
+        moca.Metropolis(ensemble, "multi-step", 500.0)
+    for name in ("Metropolis", "metropolis"):
+        assert isinstance(moca.mckernel_factory(name, ensemble, "swap", 500.0), moca.Metropolis)
+    for name in ("WangLandau", "Wang-Landau", "wang-landau"):
+        assert isinstance(moca.mckernel_factory(name, ensemble, "swap", 0.0, 10.0, 1.0), moca.WangLandau)
+    for name in ("UniformlyRandom", "uniformly-random"):
+        assert isinstance(moca.mckernel_factory(name, ensemble, "swap"), moca.UniformlyRandom)
+    subs = ensemble.sublattices
+    for name in ("fugacity", "Fugacity-Bias", "FugacityBias", "fugacity-bias"):
+        assert isinstance(moca.mcbias_factory(name, subs), moca.FugacityBias)
+    for name in ("square-charge", "SquareChargeBias", "Square-Charge-Bias"):
+        assert isinstance(moca.mcbias_factory(name, subs), moca.SquareChargeBias)
+
+
+def test_encode_decode_occupancy():  # processor/base.py:228-243
+    sc, ens = _rocksalt_ensemble()
+    proc = ens.processor
+    rng = np.random.default_rng(3)
+    occ = np.zeros(ens.num_sites, dtype=np.int32)
+    occ[: sc.size] = rng.integers(0, 3, sc.size)
+    names = proc.decode_occupancy(occ)
+    assert set(names[: sc.size]) <= {"Li+", "Mn3+", "Ti4+"} and set(names[sc.size:]) == {"O2-"}
+    enc = proc.encode_occupancy(names)
+    assert enc.dtype == np.int32 and np.array_equal(enc, occ)
+    assert np.array_equal(proc.encode_occupancy(occ), occ)  # codes pass through
+    with pytest.raises(ValueError):
+        proc.encode_occupancy(names[:-1])
+    with pytest.raises(ValueError):
+        proc.encode_occupancy(["Xx"] + names[1:])
+    with pytest.raises(NotImplementedError, match="to_npz"):
+        moca.Sampler.from_ensemble(ens, temperature=300).samples.to_hdf5("x.h5")
