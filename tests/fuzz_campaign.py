@@ -182,6 +182,7 @@ def build_case(rng, profile="any"):
         tab.set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=getattr(bias, "intercepts", None))
         desc["bias"] = kind
     st = moca.STEP_TYPES[step]
+    wl_kw = None
     if kernel == "metropolis":
         cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, st)
     else:
@@ -190,17 +191,17 @@ def build_case(rng, profile="any"):
         probe = orc.OracleEvaluator(tab)
         h = np.array([probe.natural_parameters() @ probe.feature_vector(o) for o in occ])
         up = int(pick(rng, [1, 1, 1, 3]))
-        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, st, min_enthalpy=float(h.min()) - 3.0371,
-                               max_enthalpy=float(h.max()) + 3.0113, bin_size=float(pick(rng, [0.25, 0.5, 0.11])),
-                               check_period=int(pick(rng, [50, 20, 1000])), update_period=up,
-                               flatness=float(pick(rng, [0.8, 0.3])))
+        wl_kw = dict(min_enthalpy=float(h.min()) - 3.0371, max_enthalpy=float(h.max()) + 3.0113,
+                     bin_size=float(pick(rng, [0.25, 0.5, 0.11])), check_period=int(pick(rng, [50, 20, 1000])),
+                     update_period=up, flatness=float(pick(rng, [0.8, 0.3])))
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, st, **wl_kw)
         desc["update_period"] = up
     env = None if lean else pick(rng, [None, None, None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"])
     desc.update(walkers=R, sites=int(sc.num_sites), env=env)
     seeds = rng.integers(1, 2 ** 62, size=R).astype(np.uint64)
     temps = rng.uniform(400.0, 6000.0, size=R)
     return dict(desc=desc, ens=ens, tab=tab, cfg=cfg, occ=occ, seeds=seeds, temps=temps, env=env, bias=bias,
-                wl=kernel == "wang-landau")
+                wl=kernel == "wang-landau", usher=usher, wl_kw=wl_kw, step=step)
 
 
 def run_case(case_seed, profile="any"):

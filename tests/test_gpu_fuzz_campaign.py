@@ -21,3 +21,18 @@ def test_campaign_cases(profile, first):
         if res["status"] == "ok":
             kernels.add(res["desc"]["kernel_info"].split()[0])
     assert seen["ok"] >= 10 and len(kernels) >= 2, (seen, kernels)
+
+
+def test_sampler_campaign_cases():
+    """tests/fuzz_sampler.py: the same random cases through moca.Sampler (run continuing / restarting /
+    after clear_samples, anneal, callable mod_update, bias arguments), mirrored call for call on the oracle."""
+    from tests import fuzz_sampler
+
+    ok, ops = 0, set()
+    for seed in range(13500003, 13500003 + 20):
+        res = fuzz_sampler.run_case(seed)
+        assert res["status"] != "FAIL", res
+        if res["status"] == "ok":
+            ok += 1
+            ops.update(op[0] for op in res["desc"]["ops"])
+    assert ok >= 12 and {"run", "continue", "restart", "clear"} <= ops, (ok, ops)
