@@ -60,7 +60,8 @@ def neutral_rocksalt(sc, rng, cation_charges, anion):
 
 
 def build_case(rng, profile="any"):
-    """``profile`` "lean": larger unaliased cells, no restrictions / overrides (the lean kernel families).
+    """``profile`` "lean": larger unaliased cells, no restrictions / overrides (the lean kernel families);
+    "big": the same on cells of 2000-14000 sites.
     -> dict(desc, ens, tab, cfg, occ, seeds, temps, env, bias) or None when the draw is void."""
     desc = {}
     ionic = rng.random() < 0.6
@@ -82,8 +83,10 @@ def build_case(rng, profile="any"):
                 cut[4] = float(rng.uniform(2.95, 3.3))
         desc.update(lattice="fcc", nspecies=S)
     desc["cutoffs"] = cut
-    lean = profile == "lean"
-    dims = [int(rng.integers(4, 11)) for _ in range(3)] if lean else [int(rng.integers(2, 7)) for _ in range(3)]
+    big = profile == "big"  # cells of 2000-14000 sites: potential field in HBM, pending-update lists, gx tables
+    lean = profile == "lean" or big
+    dims = ([int(rng.integers(9, 16)) for _ in range(3)] if big else
+            [int(rng.integers(4, 11)) for _ in range(3)] if lean else [int(rng.integers(2, 7)) for _ in range(3)])
     if not lean and rng.random() < 0.15:
         scm = np.diag(dims)
         scm[0, 1], scm[1, 2] = int(rng.integers(0, 2)), int(rng.integers(0, 2))
@@ -93,7 +96,7 @@ def build_case(rng, profile="any"):
     desc["supercell"] = scm
     model = synth.build_cluster_model(prim, cut)
     sc = synth.build_supercell(model, scm)
-    if sc.num_sites > (2200 if lean else 600):
+    if sc.num_sites > (14000 if big else 2200 if lean else 600) or (big and sc.num_sites < 2000):
         return None
     coefs = synth.random_coefs(model, seed=int(rng.integers(1 << 30)))
     ptype = pick(rng, ["decomposition", "decomposition", "decomposition", "expansion"] if lean else ["decomposition", "expansion"])
@@ -108,7 +111,7 @@ def build_case(rng, profile="any"):
         steps += ["table-flip", "table-flip"]
     step = pick(rng, steps)
     desc.update(kernel=kernel, step=step)
-    R = int(rng.integers(1, 7))
+    R = int(rng.integers(1, 4 if big else 7))
     P = sc.size
     # occupancies
     if ionic and (step == "table-flip" or rng.random() < 0.3):
@@ -333,7 +336,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--profile", default="any", choices=["any", "lean"])
+    ap.add_argument("--profile", default="any", choices=["any", "lean", "big"])
     args = ap.parse_args()
     seeds = [args.only] if args.only is not None else [args.seed * 1000003 + i for i in range(args.cases)]
     t0 = time.time()
