@@ -201,6 +201,11 @@ class OracleMC:
             int(reset_aux),
         )
 
+    def set_counters(self, n_steps=None, n_accepted=None):
+        ns = None if n_steps is None else np.ascontiguousarray(n_steps, dtype=np.uint64)
+        na = None if n_accepted is None else np.ascontiguousarray(n_accepted, dtype=np.uint64)
+        lib().orc_mc_set_counters(self.h, _p(ns, C.c_uint64), _p(na, C.c_uint64))
+
     def set_temperature(self, temperature):
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, float), (self.R,)))
         lib().orc_mc_set_temperature(self.h, _p(t, C.c_double))

@@ -517,6 +517,17 @@ int orc_mc_get_state(orc_mc *h, int32_t *occ, double *features, double *enthalpy
     return 0;
 }
 
+/* smolmc_set_counters: the position of every walker in its random stream / its accept counter */
+int orc_mc_set_counters(orc_mc *h, const uint64_t *n_steps, const uint64_t *n_accepted) {
+    if (n_steps) {
+        memcpy(h->nsteps, n_steps, (size_t)h->R * 8);
+        if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU) /* the check period counts the same steps */
+            for (int r = 0; r < h->R; ++r) h->wl_counter[r] = (int64_t)n_steps[r];
+    }
+    if (n_accepted) memcpy(h->naccepted, n_accepted, (size_t)h->R * 8);
+    return 0;
+}
+
 int orc_mc_get_bias(orc_mc *h, double *bias) {
     if (!h->t->bias_type) return 1;
     memcpy(bias, h->bias, (size_t)h->R * 8);

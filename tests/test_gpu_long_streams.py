@@ -1,0 +1,128 @@
+"""The step counter is the position in a walker's Philox stream (counter words step & 0xffffffff,
+step >> 32).  A production walker passes 2^32 steps after about half an hour, so every kernel
+family is run ACROSS that boundary (and across 2^33, and from a counter far beyond) against the
+oracle, whose counter arithmetic is plain 64-bit C: the 16- / 64-step random batches, the table
+kernels' proposal batches and the Wang-Landau check period all derive their phase from the counter."""
+
+import numpy as np
+import pytest
+
+from smol_amd import capi, ewald, moca, synth
+from smol_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+STARTS = [2**32 - 37, 2**33 - 5, 3 * 2**40 + 12345]
+
+
+def _run_across(tab, cfg, occ, seeds, temps, start, expect_kernel, chunks=(1, 30, 64, 7, 200)):
+    from oracle import oracle as orc
+
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith(expect_kernel), eng.kernel_info()
+    R = len(occ)
+    n0 = np.full(R, start, dtype=np.uint64) + np.arange(R, dtype=np.uint64) * np.uint64(3)  # walkers out of phase
+    for e in (eng, ora):
+        e.set_state(occ, seeds, temps)
+        e.set_counters(n0, np.zeros(R, dtype=np.uint64))
+    done = 0
+    for chunk in chunks:
+        eng.run(chunk)
+        ora.run(chunk)
+        done += chunk
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["n_steps"], n0 + np.uint64(done)) and np.array_equal(b["n_steps"], a["n_steps"])
+        assert np.array_equal(a["occupancy"], b["occupancy"]), f"start {start}: occupancies differ after {done} steps"
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+    # device-side sampling across the boundary as well
+    ring = eng.run_sampled(3, 23, occupancy=True)
+    for i in range(3):
+        ora.run(23)
+        assert np.array_equal(ring["occupancy"][i], ora.get_state()["occupancy"])
+    assert 0 < a["n_accepted"].sum()
+    if cfg.kernel_type == capi.KERNEL_WANGLANDAU:
+        wa, wb = eng.get_wl(), ora.get_wl()
+        assert np.array_equal(wa["histogram"], wb["histogram"]) and np.array_equal(wa["occurrences"], wb["occurrences"])
+        np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"], rtol=0, atol=0)
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def fcc():
+    model = synth.build_cluster_model(synth.fcc_prim(), {2: 6.0, 3: 5.0})
+    sc = synth.build_supercell(model, [5, 5, 5])
+    return sc, capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=3))
+
+
+@pytest.fixture(scope="module")
+def rocksalt():
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 6.0, 3: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    return model, sc
+
+
+def _fcc_occ(sc, R, seed):
+    return (np.random.default_rng(seed).random((R, sc.num_sites)) < 0.5).astype(np.int32)
+
+
+@pytest.mark.parametrize("start", STARTS)
+@pytest.mark.parametrize("step", [capi.STEP_SWAP, capi.STEP_FLIP], ids=["swap", "flip"])
+@pytest.mark.parametrize("force", [None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"], ids=["lean", "general", "universal"])
+def test_metropolis_across_the_counter_boundary(fcc, start, step, force, monkeypatch):
+    for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
+        monkeypatch.delenv(name, raising=False)
+    if force:
+        monkeypatch.setenv(force, "1")
+    sc, tab = fcc
+    R = 5
+    _run_across(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, step), _fcc_occ(sc, R, 1),
+                np.arange(11, 11 + R, dtype=np.uint64), np.linspace(800.0, 3000.0, R), start,
+                "lean" if force is None else force.split("_")[-1].lower())
+
+
+@pytest.mark.parametrize("start", STARTS)
+@pytest.mark.parametrize("force", [None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"], ids=["lean", "general", "universal"])
+def test_wang_landau_across_the_counter_boundary(fcc, start, force, monkeypatch):
+    """The flatness check fires where the COUNTER reaches a multiple of the check period: periods that
+    do not divide 2^32 would show a counter truncated to 32 bits."""
+    from oracle import oracle as orc
+
+    for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
+        monkeypatch.delenv(name, raising=False)
+    if force:
+        monkeypatch.setenv(force, "1")
+    sc, tab = fcc
+    R = 3
+    occ = _fcc_occ(sc, R, 2)
+    probe = orc.OracleEvaluator(tab)
+    h = np.array([probe.natural_parameters() @ probe.feature_vector(o) for o in occ])
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=float(h.min()) - 4.0371,
+                           max_enthalpy=float(h.max()) + 4.0113, bin_size=0.25, check_period=7, flatness=0.1)
+    _run_across(tab, cfg, occ, np.arange(21, 21 + R, dtype=np.uint64), 0.0, start,
+                "lean" if force is None else force.split("_")[-1].lower())
+
+
+@pytest.mark.parametrize("start", STARTS[:2])
+@pytest.mark.parametrize("two_sublattices", [False, True], ids=["cations", "cations+anions"])
+def test_table_flip_and_ewald_across_the_counter_boundary(start, two_sublattices):
+    """TableFlip proposal batches (64 steps, lane <-> step) and the lean-multi kernels with the Ewald field."""
+    prim = synth.rocksalt_prim(anion_charges=(-2.0, -1.0)) if two_sublattices else synth.rocksalt_prim()
+    model = synth.build_cluster_model(prim, {2: 6.0, 3: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 4])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=5), ewald_coefficient=0.15)
+    table = ens.composition_space().flip_table
+    tab = ens.make_tables(flip_table=table, swap_weight=0.2)
+    R, P = 4, sc.size
+    rng = np.random.default_rng(9)
+    occ = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # charge neutral: n_Li + 3 n_Mn + 4 n_Ti = 2 P (anions all O2-)
+        n_ti = 2 * int(rng.integers(1, P // 8))  # (even, so that P - 3 n_ti is)
+        n_mn = (P - 3 * n_ti) // 2
+        perm = rng.permutation(P)
+        occ[r, perm[:n_mn]] = 1
+        occ[r, perm[n_mn:n_mn + n_ti]] = 2
+    _run_across(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP), occ,
+                np.arange(31, 31 + R, dtype=np.uint64), np.linspace(3000.0, 9000.0, R), start,
+                "lean", chunks=(1, 30, 64, 70, 130))
