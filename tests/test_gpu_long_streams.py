@@ -126,3 +126,64 @@ def test_table_flip_and_ewald_across_the_counter_boundary(start, two_sublattices
     _run_across(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP), occ,
                 np.arange(31, 31 + R, dtype=np.uint64), np.linspace(3000.0, 9000.0, R), start,
                 "lean", chunks=(1, 30, 64, 70, 130))
+
+
+@pytest.mark.parametrize("kind", ["swap", "flip", "wang-landau", "table-flip", "universal"])
+def test_many_walkers_of_a_small_cell(kind, monkeypatch):
+    """10 007 walkers (a prime: the last workgroup is partial, the grid is thousands of workgroups) of
+    a 64-site cell, every one compared with the oracle: walker -> launch slot -> wave mapping, per-walker
+    seeds / temperatures / counters at scale, and the exchange-ladder launch order of the table kernel
+    (walkers at different temperatures are dealt to the slots hottest-with-coldest)."""
+    from oracle import oracle as orc
+
+    for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
+        monkeypatch.delenv(name, raising=False)
+    R = 10007
+    rng = np.random.default_rng(77)
+    if kind == "table-flip":
+        model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 4.5})
+        sc = synth.build_supercell(model, [2, 2, 4])
+        ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=6), ewald_coefficient=0.1)
+        tab = ens.make_tables(flip_table=[[1, -3, 2, 0]], swap_weight=0.3)
+        P = sc.size
+        occ = np.zeros((R, sc.num_sites), dtype=np.int32)
+        for r in range(R):
+            n_ti = 2 * int(rng.integers(1, 3))
+            perm = rng.permutation(P)
+            n_mn = (P - 3 * n_ti) // 2
+            occ[r, perm[:n_mn]] = 1
+            occ[r, perm[n_mn:n_mn + n_ti]] = 2
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    else:
+        if kind == "universal":
+            monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+        model = synth.build_cluster_model(synth.fcc_prim(), {2: 4.5, 3: 3.0})
+        sc = synth.build_supercell(model, [4, 4, 4])
+        mu = None
+        if kind == "flip":
+            mu = np.tile(np.array([[0.05, -0.05]]), (sc.num_sites, 1))
+        tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=6), mu_table=mu)
+        occ = (rng.random((R, sc.num_sites)) < 0.5).astype(np.int32)
+        if kind == "wang-landau":
+            probe = orc.OracleEvaluator(tab)
+            h = np.array([probe.natural_parameters() @ probe.feature_vector(o) for o in occ[:200]])
+            # (a window wide enough for every start: the enthalpy of 64 sites is bounded)
+            cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=float(h.min()) - 40.0371,
+                                   max_enthalpy=float(h.max()) + 40.0113, bin_size=0.5, check_period=13, flatness=0.1)
+        else:
+            cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_FLIP if kind == "flip" else capi.STEP_SWAP)
+    seeds = rng.integers(1, 2**63, size=R).astype(np.uint64)
+    temps = rng.uniform(500.0, 9000.0, size=R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, seeds, temps)
+    for chunk in (1, 16, 40):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        bad = np.flatnonzero((a["occupancy"] != b["occupancy"]).any(axis=1))
+        assert len(bad) == 0, f"{len(bad)} walkers differ, first {bad[:5]} ({eng.kernel_info()})"
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    eng.close()
