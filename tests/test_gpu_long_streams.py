@@ -187,3 +187,38 @@ def test_many_walkers_of_a_small_cell(kind, monkeypatch):
         np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
     eng.close()
+
+
+@pytest.mark.parametrize("nspecies", [9, 12])
+@pytest.mark.parametrize("mode", ["int", "corr"])
+@pytest.mark.parametrize("step", [capi.STEP_SWAP, capi.STEP_FLIP], ids=["swap", "flip"])
+def test_many_species_per_site(nspecies, mode, step):
+    """Site spaces of 9 and 12 species (the lean families stop at 8 codes per sublattice): triplet tensors
+    of 12^3 entries, 364 correlation functions -- beyond the 64 feature cells of the specialised kernels."""
+    from oracle import oracle as orc
+
+    model = synth.build_cluster_model(synth.fcc_prim(nspecies=nspecies), {2: 3.0, 3: 3.0})
+    sc = synth.build_supercell(model, [3, 3, 4])
+    mu = None
+    rng = np.random.default_rng(nspecies)
+    if step == capi.STEP_FLIP:
+        mu = np.tile(rng.uniform(-0.2, 0.2, nspecies)[None, :], (sc.num_sites, 1))
+    fm = capi.FEATURES_INTERACTIONS if mode == "int" else capi.FEATURES_CORRELATIONS
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=3), feature_mode=fm, mu_table=mu)
+    R = 4
+    occ = rng.integers(0, nspecies, (R, sc.num_sites)).astype(np.int32)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, np.arange(5, 5 + R, dtype=np.uint64), np.linspace(700.0, 4000.0, R))
+    for chunk in (1, 20, 150):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"]), eng.kernel_info()
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-9, atol=1e-7)
+    assert not eng.kernel_info().startswith("lean")
+    eng.close()
