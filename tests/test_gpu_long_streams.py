@@ -222,3 +222,38 @@ def test_many_species_per_site(nspecies, mode, step):
     np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-9, atol=1e-7)
     assert not eng.kernel_info().startswith("lean")
     eng.close()
+
+
+@pytest.mark.parametrize("nspecies", [2, 3])
+@pytest.mark.parametrize("force", [None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"], ids=["auto", "general", "universal"])
+@pytest.mark.parametrize("mode", ["int", "corr"])
+def test_clusters_of_up_to_six_sites(nspecies, force, mode, monkeypatch):
+    """Pairs to six-site clusters (SMOLMC_MAX_CLUSTER_SITES; fcc octahedra and their sub-clusters within
+    4.2 A): strides over five other members, tensors of 3^6 entries."""
+    from oracle import oracle as orc
+
+    for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
+        monkeypatch.delenv(name, raising=False)
+    if force:
+        monkeypatch.setenv(force, "1")
+    model = synth.build_cluster_model(synth.fcc_prim(nspecies=nspecies), {2: 4.2, 3: 4.2, 4: 4.2, 5: 4.2, 6: 4.2})
+    sc = synth.build_supercell(model, [4, 4, 4])
+    fm = capi.FEATURES_INTERACTIONS if mode == "int" else capi.FEATURES_CORRELATIONS
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=8), feature_mode=fm)
+    R = 5
+    rng = np.random.default_rng(4)
+    occ = rng.integers(0, nspecies, (R, sc.num_sites)).astype(np.int32)
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, np.arange(5, 5 + R, dtype=np.uint64), np.linspace(700.0, 4000.0, R))
+    for chunk in (1, 20, 150):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"]), eng.kernel_info()
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-9, atol=1e-7)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    eng.close()
