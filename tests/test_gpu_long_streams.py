@@ -257,3 +257,74 @@ def test_clusters_of_up_to_six_sites(nspecies, force, mode, monkeypatch):
     np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-9, atol=1e-7)
     assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
     eng.close()
+
+
+def _neutral(sc, prim, rng):
+    """Random charge-neutral occupancy by greedy single substitutions."""
+    q = [[0.0 if c is None else float(c) for c in prim.charges[b]] for b in sc.site_b]
+    nsp = np.array([prim.nspecies[b] for b in sc.site_b])
+    for _ in range(100):
+        occ = (rng.random(sc.num_sites) * nsp).astype(np.int32)
+        tot = sum(q[i][occ[i]] for i in range(sc.num_sites))
+        for _ in range(20 * sc.num_sites):
+            if abs(tot) < 1e-9:
+                return occ
+            i = int(rng.integers(sc.num_sites))
+            c = int(rng.integers(nsp[i]))
+            new = tot - q[i][occ[i]] + q[i][c]
+            if abs(new) < abs(tot):
+                tot, occ[i] = new, c
+    raise AssertionError("no neutral occupancy found")
+
+
+@pytest.mark.parametrize("kind", ["swap", "flip", "table-flip", "wl-swap", "wl-table-flip"])
+def test_three_active_sublattices(kind):
+    """Rocksalt cations (Li+/Mn3+/Ti4+) and anions (O2-/F-) plus both tetrahedral interstitials
+    (Li+/vacancy, one sublattice of two basis sites): four site classes, three active sublattices, a
+    CompositionSpace table of three flip vectors across them, Ewald term with a vacancy species."""
+    from oracle import oracle as orc
+
+    a = 4.2
+    lat = 0.5 * a * np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=float)
+    prim = synth.PrimCell(lat, [[0, 0, 0], [.5, .5, .5], [.25, .25, .25], [.75, .75, .75]], [3, 2, 2, 2],
+                          charges=[[1.0, 3.0, 4.0], [-2.0, -1.0], [1.0, None], [1.0, None]],
+                          species=[["Li+", "Mn3+", "Ti4+"], ["O2-", "F-"], ["Li+", "Vacancy"], ["Li+", "Vacancy"]])
+    model = synth.build_cluster_model(prim, {2: 3.2, 3: 2.2})
+    sc = synth.build_supercell(model, [3, 3, 2])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=1), ewald_coefficient=0.1)
+    assert [len(s.species) for s in ens.sublattices] == [3, 2, 2] and len(ens.sublattices[2].sites) == 2 * sc.size
+    if kind == "flip":
+        ens.chemical_potentials = {sp: 0.03 * i for i, sp in enumerate(ens.species)}
+    table = "table" in kind
+    tab = ens.make_tables(**(dict(flip_table=ens.composition_space().flip_table, swap_weight=0.2) if table else {}))
+    R = 4
+    rng = np.random.default_rng(12)
+    occ = np.array([_neutral(sc, prim, rng) for _ in range(R)])
+    step = capi.STEP_TABLE_FLIP if table else capi.STEP_FLIP if kind == "flip" else capi.STEP_SWAP
+    if kind.startswith("wl"):
+        probe = orc.OracleEvaluator(tab)
+        h = np.array([probe.natural_parameters() @ probe.feature_vector(o) for o in occ])
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, step, min_enthalpy=float(h.min()) - 6.0371,
+                               max_enthalpy=float(h.max()) + 6.0113, bin_size=0.5, check_period=40, flatness=0.2)
+    else:
+        cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    for e in (eng, ora):
+        e.set_state(occ, np.arange(40, 40 + R, dtype=np.uint64), np.linspace(1500.0, 9000.0, R))
+    for chunk in (1, 30, 64, 300):
+        eng.run(chunk)
+        ora.run(chunk)
+        x, y = eng.get_state(), ora.get_state()
+        assert np.array_equal(x["occupancy"], y["occupancy"]), eng.kernel_info()
+        assert np.array_equal(x["n_accepted"], y["n_accepted"])
+        np.testing.assert_allclose(x["enthalpy"], y["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(x["features"], y["features"], rtol=1e-10, atol=1e-8)
+    assert 0 < x["n_accepted"].sum() < x["n_steps"].sum()
+    if kind in ("swap", "flip", "table-flip"):
+        assert eng.kernel_info().startswith("lean-multi"), eng.kernel_info()
+    if table:  # charge neutrality kept
+        q = np.zeros((sc.num_sites, 3))
+        for i, b in enumerate(sc.site_b):
+            q[i, : prim.nspecies[b]] = [0.0 if c is None else c for c in prim.charges[b]]
+        assert np.allclose(q[np.arange(sc.num_sites)[None, :], x["occupancy"]].sum(axis=1), 0.0)
+    eng.close()
