@@ -1297,21 +1297,25 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             // Ewald potential field in LDS when the changeable sites are the active
             // sublattice and it fits beside the occupancies
             lp.ew_field = 0;
-            if (lean && t->has_ewald && kp.ew_act_base == sbase && kp.ew_nact == nact &&
+            // (the changeable sites may extend beyond the active ones: restricted sites, which the host
+            // API relabels behind the active sites of their sublattice; the field covers them all)
+            const int nfield = kp.ew_nact;
+            if (lean && t->has_ewald && kp.ew_act_base == sbase && nfield >= nact &&
+                (nfield == nact || getenv("SMOLMC_FIELD_ACTIVE_ONLY") == nullptr) &&
                 getenv("SMOLMC_NO_EWALD_FIELD") == nullptr) {
-                const size_t with_field = h->lean_lds + (size_t)4 * nact * 8;
+                const size_t with_field = h->lean_lds + (size_t)4 * nfield * 8;
                 // charge / diagonal term per species code must not depend on the site
                 bool uniform = kp.ew_W <= 8;
                 std::vector<double> qrow(8, 0.0), dgrow(8, 0.0);
                 for (int c = 0; uniform && c < kp.ew_W; ++c) {
                     qrow[c] = h->ew_qs_host[(size_t)sbase * kp.ew_W + c];
                     dgrow[c] = h->ew_dg_host[(size_t)sbase * kp.ew_W + c];
-                    for (int i = 0; i < nact; ++i)
+                    for (int i = 0; i < nfield; ++i)
                         if (h->ew_qs_host[(size_t)(sbase + i) * kp.ew_W + c] != qrow[c] ||
                             h->ew_dg_host[(size_t)(sbase + i) * kp.ew_W + c] != dgrow[c])
                             uniform = false;
                 }
-                if (uniform && kp.ew_field && with_field <= 150 * 1024 && (size_t)nact * 8 <= 64 * 1024) {
+                if (uniform && kp.ew_field && with_field <= 150 * 1024 && (size_t)nfield * 8 <= 64 * 1024) {
                     if (dev_upload(h, qrow.data(), 8, &lp.ew_qrow) || dev_upload(h, dgrow.data(), 8, &lp.ew_dgrow))
                         return bail(1);
                     lp.ew_phi = kp.ew_phi;
@@ -1366,7 +1370,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 // anyway: waves w and w + 4 of a workgroup sit on the same SIMD, so that the
                 // launch order (update_walker_order) can pair a hot walker with a cold one there.
                 {
-                    const size_t per_wave = (size_t)lp.Nlds + 64 * 8 + 64 + (lp.ew_field ? (size_t)nact * 8 : 0);
+                    const size_t per_wave = (size_t)lp.Nlds + 64 * 8 + 64 + (lp.ew_field ? (size_t)kp.ew_nact * 8 : 0);
                     const size_t lds8 = h->lean_lds + 4 * per_wave;
                     h->lean_wpb = 4;
                     int cus = 0; // (fewer walkers than 8 per CU: four-walker workgroups spread over more CUs)

@@ -121,6 +121,10 @@ class Engine:
         if rc:
             self._h = None
             self._chk(rc)
+        # tables whose sites were relabelled (capi.TableSet.permute_sites): occupancies and step
+        # records cross this boundary in the CALLER's numbering
+        perm = getattr(tables, "site_perm", None)
+        self._new_of, self._old_of = (None, None) if perm is None else (perm[0].copy(), perm[1].copy())
         self.R = config.n_replicas
         self.N = tables.struct.num_sites
         self.F = self._lib.smolmc_num_features(self._h)
@@ -157,6 +161,20 @@ class Engine:
             occ = occ.astype(np.int32)
         return np.ascontiguousarray(occ).reshape(shape)
 
+    def _occ_in(self, occ):
+        return occ if self._old_of is None else np.ascontiguousarray(occ[..., self._old_of])
+
+    def _occ_out(self, occ):
+        return occ if (self._new_of is None or occ is None) else np.ascontiguousarray(occ[..., self._new_of])
+
+    def _steps_in(self, steps):
+        if self._new_of is None:
+            return steps
+        steps = steps.copy()
+        sites = steps[..., 0::2]
+        steps[..., 0::2] = np.where(sites >= 0, self._new_of[np.clip(sites, 0, self.N - 1)], sites)
+        return steps
+
     # ---- state ----------------------------------------------------------------
     @property
     def natural_parameters(self):
@@ -165,7 +183,7 @@ class Engine:
         return out
 
     def set_state(self, occupancies, seeds=None, temperature=None, reset_aux=True):
-        occ = self._occ32(occupancies, (self.R, self.N))
+        occ = self._occ_in(self._occ32(occupancies, (self.R, self.N)))
         seeds = (
             np.arange(self.R, dtype=np.uint64)
             if seeds is None
@@ -199,7 +217,7 @@ class Engine:
                 _p(na, C.c_uint64), _p(ns, C.c_uint64), _p(la, C.c_uint8),
             )
         )
-        return dict(occupancy=occ, features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
+        return dict(occupancy=self._occ_out(occ), features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
                     accepted=la.astype(bool))
 
     def get_enthalpy(self):
@@ -298,7 +316,7 @@ class Engine:
         else:
             self._chk(self._lib.smolmc_get_samples(self._h, _p(H, C.c_double), _p(feat, C.c_double),
                                                    _p(acc, C.c_uint8), _p(occ, C.c_int32)))
-        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=occ)
+        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=self._occ_out(occ))
 
     def last_kernel_ms(self):
         ms = C.c_float()
@@ -311,7 +329,7 @@ class Engine:
         smolmc_replay) -> (accepted (R,n) bool, H (R,n)[, log_priori used (R,n)])."""
         uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.R, -1)
         n = uniforms.shape[1]
-        steps = capi.step_rows(steps, self.R, n)
+        steps = self._steps_in(capi.step_rows(steps, self.R, n))
         lp = None if log_priori is None else np.ascontiguousarray(log_priori, dtype=np.float64).reshape(self.R, n)
         acc = np.zeros((self.R, n), dtype=np.uint8)
         H = np.zeros((self.R, n))
@@ -326,7 +344,7 @@ class Engine:
 
     # ---- evaluator level --------------------------------------------------------
     def eval_full(self, occupancies):
-        occ = self._occ32(occupancies, (-1, self.N))
+        occ = self._occ_in(self._occ32(occupancies, (-1, self.N)))
         out = np.zeros((len(occ), self.F))
         self._chk(self._lib.smolmc_eval_full(self._h, _p(occ, C.c_int32), len(occ), _p(out, C.c_double)))
         return out
@@ -334,11 +352,11 @@ class Engine:
     def eval_delta(self, occupancy, steps):
         """steps: (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}), k <= 8, -1 = absent;
         a single step may also be given as its list of (site, code) tuples."""
-        occ = self._occ32(occupancy, (self.N,))
+        occ = self._occ_in(self._occ32(occupancy, (self.N,)))
         a = np.asarray(steps, dtype=np.int32)
         if a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 2):
             a = a.reshape(1, -1)  # one step: flat record or (site, code) pairs
-        steps = capi.step_rows(a)
+        steps = self._steps_in(capi.step_rows(a))
         out = np.zeros((len(steps), self.F))
         self._chk(
             self._lib.smolmc_eval_delta(

@@ -623,10 +623,24 @@ class Ensemble:
                                 table_ergodic=table_ergodic)
 
     # -- tables for the engine -----------------------------------------------------
-    def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1):
+    def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=False):
+        """Flattened tables of this ensemble.  ``contiguous``: relabel the sites (capi.TableSet.permute_sites;
+        the Engine converts at its boundary) so that every sublattice is one site range with its active
+        sites first -- restricted sites and sublattices split by species otherwise leave the active
+        sites scattered, which only the general kernels take."""
         tab = self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
         if flip_table is not None:
             tab = self._with_flip_table(tab, flip_table, flip_weights, swap_weight)
+        if contiguous:
+            order = []
+            for s in self._sublattices:
+                order.append(np.asarray(s.active_sites, dtype=np.int64))
+                order.append(np.asarray(s.restricted_sites, dtype=np.int64))
+            old_of = np.concatenate(order)
+            if len(old_of) == self.num_sites and not np.array_equal(old_of, np.arange(self.num_sites)):
+                new_of = np.empty(self.num_sites, dtype=np.int64)
+                new_of[old_of] = np.arange(self.num_sites)
+                tab.permute_sites(new_of)
         return tab
 
     def _with_flip_table(self, tab, flip_table, flip_weights, swap_weight):
@@ -1595,7 +1609,7 @@ class Sampler:
         ens = k0.ensemble
         key = self._model_key()
         if self._engine is None or self._engine_key != key:
-            tables = ens.make_tables(**k0.usher_kwargs)
+            tables = ens.make_tables(**k0.usher_kwargs, contiguous=os.environ.get("SMOLMC_NO_SITE_RELABEL") is None)
             if k0.bias is not None:
                 tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty,
                                 intercepts=getattr(k0.bias, "intercepts", None))

@@ -143,7 +143,7 @@ def build_case(rng, profile="any"):
     if step == "flip" or rng.random() < 0.2:
         ens.chemical_potentials = {sp: float(rng.uniform(-0.3, 0.3)) for sp in ens.species}
         desc["mu"] = True
-    if not lean and rng.random() < 0.25:
+    if rng.random() < (0.3 if lean else 0.25):
         act = np.concatenate([s.active_sites for s in ens.active_sublattices])
         ens.restrict_sites(rng.choice(act, size=max(1, len(act) // 10), replace=False))
         desc["restricted"] = True
@@ -162,6 +162,11 @@ def build_case(rng, profile="any"):
         if rng.random() < 0.3:
             usher["flip_weights"] = rng.uniform(0.5, 2.0, len(usher["flip_table"]))
     tab = ens.make_tables(**usher)
+    # the engine's tables: the same model with the sites relabelled so that every active sublattice is
+    # one site range (what the Sampler hands to the engine); the oracle keeps the original numbering
+    tab_engine = ens.make_tables(**usher, contiguous=True) if (lean or rng.random() < 0.5) else tab
+    if tab_engine.site_perm is not None:
+        desc["relabelled"] = True
     bias = None
     if kernel == "metropolis" and rng.random() < 0.35:
         kind = pick(rng, ["fugacity", "square-charge", "square-hyperplane"])
@@ -182,7 +187,8 @@ def build_case(rng, profile="any"):
             rows = int(rng.integers(1, 3))
             bias = moca.SquareHyperplaneBias(ens.sublattices, rng.integers(-2, 3, (rows, d)),
                                              rng.integers(-3, 4, rows), penalty=float(rng.uniform(0.001, 0.02)))
-        tab.set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=getattr(bias, "intercepts", None))
+        for tb in ({id(tab): tab, id(tab_engine): tab_engine}).values():
+            tb.set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=getattr(bias, "intercepts", None))
         desc["bias"] = kind
     st = moca.STEP_TYPES[step]
     wl_kw = None
@@ -203,7 +209,7 @@ def build_case(rng, profile="any"):
     desc.update(walkers=R, sites=int(sc.num_sites), env=env)
     seeds = rng.integers(1, 2 ** 62, size=R).astype(np.uint64)
     temps = rng.uniform(400.0, 6000.0, size=R)
-    return dict(desc=desc, ens=ens, tab=tab, cfg=cfg, occ=occ, seeds=seeds, temps=temps, env=env, bias=bias,
+    return dict(desc=desc, ens=ens, tab=tab, tab_engine=tab_engine, cfg=cfg, occ=occ, seeds=seeds, temps=temps, env=env, bias=bias,
                 wl=kernel == "wang-landau", usher=usher, wl_kw=wl_kw, step=step)
 
 
@@ -230,7 +236,7 @@ def _run_case(case_seed, case, rng):
     if case["env"]:
         os.environ[case["env"]] = "1"
     try:
-        eng = Engine(case["tab"], case["cfg"])
+        eng = Engine(case["tab_engine"], case["cfg"])
     finally:
         for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
             os.environ.pop(name, None)

@@ -545,3 +545,41 @@ def test_split_sublattice_sampling_matches_the_oracle(rocksalt, step):
         assert np.array_equal(occs[i], st["occupancy"])
         np.testing.assert_allclose(sampler.samples.get_enthalpies(flat=False)[i, :, 0], st["enthalpy"],
                                    rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("step", ["swap", "flip", "table-flip"])
+def test_restricted_sites_stay_on_the_specialised_kernels(rocksalt, step):
+    """Ensemble.restrict_sites (sublattice.py:84-107) scatters the active sites; the Sampler relabels the
+    sites (capi.TableSet.permute_sites) so that the lean kernels still take the model.  Checked against
+    the oracle on the UNRELABELLED tables: the restricted sites never change, the chain is the same."""
+    from oracle import oracle as orc
+
+    model, sc, coefs = rocksalt
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.15)
+    rng = np.random.default_rng(41)
+    cations = ens.sublattices[0]
+    frozen = rng.choice(cations.sites, 6, replace=False)
+    ens.restrict_sites(frozen)
+    if step == "flip":
+        ens.chemical_potentials = {sp: 0.04 * i for i, sp in enumerate(ens.species)}
+    nw = 4
+    occ = np.array([_neutral(sc, 2 + w, rng) for w in range(nw)])
+    kw = dict(flip_table=[[1, -3, 2, 0]], swap_weight=0.2) if step == "table-flip" else {}
+    seeds = [21, 22, 23, 24]
+    sampler = moca.Sampler.from_ensemble(ens, temperature=4000.0, step_type=step, nwalkers=nw, seeds=seeds, **kw)
+    sampler.run(600, occ, thin_by=150)
+    assert sampler.engine.kernel_info().startswith("lean"), sampler.engine.kernel_info()
+    assert sampler.engine.tables.site_perm is not None
+    occs = sampler.samples.get_occupancies(flat=False)
+    assert np.all(occs[:, :, frozen] == occ[None, :, frozen]) and len(np.unique(occs[:, 0], axis=0)) > 1
+    ukw = {k: v for k, v in kw.items()}
+    ora = orc.OracleMC(ens.make_tables(**ukw), capi.make_config(nw, step_type=moca.STEP_TYPES[step]))
+    ora.set_state(occ, np.array(seeds, dtype=np.uint64), 4000.0)
+    for i in range(4):
+        ora.run(150)
+        st = ora.get_state()
+        assert np.array_equal(occs[i], st["occupancy"])
+        np.testing.assert_allclose(sampler.samples.get_enthalpies(flat=False)[i, :, 0], st["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(sampler.samples.get_feature_vectors(flat=False)[i], st["features"], rtol=1e-10, atol=1e-8)
+    # evaluator calls keep the caller's numbering too
+    np.testing.assert_allclose(ens.compute_feature_vector(occs[-1, 0]), st["features"][0], rtol=1e-10, atol=1e-8)
