@@ -58,8 +58,11 @@ def local_tables_of(cluster_processor):
     return out
 
 
-def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1):
-    """capi.TableSet (= smolmc_tables + the arrays it points at) of a smol.moca.Ensemble."""
+def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=True):
+    """capi.TableSet (= smolmc_tables + the arrays it points at) of a smol.moca.Ensemble.
+    ``contiguous``: when restricted sites or sublattices split by species leave the active sites
+    scattered, relabel the sites (capi.TableSet.permute_sites; the Engine converts occupancies and
+    step records at its boundary) so that the specialised kernels still take the model."""
     ce, ew = split_processor(ensemble.processor)
     sub = ce.cluster_subspace
     decomposition = hasattr(ce, "_interaction_tensors")
@@ -73,7 +76,7 @@ def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weig
         kwargs["mu_table"] = chem["table"]
     if flip_table is not None:
         kwargs.update(flip_table=flip_table, flip_weights=flip_weights, swap_weight=swap_weight)
-    return capi.TableSet(
+    tab = capi.TableSet(
         ce.num_sites, ce.size, sub.num_orbits, sub.num_corr_functions,
         orbit_data_of(sub.orbits), tuple(ce._indices.arrays), local_tables_of(ce),
         ce._interaction_tensors if decomposition else None, ce.coefs,
@@ -81,6 +84,12 @@ def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weig
         [dict(active_sites=s.active_sites, codes=s.encoding) for s in ensemble.active_sublattices],
         **kwargs,
     )
+    if contiguous and getattr(ensemble, "sublattices", None) is not None:
+        new_of = capi.contiguous_relabelling(ce.num_sites, [(s.active_sites, s.restricted_sites)
+                                                            for s in ensemble.sublattices])
+        if new_of is not None:
+            tab.permute_sites(new_of)
+    return tab
 
 
 def engine_from_sampler_arguments(ensemble, nwalkers, kernel_type="metropolis", step_type="swap",

@@ -562,6 +562,22 @@ def step_rows(steps, *lead):
     return np.ascontiguousarray(out)
 
 
+def contiguous_relabelling(num_sites, sublattices):
+    """Site relabelling (``new_of`` for TableSet.permute_sites) that makes every sublattice one site
+    range with its active sites first, in the order of their list: ``sublattices`` = (active_sites,
+    restricted_sites) of ALL sublattices of the ensemble, in order.  None when the sites already are
+    numbered that way (or the sublattices do not partition the sites)."""
+    order = [np.asarray(x, dtype=np.int64) for pair in sublattices for x in pair]
+    old_of = np.concatenate(order) if order else np.zeros(0, np.int64)
+    if len(old_of) != num_sites or not np.array_equal(np.sort(old_of), np.arange(num_sites)):
+        return None
+    if np.array_equal(old_of, np.arange(num_sites)):
+        return None
+    new_of = np.empty(num_sites, dtype=np.int64)
+    new_of[old_of] = np.arange(num_sites)
+    return new_of
+
+
 def make_config(
     n_replicas,
     kernel_type=KERNEL_METROPOLIS,

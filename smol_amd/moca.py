@@ -632,14 +632,9 @@ class Ensemble:
         if flip_table is not None:
             tab = self._with_flip_table(tab, flip_table, flip_weights, swap_weight)
         if contiguous:
-            order = []
-            for s in self._sublattices:
-                order.append(np.asarray(s.active_sites, dtype=np.int64))
-                order.append(np.asarray(s.restricted_sites, dtype=np.int64))
-            old_of = np.concatenate(order)
-            if len(old_of) == self.num_sites and not np.array_equal(old_of, np.arange(self.num_sites)):
-                new_of = np.empty(self.num_sites, dtype=np.int64)
-                new_of[old_of] = np.arange(self.num_sites)
+            new_of = capi.contiguous_relabelling(self.num_sites, [(s.active_sites, s.restricted_sites)
+                                                                  for s in self._sublattices])
+            if new_of is not None:
                 tab.permute_sites(new_of)
         return tab
 
