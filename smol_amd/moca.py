@@ -1293,6 +1293,21 @@ class SampleContainer:
         np.savez_compressed(path, nsamples=self.num_samples, total_mc_steps=self._total_steps,
                             **{f"trace/{k}": v for k, v in self._all().items()})
 
+    def get_sampled_species(self, indices, flat=True):
+        """Species of every site for the samples ``indices`` -- what ``get_sampled_structures``
+        (container.py:144-181) returns as pymatgen Structures, here as lists of species names in site
+        order (``Processor.decode_occupancy``; lattice and coordinates are the supercell's own)."""
+        indices = [indices] if isinstance(indices, (int, np.integer)) else list(indices)
+        occupancies = self.get_occupancies(flat=flat)[indices]
+        decode = self._ensemble.processor.decode_occupancy
+        if flat:
+            return [decode(occu) for occu in occupancies]
+        return [[decode(occu) for occu in walkers] for walkers in occupancies]
+
+    def get_sampled_structures(self, indices, flat=True):
+        raise NotImplementedError("pymatgen Structures are not built here; get_sampled_species(indices) gives the "
+                                  "species of every site, in the site order of the supercell")
+
     def to_hdf5(self, file_path):
         """container.py:615: HDF5 needs h5py, which this build does not depend on -- the same content
         goes to ``to_npz`` (one file) or to the streaming directory of ``get_backend``."""

@@ -424,3 +424,23 @@ def test_relabelled_sites_are_the_same_model(step):
         np.testing.assert_allclose(sa["features"], sb["features"], rtol=1e-10, atol=1e-9)
         np.testing.assert_allclose(oa.get_bias(), ob.get_bias(), rtol=1e-10, atol=1e-9)
     assert 0 < sa["n_accepted"].sum()
+
+
+def test_get_sampled_species():  # container.py:144-181 without pymatgen
+    sc, ens = _rocksalt_ensemble()
+    s = moca.Sampler.from_ensemble(ens, temperature=500, nwalkers=2)
+    rng = np.random.default_rng(2)
+    F = len(ens.natural_parameters)
+    occs = []
+    for i in range(3):
+        occ = np.zeros((2, ens.num_sites), dtype=np.int32)
+        occ[:, : sc.size] = rng.integers(0, 3, (2, sc.size))
+        occs.append(occ)
+        s.samples.save_sampled_trace(moca.Trace(occupancy=occ, features=np.zeros((2, F)), enthalpy=np.zeros((2, 1)),
+                                                temperature=np.full((2, 1), 500.0), accepted=np.ones((2, 1), bool)), 1)
+    flat = s.samples.get_sampled_species([0, 5])
+    assert flat[0] == ens.processor.decode_occupancy(occs[0][0]) and flat[1] == ens.processor.decode_occupancy(occs[2][1])
+    nested = s.samples.get_sampled_species(1, flat=False)
+    assert len(nested) == 1 and len(nested[0]) == 2 and nested[0][1] == ens.processor.decode_occupancy(occs[1][1])
+    with pytest.raises(NotImplementedError, match="get_sampled_species"):
+        s.samples.get_sampled_structures([0])
