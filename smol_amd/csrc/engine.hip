@@ -1390,7 +1390,13 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         // TableFlip take the general kernel)
         const bool multi_bias_ok = !t->bias_type || (t->bias_type != SMOLMC_BIAS_SQUARE_HYPERPLANE &&
                                                      cfg->step_type != SMOLMC_STEP_TABLE_FLIP);
-        if (!lean && h->lean_tables && !h->lean_kf && !wl && multi_bias_ok && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        // Wang-Landau on this layout (round 5; mc_lean_multi_kernel<..., WLK>): any number of classes the
+        // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves; the
+        // Wang-Landau TableFlip stays on the universal kernel.  SMOLMC_NO_WL_MULTI: A/B switch.
+        const int wl_sum_mode = (cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
+        const bool multi_wl_ok = !wl || (!table && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && cfg->wl_update_period < (1ll << 31) &&
+                                         getenv("SMOLMC_NO_WL_MULTI") == nullptr);
+        if (!lean && h->lean_tables && !h->lean_kf && multi_wl_ok && multi_bias_ok && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
@@ -1456,7 +1462,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             }
             // LDS: shared tables + slot records, per wave occupancy + scratch + accumulators (+ field)
             const size_t nrec = (size_t)h->lean_ncls * h->lean_nslot * 64;
-            const size_t shared = ((size_t)lp.dt_len + 96 + (table ? 80 : 0)) * 8 + nrec * 24;
+            // (Wang-Landau: + feature scale and feature index of every slot record)
+            const size_t shared = ((size_t)lp.dt_len + 96 + (table ? 80 : 0)) * 8 + nrec * 24 + (wl ? nrec * 12 : 0);
             // waves per workgroup: the shared tables are paid once per workgroup, so pick the size
             // that keeps the most waves resident per CU (160 KiB of LDS)
             auto layout = [&](size_t per_wave_bytes, int &wpb_out) {
@@ -1474,7 +1481,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             // state, when all walkers still fit the chip in one round with it there (an accepted
             // flip then reads its G row only, no read-modify-write of phi through L2), or for
             // canonical swaps whenever it fits; else the HBM copy is used in place (ew_field 2).  SMOLMC_MULTI_PHI_HBM / _LDS force either (test hooks).
-            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 + nrec * (table ? 16 : 8);
+            // (Wang-Landau: entropies, step counts and cached rows instead of the accumulator cells)
+            const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 +
+                                     (wl ? wl_multi_wave_bytes(h->L, h->F, wl_sum_mode) : nrec * (table ? 16 : 8));
             bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
             if (t->has_ewald && !phi_lds) {
                 int cus = 0, w = 0;
@@ -1525,6 +1534,16 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.occ = kp.occ; lp.enthalpy = kp.enthalpy; lp.features = kp.features; lp.beta = kp.beta;
                 lp.seeds = kp.seeds; lp.nsteps = kp.nsteps; lp.nacc = kp.nacc; lp.last_acc = kp.last_acc;
                 lp.R = h->R; lp.N = h->N; lp.Npad = h->Npad; lp.F = h->F; lp.Fce = h->Fce;
+                if (wl) {
+                    lp.wl.L = h->L;
+                    lp.wl.vmin = kp.wl_min; lp.wl.vmax = kp.wl_max; lp.wl.bin = kp.wl_bin;
+                    lp.wl.flat = kp.wl_flat; lp.wl.div = kp.wl_div;
+                    lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
+                    lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
+                    lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
+                    lp.wl.sum_mode = wl_sum_mode;
+                    h->lean_multi_wl = true;
+                }
                 lp.ew_field = 0;
                 if (t->has_ewald) {
                     lp.ew_W = kp.ew_W; lp.ew_nact = kp.ew_nact; lp.ew_act_base = kp.ew_act_base;
@@ -1860,7 +1879,9 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
             snprintf(buf + used, (size_t)n - used, " gx=%dx%dx%dx%d", h->ew_gx_blocks, h->ew_gx_dims[0], h->ew_gx_dims[1],
                      h->ew_gx_dims[2]);
         else if (h->lean && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && used + 8 < (size_t)n)
-            snprintf(buf + used, (size_t)n - used, getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3");
+            snprintf(buf + used, (size_t)n - used, h->lean_multi_wl ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
+        if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
+            snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");
     }
     return 0;
 }
@@ -2042,6 +2063,9 @@ static int update_walker_order(smolmc_handle *h, LeanParams &lp) {
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
     TRY(update_walker_order(h, lp));
+    if (h->lean_multi_wl)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_wl_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_4(h, lp) : smolmc_launch_multi_wl_8(h, lp));
     if (h->lean_multi && lp.bias_type)
         return h->lean_nslot == 2 ? smolmc_launch_multi_bias_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_4(h, lp) : smolmc_launch_multi_bias_8(h, lp));
@@ -2222,6 +2246,9 @@ static int smolmc_launch_lean_replay(smolmc_handle *h, const LeanParams &lp) {
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_replay_4(h, lp) : smolmc_launch_multi_bias_replay_8(h, lp));
     if (lp.bias_type) return h->lean_nslot == 2 ? smolmc_launch_lean_bias_replay_2(h, lp) : smolmc_launch_lean_bias_replay_4(h, lp);
 #endif
+    if (h->lean_multi_wl)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_wl_replay_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_replay_4(h, lp) : smolmc_launch_multi_wl_replay_8(h, lp));
     if (h->lean_multi)
         return h->lean_nslot == 2 ? smolmc_launch_multi_replay_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_replay_4(h, lp) : smolmc_launch_multi_replay_8(h, lp));

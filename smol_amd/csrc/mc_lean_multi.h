@@ -33,6 +33,64 @@ struct MultiRec { // slot record, 24 bytes
     double w;
 };
 
+// ---- Wang-Landau on the multi-class layout (WLK, round 5) -----------------------------------------
+// kernel/wanglandau.py:186-266 for every model class this kernel takes (several site classes = active
+// sublattices, up to 512 clusters per site, mu rows, the Ewald field in LDS or HBM) and for any
+// update_period.  Per walker in LDS:
+//   * S[L]      float64 entropies (the accept test reads S[bin], S[new bin]; += m per counted step);
+//   * cnt[L]    uint32: counted steps per bin SINCE the launch started / the last successful flatness
+//               check -- histogram and occurrences gain one together (wanglandau.py:241-245), so one
+//               delta serves both: the HBM arrays keep the base values and take the deltas when the
+//               histogram is reset and when the launch ends (8 + 4 bytes per bin instead of 24);
+//   * occb[L]   float64 occurrences at launch start, ONLY when update_period > 1 (the running-mean
+//               recurrence :235-239 then needs total = occurrences[bin] on every step);
+//   * rows      direct-mapped cache of WL_ROWS per-bin feature rows (sums for update_period 1: a run of
+//               steps in one state adds run_n * features when it ends; running means otherwise).
+// The current feature vector lives in the lanes of one register (lane f < F), updated on accepted
+// steps through the shadow cells of mc_wl.h; the enthalpy is carried as the reference carries it
+// (_current_enthalpy += delta, :216-218) and every decision is the exact float64 one.
+// (wl_multi_wave_bytes, the size of that state, is in smolmc_common.h: the host sizes the launch with it)
+// a cached row changes its bin: the old bin's row goes to HBM (sums: added, the rows of a walker are
+// touched by its own wave only; means: stored) and the new bin's comes in (means only; a row of sums
+// starts from zero).  Out of line: global-memory instructions that exist on some paths of the step loop
+// only make the compiler's s_waitcnt insertion conservative on every path (NOTES.md).
+__device__ __noinline__ void wl_multi_row_swap(double *grows, double *crow, int old_bin, int new_bin, int F, int lane,
+                                               int sum_mode) {
+    if (lane < F) {
+        if (old_bin >= 0) {
+            if (sum_mode) unsafeAtomicAdd(grows + (size_t)old_bin * F + lane, crow[lane]);
+            else grows[(size_t)old_bin * F + lane] = crow[lane];
+        }
+        crow[lane] = sum_mode ? 0.0 : grows[(size_t)new_bin * F + lane];
+    }
+}
+// flatness check (wanglandau.py:253-264) on the compact records: histogram = HBM base + LDS delta; on
+// success the histogram is reset, the deltas move into the occurrences and m shrinks
+__device__ __noinline__ double wl_multi_flatness_check(const double *S, uint32_t *cnt, double *occb, long long *hist_g,
+                                                       long long *occ_g, int L, double flat, double div, double wl_m, int lane) {
+    long n = 0;
+    double sum = 0;
+    for (int i = lane; i < L; i += 64)
+        if (S[i] > 0) { n++; sum += (double)(hist_g[i] + (long long)cnt[i]); }
+    const double tn = wave_sum_all((double)n), tsum = wave_sum_all(sum);
+    if (tn >= 2.0) {
+        const double thr = flat * (tsum / tn);
+        int bad = 0;
+        for (int i = lane; i < L; i += 64)
+            if (S[i] > 0 && !((double)(hist_g[i] + (long long)cnt[i]) > thr)) bad = 1;
+        if (__ballot(bad) == 0ull) {
+            for (int i = lane; i < L; i += 64) {
+                hist_g[i] = 0;
+                occ_g[i] += (long long)cnt[i];
+                if (occb) occb[i] += (double)cnt[i];
+                cnt[i] = 0u;
+            }
+            wl_m = wl_m / div;
+        }
+    }
+    return wl_m;
+}
+
 // ONE: a single site class (the 257..512-clusters-per-site models): the slot records stay in
 // registers for the whole launch instead of being re-read from LDS for every flip.
 // BIAS: FugacityBias / SquareChargeBias (bias.py:96-287) with one bias row per sublattice,
@@ -44,8 +102,10 @@ struct MultiRec { // slot record, 24 bytes
 // index-row fetches, see mc_lean.h).
 // REPLAY: proposals and uniforms from the host in the reference's draw order (see mc_lean_kernel;
 // instantiated in multi_replay_n*.hip).
-template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false>
+// WLK: the Wang-Landau kernel on this layout (see above; multi_wl_n*.hip).
+template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false, bool WLK = false>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
+    static_assert(!(WLK && BIAS), "Cannot apply bias to Wang-Landau simulation (wanglandau.py:127-128)");
     constexpr bool HAS_EW = EWM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -59,16 +119,26 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     double *s_q = s_mu + 32, *s_dg = s_mu + 64;
     MultiRec *s_rec = (MultiRec *)(s_mu + 96);
     const int nrec = NC * NSLOT * 64;
+    // (WLK) feature scale and feature index of every slot record, read on accepted steps only
+    double *s_fs = (double *)(s_rec + nrec);
+    uint32_t *s_ft = (uint32_t *)(s_fs + (WLK ? nrec : 0));
+    unsigned char *shared_end = (unsigned char *)(s_ft + (WLK ? ((nrec + 3) & ~3) : 0));
     // per wave: occupancy [Nlds] | zero pad 64 | feature scratch [64] | acc cells [NC][NSLOT][64] | phi
-    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 8 +
-                            ((EWM == 1) ? (size_t)P.ew_nact * 8 : 0);
-    unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
+    // (WLK: S [L] | cnt [L] | occb [L] (update_period > 1) | rows [WL_ROWS][F] instead of the acc cells)
+    const int wl_sum_mode = WLK ? P.wl.sum_mode : 1;
+    const size_t state_bytes = WLK ? wl_multi_wave_bytes(P.wl.L, P.F, wl_sum_mode) : (size_t)nrec * 8;
+    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + state_bytes + ((EWM == 1) ? (size_t)P.ew_nact * 8 : 0);
+    unsigned char *wbase = shared_end + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     double *s_feat = (double *)(wbase + P.Nlds + 64);
     double *s_acc = s_feat + 64;
+    double *wl_S = s_acc;                                                   // WLK
+    uint32_t *wl_cnt = (uint32_t *)(wl_S + (WLK ? P.wl.L : 0));
+    double *wl_occb = (double *)((unsigned char *)wl_cnt + (WLK ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *s_rows = wl_occb + ((WLK && !wl_sum_mode) ? P.wl.L : 0);
     // Ewald potential field: LDS copy (ew_field 1) or the walker's HBM array itself (ew_field 2)
     constexpr bool phi_lds = EWM == 1;
-    double *phi = phi_lds ? s_acc + nrec : P.ew_phi + (size_t)r * P.ew_nact;
+    double *phi = phi_lds ? (double *)((unsigned char *)s_acc + state_bytes) : P.ew_phi + (size_t)r * P.ew_nact;
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
     if (threadIdx.x < 32) {
@@ -83,6 +153,10 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         rec.st8[0] = sl.stride8[0]; rec.st8[1] = sl.stride8[1]; rec.st8[2] = sl.stride8[2];
         rec.w = sl.w;
         s_rec[i] = rec;
+        if (WLK) {
+            s_fs[i] = sl.live ? sl.fs : 0.0;
+            s_ft[i] = sl.feat;
+        }
     }
     const bool live = r < P.R;
     if (live) {
@@ -90,7 +164,16 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         for (int i = lane; i < P.Npad / 4; i += 64)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = 0.0;
-        for (int i = lane; i < nrec; i += 64) s_acc[i] = 0.0;
+        if (!WLK)
+            for (int i = lane; i < nrec; i += 64) s_acc[i] = 0.0;
+        if (WLK) {
+            for (int i = lane; i < P.wl.L; i += 64) {
+                wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+                wl_cnt[i] = 0u;
+                if (!wl_sum_mode) wl_occb[i] = (double)P.wl.occur[(size_t)r * P.wl.L + i];
+            }
+            for (int i = lane; i < SMOLMC_WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
+        }
         if (phi_lds)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
     }
@@ -105,12 +188,54 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     const uint32_t nt8 = P.nt8, snt8 = P.snt8;
     const int abase = P.ew_act_base;
     double acc_mu = 0.0, acc_ew = 0.0;
-    constexpr bool FAST = !HAS_EW && !BIAS; // float32 accept pre-test (Ewald / biased variants take the exact path)
+    constexpr bool FAST = !HAS_EW && !BIAS && !WLK; // float32 accept pre-test (Ewald / biased / Wang-Landau variants take the exact path)
     const int btype = BIAS ? P.bias_type : 0;
     double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
     float thr_lo = 0.0f, thr_hi = 0.0f;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    // ---- Wang-Landau state (WLK) ----
+    double fcur = base_feat;                  // lane f < F: the walker's current feature vector (_current_features)
+    double Hcur = H;                          // _current_enthalpy (wanglandau.py:216-218)
+    const double wl_vmin = WLK ? P.wl.vmin : 0.0, wl_bin = WLK ? P.wl.bin : 1.0, wl_inv_bin = 1.0 / wl_bin;
+    double wl_m = WLK ? P.wl.m[r] : 0.0;
+    int wb = 0;                               // current bin (walkers start inside the window: smolmc_set_state)
+    if (WLK) wb = min(max(uni((int)floordiv_exact(Hcur - wl_vmin, wl_bin)), 0), P.wl.L - 1);
+    const long long wl_counter0 = WLK ? P.wl.counter[r] : 0;
+    const uint32_t wl_check = WLK ? (uint32_t)P.wl.check : 0u, wl_upd = WLK ? (uint32_t)P.wl.update : 1u;
+    // counters modulo the periods (the host refuses periods >= 2^31; check period 0 = no device-side check:
+    // the remainder starts at 1 and cannot wrap to 0 inside a launch of < 2^30 steps)
+    uint32_t wl_rem_check = (WLK && wl_check) ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_check)) : 1u;
+    uint32_t wl_rem_upd = WLK ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_upd)) : 0u;
+    uint32_t wl_run_n = 0;                    // sums: post-steps of the current (bin, features) state not yet in its row
+    int vtag = -1;                            // lane i < WL_ROWS: the bin cached in row i (-1: none)
+    const int f_ew = P.Fce, f_mu = P.Fce + (HAS_EW ? 1 : 0);
+    // shadow copies of the feature cells for the accepted steps' deltas (see mc_wl.h): lane l adds into
+    // copy l % wl_k, a reader sums the copies; cell 63 is never written (the address of "no copy")
+    const int wl_k = max(1, min(8, 63 / max(P.F, 1)));
+    const uint32_t wl_shadow = (uint32_t)((lane % wl_k) * P.F);
+    const int wl_rd0 = lane < P.F ? lane : 63, wl_rdstep = lane < P.F ? P.F : 0; // copy k of feature `lane`: cell wl_rd0 + k wl_rdstep
+    const bool wl_zero_lane = lane < wl_k * P.F;
+    // the cached row of a bin (evicting what the slot held)
+    auto wl_row_of = [&](const int bin) -> double * {
+        const int slot = bin & (SMOLMC_WL_ROWS - 1);
+        const int tag = (int)rdlane((uint32_t)vtag, slot);
+        double *crow = s_rows + (uint32_t)slot * (uint32_t)P.F;
+        if (tag != bin) {
+            const LeanParamsKernarg Q = rare_params();
+            wl_multi_row_swap(Q->wl.meanf + (size_t)r * Q->wl.L * Q->F, crow, tag, bin, Q->F, lane, wl_sum_mode);
+            vtag = lane == slot ? bin : vtag;
+        }
+        return crow;
+    };
+    // sums: the post-steps spent in the current state go to the bin's row when the state ends
+    auto wl_flush_run = [&]() {
+        if (wl_run_n != 0u) {
+            double *crow = wl_row_of(wb);
+            if (lane < P.F) crow[lane] = fma((double)wl_run_n, fcur, crow[lane]);
+            wl_run_n = 0u;
+        }
+    };
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
     long long smp_index = 0;
     constexpr int ROW = NSLOT * MM;
@@ -485,6 +610,22 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         }
         double dH = 0.0, dEw = HAS_EW ? ew_uni : 0.0;
         bool accepted = false, decided = false;
+        int wnb = wb;
+        if (WLK) { // WangLandau._accept_step (wanglandau.py:186-202): exact float64 delta, exact floor division
+            dH = wave_sum_all(e);
+            if (HAS_EW) dH += P.ew_coef * dEw;
+            if (HAS_MU) dH -= dMu;
+            const double lu = REPLAY ? lu_rp
+                                     : __hiloint2double((int)rdlane((uint32_t)__double2hiint(logu), l4),
+                                                        (int)rdlane((uint32_t)__double2loint(logu), l4));
+            const double new_h = Hcur + dH;
+            if (__ballot(!(new_h < wl_vmin || new_h >= P.wl.vmax)) != 0ull) {
+                wnb = uni((int)floordiv_exact_inv(new_h - wl_vmin, wl_bin, wl_inv_bin));
+                const double ex = wl_S[wb] - wl_S[wnb] + 0.0; // (+ log a-priori factor: 0 for flips / swaps)
+                accepted = __ballot((ex >= 0.0) || (ex > lu)) != 0ull;
+            }
+            decided = true;
+        }
         if (FAST) { // float32 pre-test (see mc_lean_kernel)
             const float ef = (float)((HAS_MU && lane == 0) ? e - dMu : e);
             const float S = wave_sum_f32_uniform(ef);
@@ -508,10 +649,33 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         if (accepted) {
             bias_acc += dB;
             charge += dQ;
-            double *cell = s_acc + ((size_t)cls1 * NSLOT) * 64 + lane;
+            if (WLK) {
+                // the state (bin, features) ends here: its post-steps go to the bin's row (sums)
+                if (wl_sum_mode) wl_flush_run();
+                // _do_accept_step (wanglandau.py:204-220): features and enthalpy follow the step
+                const double *fsp = s_fs + ((size_t)cls1 * NSLOT) * 64 + lane;
+                const uint32_t *ftp = s_ft + ((size_t)cls1 * NSLOT) * 64 + lane;
 #pragma unroll
-            for (int it = 0; it < NSLOT; ++it)
-                cell[it * 64] += STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+                for (int it = 0; it < NSLOT; ++it) {
+                    const double d = STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+                    __hip_atomic_fetch_add(&s_feat[ftp[it * 64] + wl_shadow], fsp[it * 64] * d, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                double df = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) df += s_feat[k < wl_k ? wl_rd0 + k * wl_rdstep : 63];
+                if (wl_zero_lane) s_feat[lane] = 0.0;
+                if (HAS_EW) df += lane == f_ew ? dEw : 0.0;
+                if (HAS_MU) df += lane == f_mu ? dMu : 0.0;
+                fcur += df;
+                Hcur += dH;
+                wb = wnb;
+            } else {
+                double *cell = s_acc + ((size_t)cls1 * NSLOT) * 64 + lane;
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    cell[it * 64] += STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
+            }
             if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
             if (HAS_EW) {
@@ -542,10 +706,40 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             occ[a1] = (uint8_t)o1;
         }
         if (!ONE) row1 = rown;
+        if (WLK) { // WangLandau._do_post_step (wanglandau.py:222-266), accepted or not
+            if (wl_sum_mode) {
+                wl_run_n++;
+            } else { // running mean with total = occurrences[bin] as they are now (:233-239)
+                double *crow = wl_row_of(wb);
+                const double total = wl_occb[wb] + (double)wl_cnt[wb];
+                const double inv = 1.0 / (total + 1.0);
+                if (lane < P.F) crow[lane] = inv * (fcur + total * crow[lane]);
+            }
+            if (++wl_rem_upd == wl_upd) { // entropy, histogram, occurrences every update_period steps (:241-245)
+                wl_rem_upd = 0u;
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            if (++wl_rem_check == wl_check) wl_rem_check = 0u;
+            if (wl_rem_check == 0u) {
+                const LeanParamsKernarg Q = rare_params();
+                const size_t o = (size_t)r * Q->wl.L;
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, wl_sum_mode ? nullptr : wl_occb, Q->wl.hist + o, Q->wl.occur + o,
+                                               Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
+            }
+        }
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(0);
 #endif
-        if (REPLAY) { // accept flag and running enthalpy of every step (what smolmc_replay returns)
+        if (REPLAY && WLK) {
+            if (lane == 0) {
+                const size_t k = (size_t)r * nsteps32 + it_step;
+                P.rp_acc[k] = (uint8_t)(nacc_add != nacc_before);
+                P.rp_H[k] = Hcur;
+            }
+        } else if (REPLAY) { // accept flag and running enthalpy of every step (what smolmc_replay returns)
             double lane_e = 0.0;
             for (int i = lane; i < nrec; i += 64) lane_e = fma(s_rec[i].w, s_acc[i], lane_e);
             const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0));
@@ -564,6 +758,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             smp_countdown = (uint32_t)Q->smp.every;
             const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
+            double Hnow;
+            if (WLK) {
+                if (lane < qF) q_feat[row * qF + lane] = fcur;
+                Hnow = Hcur;
+            } else {
             s_feat[lane] = 0.0;
             double lane_e = 0.0;
             for (int i = lane; i < nrec; i += 64) {
@@ -576,7 +775,8 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
             if (HAS_EW && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
             if (HAS_MU && lane == qFce + (HAS_EW ? 1 : 0)) q_feat[row * qF + lane] = base_feat + acc_mu;
-            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? Q->ew_coef * acc_ew : 0.0));
+            Hnow = H + (wave_sum_all(lane_e) - acc_mu + (HAS_EW ? Q->ew_coef * acc_ew : 0.0));
+            }
             if (lane == 0) {
                 Q->smp.H[row] = Hnow;
                 Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
@@ -599,6 +799,30 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         for (int i = lane; i < P.Npad / 4; i += 64)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
+    if (WLK) {
+        if (wl_sum_mode) wl_flush_run(); // the unfinished run of the current state
+        for (int slot = 0; slot < SMOLMC_WL_ROWS; ++slot) { // cached rows back to HBM
+            const int tag = (int)rdlane((uint32_t)vtag, slot);
+            if (tag >= 0 && lane < P.F) {
+                double *g = P.wl.meanf + ((size_t)r * P.wl.L + tag) * P.F + lane;
+                const double v = s_rows[(uint32_t)slot * (uint32_t)P.F + lane];
+                if (wl_sum_mode) unsafeAtomicAdd(g, v);
+                else *g = v;
+            }
+        }
+        for (int i = lane; i < P.wl.L; i += 64) {
+            const size_t o = (size_t)r * P.wl.L + i;
+            P.wl.entropy[o] = wl_S[i];
+            P.wl.hist[o] += (long long)wl_cnt[i];
+            P.wl.occur[o] += (long long)wl_cnt[i];
+        }
+        if (lane < P.F) featp[lane] = fcur;
+        H = Hcur;
+        if (lane == 0) {
+            P.wl.m[r] = wl_m;
+            P.wl.counter[r] = wl_counter0 + (long long)nsteps32;
+        }
+    } else {
     s_feat[lane] = 0.0;
     double lane_e = 0.0;
     for (int i = lane; i < nrec; i += 64) {
@@ -610,13 +834,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
     if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     H += wave_sum_all(lane_e) - acc_mu + (HAS_EW ? P.ew_coef * acc_ew : 0.0);
+    }
     if (btype && lane == 0) {
         P.bias[r] += bias_acc;
         if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
     }
     if (lane == 0) {
-        if (HAS_EW) featp[P.Fce] += acc_ew;
-        if (HAS_MU) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
+        if (HAS_EW && !WLK) featp[P.Fce] += acc_ew;
+        if (HAS_MU && !WLK) featp[P.Fce + (HAS_EW ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
@@ -625,13 +850,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false, bool REPLAY = false>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false, bool REPLAY = false, bool WLK = false>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
     // one site class with more than 256 clusters per site: slot records in registers
-    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8, BIAS, REPLAY>
-                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false, BIAS, REPLAY>;
+    auto kern = (NSLOT == 8 && lp.m_ncls == 1) ? mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, NSLOT == 8, BIAS, REPLAY, WLK>
+                                               : mc_lean_multi_kernel<NSLOT, MM, STEP, MU, EW, false, BIAS, REPLAY, WLK>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -653,6 +878,21 @@ template <int NSLOT, int MM, int STEP, bool BIAS> static int launch_multi_me(smo
 template <int NSLOT, int MM, bool BIAS = false> static int launch_multi_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_multi_me<NSLOT, MM, SMOLMC_STEP_SWAP, BIAS>(h, lp);
     return launch_multi_me<NSLOT, MM, SMOLMC_STEP_FLIP, BIAS>(h, lp);
+}
+// Wang-Landau variants (multi_wl_n*.hip, multi_wl_replay_n*.hip)
+template <int NSLOT, int MM, int STEP, bool REPLAY> static int launch_multi_wl_me(smolmc_handle *h, const LeanParams &lp) {
+    const bool mu = lp.m_mu != nullptr;
+    if (lp.ew_field == 1)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, false, REPLAY, true>(h, lp);
+    if (lp.ew_field == 2)
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, false, REPLAY, true>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, false, REPLAY, true>(h, lp);
+}
+template <int NSLOT, bool REPLAY = false> static int launch_multi_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
+    const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
+    if (h->lean_mm == 2)
+        return swap ? launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_SWAP, REPLAY>(h, lp) : launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_FLIP, REPLAY>(h, lp);
+    return swap ? launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_SWAP, REPLAY>(h, lp) : launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_FLIP, REPLAY>(h, lp);
 }
 // replay variants (multi_replay_n*.hip)
 template <int NSLOT, int MM, int STEP> static int launch_multi_replay_me(smolmc_handle *h, const LeanParams &lp) {

@@ -579,6 +579,7 @@ struct smolmc_handle {
     bool lean_tables = false, lean = false;
     int lean_nslot = 0, lean_mm = 0, lean_ncls = 0;
     bool lean_multi = false;            // dispatch to mc_lean_multi_kernel
+    bool lean_multi_wl = false;         // ... its Wang-Landau variant (WLK)
     bool lean_solo = false;             // mc_lean_kernel in its one-wave-per-workgroup layout
     int lean_occ = 0;                   // > 0: the solo instantiation held to this many waves per SIMD
     int lean_wpb = 4;          // TableFlip kernel: walkers (waves) per workgroup -- 8 when one such workgroup fills a CU's LDS (see launch_table_ewm)
@@ -680,6 +681,12 @@ int smolmc_launch_multi_bias_replay_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_replay_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_replay_8(smolmc_handle *h, const LeanParams &lp);
 #define SMOLMC_WL_ROWS 32  // mc_wl_kernel: cached rows of per-bin feature sums per walker (LDS)
+// per-walker LDS bytes of the Wang-Landau state of mc_lean_multi_kernel<..., WLK> (mc_lean_multi.h):
+// S f64 [L] | counted steps u32 [L] | occurrences at launch start f64 [L] (running means only) | cached rows
+__host__ __device__ inline size_t wl_multi_wave_bytes(int L, int F, int sum_mode) {
+    return (size_t)L * 8 + (((size_t)L * 4 + 7) & ~(size_t)7) + (sum_mode ? 0 : (size_t)L * 8) +
+           (size_t)SMOLMC_WL_ROWS * F * 8;
+}
 #define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
 int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_corr_4(smolmc_handle *h, const LeanParams &lp);
@@ -697,6 +704,12 @@ int smolmc_launch_lean_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_replay_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_replay_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_replay_8(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_8(smolmc_handle *h, const LeanParams &lp);

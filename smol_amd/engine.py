@@ -172,7 +172,10 @@ class Engine:
             return steps
         steps = steps.copy()
         sites = steps[..., 0::2]
-        steps[..., 0::2] = np.where(sites >= 0, self._new_of[np.clip(sites, 0, self.N - 1)], sites)
+        # (a site beyond the cell is left as it is: the C side rejects it -- mapping it through the
+        # relabelling would turn it into a valid site and evaluate a step nobody asked for)
+        ok = (sites >= 0) & (sites < self.N)
+        steps[..., 0::2] = np.where(ok, self._new_of[np.where(ok, sites, 0)], sites)
         return steps
 
     # ---- state ----------------------------------------------------------------
@@ -352,12 +355,16 @@ class Engine:
         return out
 
     def eval_delta(self, occupancy, steps):
-        """steps: (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}), k <= 8, -1 = absent;
-        a single step may also be given as its list of (site, code) tuples."""
+        """steps: an ndarray of (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}), k <= 8,
+        -1 = absent -- n steps, exactly what capi.step_rows makes of it (an (n, 2) array is n single
+        flips); a flat record is one step.  ONE step may also be given the way the reference's ushers
+        return it, as a Python list of (site, code) tuples (mcusher.py:104-116)."""
         occ = self._occ_in(self._occ32(occupancy, (self.N,)))
+        as_pairs = isinstance(steps, (list, tuple)) and len(steps) > 0 and all(
+            isinstance(f, (list, tuple)) and len(f) == 2 for f in steps)
         a = np.asarray(steps, dtype=np.int32)
-        if a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 2):
-            a = a.reshape(1, -1)  # one step: flat record or (site, code) pairs
+        if a.ndim == 1 or as_pairs:
+            a = a.reshape(1, -1)  # one step: flat record or a list of (site, code) tuples
         steps = self._steps_in(capi.step_rows(a))
         out = np.zeros((len(steps), self.F))
         self._chk(

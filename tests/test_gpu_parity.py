@@ -752,6 +752,9 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),
     ("fcc3_indicator_skew", "corr", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
     ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "wang-landau", "general"),    # WL keeps K > 1 on mc_kernel
+    ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "wang-landau", "lean-multi"),   # WL + two sublattices (round 5)
+    ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "wang-landau", "lean-multi"),
+    ("rocksalt333_two_sublattices", "corr", capi.STEP_FLIP, "muG", "wang-landau", "general"),     # K > 1 of a multi-class model
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),

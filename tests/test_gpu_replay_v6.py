@@ -78,6 +78,8 @@ def test_reference_trajectories_replay(tag, kernel, monkeypatch, capfd):
         assert info.startswith("lean") and path == "lean-table", (info, path)  # the TableFlip kernels of config 5
     if kernel == "auto" and tag in LEAN_PLAIN:
         assert info.startswith("lean") and path == "lean", (info, path)
+    if kernel == "auto" and tag == "B_wlup3":  # update_period 3: the Wang-Landau variant of the multi-class kernel (round 5)
+        assert info.startswith("lean-multi") and "wl=multi-mean" in info and path == "lean", (info, path)
 
 
 @pytest.mark.parametrize("kernel", ["auto", "universal"])

@@ -128,8 +128,10 @@ def test_wang_landau_on_the_universal_kernel(update_period, monkeypatch):
 
 
 def test_wang_landau_update_period_on_the_general_kernel(monkeypatch):
-    """update_period > 1 forces mc_kernel (engine.hip lean eligibility): native stream vs the oracle."""
+    """update_period > 1 on mc_kernel (its path until round 5; SMOLMC_NO_WL_MULTI keeps it reachable):
+    native stream vs the oracle."""
     monkeypatch.delenv("SMOLMC_FORCE_UNIVERSAL", raising=False)
+    monkeypatch.setenv("SMOLMC_NO_WL_MULTI", "1")
     tab, cfg, occ0, _ = build("B_wlup3", n_replicas=3)
     eng, ora = _pair(tab, cfg, np.tile(occ0, (3, 1)), [4, 5, 6], 0.0)
     assert eng.kernel_info().startswith("general"), eng.kernel_info()
