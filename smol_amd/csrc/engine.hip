@@ -1466,14 +1466,24 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             const size_t shared = ((size_t)lp.dt_len + 96 + (table ? 80 : 0)) * 8 + nrec * 24 + (wl ? nrec * 12 : 0);
             // waves per workgroup: the shared tables are paid once per workgroup, so pick the size
             // that keeps the most waves resident per CU (160 KiB of LDS)
+            // ... and, at equal residency, the size that spreads the walkers over the most CUs: 1024 walkers in
+            // eight-wave workgroups are 128 workgroups -- half the chip idle, two waves per SIMD on the other half
+            int cus_l = 0;
+            if (hipDeviceGetAttribute(&cus_l, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus_l = 256;
             auto layout = [&](size_t per_wave_bytes, int &wpb_out) {
                 int best_waves = 0;
+                long best_rounds = 0, best_busy = 0;
                 wpb_out = 0;
                 for (int w : {8, 4, 2, 1}) {
                     const size_t need = shared + per_wave_bytes * w;
                     if (need > 160 * 1024 - 512) continue;
                     const int waves = (int)((160 * 1024) / need) * w;
-                    if (waves > best_waves) { best_waves = waves; wpb_out = w; }
+                    const long R_ = cfg->n_replicas, blocks = (R_ + w - 1) / w;
+                    const long rounds = (R_ + (long)waves * cus_l - 1) / ((long)waves * cus_l);
+                    const long busy = std::min<long>(blocks, cus_l); // CUs that get a workgroup in the first round
+                    const bool better = wpb_out == 0 || rounds < best_rounds ||
+                                        (rounds == best_rounds && (busy > best_busy || (busy == best_busy && waves > best_waves)));
+                    if (better) { best_waves = waves; best_rounds = rounds; best_busy = busy; wpb_out = w; }
                 }
                 return best_waves;
             };
@@ -1495,7 +1505,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 // (beyond: 4.1e9 with the HBM field against 3.0e9)
                 // -- provided at least 8 waves per CU stay resident: at 3 (config 7, 27 KiB of field
                 // per walker) the LDS copy measured 9.6 against 7.4 us per step
-                if ((long)waves * cus >= (long)cfg->n_replicas || (cfg->step_type == SMOLMC_STEP_SWAP && waves >= 8) ||
+                // (Wang-Landau accepts three steps of four: the field update is the step, the LDS copy pays for flips too)
+                if ((long)waves * cus >= (long)cfg->n_replicas || ((cfg->step_type == SMOLMC_STEP_SWAP || wl) && waves >= 8) ||
                     getenv("SMOLMC_MULTI_PHI_LDS") != nullptr)
                     phi_lds = waves > 0;
             }

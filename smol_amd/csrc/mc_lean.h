@@ -200,22 +200,26 @@ __device__ __forceinline__ void field_apply_flips(double *phi, int lane, int nfl
 template <int FOOT = 1>
 __device__ __forceinline__ void field_apply2(const LeanParams &P, double *phi, int lane, int s1, double dq1,
                                              int s2, double dq2) {
-    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
     const int j1 = s1 - P.sbase, j2 = s2 - P.sbase;
-    // entry j1 must not see its own flip (but does see flip 2) and vice versa: both are patched
-    // after the sweep from the values saved here
-    const double keep1 = phi[j1], keep2 = phi[j2];
-    const double c12 = g2[j1], c21 = g1[j2]; // cross terms G[s2][s1], G[s1][s2]
     const LeanParamsKernarg Q = rare_params();
     const unsigned char *gx = (const unsigned char *)Q->ew_gx;
     if (gx != nullptr) {
+        // translation-compressed tables: G[s][s] = 0 there, so the multi-flip sweep leaves every entry right --
+        // entry j1 gains dq1 * 0 + dq2 * G[s2][j1] -- and nothing is patched.  (Until round 5 the cross terms
+        // were still read from the ROWS of the full site kernel here, two scalar loads from a 16 MB matrix per
+        // accepted swap: an HBM round trip that every LDS wait behind it -- lgkmcnt is shared -- sat on.)
         const uint32_t *E8 = Q->ew_E8, *S8 = Q->ew_S8;
         const uint32_t s8[2] = {S8[j1], S8[j2]};
         const double d[2] = {dq1, dq2};
         field_sweep_gx_multi<2, FOOT>(phi, E8, gx, lane, P.ew_nact, s8, d);
-    } else {
-        field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
+        return;
     }
+    const double *g1 = P.ew_G + (size_t)s1 * P.ew_nact, *g2 = P.ew_G + (size_t)s2 * P.ew_nact;
+    // entry j1 must not see its own flip (but does see flip 2) and vice versa: both are patched
+    // after the sweep from the values saved here
+    const double keep1 = phi[j1], keep2 = phi[j2];
+    const double c12 = g2[j1], c21 = g1[j2]; // cross terms G[s2][s1], G[s1][s2]
+    field_sweep<true>(phi, g1, g2, lane, P.ew_nact, dq1, dq2);
     if (j1 != j2) {
         phi[j1] = fma(dq2, c12, keep1);
         phi[j2] = fma(dq1, c21, keep2);

@@ -44,8 +44,9 @@ struct MultiRec { // slot record, 24 bytes
 //               histogram is reset and when the launch ends (8 + 4 bytes per bin instead of 24);
 //   * occb[L]   float64 occurrences at launch start, ONLY when update_period > 1 (the running-mean
 //               recurrence :235-239 then needs total = occurrences[bin] on every step);
-//   * rows      direct-mapped cache of WL_ROWS per-bin feature rows (sums for update_period 1: a run of
-//               steps in one state adds run_n * features when it ends; running means otherwise).
+//   * rows      update_period 1 (per-bin feature SUMS): a log of WL_ROWS finished runs {bin, run_n * features}
+//               (a run = the post-steps spent in one state), written to the rows in HBM in bursts;
+//               update_period > 1 (running means): a direct-mapped cache of WL_ROWS rows.
 // The current feature vector lives in the lanes of one register (lane f < F), updated on accepted
 // steps through the shadow cells of mc_wl.h; the enthalpy is carried as the reference carries it
 // (_current_enthalpy += delta, :216-218) and every decision is the exact float64 one.
@@ -91,6 +92,7 @@ __device__ __noinline__ double wl_multi_flatness_check(const double *S, uint32_t
     return wl_m;
 }
 
+#define WLM_LOG SMOLMC_WLM_LOG // entries of the log of finished runs (sums)
 // ONE: a single site class (the 257..512-clusters-per-site models): the slot records stay in
 // registers for the whole launch instead of being re-read from LDS for every flip.
 // BIAS: FugacityBias / SquareChargeBias (bias.py:96-287) with one bias row per sublattice,
@@ -172,7 +174,8 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 wl_cnt[i] = 0u;
                 if (!wl_sum_mode) wl_occb[i] = (double)P.wl.occur[(size_t)r * P.wl.L + i];
             }
-            for (int i = lane; i < SMOLMC_WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
+            if (!wl_sum_mode)
+                for (int i = lane; i < SMOLMC_WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
         }
         if (phi_lds)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
@@ -228,12 +231,34 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         }
         return crow;
     };
-    // sums: the post-steps spent in the current state go to the bin's row when the state ends
+    // Sums (update_period 1): the post-steps spent in the current state (bin, features) add run_n * features to
+    // the bin's row when the state ends.  The rows are NOT cached by bin: with an Ewald term a swap moves the
+    // enthalpy by several bins' worth, the walker revisits a bin after hundreds of others, and every miss of a
+    // direct-mapped cache was a global atomic in the step loop -- vmcnt counts in order, so the next index-row
+    // wait sat on its acknowledgement (~1000 cycles per accepted step, measured).  Finished runs are LOGGED in
+    // LDS instead, WL_ROWS entries {bin, run_n * features}, and the log goes to the rows in HBM in one burst of
+    // fire-and-forget atomics (the rows of a walker are touched by its own wave only).
+    int wl_nlog = 0;
+    // (64 / F entries per atomic instruction: lane l carries feature l % F of entry base + l / F)
+    const int wl_epi = max(1, 64 / max(P.F, 1)), wl_lane_e = lane / max(P.F, 1), wl_lane_f = lane - wl_lane_e * P.F;
+    auto wl_log_flush = [&]() {
+        const LeanParamsKernarg Q = rare_params();
+        double *grows = Q->wl.meanf + (size_t)r * Q->wl.L * Q->F;
+        const int qF = Q->F;
+        for (int base = 0; base < wl_nlog; base += wl_epi) {
+            const int e = base + wl_lane_e;
+            const int bin = __shfl(vtag, e & 63); // (uniform control flow: ds_bpermute reads switched-off lanes otherwise)
+            if (wl_lane_e < wl_epi && e < wl_nlog)
+                unsafeAtomicAdd(grows + (size_t)bin * qF + wl_lane_f, s_rows[(uint32_t)base * (uint32_t)qF + lane]);
+        }
+        wl_nlog = 0;
+    };
     auto wl_flush_run = [&]() {
         if (wl_run_n != 0u) {
-            double *crow = wl_row_of(wb);
-            if (lane < P.F) crow[lane] = fma((double)wl_run_n, fcur, crow[lane]);
+            if (lane < P.F) s_rows[(uint32_t)wl_nlog * (uint32_t)P.F + lane] = (double)wl_run_n * fcur;
+            vtag = lane == wl_nlog ? wb : vtag;
             wl_run_n = 0u;
+            if (++wl_nlog == WLM_LOG) wl_log_flush();
         }
     };
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
@@ -250,7 +275,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     double logu = 0.0;
     int vsite = 0, vaddr = 0, vsub = 0;
     int cand[4] = {0, 0, 0, 0}, canda[4] = {0, 0, 0, 0};
-    double vGc = 0.0;
+    double vGc[4] = {0.0, 0.0, 0.0, 0.0}; // swap + Ewald: cross terms G[candidate j of the lane][site of the lane's step]
     unsigned long long batch_base = ~0ull;
     RowWords<NW> row1;
 
@@ -321,6 +346,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         return v >= 0 ? v : P.m_sbase[0];
     };
     if (REPLAY && nsteps32) row1 = load_row<NW>(idx_rs, lane_voff, (uint32_t)rp_site(0u) * SITE_BYTES);
+#ifdef SMOLMC_EXP_PHASES // experiment: shader cycles per phase of a step (walker 0 prints the averages)
+    long long mph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long mph_t = clock64();
+#define MULTI_PHASE(i) { const long long tn = clock64(); mph[i] += tn - mph_t; mph_t = tn; }
+#else
+#define MULTI_PHASE(i)
+#endif
     for (uint32_t it_step = 0; it_step < nsteps32; ++it_step, ++step) {
         const unsigned long long base = step & ~15ull;
         if (!REPLAY && base != batch_base) {
@@ -360,7 +392,24 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 cand[3] = sb + (int)__umulhi(o.w[3], na);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) canda[j] = lean_swz(cand[j], swa, swm, swb);
-                if (HAS_EW) vGc = P.ew_G[(size_t)cand[0] * P.ew_nact + (vsite - abase)];
+                if (HAS_EW) {
+                    // Cross terms of the lane's FOUR candidates with its step's site, a batch ahead.  From the
+                    // translation-compressed tables when the model has them (entry (s, j) at E8[j] + S8[s]: 108 KB,
+                    // L2-resident); else from the rows of the site kernel.  (Until round 5 only the first-round
+                    // candidate's term came with the batch; a later candidate -- 4 steps of 10 -- read G[s2][s1]
+                    // from a 16 MB matrix in the step: an HBM round trip in front of every such decision.)
+                    const LeanParamsKernarg Q = rare_params();
+                    const unsigned char *gxq = (const unsigned char *)Q->ew_gx;
+                    if (gxq != nullptr) {
+                        const uint32_t *qS8 = Q->ew_S8;
+                        const uint32_t e1 = Q->ew_E8[vsite - abase];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vGc[j] = *(const double *)(gxq + (size_t)(e1 + qS8[cand[j] - abase]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vGc[j] = P.ew_G[(size_t)cand[j] * P.ew_nact + (vsite - abase)];
+                    }
+                }
             }
             if (pend_on) {
                 const uint32_t *pE8 = rare_params()->ew_E8;
@@ -421,7 +470,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         if (!ONE) rown = load_row<NW>(idx_rs, lane_voff, nsite_pf * SITE_BYTES);
 
         const int o1 = uni((int)occ[a1]);
-        int nfl, s2, a2, n1, n2 = 0, o2 = 0, fb = -1; // (swap: s2 / a2 / o2 are set by every proposal outcome)
+        int nfl, s2, a2, n1, n2 = 0, o2 = 0; // (swap: s2 / a2 / o2 are set by every proposal outcome)
+        double cross_b = 0.0;  // cross term G[s2][s1] of a partner that came from the batch's candidates
+        bool have_cross = false;
         uint32_t e8_2 = 0xffffffffu; // E8 of the swap partner when it came from the batch's candidates
         if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         if (REPLAY) { // the recorded proposal
@@ -461,7 +512,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         a2 = (int)rdlane((uint32_t)canda[J], b);                                                   \
         o2 = (int)rdlane((uint32_t)v##J, b);                                                       \
         if (PEND) e8_2 = rdlane(vE8c[J], b);                                                       \
-        if (J == 0) fb = b;                                                                        \
+        if (HAS_EW) {                                                                              \
+            cross_b = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc[J]), b),           \
+                                       (int)rdlane((uint32_t)__double2loint(vGc[J]), b));          \
+            have_cross = true;                                                                     \
+        }                                                                                          \
     }
             SMOLMC_CAND_MASK(0)
             if (m0) SMOLMC_CAND_TAKE(0)
@@ -516,6 +571,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(2);
 #endif
+        MULTI_PHASE(0)
         // potential at the two sites (HBM copy of the field: global loads, issued AHEAD of the
         // partner's row so that the wait for that row does not cover them as well)
         double p1 = 0.0, p2 = 0.0;
@@ -579,10 +635,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             }
             if (HAS_EW) {
                 dq2 = s_q[sub1 * 8 + n2] - s_q[sub1 * 8 + o2];
-                const double cross =
-                    fb >= 0 ? __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc), fb),
-                                               (int)rdlane((uint32_t)__double2loint(vGc), fb))
-                            : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - abase)];
+                const double cross = have_cross ? cross_b : P.ew_G[(size_t)s2 * P.ew_nact + (s1 - abase)];
                 ew_uni += 2.0 * dq2 * ((p2 + corr2) + dq1 * cross) + (s_dg[sub1 * 8 + n2] - s_dg[sub1 * 8 + o2]);
             }
         }
@@ -611,6 +664,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         double dH = 0.0, dEw = HAS_EW ? ew_uni : 0.0;
         bool accepted = false, decided = false;
         int wnb = wb;
+        MULTI_PHASE(1)
         if (WLK) { // WangLandau._accept_step (wanglandau.py:186-202): exact float64 delta, exact floor division
             dH = wave_sum_all(e);
             if (HAS_EW) dH += P.ew_coef * dEw;
@@ -646,12 +700,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         }
         nacc_before = nacc_add;
+        MULTI_PHASE(2)
         if (accepted) {
             bias_acc += dB;
             charge += dQ;
             if (WLK) {
                 // the state (bin, features) ends here: its post-steps go to the bin's row (sums)
                 if (wl_sum_mode) wl_flush_run();
+                MULTI_PHASE(6)
                 // _do_accept_step (wanglandau.py:204-220): features and enthalpy follow the step
                 const double *fsp = s_fs + ((size_t)cls1 * NSLOT) * 64 + lane;
                 const uint32_t *ftp = s_ft + ((size_t)cls1 * NSLOT) * 64 + lane;
@@ -678,6 +734,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             }
             if (STEP == SMOLMC_STEP_FLIP) occ[a1] = (uint8_t)n1;
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
+            MULTI_PHASE(3)
             if (HAS_EW) {
                 if (phi_lds) {
                     if (STEP == SMOLMC_STEP_SWAP) {
@@ -702,6 +759,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             acc_mu += dMu;
             acc_ew += dEw;
             nacc_add++;
+            MULTI_PHASE(4)
         } else if (STEP == SMOLMC_STEP_SWAP) {
             occ[a1] = (uint8_t)o1;
         }
@@ -733,6 +791,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #ifndef SMOLMC_NO_SETPRIO
         if (!ONE) __builtin_amdgcn_s_setprio(0);
 #endif
+        MULTI_PHASE(5)
         if (REPLAY && WLK) {
             if (lane == 0) {
                 const size_t k = (size_t)r * nsteps32 + it_step;
@@ -790,6 +849,13 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         }
     }
 
+#ifdef SMOLMC_EXP_PHASES
+    if (r == 0 && lane == 0)
+        printf("multi phases (cycles per step): skeleton+proposal %.0f | gathers+tables %.0f | decision %.0f | accept: features+occupancy %.0f | "
+               "field %.0f | post-step+rest %.0f | (row flush %.0f)\n",
+               (double)mph[0] / (double)nsteps32, (double)mph[1] / (double)nsteps32, (double)mph[2] / (double)nsteps32,
+               (double)mph[3] / (double)nsteps32, (double)mph[4] / (double)nsteps32, (double)mph[5] / (double)nsteps32, (double)mph[6] / (double)nsteps32);
+#endif
     // ---- write back ---------------------------------------------------------------
     if (pend_on && npend > 0) flush_pending(); // (phi in HBM is complete between launches)
     if (phi_lds)
@@ -800,14 +866,14 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
     if (WLK) {
-        if (wl_sum_mode) wl_flush_run(); // the unfinished run of the current state
-        for (int slot = 0; slot < SMOLMC_WL_ROWS; ++slot) { // cached rows back to HBM
-            const int tag = (int)rdlane((uint32_t)vtag, slot);
-            if (tag >= 0 && lane < P.F) {
-                double *g = P.wl.meanf + ((size_t)r * P.wl.L + tag) * P.F + lane;
-                const double v = s_rows[(uint32_t)slot * (uint32_t)P.F + lane];
-                if (wl_sum_mode) unsafeAtomicAdd(g, v);
-                else *g = v;
+        if (wl_sum_mode) {
+            wl_flush_run(); // the unfinished run of the current state
+            wl_log_flush();
+        } else {
+            for (int slot = 0; slot < SMOLMC_WL_ROWS; ++slot) { // cached rows (running means) back to HBM
+                const int tag = (int)rdlane((uint32_t)vtag, slot);
+                if (tag >= 0 && lane < P.F)
+                    P.wl.meanf[((size_t)r * P.wl.L + tag) * P.F + lane] = s_rows[(uint32_t)slot * (uint32_t)P.F + lane];
             }
         }
         for (int i = lane; i < P.wl.L; i += 64) {

@@ -314,29 +314,36 @@ __device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t
                                                      int na, const uint32_t (&s8)[NF], const double (&dq)[NF], int gstart = 0) {
     const int ngf = na >> 6; // full groups of 64 entries
     int g = gstart;          // (groups below gstart: done by the caller, see field_sweep_gx_pre27)
-    while (ngf - g >= U) {
-        const int nb = min(NB, (ngf - g) / U); // full batches of this chunk (uniform)
-        const uint32_t *pe = E8 + g * 64 + lane;
+    // Chunks of up to NB batches of U groups: the E8 entries of the whole chunk are fetched first, then the
+    // batches run, each one round trip to the tables.  When fewer than U groups are left the last batch is
+    // shifted back so that it ends on the last full group; the groups it shares with the batch before are
+    // rewritten unchanged (coefficient 0).  (Flips and swaps only: with the three or four flips of a TableFlip
+    // step the extra unrolled batch costs those kernels their registers -- 250 VGPRs, 128 SGPR spills.  Round 5
+    // added the swaps and put the shifted batch into the chunk: the seven groups a 16-group lattice -- the
+    // reference's LiNiO2 model in an 8^3 cell -- leaves after one batch of nine were seven dependent chains
+    // E8 -> table entries -> phi, 8000 cycles per accepted swap.)
+    constexpr bool SHIFT = NF <= 2;
+    while (ngf >= U && g < ngf) {
+        const int rem = ngf - g;
+        const int nb = min(NB, rem / U);                       // full batches of this chunk (uniform)
+        const bool tail = SHIFT && nb < NB && rem > nb * U;    // + one shifted batch
+        const int nbt = nb + (tail ? 1 : 0);
+        if (nbt == 0) break;
+        const int g_tail = ngf - U, ff_tail = g + nb * U - g_tail; // the shifted batch: first group, first fresh group
         uint32_t e[NB][U];
 #pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nbt) { // (uniform)
+                const uint32_t *pe = E8 + (b < nb ? g + b * U : g_tail) * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < U; ++u) e[b][u] = pe[64 * u];
+            }
+        }
+#pragma unroll
         for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int u = 0; u < U; ++u) e[b][u] = pe[64 * min(b * U + u, nb * U - 1)]; // (clamped: reads only)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-            if (b < nb) field_sweep_gx_groups<NF, U>(phi + (g + b * U) * 64 + lane, e[b], gx, s8, dq, 0);
-        g += nb * U;
-    }
-    if (NF == 1 && g < ngf && ngf >= U) { // fewer than a batch left: one more batch, shifted back onto the end
-        // (single flips only: with several flips per step the extra unrolled batch costs the
-        // TableFlip kernels their registers -- 250 VGPRs, 128 SGPR spills)
-        const int g0 = ngf - U;
-        const uint32_t *pe = E8 + g0 * 64 + lane;
-        uint32_t e[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = pe[64 * u];
-        field_sweep_gx_groups<NF, U>(phi + g0 * 64 + lane, e, gx, s8, dq, g - g0);
-        g = ngf;
+            if (b < nbt)
+                field_sweep_gx_groups<NF, U>(phi + (b < nb ? g + b * U : g_tail) * 64 + lane, e[b], gx, s8, dq, b < nb ? 0 : ff_tail);
+        g = tail ? ngf : g + nb * U;
     }
     for (; g < ngf; ++g) { // (lattices of fewer than U groups) group by group
         const uint32_t e = E8[g * 64 + lane];
@@ -682,10 +689,12 @@ int smolmc_launch_multi_bias_replay_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_bias_replay_8(smolmc_handle *h, const LeanParams &lp);
 #define SMOLMC_WL_ROWS 32  // mc_wl_kernel: cached rows of per-bin feature sums per walker (LDS)
 // per-walker LDS bytes of the Wang-Landau state of mc_lean_multi_kernel<..., WLK> (mc_lean_multi.h):
-// S f64 [L] | counted steps u32 [L] | occurrences at launch start f64 [L] (running means only) | cached rows
+// S f64 [L] | counted steps u32 [L] | sums: a log of SMOLMC_WLM_LOG finished runs [F] -- running means: occurrences at
+// launch start f64 [L] and SMOLMC_WL_ROWS cached rows [F]
+#define SMOLMC_WLM_LOG 16
 __host__ __device__ inline size_t wl_multi_wave_bytes(int L, int F, int sum_mode) {
-    return (size_t)L * 8 + (((size_t)L * 4 + 7) & ~(size_t)7) + (sum_mode ? 0 : (size_t)L * 8) +
-           (size_t)SMOLMC_WL_ROWS * F * 8;
+    return (size_t)L * 8 + (((size_t)L * 4 + 7) & ~(size_t)7) +
+           (sum_mode ? (size_t)SMOLMC_WLM_LOG * F * 8 : (size_t)L * 8 + (size_t)SMOLMC_WL_ROWS * F * 8);
 }
 #define SMOLMC_LEAN_MAX_KF 6 // correlation functions per orbit served by the lean kernels (ternary triplets)
 int smolmc_launch_lean_corr_2(smolmc_handle *h, const LeanParams &lp);
