@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 6
+#define SMOLMC_ABI_VERSION 7
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
@@ -252,10 +252,24 @@ int smolmc_sync(smolmc_handle *h);
  * steps, one row per walker -- what Sampler.sample yields and
  * SampleContainer.save_sampled_trace stores (sampler/sampler.py:195-210,
  * container.py:384-397): enthalpy, features, the accept flag of the last step of the
- * block, and (flags bit 0) the occupancy.  Buffers live on the device until the next
- * smolmc_run_sampled / smolmc_destroy; smolmc_get_samples copies them out
- * ([nsamples x R (x F | x N)], NULLs allowed). */
+ * block and, as `flags` asks (SMOLMC_SAMPLE_*): the occupancy; trace.bias (kernel/base.py:307-311,
+ * 362-363); the Wang-Landau trace (wanglandau.py:247-251: entropy, histogram, occurrences,
+ * cumulative mean features, mod_factor of every walker AT that sample).
+ *
+ * A sample ring of two slots (ABI 7): the call returns as soon as the launches are queued; when they
+ * finish the block is copied to a pinned host mirror on a stream of its own, so that the download of
+ * block k overlaps the kernel of block k + 1 (the reference streams samples while it runs,
+ * sampler/sampler.py:286-291, container.py:420-437).  The intended sequence is
+ *     run_sampled(0); run_sampled(1); get_samples -> block 0; run_sampled(2); get_samples -> block 1; ...
+ * smolmc_get_samples* deliver the OLDEST block not yet delivered (waiting for its copy only, not for
+ * younger launches); with none pending they deliver the newest block again.  A third
+ * smolmc_run_sampled while two blocks are pending drops the older one.  Nothing is allocated per call
+ * once the slots have grown to the block size. */
+#define SMOLMC_SAMPLE_OCCUPANCY 1 /* flags bit 0 */
+#define SMOLMC_SAMPLE_BIAS 2      /* flags bit 1: trace.bias (error without an MCBias term) */
+#define SMOLMC_SAMPLE_WL 4        /* flags bit 2: the Wang-Landau trace (error on a Metropolis handle) */
 int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags);
+/* [nsamples x R (x F | x N)], NULLs allowed */
 int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
                        uint8_t *accepted, int32_t *occupancy);
 /* smolmc_get_samples with the occupancies as bytes, [nsamples x R x N] uint8 -- the device
@@ -264,6 +278,12 @@ int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
  * < 256 by construction, smolmc_tables.n_codes). */
 int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double *features,
                           uint8_t *accepted, uint8_t *occupancy);
+/* ... and the columns ABI 7 added (each may be NULL; asking for one that was not recorded is an error):
+ * bias [nsamples x R]; wl_entropy / wl_histogram / wl_occurrences [nsamples x R x L], wl_mean_features
+ * [nsamples x R x L x F], wl_mod_factor [nsamples x R] (as smolmc_get_wl returns them, at every sample). */
+int smolmc_get_samples_ex(smolmc_handle *h, double *enthalpy, double *features, uint8_t *accepted,
+                          uint8_t *occupancy_u8, double *bias, double *wl_entropy, int64_t *wl_histogram,
+                          int64_t *wl_occurrences, double *wl_mean_features, double *wl_mod_factor);
 /* Same loop driven by host-provided proposals ("replay mode"): what
  * StandardSingleStepMixin.single_step (kernel/base.py:145-166) does after mcusher.propose_step
  * returned, with the numbers the reference's Generator produced.

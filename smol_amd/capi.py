@@ -23,7 +23,8 @@ STEP_FLIP = 0
 STEP_SWAP = 1
 STEP_TABLE_FLIP = 2
 BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE, BIAS_SQUARE_HYPERPLANE = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
+SAMPLE_OCCUPANCY, SAMPLE_BIAS, SAMPLE_WL = 1, 2, 4  # SMOLMC_SAMPLE_* flags of smolmc_run_sampled
 MAX_STEP_FLIPS = 8              # SMOLMC_MAX_STEP_FLIPS
 STEP_ROW = 2 * MAX_STEP_FLIPS   # SMOLMC_STEP_ROW: int32 per step record (site, code) x 8, -1 = no flip
 

@@ -1,5 +1,6 @@
 // engine.hip -- C-ABI (include/smolmc.h), host-side table preparation and the evaluation kernels.
 #include <array>
+#include <thread>
 
 #include "smolmc_common.h"
 
@@ -996,7 +997,6 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         h->L = (int)ceil((cfg->wl_max_enthalpy - cfg->wl_min_enthalpy) / cfg->wl_bin_size);
     }
     memset(&h->kp, 0, sizeof(KParams));
-    memset(&h->smp, 0, sizeof(SampleBufs));
     KParams &kp = h->kp;
     if (int rc = validate_tables(t)) return bail(rc);
     // species codes a site may carry: max_species by default, the largest sublattice code + 1 on
@@ -2095,13 +2095,14 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
 }
 
 static void free_samples(smolmc_handle *h) {
-    if (h->smp.H) hipFree(h->smp.H);
-    if (h->smp.feat) hipFree(h->smp.feat);
-    if (h->smp.acc) hipFree(h->smp.acc);
-    if (h->smp.occ) hipFree(h->smp.occ);
-    memset(&h->smp, 0, sizeof(SampleBufs));
-    h->smp_n = 0;
-    h->smp_has_occ = false;
+    for (SampleSlot &sl : h->slots) {
+        if (sl.copy_done) { hipEventSynchronize(sl.copy_done); hipEventDestroy(sl.copy_done); }
+        if (sl.kernel_done) hipEventDestroy(sl.kernel_done);
+        if (sl.d) hipFree(sl.d);
+        if (sl.hst) hipHostFree(sl.hst);
+        sl = SampleSlot();
+    }
+    if (h->copy_stream) { hipStreamDestroy(h->copy_stream); h->copy_stream = nullptr; }
 }
 
 // parameter block of a universal-kernel launch: the handle's current KParams; on a lean handle (a
@@ -2169,66 +2170,220 @@ extern "C" int smolmc_run(smolmc_handle *h, int64_t nsteps) {
     return run_steps(h, nsteps, none);
 }
 
+// ---- device-side sampling: a ring of two slots with asynchronous download ---------
+// One sample of every walker from the handle's state arrays into row j of a slot -- for the kernels that do
+// not record in-kernel (Wang-Landau: the per-walker L and L x F arrays; MCBias: the running bias): the
+// block is then a sequence { launch of thin_by steps; this snapshot } queued on the stream, no host round trip.
+struct SnapshotArgs {
+    const uint8_t *occ; const double *features, *enthalpy; const uint8_t *last_acc; const double *bias;
+    const double *wl_S; const long long *wl_hist, *wl_occ; const double *wl_mf, *wl_m;
+    uint8_t *o_occ; double *o_feat, *o_H; uint8_t *o_acc; double *o_bias;
+    double *o_wlS; long long *o_wlh, *o_wlo; double *o_wlf, *o_wlm;
+    int R, F, L, Npad, mf_is_sums;
+};
+__global__ void __launch_bounds__(256) sample_snapshot_kernel(const SnapshotArgs A, long long j) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const size_t row = (size_t)j * A.R + r;
+    if (A.o_occ) {
+        const uint32_t *src = (const uint32_t *)(A.occ + (size_t)r * A.Npad);
+        uint32_t *dst = (uint32_t *)(A.o_occ + row * A.Npad);
+        for (int i = t; i < A.Npad / 4; i += 256) dst[i] = src[i];
+    }
+    for (int i = t; i < A.F; i += 256) A.o_feat[row * A.F + i] = A.features[(size_t)r * A.F + i];
+    if (t == 0) {
+        A.o_H[row] = A.enthalpy[r];
+        A.o_acc[row] = A.last_acc[r];
+        if (A.o_bias) A.o_bias[row] = A.bias[r];
+        if (A.o_wlm) A.o_wlm[row] = A.wl_m[r];
+    }
+    if (A.o_wlS) {
+        const size_t src = (size_t)r * A.L, dst = row * A.L;
+        for (int i = t; i < A.L; i += 256) {
+            A.o_wlS[dst + i] = A.wl_S[src + i];
+            A.o_wlh[dst + i] = A.wl_hist[src + i];
+            A.o_wlo[dst + i] = A.wl_occ[src + i];
+        }
+        // (mean = sum / occurrences where the kernel keeps per-bin SUMS, see wl_meanf_convert_kernel)
+        for (size_t i = t; i < (size_t)A.L * A.F; i += 256) {
+            double v = A.wl_mf[src * A.F + i];
+            if (A.mf_is_sums) {
+                const long long n = A.wl_occ[src + i / A.F];
+                if (n > 0) v /= (double)n;
+            }
+            A.o_wlf[dst * A.F + i] = v;
+        }
+    }
+}
+
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags) {
     if (!h) return fail("null handle");
     if (nsamples <= 0 || thin_by <= 0) return fail("nsamples and thin_by must be positive");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    free_samples(h);
-    const size_t rows = (size_t)nsamples * h->R;
-    HIPCHK(hipMalloc((void **)&h->smp.H, rows * 8));
-    HIPCHK(hipMalloc((void **)&h->smp.feat, rows * h->F * 8));
-    HIPCHK(hipMalloc((void **)&h->smp.acc, rows));
-    if (flags & 1) {
-        HIPCHK(hipMalloc((void **)&h->smp.occ, rows * h->Npad));
-        h->smp_has_occ = true;
+    const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    if ((flags & SMOLMC_SAMPLE_BIAS) && !h->kp.bias_type) return fail("the model has no bias term");
+    if ((flags & SMOLMC_SAMPLE_WL) && !wl) return fail("handle is not a Wang-Landau kernel");
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    SampleSlot &sl = h->slots[h->next_slot];
+    h->next_slot ^= 1;
+    if (!sl.kernel_done) {
+        HIPCHK(hipEventCreateWithFlags(&sl.kernel_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.copy_done, hipEventDisableTiming));
     }
-    h->smp.every = thin_by;
-    h->smp_n = nsamples;
-    return run_steps(h, nsamples * thin_by, h->smp);
+    // layout of the block inside the slot's arenas
+    const size_t rows = (size_t)nsamples * h->R, F = (size_t)h->F, L = (size_t)h->L;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += up256(bytes); return o; };
+    sl.o_H = take(rows * 8);
+    sl.o_feat = take(rows * F * 8);
+    sl.o_acc = take(rows);
+    sl.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? take(rows * 8) : 0;
+    sl.o_wlm = sl.o_wlS = sl.o_wlh = sl.o_wlo = sl.o_wlf = 0;
+    if (flags & SMOLMC_SAMPLE_WL) {
+        sl.o_wlm = take(rows * 8);
+        sl.o_wlS = take(rows * L * 8);
+        sl.o_wlh = take(rows * L * 8);
+        sl.o_wlo = take(rows * L * 8);
+        sl.o_wlf = take(rows * L * F * 8);
+    }
+    sl.o_occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? take(rows * h->Npad) : 0;
+    // the slot's previous block must have left the device (and its pinned mirror is about to be reused: a
+    // block the caller never fetched is dropped here)
+    if (sl.state != 0) HIPCHK(hipEventSynchronize(sl.copy_done));
+    if (at > sl.cap) {
+        if (sl.d) hipFree(sl.d);
+        if (sl.hst) hipHostFree(sl.hst);
+        sl.d = sl.hst = nullptr;
+        sl.cap = 0;
+        HIPCHK(hipMalloc((void **)&sl.d, at));
+        HIPCHK(hipHostMalloc((void **)&sl.hst, at, hipHostMallocDefault));
+        sl.cap = at;
+    }
+    sl.used = at;
+    sl.n = nsamples;
+    sl.flags = flags;
+    sl.state = 0;
+    SampleBufs smp;
+    memset(&smp, 0, sizeof(smp));
+    smp.every = thin_by;
+    smp.H = (double *)(sl.d + sl.o_H);
+    smp.feat = (double *)(sl.d + sl.o_feat);
+    smp.acc = sl.d + sl.o_acc;
+    smp.occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? sl.d + sl.o_occ : nullptr;
+    if (!(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL))) {
+        TRY(run_steps(h, nsamples * thin_by, smp)); // the kernels record the rows themselves, one launch
+    } else {
+        SampleBufs none;
+        memset(&none, 0, sizeof(none));
+        KParams &kp = h->kp;
+        SnapshotArgs A;
+        memset(&A, 0, sizeof(A));
+        A.occ = kp.occ; A.features = kp.features; A.enthalpy = kp.enthalpy; A.last_acc = kp.last_acc; A.bias = kp.bias;
+        A.wl_S = kp.wl_entropy; A.wl_hist = kp.wl_hist; A.wl_occ = kp.wl_occur; A.wl_mf = kp.wl_meanf; A.wl_m = kp.wl_m;
+        A.o_occ = smp.occ; A.o_feat = smp.feat; A.o_H = smp.H; A.o_acc = smp.acc;
+        A.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? (double *)(sl.d + sl.o_bias) : nullptr;
+        if (flags & SMOLMC_SAMPLE_WL) {
+            A.o_wlm = (double *)(sl.d + sl.o_wlm); A.o_wlS = (double *)(sl.d + sl.o_wlS);
+            A.o_wlh = (long long *)(sl.d + sl.o_wlh); A.o_wlo = (long long *)(sl.d + sl.o_wlo);
+            A.o_wlf = (double *)(sl.d + sl.o_wlf);
+        }
+        A.R = h->R; A.F = h->F; A.L = h->L; A.Npad = h->Npad;
+        for (int64_t j = 0; j < nsamples; ++j) {
+            TRY(run_steps(h, thin_by, none));
+            A.mf_is_sums = h->wl_sums ? 1 : 0; // (the representation the launch left the per-bin statistics in)
+            hipLaunchKernelGGL(sample_snapshot_kernel, dim3((unsigned)h->R), dim3(256), 0, h->stream, A, (long long)j);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // download on the copy stream as soon as the block is complete; the next block's launches do not wait for it
+    HIPCHK(hipEventRecord(sl.kernel_done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, sl.kernel_done, 0));
+    HIPCHK(hipMemcpyAsync(sl.hst, sl.d, sl.used, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipEventRecord(sl.copy_done, h->copy_stream));
+    // (the next writer of this slot's arenas -- the call after next -- waits for copy_done above)
+    sl.state = 1;
+    sl.seq = ++h->slot_seq;
+    return 0;
 }
 
-// rows of the device ring to the host: scalars always, occupancies as int32 (the reference's
-// trace dtype) or as the ring's own bytes
+// host side of a delivery: pinned mirror -> the caller's arrays, a few threads for the big ones (the copy of a
+// block overlaps the kernel of the next one as long as it is shorter)
+static void host_copy(void *dst, const void *src, size_t bytes) {
+    const size_t big = (size_t)8 << 20;
+    if (bytes < big) { memcpy(dst, src, bytes); return; }
+    const int nt = 4;
+    std::thread th[nt];
+    const size_t part = (bytes / nt + 63) & ~(size_t)63;
+    for (int k = 0; k < nt; ++k) {
+        const size_t a = std::min(bytes, part * k), b = std::min(bytes, part * (k + 1));
+        th[k] = std::thread([=]() { memcpy((char *)dst + a, (const char *)src + a, b - a); });
+    }
+    for (int k = 0; k < nt; ++k) th[k].join();
+}
+// occupancy rows: Npad bytes apart in the ring, N bytes (uint8) or N int32 in the caller's array
+template <typename T> static void host_copy_occ(T *dst, const uint8_t *src, size_t rows, int N, int Npad) {
+    auto work = [=](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const uint8_t *s = src + r * Npad;
+            T *d = dst + r * (size_t)N;
+            if (sizeof(T) == 1) memcpy(d, s, (size_t)N);
+            else for (int i = 0; i < N; ++i) d[i] = (T)s[i];
+        }
+    };
+    if (rows * (size_t)N < ((size_t)8 << 20)) { work(0, rows); return; }
+    const int nt = 4;
+    std::thread th[nt];
+    for (int k = 0; k < nt; ++k) th[k] = std::thread(work, rows * k / nt, rows * (k + 1) / nt);
+    for (int k = 0; k < nt; ++k) th[k].join();
+}
+
 static int get_samples_impl(smolmc_handle *h, double *enthalpy, double *features, uint8_t *accepted,
-                            int32_t *occ32, uint8_t *occ8) {
+                            int32_t *occ32, uint8_t *occ8, double *bias, double *wl_S, int64_t *wl_hist,
+                            int64_t *wl_occ, double *wl_mf, double *wl_m) {
     if (!h) return fail("null handle");
-    if (h->smp_n == 0) return fail("no samples recorded: call smolmc_run_sampled first");
+    // the oldest block not yet delivered; with none pending, the newest delivered one again
+    SampleSlot *sl = nullptr;
+    for (SampleSlot &c : h->slots)
+        if (c.state == 1 && (!sl || c.seq < sl->seq)) sl = &c;
+    if (!sl)
+        for (SampleSlot &c : h->slots)
+            if (c.state == 2 && (!sl || c.seq > sl->seq)) sl = &c;
+    if (!sl) return fail("no samples recorded: call smolmc_run_sampled first");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const size_t rows = (size_t)h->smp_n * h->R;
-    if (enthalpy) HIPCHK(hipMemcpy(enthalpy, h->smp.H, rows * 8, hipMemcpyDeviceToHost));
-    if (features) HIPCHK(hipMemcpy(features, h->smp.feat, rows * h->F * 8, hipMemcpyDeviceToHost));
-    if (accepted) HIPCHK(hipMemcpy(accepted, h->smp.acc, rows, hipMemcpyDeviceToHost));
-    if ((occ32 || occ8) && !h->smp_has_occ) return fail("occupancies were not recorded (flags bit 0)");
-    if (occ32) {
-        int *d32 = nullptr;
-        const size_t total = rows * h->N;
-        HIPCHK(hipMalloc((void **)&d32, total * 4));
-        hipLaunchKernelGGL(unpack_occ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           h->stream, h->smp.occ, d32, h->N, h->Npad, total);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(occ32, d32, total * 4, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        hipFree(d32);
-        if (e != hipSuccess) return fail(std::string("sample download: ") + hipGetErrorString(e));
-    }
-    if (occ8) { // ring rows are Npad bytes apart, the host rows N
-        if (h->Npad == h->N)
-            HIPCHK(hipMemcpy(occ8, h->smp.occ, rows * h->N, hipMemcpyDeviceToHost));
-        else
-            HIPCHK(hipMemcpy2D(occ8, (size_t)h->N, h->smp.occ, (size_t)h->Npad, (size_t)h->N, rows,
-                               hipMemcpyDeviceToHost));
-    }
+    HIPCHK(hipEventSynchronize(sl->copy_done));
+    const size_t rows = (size_t)sl->n * h->R, F = (size_t)h->F, L = (size_t)h->L;
+    if ((occ32 || occ8) && !(sl->flags & SMOLMC_SAMPLE_OCCUPANCY)) return fail("occupancies were not recorded (flags bit 0)");
+    if (bias && !(sl->flags & SMOLMC_SAMPLE_BIAS)) return fail("the bias was not recorded (flags bit 1)");
+    if ((wl_S || wl_hist || wl_occ || wl_mf || wl_m) && !(sl->flags & SMOLMC_SAMPLE_WL))
+        return fail("the Wang-Landau trace was not recorded (flags bit 2)");
+    if (enthalpy) host_copy(enthalpy, sl->hst + sl->o_H, rows * 8);
+    if (features) host_copy(features, sl->hst + sl->o_feat, rows * F * 8);
+    if (accepted) host_copy(accepted, sl->hst + sl->o_acc, rows);
+    if (bias) host_copy(bias, sl->hst + sl->o_bias, rows * 8);
+    if (wl_m) host_copy(wl_m, sl->hst + sl->o_wlm, rows * 8);
+    if (wl_S) host_copy(wl_S, sl->hst + sl->o_wlS, rows * L * 8);
+    if (wl_hist) host_copy(wl_hist, sl->hst + sl->o_wlh, rows * L * 8);
+    if (wl_occ) host_copy(wl_occ, sl->hst + sl->o_wlo, rows * L * 8);
+    if (wl_mf) host_copy(wl_mf, sl->hst + sl->o_wlf, rows * L * F * 8);
+    if (occ8) host_copy_occ<uint8_t>(occ8, sl->hst + sl->o_occ, rows, h->N, h->Npad);
+    if (occ32) host_copy_occ<int32_t>(occ32, sl->hst + sl->o_occ, rows, h->N, h->Npad);
+    sl->state = 2;
     return 0;
 }
 extern "C" int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
                                   uint8_t *accepted, int32_t *occupancy) {
-    return get_samples_impl(h, enthalpy, features, accepted, occupancy, nullptr);
+    return get_samples_impl(h, enthalpy, features, accepted, occupancy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 extern "C" int smolmc_get_samples_u8(smolmc_handle *h, double *enthalpy, double *features,
                                      uint8_t *accepted, uint8_t *occupancy) {
-    return get_samples_impl(h, enthalpy, features, accepted, nullptr, occupancy);
+    return get_samples_impl(h, enthalpy, features, accepted, nullptr, occupancy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+extern "C" int smolmc_get_samples_ex(smolmc_handle *h, double *enthalpy, double *features, uint8_t *accepted,
+                                     uint8_t *occupancy_u8, double *bias, double *wl_entropy, int64_t *wl_histogram,
+                                     int64_t *wl_occurrences, double *wl_mean_features, double *wl_mod_factor) {
+    return get_samples_impl(h, enthalpy, features, accepted, nullptr, occupancy_u8, bias, wl_entropy, wl_histogram,
+                            wl_occurrences, wl_mean_features, wl_mod_factor);
 }
 
 // lean replay kernels that exist: Metropolis flips / swaps (plain, KF, with MCBias), multi-sublattice,

@@ -561,6 +561,20 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// One slot of the sample ring: `n` samples x R walkers recorded by one smolmc_run_sampled call.  Every array is a
+// range of ONE device arena and of ONE pinned host arena with the same offsets (a single asynchronous copy moves it).
+struct SampleSlot {
+    unsigned char *d = nullptr, *hst = nullptr; // device arena, pinned host mirror
+    size_t cap = 0;                             // bytes allocated (grow-only)
+    size_t used = 0;                            // bytes of the recorded block
+    size_t o_H = 0, o_feat = 0, o_acc = 0, o_occ = 0, o_bias = 0, o_wlm = 0, o_wlS = 0, o_wlh = 0, o_wlo = 0, o_wlf = 0;
+    long long n = 0;                            // samples in the block
+    int flags = 0;                              // SMOLMC_SAMPLE_* the block was recorded with
+    int state = 0;                              // 0 empty, 1 recorded and not yet delivered, 2 delivered
+    unsigned long long seq = 0;                 // order of recording
+    hipEvent_t kernel_done = nullptr, copy_done = nullptr;
+};
+
 struct smolmc_handle {
     smolmc_config cfg;
     int device = 0;
@@ -596,10 +610,12 @@ struct smolmc_handle {
     std::vector<int> site_class_host;   // site -> class (255 = no clusters)
     size_t lean_lds = 0;
     LeanParams lp;
-    // device-side samples of the last smolmc_run_sampled
-    SampleBufs smp;
-    long long smp_n = 0;
-    bool smp_has_occ = false;
+    // device-side samples (smolmc_run_sampled): two ring slots, each a device arena + a pinned host mirror; the
+    // download of a slot runs on its own stream while the next block's kernel fills the other slot (see engine.hip)
+    SampleSlot slots[2];
+    int next_slot = 0;
+    unsigned long long slot_seq = 0;
+    hipStream_t copy_stream = nullptr;
     // scratch
     uint8_t *d_eval_occ = nullptr;
     size_t eval_occ_cap = 0;

@@ -44,6 +44,7 @@ SYMBOLS = {
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
     "smolmc_get_samples": (C.c_int, [_HP, _f64p, _f64p, _u8p, _i32p]),
     "smolmc_get_samples_u8": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p]),
+    "smolmc_get_samples_ex": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p, _f64p, _f64p, _i64p, _i64p, _f64p, _f64p]),
     "smolmc_replay": (C.c_int, [_HP, C.c_int64, _i32p, _f64p, _f64p, _u8p, _f64p, _f64p]),
     "smolmc_last_kernel_ms": (C.c_int, [_HP, C.POINTER(C.c_float)]),
     "smolmc_eval_full": (C.c_int, [_HP, _i32p, C.c_int, _f64p]),
@@ -304,24 +305,57 @@ class Engine:
     def sync(self):
         self._chk(self._lib.smolmc_sync(self._h))
 
-    def run_sampled(self, nsamples, thin_by, occupancy=True, packed=False):
+    def run_sampled(self, nsamples, thin_by, occupancy=True, packed=False, bias=False, wl=False):
         """Advance nsamples*thin_by steps recording one sample per walker every thin_by steps
         on the device; returns dict(enthalpy (ns,R), features (ns,R,F), accepted (ns,R) bool,
-        occupancy (ns,R,N) or None).  Occupancies come back as int32 (the reference's trace
-        dtype) or, with ``packed``, as the ring's own uint8 -- a quarter of the transfer."""
-        ns = int(nsamples)
-        self._chk(self._lib.smolmc_run_sampled(self._h, ns, int(thin_by), 1 if occupancy else 0))
+        occupancy (ns,R,N) or None[, bias (ns,R)][, the Wang-Landau trace]).  Occupancies come back as
+        int32 (the reference's trace dtype) or, with ``packed``, as the ring's own uint8 -- a quarter
+        of the transfer.  = ``run_sampled_async`` + ``fetch_samples``."""
+        self.run_sampled_async(nsamples, thin_by, occupancy=occupancy, bias=bias, wl=wl)
+        return self.fetch_samples(packed=packed)
+
+    def run_sampled_async(self, nsamples, thin_by, occupancy=True, bias=False, wl=False):
+        """Queue one block of the device ring (smolmc_run_sampled): returns at once.  The ring has two
+        slots; queue block k + 1 BEFORE fetching block k and the download of k overlaps the kernel of
+        k + 1 (the order ``fetch_samples`` delivers in: oldest first)."""
+        flags = ((capi.SAMPLE_OCCUPANCY if occupancy else 0) | (capi.SAMPLE_BIAS if bias else 0) |
+                 (capi.SAMPLE_WL if wl else 0))
+        self._chk(self._lib.smolmc_run_sampled(self._h, int(nsamples), int(thin_by), flags))
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((int(nsamples), flags))
+        del self._pending[:-2]  # (a third block drops the oldest, as the C side does)
+
+    def fetch_samples(self, packed=False):
+        """The oldest block queued with ``run_sampled_async`` that was not fetched yet (waits for ITS
+        download only)."""
+        if not getattr(self, "_pending", None):
+            raise EngineError("no samples recorded: call run_sampled_async first")
+        ns, flags = self._pending.pop(0)
         H = np.empty((ns, self.R))
         feat = np.empty((ns, self.R, self.F))
         acc = np.empty((ns, self.R), dtype=np.uint8)
-        occ = np.empty((ns, self.R, self.N), dtype=np.uint8 if packed else np.int32) if occupancy else None
-        if packed:
-            self._chk(self._lib.smolmc_get_samples_u8(self._h, _p(H, C.c_double), _p(feat, C.c_double),
-                                                      _p(acc, C.c_uint8), _p(occ, C.c_uint8)))
+        with_occ = bool(flags & capi.SAMPLE_OCCUPANCY)
+        extra = {}
+        if flags & capi.SAMPLE_BIAS:
+            extra["bias"] = np.empty((ns, self.R))
+        if flags & capi.SAMPLE_WL:
+            extra.update(entropy=np.empty((ns, self.R, self.L)), histogram=np.empty((ns, self.R, self.L), dtype=np.int64),
+                         occurrences=np.empty((ns, self.R, self.L), dtype=np.int64),
+                         mean_features=np.empty((ns, self.R, self.L, self.F)), mod_factor=np.empty((ns, self.R)))
+        if packed or extra:
+            occ = np.empty((ns, self.R, self.N), dtype=np.uint8) if with_occ else None
+            self._chk(self._lib.smolmc_get_samples_ex(
+                self._h, _p(H, C.c_double), _p(feat, C.c_double), _p(acc, C.c_uint8), _p(occ, C.c_uint8),
+                _p(extra.get("bias"), C.c_double), _p(extra.get("entropy"), C.c_double),
+                _p(extra.get("histogram"), C.c_int64), _p(extra.get("occurrences"), C.c_int64),
+                _p(extra.get("mean_features"), C.c_double), _p(extra.get("mod_factor"), C.c_double)))
+            if occ is not None and not packed:
+                occ = occ.astype(np.int32)
         else:
+            occ = np.empty((ns, self.R, self.N), dtype=np.int32) if with_occ else None
             self._chk(self._lib.smolmc_get_samples(self._h, _p(H, C.c_double), _p(feat, C.c_double),
                                                    _p(acc, C.c_uint8), _p(occ, C.c_int32)))
-        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=self._occ_out(occ))
+        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=self._occ_out(occ), **extra)
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -1711,9 +1711,10 @@ class Sampler:
 
     def _sample_blocks(self, nsteps, initial_occupancies, thin_by, max_block=0, state_loaded=False):
         """Generator over blocks of thinned samples, dict name -> (n, nwalkers, ...): the unit
-        the device ring delivers.  Metropolis without bias: ``smolmc_run_sampled`` records n
-        samples inside one launch; Wang-Landau and biased kernels (per-walker L x F arrays /
-        running bias in the trace) come back one sample per launch."""
+        the device ring delivers (``smolmc_run_sampled``, ABI 7): the samples of a block are recorded on
+        the device -- inside one launch for Metropolis kernels, as launch + snapshot pairs queued without
+        a host round trip for biased and Wang-Landau kernels (trace.bias; the per-walker L and L x F
+        arrays of the Wang-Landau trace) -- and the block's download overlaps the next block's kernel."""
         if nsteps % thin_by != 0:
             warnings.warn(
                 f"The number of steps {nsteps} is not a multiple of thin_by  {thin_by}. The last "
@@ -1726,28 +1727,51 @@ class Sampler:
         eng = self._get_engine()
         nsamples = nsteps // thin_by
         k0 = self._kernels[0]
-        if isinstance(k0, WangLandau) or k0.bias is not None:
-            host_checks = isinstance(k0, WangLandau) and k0._mod_callable is not None
+        is_wl, has_bias = isinstance(k0, WangLandau), k0.bias is not None
+        if is_wl and k0._mod_callable is not None:
+            # a callable mod_update (wanglandau.py:100-105): the flatness checks run on the host between
+            # launches, so these samples come back one launch at a time
             for _ in range(nsamples):
-                if host_checks:
-                    self._wl_run_with_host_checks(eng, thin_by)
-                else:
-                    eng.run(thin_by)
+                self._wl_run_with_host_checks(eng, thin_by)
                 yield {k: v[None] for k, v in self._current_trace(eng).items()}
             return
         nw, N = len(self._kernels), k0.ensemble.num_sites
-        per_block = max(1, min(nsamples, (256 << 20) // max(1, nw * N)))  # ~256 MiB of occupancy bytes
+        # bytes of one sample of all walkers in the ring: occupancy bytes + features (+ the Wang-Landau trace:
+        # entropy / histogram / occurrences [L] and the mean features [L x F] of every walker, wanglandau.py:247-251)
+        F = len(k0.ensemble.natural_parameters)
+        per_sample = nw * (N + 8 * F + 17)
+        if is_wl:
+            L = len(k0._levels)
+            per_sample += nw * L * (24 + 8 * F)
+        per_block = max(1, min(nsamples, (256 << 20) // max(1, per_sample)))  # <= ~256 MiB per ring slot
+        # ... and several blocks per run, so that the download of one overlaps the kernel of the next (the ring
+        # has two slots: block k + 1 is queued before block k is fetched)
+        if nsamples * per_sample > (32 << 20):
+            per_block = min(per_block, max(1, -(-nsamples // 8)))
         if max_block > 0:
             per_block = min(per_block, int(max_block))
         temps = self._temperatures().reshape(1, nw, 1)
-        for start in range(0, nsamples, per_block):
-            n = min(per_block, nsamples - start)
-            ring = eng.run_sampled(n, thin_by, occupancy=True, packed=True)
+        sizes = [min(per_block, nsamples - start) for start in range(0, nsamples, per_block)]
+
+        def queue(n):
+            eng.run_sampled_async(n, thin_by, occupancy=True, bias=has_bias, wl=is_wl)
+
+        if sizes:
+            queue(sizes[0])
+        for i, n in enumerate(sizes):
+            if i + 1 < len(sizes):
+                queue(sizes[i + 1])
+            ring = eng.fetch_samples(packed=True)
             block = dict(occupancy=ring["occupancy"], features=ring["features"],
                          enthalpy=ring["enthalpy"][..., None], temperature=np.broadcast_to(temps, (n, nw, 1)),
                          accepted=ring["accepted"][..., None])
-            if not isinstance(k0, Metropolis):  # (UniformlyRandom: no temperature in the trace)
+            if not isinstance(k0, Metropolis):  # (UniformlyRandom, Wang-Landau: no temperature in the trace)
                 del block["temperature"]
+            if has_bias:
+                block["bias"] = ring["bias"][..., None]
+            if is_wl:
+                block.update(histogram=ring["histogram"], occurrences=ring["occurrences"], entropy=ring["entropy"],
+                             cumulative_mean_features=ring["mean_features"], mod_factor=ring["mod_factor"][..., None])
             yield block
 
     def _wl_run_with_host_checks(self, eng, nsteps):

@@ -1,0 +1,212 @@
+"""The device-side sample ring of ABI 7 (smolmc_run_sampled / smolmc_get_samples_ex): two slots, asynchronous
+download, the `bias` column (kernel/base.py:307-311,362-363) and the Wang-Landau trace
+(wanglandau.py:247-251) -- what Sampler.sample yields and SampleContainer.save_sampled_trace stores
+(sampler/sampler.py:195-210, container.py:384-397).  Every recorded row is checked against the oracle
+stepped to the same point."""
+
+import numpy as np
+import pytest
+
+from smol_amd import capi
+from tests.cases import load_case, tables_for
+from tests.v6_cases import build
+
+pytestmark = pytest.mark.gpu
+MODES = {"int": capi.FEATURES_INTERACTIONS, "corr": capi.FEATURES_CORRELATIONS}
+ENV = ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL", "SMOLMC_NO_WL_MULTI", "SMOLMC_LAUNCH_CHUNK")
+
+
+def _pair(tab, cfg, occ, seeds, temp):
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    eng.set_state(occ, seeds, temp)
+    ora.set_state(occ, seeds, temp)
+    return eng, ora
+
+
+def _check_rows(smp, ora, thin, bias=False, wl=False):
+    for i in range(len(smp["enthalpy"])):
+        ora.run(thin)
+        b = ora.get_state()
+        assert np.array_equal(smp["occupancy"][i], b["occupancy"])
+        assert np.array_equal(smp["accepted"][i], b["accepted"])
+        np.testing.assert_allclose(smp["enthalpy"][i], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(smp["features"][i], b["features"], rtol=1e-10, atol=1e-8)
+        if bias:
+            np.testing.assert_allclose(smp["bias"][i], ora.get_bias(), rtol=1e-10, atol=1e-9)
+        if wl:
+            y = ora.get_wl()
+            assert np.array_equal(smp["histogram"][i], y["histogram"])
+            assert np.array_equal(smp["occurrences"][i], y["occurrences"])
+            np.testing.assert_allclose(smp["entropy"][i], y["entropy"], rtol=0, atol=0)
+            np.testing.assert_allclose(smp["mean_features"][i], y["mean_features"], rtol=1e-10, atol=1e-8)
+            np.testing.assert_allclose(smp["mod_factor"][i], y["mod_factor"])
+
+
+@pytest.mark.parametrize("force", [None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"], ids=["auto", "general", "universal"])
+@pytest.mark.parametrize("tag", ["BC_fug_flip_int", "BC_sqc_flip_corr", "BG_hyp_flip_int", "BG_sqc_swap_int"])
+def test_bias_column_of_the_ring(tag, force, monkeypatch):
+    """Biased Metropolis handles (Fugacity, SquareCharge, SquareHyperplane; lean, lean-multi, general and
+    universal kernels): `bias` of every sample = the oracle's trace.bias at that step."""
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    if force:
+        monkeypatch.setenv(force, "1")
+    R = 4
+    tab, cfg, occ0, temp = build(tag, n_replicas=R)
+    eng, ora = _pair(tab, cfg, np.tile(occ0, (R, 1)), np.arange(R, dtype=np.uint64) + np.uint64(77), temp)
+    eng.run(9)
+    ora.run(9)
+    smp = eng.run_sampled(6, 17, bias=True)
+    assert smp["bias"].shape == (6, R)
+    _check_rows(smp, ora, 17, bias=True)
+    np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=1e-10, atol=1e-9)
+    with pytest.raises((RuntimeError, ValueError), match="Wang-Landau"):
+        eng.run_sampled(1, 1, wl=True)
+    eng.close()
+
+
+@pytest.mark.parametrize("which", ["lean-wl", "multi-wl", "multi-wl-mean", "general", "universal"])
+def test_wang_landau_trace_of_the_ring(which, monkeypatch):
+    """The Wang-Landau trace at every sample -- entropy, histogram, occurrences, cumulative mean features,
+    mod_factor of every walker -- on mc_wl_kernel (per-bin SUMS on the device: the ring holds means), the
+    multi-class kernel (sums and running means), mc_kernel and the universal kernel."""
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    if which == "general":
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    if which == "universal":
+        monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
+    R = 3
+    if which.startswith("multi"):
+        name = "rocksalt333_two_sublattices"
+        c = load_case(name)
+        tab = tables_for(name, MODES["int"])
+        nsp = np.array([c["sc"].model.prim.nspecies[b] for b in c["sc"].site_b])
+        occ = (np.random.default_rng(5).random((R, c["sc"].num_sites)) * nsp).astype(np.int32)
+        from oracle import oracle as orc
+
+        ev = orc.OracleEvaluator(tab)
+        h = np.array([ev.feature_vector(o) @ ev.natural_parameters() for o in occ])
+        cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=h.min() - 5.3, max_enthalpy=h.max() + 4.1,
+                               bin_size=0.17, check_period=30, update_period=2 if which.endswith("mean") else 1, flatness=0.2)
+    else:
+        tab, cfg, occ0, _ = build("B_wlup3", n_replicas=R)
+        cfg.wl_update_period = 1
+        cfg.wl_check_period = 40
+        occ = np.tile(occ0, (R, 1))
+    eng, ora = _pair(tab, cfg, occ, [4, 5, 6], 0.0)
+    info = eng.kernel_info()
+    want = {"lean-wl": "wl=v3", "multi-wl": "wl=multi", "multi-wl-mean": "wl=multi-mean", "general": "general", "universal": "universal"}[which]
+    assert want in info, info
+    eng.run(7)
+    ora.run(7)
+    smp = eng.run_sampled(5, 29, wl=True)
+    _check_rows(smp, ora, 29, wl=True)
+    # the handle goes on from the last sample, in whatever representation the kernel keeps its statistics
+    eng.run(50)
+    ora.run(50)
+    x, y = eng.get_wl(), ora.get_wl()
+    assert np.array_equal(x["histogram"], y["histogram"])
+    np.testing.assert_allclose(x["mean_features"], y["mean_features"], rtol=1e-10, atol=1e-8)
+    with pytest.raises((RuntimeError, ValueError), match="bias"):
+        eng.run_sampled(1, 1, bias=True)
+    eng.close()
+
+
+def test_two_slots_deliver_in_order_and_drop_the_oldest(monkeypatch):
+    """run_sampled_async x 2, then fetch x 2: blocks come back oldest first, each the chain's continuation;
+    a third block queued before any fetch drops the first (smolmc.h); fetching with nothing pending
+    delivers the newest block again; sizes may change from block to block (the slots grow)."""
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    name = "fcc_prim666_triplets"
+    c = load_case(name)
+    tab = tables_for(name, MODES["int"])
+    R = 5
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_SWAP)
+    occ = (np.random.default_rng(3).random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    eng, ora = _pair(tab, cfg, occ, np.arange(R, dtype=np.uint64) + np.uint64(1), 1800.0)
+    eng.run_sampled_async(3, 11)
+    eng.run_sampled_async(9, 7)
+    a = eng.fetch_samples()
+    assert a["enthalpy"].shape == (3, R)
+    _check_rows(a, ora, 11)
+    eng.run_sampled_async(2, 40, occupancy=False)
+    b = eng.fetch_samples(packed=True)
+    assert b["occupancy"].dtype == np.uint8 and b["enthalpy"].shape == (9, R)
+    _check_rows(b, ora, 7)
+    d = eng.fetch_samples()
+    assert d["occupancy"] is None and d["enthalpy"].shape == (2, R)
+    ora.run(80)
+    np.testing.assert_allclose(d["enthalpy"][-1], ora.get_state()["enthalpy"], rtol=1e-10, atol=1e-8)
+    # three blocks without a fetch: the oldest is dropped, the other two arrive in order
+    eng.run_sampled_async(1, 5)
+    eng.run_sampled_async(2, 5)
+    eng.run_sampled_async(3, 5)
+    ora.run(5)
+    x = eng.fetch_samples()
+    assert x["enthalpy"].shape == (2, R)
+    _check_rows(x, ora, 5)
+    y = eng.fetch_samples()
+    assert y["enthalpy"].shape == (3, R)
+    _check_rows(y, ora, 5)
+    st = eng.get_state()
+    assert np.array_equal(st["occupancy"], ora.get_state()["occupancy"])
+    # C level: nothing pending -> the newest block again
+    H = np.zeros((3, R))
+    import ctypes as C
+
+    eng._chk(eng._lib.smolmc_get_samples(eng._h, H.ctypes.data_as(C.POINTER(C.c_double)), None, None, None))
+    np.testing.assert_array_equal(H, y["enthalpy"])
+    eng.close()
+
+
+def test_sampler_runs_biased_and_wang_landau_kernels_through_the_ring():
+    """moca.Sampler.run on a biased Metropolis kernel and on a Wang-Landau kernel = the same chains as the
+    oracle stepped by hand, sample for sample (the trace columns smol's container stores)."""
+    from oracle import oracle as orc
+    from smol_amd import moca, synth
+
+    model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 5.0, 3: 4.2})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=4))
+    ens.chemical_potentials = {sp: 0.04 * i for i, sp in enumerate(ens.species)}
+    nw = 3
+    rng = np.random.default_rng(9)
+    nsp = np.array([model.prim.nspecies[b] for b in sc.site_b])
+    occ = (rng.random((nw, sc.num_sites)) * nsp).astype(np.int32)
+    sampler = moca.Sampler.from_ensemble(ens, temperature=3000.0, nwalkers=nw, step_type="flip", seeds=[3, 4, 5],
+                                         bias_type="square-charge", bias_kwargs={"penalty": 0.3})
+    sampler.run(20 * 13, occ, thin_by=13)
+    eng = sampler.engine
+    ora = orc.OracleMC(eng.tables, eng.config)
+    ora.set_state(occ, np.array([k.seed64 for k in sampler.mckernels], dtype=np.uint64), 3000.0)
+    s = sampler.samples
+    assert s.num_samples == 20 and "bias" in s.traced_values
+    for i in range(20):
+        ora.run(13)
+        np.testing.assert_allclose(s.get_trace_value("bias", flat=False)[i, :, 0], ora.get_bias(), rtol=1e-10, atol=1e-9)
+        assert np.array_equal(s.get_occupancies(flat=False)[i], ora.get_state()["occupancy"])
+    # Wang-Landau
+    ens2 = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=4))
+    ev = orc.OracleEvaluator(ens2.make_tables())
+    occ2 = np.tile(occ[:1], (2, 1))
+    h0 = float(ev.feature_vector(occ2[0]) @ ev.natural_parameters())
+    wls = moca.Sampler.from_ensemble(ens2, h0 - 9.3, h0 + 7.9, 0.4, kernel_type="Wang-Landau", step_type="swap", nwalkers=2,
+                                     seeds=[8, 9], check_period=25, flatness=0.2)
+    wls.run(12 * 31, occ2, thin_by=31)
+    eng2 = wls.engine
+    ora2 = orc.OracleMC(eng2.tables, eng2.config)
+    ora2.set_state(occ2, np.array([k.seed64 for k in wls.mckernels], dtype=np.uint64), 0.0)
+    s2 = wls.samples
+    for i in range(12):
+        ora2.run(31)
+        y = ora2.get_wl()
+        assert np.array_equal(s2.get_trace_value("histogram", flat=False)[i], y["histogram"])
+        np.testing.assert_allclose(s2.get_trace_value("entropy", flat=False)[i], y["entropy"], rtol=0, atol=0)
+        np.testing.assert_allclose(s2.get_trace_value("cumulative_mean_features", flat=False)[i], y["mean_features"],
+                                   rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(s2.get_trace_value("mod_factor", flat=False)[i, :, 0], y["mod_factor"])
