@@ -52,6 +52,22 @@ METRIC = "attempted MC flips/s (node) + ns/flip/replica, 4096-site FCC canonical
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 
 
+def _xcd_count(cus):
+    """XCDs of the GPUs of this node: `num_xcc` of the KFD topology (simd_count > 0 marks a GPU node); when the
+    topology is not readable, one XCD per 32 CUs (MI355X: 256 CUs in 8 XCDs)."""
+    import glob
+
+    best = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            kv = dict(ln.split()[:2] for ln in open(f) if len(ln.split()) >= 2)
+            if int(kv.get("simd_count", 0)) > 0:
+                best = max(best, int(kv.get("num_xcc", 0)))
+        except (OSError, ValueError):
+            pass
+    return best or max(1, cus // 32)
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (the GPU box shows 256 hardware threads but grants a 16-CPU quota)."""
@@ -453,10 +469,43 @@ def time_other_configs(device, rank=0, world=1, red_dev="cuda"):
         info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
         record(wl3, info, first, steady, issue_roof("config3", ewald_note), wl3.n_walkers, launches=10)
+        # (the headline figure of this entry is the cost of REJECTED proposals: say so where a reader looks first)
+        out[-1]["state"] = "reject-path only (no mixed steady state exists, acceptance ~ 0: see `transient` and config 9)"
         wl9 = workloads.config9()
         info, first, steady = _engine_run(Engine, wl9, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
         record(wl9, info, first, steady, issue_roof("config9", ewald_note), wl9.n_walkers, launches=10)
+
+    if world == 1:
+        # H1, the function north_star names first (evaluator.pyx:211-265, ClusterExpansionProcessor): the headline
+        # model and config 3 with the CORRELATION-function trace.  K = 1 per orbit (binary): the lean kernel with
+        # tables made from the correlation tensors; K = 3 / 4 / 6 (ternary): the KF instantiations (lean_corr_n*.hip).
+        wl12 = workloads.config12()
+        info, first, _ = _engine_run(Engine, wl12, device, clock, 5, 100_000)
+        record(wl12, info, first, None,
+               issue_roof("config12", "H1 (correlation trace), K = 1 function per orbit: the headline kernel on tables made "
+                                      "from the correlation tensors (DESIGN.md 4.1a)"), wl12.n_walkers, launches=5)
+        wl13 = workloads.config13()
+        info, first, steady = _engine_run(Engine, wl13, device, clock, 10, 20_000, equil=EQUIL_STEPS[3], transient_mc=2000)
+        record(wl13, info, first, steady,
+               issue_roof("config13", "H1 (correlation trace), K = 3 / 4 / 6 functions per orbit: decision from one folded "
+                                      "table per slot, the K function tables read on accepted steps only (DESIGN.md 4.1a)"),
+               wl13.n_walkers, launches=10)
+        out[-1]["state"] = "reject-path only (config 3's lattice: see config 3 above); the transient window is the figure"
+        # the reference's own model (LiNiO2, two active sublattices, Ewald) under Wang-Landau: mc_lean_multi_kernel<..., WLK>
+        try:
+            wl11 = workloads.config11(count=4)
+            probe = Engine(wl11.tables, capi.make_config(1, device=device))
+            h11 = float(probe.natural_parameters @ probe.eval_full(wl11.occupancy[:1])[0])
+            probe.close()
+            for count in (1024, 4096):
+                wl11 = workloads.config11(count=count, h0=h11)
+                info, first, _ = _engine_run(Engine, wl11, device, clock, 5, 2000)
+                record(wl11, info, first, None,
+                       issue_roof("config11", "Wang-Landau on two active sublattices + Ewald field in LDS: three steps of four "
+                                              "are accepted and sweep the field (DESIGN.md 4.1c)"), wl11.n_walkers, launches=5)
+        except OSError as e:  # (the slimmed model file travels with tests/golden)
+            out.append(dict(config="config11: LiNiO2 under Wang-Landau", error=str(e)))
 
     if world == 1:
         # config 3 on the LITERAL formulation of ewald.pyx:38-58 (two rows of the 382 MB matrix gathered per
@@ -694,6 +743,18 @@ def main():
         sys.stderr.write(f"bench.py: {rccl_ranks} ranks took part in the all-reduce, --gpus {args.gpus}\n")
         raise SystemExit(4)
 
+    # what every rank runs on (the first N > 1 line must describe itself): device name, architecture, CUs and
+    # XCDs (the KFD topology's num_xcc of the GPU nodes -- identical GPUs on one node; else derived from the CUs)
+    prop = torch.cuda.get_device_properties(device)
+    my_dev = dict(rank=rank, device=device, name=prop.name, arch=getattr(prop, "gcnArchName", "?"),
+                  compute_units=int(prop.multi_processor_count), xcds=_xcd_count(int(prop.multi_processor_count)),
+                  hbm_gib=round(prop.total_memory / 2**30, 1))
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev)
+    else:
+        devs = [my_dev]
+
     from smol_amd import capi, parallel, workloads
     from smol_amd.engine import Engine
 
@@ -825,6 +886,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "devices": devs,
             "config": {
                 "workload": wl.name,
                 "replicas_per_gpu": R,

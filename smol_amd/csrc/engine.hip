@@ -1292,7 +1292,11 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             }
             // (Wang-Landau: per-bin records and the cached rows of per-bin feature sums, mc_wl.h)
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
-                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 + (wl ? (size_t)h->L * 24 + (size_t)SMOLMC_WL_ROWS * h->F * 8 : 0));
+                          (size_t)4 * (lp.Nlds + 64 * 8 + 64 +
+                                       (wl ? std::max(wl_lean_bins_bytes(h->L) + (size_t)SMOLMC_WL_ROWS * h->F * 8,
+                                                      // (round 2's variant inside mc_lean_kernel, A/B switch: 24-byte records)
+                                                      getenv("SMOLMC_WL_V2") ? (size_t)h->L * 24 : (size_t)0)
+                                           : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
             // Ewald potential field in LDS when the changeable sites are the active
             // sublattice and it fits beside the occupancies
@@ -2432,6 +2436,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     // every flip: a changeable site of an active sublattice (the lean kernels index their tables
     // relative to the active range; a code beyond the site's species would index past its tensors)
     int max_flips = 0;
+    bool repeated_site = false; // a record that flips one site twice (sequential-flip semantics, expansion.py:217-229)
     for (size_t i = 0; i < n; ++i) {
         const int32_t *st = steps + i * SMOLMC_STEP_ROW;
         int nf = 0;
@@ -2440,6 +2445,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
             if (site >= h->N) return fail("replay step out of range");
             if (!h->site_active[site]) return fail("replay step out of range: the site is not changeable (not on an active sublattice)");
             if (code < 0 || code >= (int)h->site_ncodes[site]) return fail("replay step out of range (species code)");
+            for (int g = 0; g < nf; ++g) repeated_site |= st[2 * g] == site;
         }
         max_flips = std::max(max_flips, nf);
     }
@@ -2453,9 +2459,13 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     // handles and SMOLMC_REPLAY_UNIVERSAL take the universal kernel; SMOLMC_REPLAY_GENERAL: mc_kernel.
     const bool two_flip_ok = max_flips <= 2 && !priori_given && !table;
     const bool want_general = getenv("SMOLMC_REPLAY_GENERAL") != nullptr && two_flip_ok && h->general_ok;
-    const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30);
+    // (the lean TableFlip replay kernels pick sites without replacement like the usher: a record with a repeated
+    // site -- valid for the boundary -- takes the universal kernel, which evaluates it flip by flip)
+    const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30) && !repeated_site;
+    // (a Flip handle's own kernel takes single flips: records of two flips go to mc_kernel / the universal kernel)
+    const bool lean_shape_ok = two_flip_ok && (h->cfg.step_type != SMOLMC_STEP_FLIP || max_flips <= 1);
     const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&
-                             ((two_flip_ok && smolmc_lean_replay_takes(h)) || lean_table_replay);
+                             ((lean_shape_ok && smolmc_lean_replay_takes(h)) || lean_table_replay);
     const bool general_replay = !lean_replay && !h->univ && two_flip_ok && h->general_ok && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr;
     if (getenv("SMOLMC_DEBUG"))
         fprintf(stderr, "[smolmc] replay path=%s max_flips=%d priori_given=%d\n",

@@ -303,6 +303,33 @@ __device__ __noinline__ double wl_flatness_check(const double *wl_S, long long *
     return wl_m;
 }
 
+// flatness check (wanglandau.py:253-264) on the compact records: histogram = HBM base + LDS delta; on
+// success the histogram is reset, the deltas move into the occurrences and m shrinks
+__device__ __noinline__ double wl_multi_flatness_check(const double *S, uint32_t *cnt, double *occb, long long *hist_g,
+                                                       long long *occ_g, int L, double flat, double div, double wl_m, int lane) {
+    long n = 0;
+    double sum = 0;
+    for (int i = lane; i < L; i += 64)
+        if (S[i] > 0) { n++; sum += (double)(hist_g[i] + (long long)cnt[i]); }
+    const double tn = wave_sum_all((double)n), tsum = wave_sum_all(sum);
+    if (tn >= 2.0) {
+        const double thr = flat * (tsum / tn);
+        int bad = 0;
+        for (int i = lane; i < L; i += 64)
+            if (S[i] > 0 && !((double)(hist_g[i] + (long long)cnt[i]) > thr)) bad = 1;
+        if (__ballot(bad) == 0ull) {
+            for (int i = lane; i < L; i += 64) {
+                hist_g[i] = 0;
+                occ_g[i] += (long long)cnt[i];
+                if (occb) occb[i] += (double)cnt[i];
+                cnt[i] = 0u;
+            }
+            wl_m = wl_m / div;
+        }
+    }
+    return wl_m;
+}
+
 // LDS access by absolute address (SOLO layout: the occupancy starts at LDS address 0; going
 // through the `extern __shared__` symbol would cost one "+ symbol" VALU add per access)
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;

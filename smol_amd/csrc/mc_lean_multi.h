@@ -65,33 +65,7 @@ __device__ __noinline__ void wl_multi_row_swap(double *grows, double *crow, int 
         crow[lane] = sum_mode ? 0.0 : grows[(size_t)new_bin * F + lane];
     }
 }
-// flatness check (wanglandau.py:253-264) on the compact records: histogram = HBM base + LDS delta; on
-// success the histogram is reset, the deltas move into the occurrences and m shrinks
-__device__ __noinline__ double wl_multi_flatness_check(const double *S, uint32_t *cnt, double *occb, long long *hist_g,
-                                                       long long *occ_g, int L, double flat, double div, double wl_m, int lane) {
-    long n = 0;
-    double sum = 0;
-    for (int i = lane; i < L; i += 64)
-        if (S[i] > 0) { n++; sum += (double)(hist_g[i] + (long long)cnt[i]); }
-    const double tn = wave_sum_all((double)n), tsum = wave_sum_all(sum);
-    if (tn >= 2.0) {
-        const double thr = flat * (tsum / tn);
-        int bad = 0;
-        for (int i = lane; i < L; i += 64)
-            if (S[i] > 0 && !((double)(hist_g[i] + (long long)cnt[i]) > thr)) bad = 1;
-        if (__ballot(bad) == 0ull) {
-            for (int i = lane; i < L; i += 64) {
-                hist_g[i] = 0;
-                occ_g[i] += (long long)cnt[i];
-                if (occb) occb[i] += (double)cnt[i];
-                cnt[i] = 0u;
-            }
-            wl_m = wl_m / div;
-        }
-    }
-    return wl_m;
-}
-
+// (wl_multi_flatness_check, the flatness check on the compact records, is in mc_lean.h: mc_wl_kernel shares it)
 #define WLM_LOG SMOLMC_WLM_LOG // entries of the log of finished runs (sums)
 // ONE: a single site class (the 257..512-clusters-per-site models): the slot records stay in
 // registers for the whole launch instead of being re-read from LDS for every flip.

@@ -43,36 +43,12 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WL_LDS_F64P(a) ((lds_f64_t *)(a))
 #define WL_LDS_I64P(a) ((__attribute__((address_space(3))) long long *)(a))
+#define WL_LDS_U32P(a) ((__attribute__((address_space(3))) uint32_t *)(a))
 #else
 #define WL_LDS_F64P(a) ((double *)(uintptr_t)(a))
 #define WL_LDS_I64P(a) ((long long *)(uintptr_t)(a))
+#define WL_LDS_U32P(a) ((uint32_t *)(uintptr_t)(a))
 #endif
-
-struct WlBin {
-    double S;
-    long long hist, occur;
-};
-
-// Wang-Landau flatness check (wanglandau.py:253-264), every check_period steps, on the record
-// layout: out of line, its temporaries stay out of the step loop's register allocation.
-__device__ __noinline__ double wl_flatness_check_rec(WlBin *rec, int L, double flat, double div, double wl_m, int lane) {
-    long cnt = 0;
-    double sum = 0;
-    for (int i = lane; i < L; i += 64)
-        if (rec[i].S > 0) { cnt++; sum += (double)rec[i].hist; }
-    const double tcnt = wave_sum_all((double)cnt), tsum = wave_sum_all(sum);
-    if (tcnt >= 2.0) {
-        const double thr = flat * (tsum / tcnt);
-        int bad = 0;
-        for (int i = lane; i < L; i += 64)
-            if (rec[i].S > 0 && !((double)rec[i].hist > thr)) bad = 1;
-        if (__ballot(bad) == 0ull) {
-            for (int i = lane; i < L; i += 64) rec[i].hist = 0;
-            wl_m = wl_m / div;
-        }
-    }
-    return wl_m;
-}
 
 // Eviction of one cached row of per-bin feature sums: added to the bin's row in HBM (the rows of
 // a walker are touched by its own wave only; the atomic is used for its fire-and-forget form) and
@@ -98,20 +74,28 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
-    const int r = uni(blockIdx.x * nwaves + wave);
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (size_t)P.wl.L * 24 + (size_t)WL_ROWS * P.F * 8 +
+    const int slot = uni(blockIdx.x * nwaves + wave);
+    // (group rotation, see launch_wl_kern: the walker of a launch slot)
+    const int r = P.launch_slots ? ((P.rot_j + slot / P.rot_s) % P.rot_g) * P.rot_s + slot % P.rot_s : slot;
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + wl_lean_bins_bytes(P.wl.L) + (size_t)WL_ROWS * P.F * 8 +
                             (EWF ? (size_t)P.ew_nact * 8 : 0);
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len, *s_q = s_mu + 8, *s_dg = s_mu + 16; // [8] each: mu / charge / diagonal term per code
     unsigned char *wbase = (unsigned char *)(s_dt + P.dt_len + 24) + (size_t)wave * per_wave;
     uint8_t *occ = wbase; // indexed by SWIZZLED site address
     double *s_cell = (double *)(wbase + P.Nlds); // 64 doubles: shadow copies of a run's feature sums
-    // per-bin records {entropy, histogram, occurrences} (24 bytes: the three lane-0 updates of a step
-    // and the entropy reads around the current bin are one address + immediate offsets), with one
-    // guard record before bin 0 and one behind bin L-1 (read, never selected)
-    WlBin *wl_rec = (WlBin *)(s_cell + 64) + 1;
-    const uint32_t rec0 = (uint32_t)(uintptr_t)wl_rec; // LDS byte address of bin 0's record
-    double *s_rows = (double *)(wl_rec + P.wl.L + 1);   // cached rows of per-bin feature sums [WL_ROWS][F]
+    // Per-bin state (round 5): the entropies S [L] as float64 -- with one guard entry before bin 0 and one behind
+    // bin L-1 (read, never selected) -- and ONE uint32 count per bin: the steps spent there since the launch started
+    // / the last successful flatness check.  Histogram and occurrences gain one together on every step
+    // (wanglandau.py:241-245, update_period 1), so the HBM arrays keep the base values and take the count when the
+    // histogram is reset and when the launch ends: 12 bytes per bin instead of round 3's 24-byte records
+    // {entropy, histogram, occurrences} -- config 4 fits three workgroups per CU instead of two, and the post-step is
+    // two LDS atomics instead of three.
+    double *wl_S = s_cell + 64 + 1;
+    const uint32_t rec0 = (uint32_t)(uintptr_t)wl_S; // LDS byte address of bin 0's entropy
+    uint32_t *wl_cnt = (uint32_t *)(wl_S + P.wl.L + 1);
+    const uint32_t cnt0 = (uint32_t)(uintptr_t)wl_cnt;
+    double *s_rows = (double *)((unsigned char *)(s_cell + 64) + wl_lean_bins_bytes(P.wl.L)); // cached rows of per-bin feature sums [WL_ROWS][F]
     double *phi = s_rows + (size_t)WL_ROWS * P.F;       // EWF: Ewald potential field [ew_nact]
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -120,21 +104,17 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
         s_q[threadIdx.x] = EWF ? P.ew_qrow[threadIdx.x] : 0.0;
         s_dg[threadIdx.x] = EWF ? P.ew_dgrow[threadIdx.x] : 0.0;
     }
-    const bool live = r < P.R;
+    const bool live = P.launch_slots ? slot < P.launch_slots : r < P.R;
     if (live) {
         const uint32_t *src = (const uint32_t *)(P.occ + (size_t)r * P.Npad);
         for (int i = lane; i < P.Npad / 4; i += 64)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_cell[lane] = 0.0;
         for (int i = lane; i < P.wl.L; i += 64) {
-            wl_rec[i].S = P.wl.entropy[(size_t)r * P.wl.L + i];
-            wl_rec[i].hist = P.wl.hist[(size_t)r * P.wl.L + i];
-            wl_rec[i].occur = P.wl.occur[(size_t)r * P.wl.L + i];
+            wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+            wl_cnt[i] = 0u;
         }
-        if (lane < 2) {
-            WlBin &g = wl_rec[lane ? P.wl.L : -1];
-            g.S = 0.0; g.hist = 0; g.occur = 0;
-        }
+        if (lane < 2) wl_S[lane ? P.wl.L : -1] = 0.0;
         for (int i = lane; i < WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
         if (EWF)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
@@ -397,7 +377,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             // (lane l holds S[b - 8 + l], clamped into the guard records: one LDS read serves the
             // accept test through v_readlane for |new bin - bin| <= 8)
             const uint32_t widx1 = (uint32_t)min(max(b - 7 + lane, 0), Lm1 + 2); // record index + 1
-            const double win = *WL_LDS_F64P(rec0 - 24u + __umul24(widx1, 24u));
+            const double win = *WL_LDS_F64P(rec0 - 8u + 8u * widx1);
             int nfl, s2, a2, n1, n2 = 0, o2 = 0;
             if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
             if (REPLAY) { // the recorded proposal (a swap kernel takes proper swaps only)
@@ -568,7 +548,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                         Snb = __hiloint2double((int)rdlane((uint32_t)__double2hiint(win), dl),
                                                (int)rdlane((uint32_t)__double2loint(win), dl));
                     else
-                        Snb = *WL_LDS_F64P(rec0 + 24u * (uint32_t)nb);
+                        Snb = *WL_LDS_F64P(rec0 + 8u * (uint32_t)nb);
                     const double ex = win - Snb + 0.0; // lane 8: S[bin] - S[new bin]
                     accepted = ((__ballot((ex >= 0.0) | (ex > lu)) >> 8) & 1ull) != 0ull;
                     decided = true;
@@ -586,7 +566,7 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
                 dHa = dH;
                 if (__ballot(!(new_h < vmin || new_h >= P.wl.vmax)) != 0ull) {
                     nb = uni((int)floordiv_exact_inv(new_h - vmin, bin, inv_bin));
-                    const double ex = win - *WL_LDS_F64P(rec0 + 24u * (uint32_t)nb) + 0.0;
+                    const double ex = win - *WL_LDS_F64P(rec0 + 8u * (uint32_t)nb) + 0.0;
                     accepted = ((__ballot((ex >= 0.0) | (ex > lu)) >> 8) & 1ull) != 0ull;
                 }
             }
@@ -636,10 +616,8 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             if (++wl_rem_check == wl_check) wl_rem_check = 0;
 #ifndef WL_EXP_NOATOM // (timing experiments: -DWL_EXP_* remove one part each; wrong results)
             if (lane == 0) { // LDS atomics without return value
-                const uint32_t wb = rec0 + 24u * (uint32_t)b;
-                __hip_atomic_fetch_add(WL_LDS_F64P(wb), wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(WL_LDS_I64P(wb + 8u), 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(WL_LDS_I64P(wb + 16u), 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(WL_LDS_F64P(rec0 + 8u * (uint32_t)b), wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(WL_LDS_U32P(cnt0 + 4u * (uint32_t)b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
 #endif
             s1 = s1n;
@@ -657,7 +635,9 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
             }
             if (wl_rem_check == 0) {
                 const LeanParamsKernarg Q = rare_params();
-                wl_m = wl_flatness_check_rec(wl_rec, Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
+                const size_t o = (size_t)r * Q->wl.L;
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, nullptr, Q->wl.hist + o, Q->wl.occur + o, Q->wl.L, Q->wl.flat,
+                                               Q->wl.div, wl_m, lane);
             }
             l4 += 4;
             l64 += 1;
@@ -718,9 +698,10 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
     if (EWF)
         for (int j = lane; j < P.ew_nact; j += 64) P.ew_phi[(size_t)r * P.ew_nact + j] = phi[j];
     for (int i = lane; i < P.wl.L; i += 64) {
-        P.wl.entropy[(size_t)r * P.wl.L + i] = wl_rec[i].S;
-        P.wl.hist[(size_t)r * P.wl.L + i] = wl_rec[i].hist;
-        P.wl.occur[(size_t)r * P.wl.L + i] = wl_rec[i].occur;
+        const size_t o = (size_t)r * P.wl.L + i;
+        P.wl.entropy[o] = wl_S[i];
+        P.wl.hist[o] += (long long)wl_cnt[i];
+        P.wl.occur[o] += (long long)wl_cnt[i];
     }
     if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
     const double Hend = exact_enthalpy();
@@ -737,15 +718,51 @@ __global__ void __launch_bounds__(256) mc_wl_kernel(const LeanParams P) {
 #undef key0
 #undef key1
 
+static long wl_gcd(long a, long b) { while (b) { const long t = a % b; a = b; b = t; } return a; }
+
+// Launch.  GROUP ROTATION (round 5): the kernel's residency is set by LDS -- config 4: three four-walker
+// workgroups per CU, 3072 walkers on 256 CUs -- and a step of this kernel takes as long at three waves per SIMD as
+// at one (latency, not issue).  4096 walkers in one launch are therefore a full round of 3072 followed by a round of
+// 1024 that takes just as long: 34 ms for 20000 steps against 18.8 ms for 3072 walkers.  When the walkers exceed the
+// residency C by less than 4x and split into groups of s = gcd(R, C) walkers, the launch becomes g = R / s
+// sub-launches of c = C / s groups each -- sub-launch j runs groups j, j + 1, ..., j + c - 1 (mod g) for steps / c
+// steps -- every group runs c times, every sub-launch fills the chip exactly: time R / C instead of ceil(R / C)
+// rounds.  Walkers are independent and carry their whole state through HBM between launches, so the chains are
+// the chains of one long launch (SMOLMC_NO_ROTATE: A/B switch; tests compare both against the oracle).
 template <int NSLOT, int MM, int STEP, bool REPLAY, bool MU, bool EW>
 static int launch_wl_kern(smolmc_handle *h, const LeanParams &lp) {
-    const unsigned grid = (unsigned)((h->R + 3) / 4);
     auto kern = mc_wl_kernel<NSLOT, MM, STEP, REPLAY, MU, EW>;
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds));
+    long C = 0;
+    if (!REPLAY && lp.smp.every == 0 && getenv("SMOLMC_NO_ROTATE") == nullptr) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, h->lean_lds) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess)
+            C = 4L * per_cu * cus;
+    }
+    const long R = h->R, s = C > 0 ? wl_gcd(R, C) : 0;
+    const long c = s ? C / s : 0, g = s ? R / s : 0;
+    const bool rotate = C > 0 && R > C && R < 4 * C && s % 4 == 0 && c <= 16 && g <= 64 && lp.steps >= 64 * c;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), h->lean_lds, h->stream, lp);
-    HIPCHK(hipGetLastError());
+    LeanParams q = lp;
+    long long left = lp.steps;
+    if (rotate) {
+        q.launch_slots = (int)(c * s); q.rot_s = (int)s; q.rot_g = (int)g;
+        q.steps = lp.steps / c;
+        for (int j = 0; j < (int)g; ++j) {
+            q.rot_j = j;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(c * s / 4)), dim3(256), h->lean_lds, h->stream, q);
+        }
+        HIPCHK(hipGetLastError());
+        left = lp.steps - q.steps * c; // (steps % c: all walkers together below)
+        q.launch_slots = 0;
+    }
+    if (left > 0) {
+        q.steps = left;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((h->R + 3) / 4)), dim3(256), h->lean_lds, h->stream, q);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return 0;

@@ -486,6 +486,9 @@ struct LeanParams {
     // read through rare_params() where an accepted flip needs them, never live across the step loop
     const double *ew_gx;
     const uint32_t *ew_E8, *ew_S8;
+    // group rotation (mc_wl_kernel, see launch_wl_kern): this launch runs launch_slots walkers, slot q = walker
+    // ((rot_j + q / rot_s) % rot_g) * rot_s + q % rot_s; launch_slots 0 = all R walkers, slot q = walker q
+    int launch_slots, rot_s, rot_g, rot_j;
     // replay (REPLAY instantiations only): host-provided proposals / uniforms, per-step outputs
     const int *rp_steps;   // [R][steps][4]
     const double *rp_u;    // [R][steps]
@@ -708,6 +711,8 @@ int smolmc_launch_multi_bias_replay_8(smolmc_handle *h, const LeanParams &lp);
 // S f64 [L] | counted steps u32 [L] | sums: a log of SMOLMC_WLM_LOG finished runs [F] -- running means: occurrences at
 // launch start f64 [L] and SMOLMC_WL_ROWS cached rows [F]
 #define SMOLMC_WLM_LOG 16
+// per-walker LDS bytes of the per-bin state of mc_wl_kernel (mc_wl.h): entropies f64 [L + 2 guards] | step counts u32 [L]
+__host__ __device__ inline size_t wl_lean_bins_bytes(int L) { return ((size_t)L + 2) * 8 + (((size_t)L * 4 + 7) & ~(size_t)7); }
 __host__ __device__ inline size_t wl_multi_wave_bytes(int L, int F, int sum_mode) {
     return (size_t)L * 8 + (((size_t)L * 4 + 7) & ~(size_t)7) +
            (sum_mode ? (size_t)SMOLMC_WLM_LOG * F * 8 : (size_t)L * 8 + (size_t)SMOLMC_WL_ROWS * F * 8);

@@ -116,12 +116,13 @@ def _mu_rows(sc, scale):
     return mu
 
 
-def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=None):
+def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=None, feature_mode=capi.FEATURES_INTERACTIONS):
     """BASELINE configs[2]: ternary rocksalt dim^3, triplet CE + Ewald, semigrand flip."""
     model, sc, ew = _rocksalt(dim)
     temperature = CONFIG3_T if temperature is None else temperature
     mu = _mu_rows(sc, CONFIG3_MU if mu_scale is None else mu_scale)
-    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu,
+                                   feature_mode=feature_mode)
     return Workload(
         3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip",
         sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_FLIP),
@@ -243,5 +244,49 @@ def config10(first=0, count=1024, dim=12, mc=2000, h0=None):
         sc, tab, kw, neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777), 0.0, 1, mc)
 
 
+def config11(first=0, count=1024, dim=8, mc=2000, h0=None, step=capi.STEP_SWAP, update_period=1):
+    """(not in BASELINE.json) the model the reference ships -- LiNiO2 with Li+/vacancy and Ni3+/Ni4+ disorder and an
+    Ewald term (docs/src/notebooks/data/basic_ce_ewald.mson, slimmed copy under tests/golden) -- in a dim^3 cell
+    under Wang-Landau: two active sublattices, the class mc_lean_multi_kernel<..., WLK> took over from mc_kernel in
+    round 5.  Window of 512 bins of 0.5 eV around the starting enthalpy ``h0`` (evaluated by the caller, as for config 4)."""
+    import os
+
+    from . import mson
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lno_ce_ewald.mson.json.gz")
+    ce = mson.load_mson(path)
+    tab = ce.tables(np.diag([dim] * 3))
+    cell = tab.supercell
+    P = cell.size
+    occ = np.ones((count, cell.num_sites), dtype=np.int32)
+    occ[:, 2 * P:] = 0
+    for i in range(count):  # half the Li sites vacant, as many Ni4+: charge neutral
+        rng = np.random.default_rng(3 * 100003 + first + i)
+        occ[i, rng.permutation(P)[:P // 2]] = 0
+        occ[i, P + rng.permutation(P)[:P // 2]] = 0
+    kw = dict(kernel=capi.KERNEL_WANGLANDAU, step=step)
+    if h0 is not None:
+        kw.update(min_enthalpy=h0 - 160.37, max_enthalpy=h0 + 95.63, bin_size=0.5, flatness=0.8, check_period=1000,
+                  update_period=update_period)
+    return Workload(
+        11, f"config11: LiNiO2 {dim}^3 ({cell.num_sites} sites, the reference's basic_ce_ewald.mson), CE + Ewald, "
+            "Wang-Landau swaps on two active sublattices, 512 bins",
+        cell, tab, kw, occ, _seeds(first, count, 777), 0.0, 2 if step == capi.STEP_SWAP else 1, mc)
+
+
+def config12(**kw):
+    """config 2 with the correlation-function trace (ClusterExpansionProcessor, evaluator.pyx:211-265; K = 1 per orbit)."""
+    w = config2(feature_mode=capi.FEATURES_CORRELATIONS, **kw)
+    w.key = 12
+    return w
+
+
+def config13(**kw):
+    """config 3 with the correlation-function trace (K = 3 / 4 / 6 functions per orbit: the KF kernels)."""
+    w = config3(feature_mode=capi.FEATURES_CORRELATIONS, **kw)
+    w.key, w.name = 13, w.name.replace("config3:", "config13 (config 3, correlation trace):")
+    return w
+
+
 BUILDERS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: config6, 7: config7,
-            8: config8, 9: config9, 10: config10}
+            8: config8, 9: config9, 10: config10, 11: config11, 12: config12, 13: config13}

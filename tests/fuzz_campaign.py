@@ -6,7 +6,7 @@ dispatch overrides (auto / SMOLMC_FORCE_GENERAL / SMOLMC_FORCE_UNIVERSAL), each 
 engine and on the CPU oracle with the same Philox streams: occupancies, accept counters and
 Wang-Landau histograms bit-equal, enthalpies / features / bias / entropies to 1e-10.
 
-    python tests/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean] [--out gpurun_out/fuzz.jsonl]
+    python tests/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean|big|fast] [--out gpurun_out/fuzz.jsonl]
 
 The campaign itself is time-boxed and not collected by pytest (tests/test_gpu_fuzz_campaign.py runs a
 fixed handful of its cases); the oracle is the checker here, as everywhere under tests/.  A failing case
@@ -64,10 +64,15 @@ def build_case(rng, profile="any"):
     "big": the same on cells of 2000-14000 sites.
     -> dict(desc, ens, tab, cfg, occ, seeds, temps, env, bias) or None when the draw is void."""
     desc = {}
-    ionic = rng.random() < 0.6
+    # "fast": the shapes of the specialised kernel families the BASELINE configurations and the reference's own
+    # model run on -- two active sublattices (lean-multi), TableFlip on one and on two sublattices (table /
+    # table-multi), Wang-Landau on one class (mc_wl_kernel) and on several / with update_period 3 (the
+    # Wang-Landau variant of the multi-class kernel) -- on unaliased cells, the handle's own kernel only
+    fast = profile == "fast"
+    ionic = fast or rng.random() < 0.6
     if ionic:
         cations = pick(rng, [(1.0, 3.0, 4.0), (1.0, 3.0), (1.0, 3.0, None), (1.0, 3.0, 4.0, 5.0), (2.0, 4.0)])
-        anion = pick(rng, [(-2.0,), (-2.0,), (-2.0, -1.0)])
+        anion = pick(rng, [(-2.0,), (-2.0, -1.0), (-2.0, -1.0)] if fast else [(-2.0,), (-2.0,), (-2.0, -1.0)])
         prim = synth.rocksalt_prim(cation_charges=cations, anion_charges=anion)
         cut = {2: float(rng.uniform(4.3, 6.5))}
         if rng.random() < 0.6:
@@ -84,7 +89,7 @@ def build_case(rng, profile="any"):
         desc.update(lattice="fcc", nspecies=S)
     desc["cutoffs"] = cut
     big = profile == "big"  # cells of 2000-14000 sites: potential field in HBM, pending-update lists, gx tables
-    lean = profile == "lean" or big
+    lean = profile == "lean" or big or fast
     dims = ([int(rng.integers(9, 16)) for _ in range(3)] if big else
             [int(rng.integers(4, 11)) for _ in range(3)] if lean else [int(rng.integers(2, 7)) for _ in range(3)])
     if not lean and rng.random() < 0.15:
@@ -108,8 +113,10 @@ def build_case(rng, profile="any"):
     steps = ["flip", "swap"]
     table_ok = ionic and None not in desc["cations"]
     if table_ok:
-        steps += ["table-flip", "table-flip"]
+        steps += ["table-flip", "table-flip"] + (["table-flip"] * 2 if fast else [])
     step = pick(rng, steps)
+    if fast:  # (Wang-Landau TableFlip runs on the universal kernel: not this profile's subject)
+        kernel = "metropolis" if step == "table-flip" else pick(rng, ["metropolis", "wang-landau", "wang-landau"])
     desc.update(kernel=kernel, step=step)
     R = int(rng.integers(1, 4 if big else 7))
     P = sc.size
@@ -143,7 +150,7 @@ def build_case(rng, profile="any"):
     if step == "flip" or rng.random() < 0.2:
         ens.chemical_potentials = {sp: float(rng.uniform(-0.3, 0.3)) for sp in ens.species}
         desc["mu"] = True
-    if rng.random() < (0.3 if lean else 0.25):
+    if rng.random() < (0.1 if fast else 0.3 if lean else 0.25):
         act = np.concatenate([s.active_sites for s in ens.active_sublattices])
         ens.restrict_sites(rng.choice(act, size=max(1, len(act) // 10), replace=False))
         desc["restricted"] = True
@@ -269,7 +276,8 @@ def _run_case(case_seed, case, rng):
     # device-side thinning (smolmc_run_sampled): every recorded row is the oracle's state at that step
     desc["stage"] = "sampled"
     ns, thin = int(rng.integers(1, 5)), int(rng.integers(1, 40))
-    ring = eng.run_sampled(ns, thin, occupancy=True)
+    # (ABI 7: with the `bias` column / the Wang-Landau trace of every sample where the kernel has them)
+    ring = eng.run_sampled(ns, thin, occupancy=True, bias=case["bias"] is not None, wl=case["wl"])
     for i in range(ns):
         ora.run(thin)
         b = ora.get_state()
@@ -277,6 +285,15 @@ def _run_case(case_seed, case, rng):
         np.testing.assert_allclose(ring["enthalpy"][i], b["enthalpy"], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(ring["features"][i], b["features"], rtol=RTOL, atol=ATOL)
         assert np.array_equal(ring["accepted"][i], b["accepted"])
+        if case["bias"] is not None:
+            np.testing.assert_allclose(ring["bias"][i], ora.get_bias(), rtol=RTOL, atol=ATOL)
+        if case["wl"]:
+            wb = ora.get_wl()
+            assert np.array_equal(ring["histogram"][i], wb["histogram"]), f"sampled WL histogram {i} differs"
+            assert np.array_equal(ring["occurrences"][i], wb["occurrences"])
+            np.testing.assert_allclose(ring["entropy"][i], wb["entropy"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(ring["mean_features"][i], wb["mean_features"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(ring["mod_factor"][i], wb["mod_factor"], rtol=0, atol=0)
     # the running features are the recomputed ones (checked BEFORE the replay: a record that flips a
     # site twice prices the chemical work of both flips against the occupancy before the step,
     # ensemble.py:368-374, so the running feature legitimately leaves the recomputed one there)
@@ -342,7 +359,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--profile", default="any", choices=["any", "lean", "big"])
+    ap.add_argument("--profile", default="any", choices=["any", "lean", "big", "fast"])
     args = ap.parse_args()
     seeds = [args.only] if args.only is not None else [args.seed * 1000003 + i for i in range(args.cases)]
     t0 = time.time()
@@ -359,7 +376,8 @@ def main():
                        trace=traceback.format_exc().splitlines()[-6:])
         counts[res["status"]] += 1
         if res["status"] == "ok":
-            k = res["desc"]["kernel_info"].split()[0]
+            d = res["desc"]  # kernel family / step type (/ Wang-Landau): which kernels the campaign actually reached
+            k = d["kernel_info"].split()[0] + "/" + d["step"] + ("/wl" if d["kernel"] == "wang-landau" else "")
             kernels[k] = kernels.get(k, 0) + 1
         if res["status"] == "FAIL" or args.only is not None:
             print(json.dumps(res, default=str), flush=True)

@@ -455,6 +455,14 @@ def neutral_occ_G(sc, n_ti, n_f, rng):
     return occ
 
 
+# Temperatures of the four biased Flip chains.  Round 4 ran them at the temperature of their model's TableFlip
+# chains (2500 / 5000 K), where single flips -- each one changes the cell's net charge -- were accepted 2-4 % of
+# the time: the accept -> update running bias / charge / hyperplane sums path was pinned by a few dozen events.
+# Round 5: temperatures that put every chain at an acceptance of 0.15-0.5.
+T_BIASED = {k: float(os.environ.get("V6_T_" + k, v)) for k, v in
+            dict(BC_fug_flip_int=80000.0, BC_sqc_flip_corr=10000.0, BG_hyp_flip_int=15000.0, BG_fug_flip_corr=30000.0).items()}
+
+
 def main():
     from smol_amd import synth
 
@@ -523,12 +531,14 @@ def main():
     # biases with Flip steps (semigrand, mu + Ewald)
     rng = np.random.default_rng(507)
     bias = FugacityBias(subsC, fus)
-    put("BC_fug_flip_int", run_metropolis(proc, "int", Flip(subsC, rng), rng, 2500.0, occ0, 2000, bias=bias))
+    put("BC_fug_flip_int", run_metropolis(proc, "int", Flip(subsC, rng), rng, T_BIASED["BC_fug_flip_int"], occ0, 2000, bias=bias))
     rng = np.random.default_rng(508)
     bias = SquareChargeBias(subsC, penalty=0.05)
-    put("BC_sqc_flip_corr", run_metropolis(proc, "corr", Flip(subsC, rng), rng, 2500.0, occ0, 2000, bias=bias))
+    put("BC_sqc_flip_corr", run_metropolis(proc, "corr", Flip(subsC, rng), rng, T_BIASED["BC_sqc_flip_corr"], occ0, 2000, bias=bias))
     traj["BC_sqc_table"], traj["BC_sqc_penalty"] = bias._c_table, np.array([0.05])
-    traj["BC_T"] = np.array([2500.0])
+    traj["BC_T"] = np.array([2500.0])  # (kept: the key round 4's fixture carried; the chains use their own below)
+    for k, v in T_BIASED.items():
+        traj[k + "_T"] = np.array([v])
     proc.mu_table = None
 
     # ---- case G: two active sublattices (27 cations + 27 anions), two flip vectors ------------------
@@ -563,7 +573,7 @@ def main():
     b_h = np.array([0, 9])
     rng = np.random.default_rng(603)
     bias = SquareHyperplaneBias(subsG, A_h, b_h, penalty=0.02)
-    put("BG_hyp_flip_int", run_metropolis(proc, "int", Flip(subsG, rng), rng, 5000.0, occ0, 2000, bias=bias))
+    put("BG_hyp_flip_int", run_metropolis(proc, "int", Flip(subsG, rng), rng, T_BIASED["BG_hyp_flip_int"], occ0, 2000, bias=bias))
     traj["BG_hyp_A"], traj["BG_hyp_b"], traj["BG_hyp_penalty"] = A_h, b_h, np.array([0.02])
     traj["BG_hyp_dim_ids"] = OU.get_dim_ids_table(subsG)
     rng = np.random.default_rng(604)
@@ -573,7 +583,7 @@ def main():
     rng = np.random.default_rng(605)
     fusG = [[0.2, 0.3, 0.5], [0.65, 0.35]]
     bias = FugacityBias(subsG, fusG)
-    put("BG_fug_flip_corr", run_metropolis(proc, "corr", Flip(subsG, rng), rng, 5000.0, occ0, 2000, bias=bias))
+    put("BG_fug_flip_corr", run_metropolis(proc, "corr", Flip(subsG, rng), rng, T_BIASED["BG_fug_flip_corr"], occ0, 2000, bias=bias))
     traj["BG_fug_table"] = bias._fu_table
     proc.mu_table = None
 

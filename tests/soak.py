@@ -2,7 +2,7 @@
 """Long-run soak of the two main lean shapes on one GPU: many steps per walker, then the running
 trace against a from-scratch evaluation of every walker (Engine.audit_drift), composition
 conservation for the canonical shape, and a short oracle continuation of a few walkers from the
-final state (same streams).  Usage: python tools/soak.py [--steps N]"""
+final state (same streams).  Usage: python tests/soak.py [--steps N]"""
 import argparse
 import json
 import os

@@ -3,7 +3,7 @@ sizes (small cells name a site twice often -> the duplicate / fallback paths), s
 counts, single- and multi-sublattice models; prints one line per case and exits non-zero on the
 first mismatch.  (The oracle is the checker here, as in tests/.)
 
-  python tools/stress_table_flip.py [--steps 20000]
+  python tests/stress_table_flip.py [--steps 20000]
 """
 import argparse
 import os

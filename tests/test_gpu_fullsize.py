@@ -151,8 +151,11 @@ def test_config4_full_size_wang_landau_identities(config2):
     # every in-window step adds one occurrence and mod_factor of entropy (update_period 1);
     # histograms were reset at most at the flatness checks
     assert np.all(wl["occurrences"].sum(axis=1) == nsteps)
-    np.testing.assert_allclose(wl["entropy"].sum(axis=1) >= wl["mod_factor"] * 0, True)
     assert np.all(wl["histogram"].sum(axis=1) <= nsteps)
+    # ... and the entropy added over all bins is the sum of the modification factors the steps were taken at:
+    # between n m_final (every step after the last reduction) and n m_0
+    assert np.all(wl["entropy"].sum(axis=1) >= nsteps * wl["mod_factor"] * (1 - 1e-12))
+    assert np.all(wl["entropy"].sum(axis=1) <= nsteps * cfg.wl_mod_factor * (1 + 1e-12))
     assert np.all((wl["entropy"] > 0) == (wl["occurrences"] > 0))
     # the per-bin mean features average to the global mean weighted by occurrences; each mean
     # row reproduces an enthalpy inside its bin
@@ -164,6 +167,26 @@ def test_config4_full_size_wang_landau_identities(config2):
     assert np.all(h_bin >= edges - 1e-9) and np.all(h_bin < edges + 0.5 + 1e-9)
     # running trace == from-scratch evaluation
     np.testing.assert_allclose(st["features"], eng.eval_full(st["occupancy"]), rtol=RTOL, atol=ATOL)
+    # oracle spot check: four walkers of the SAME launches (walkers 0, 1, 511, 1023 of the 1024; a walker's chain
+    # depends on its seed and start only) followed step for step on the CPU -- occupancies, counters, histograms,
+    # occurrences, entropies bit-equal, per-bin mean features 1e-10
+    from oracle import oracle as orc
+
+    pick = np.array([0, 1, 511, 1023])
+    cfg4 = capi.make_config(len(pick), capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, min_enthalpy=h0 - 160.37,
+                            max_enthalpy=h0 + 96.11, bin_size=0.5, flatness=0.8, check_period=1000)
+    ora = orc.OracleMC(tab, cfg4)
+    ora.set_state(occ0[pick], seeds[pick], 0.0)
+    ora.run(nsteps)
+    so, wo = ora.get_state(), ora.get_wl()
+    assert np.array_equal(st["occupancy"][pick], so["occupancy"])
+    assert np.array_equal(st["n_accepted"][pick], so["n_accepted"])
+    np.testing.assert_allclose(st["enthalpy"][pick], so["enthalpy"], rtol=RTOL, atol=1e-7)
+    assert np.array_equal(wl["histogram"][pick], wo["histogram"])
+    assert np.array_equal(wl["occurrences"][pick], wo["occurrences"])
+    np.testing.assert_allclose(wl["entropy"][pick], wo["entropy"], rtol=0, atol=0)
+    np.testing.assert_allclose(wl["mean_features"][pick], wo["mean_features"], rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(wl["mod_factor"][pick], wo["mod_factor"])
 
 
 def test_config5_full_size_properties():

@@ -1,7 +1,8 @@
 """A fixed handful of cases of the randomised differential campaign (tests/fuzz_campaign.py: random
 model x kernel x usher x bias x dispatch override, native + device-sampled + replayed steps, GPU vs
 oracle).  The campaign proper is run by hand with a time box; profiles/r04_fuzz_campaign.json holds
-the summary of the round's runs (7000+ cases, no mismatch)."""
+the summary of round 4's runs (7000+ cases, no mismatch), profiles/r05_fuzz_campaign.json round 5's (incl. the
+`fast` profile: lean-multi, table, table-multi, Wang-Landau lean / multi shapes only)."""
 
 import pytest
 
@@ -10,7 +11,7 @@ from tests import fuzz_campaign
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("profile,first", [("any", 11000003), ("lean", 12000006)])
+@pytest.mark.parametrize("profile,first", [("any", 11000003), ("lean", 12000006), ("fast", 14000009)])
 def test_campaign_cases(profile, first):
     seen = {"ok": 0, "void": 0}
     kernels = set()

@@ -384,6 +384,57 @@ def test_wang_landau_bin_pretest_is_decision_neutral(scale, monkeypatch):
     assert wa["histogram"].sum() > 0 and (wa["occurrences"] > 0).sum(axis=1).min() > 3
 
 
+def test_wang_landau_group_rotation_runs_the_same_chains(monkeypatch):
+    """More walkers than mc_wl_kernel keeps resident (4096 against 3072 on 256 CUs): the launch is split into
+    sub-launches that each fill the chip with a rotating subset of walker groups (mc_wl.h, launch_wl_kern).  Every
+    walker still takes exactly nsteps steps of its own chain: equal to one plain launch (SMOLMC_NO_ROTATE) in
+    occupancies, counters, histograms, occurrences and entropies bit for bit, and to the oracle on a few walkers."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    monkeypatch.delenv("SMOLMC_NO_ROTATE", raising=False)
+    tab = tables_for("fcc_prim666_triplets", MODES["int"])
+    c = load_case("fcc_prim666_triplets")
+    R = 4096
+    rng = np.random.default_rng(99)
+    occ0 = (rng.random((R, c["sc"].num_sites)) < 0.5).astype(np.int32)
+    ev = orc.OracleEvaluator(tab)
+    h0 = np.array([ev.feature_vector(o) @ ev.natural_parameters() for o in occ0[:64]])
+    kw = dict(min_enthalpy=h0.min() - 6.37, max_enthalpy=h0.max() + 6.11, bin_size=0.25, check_period=50, flatness=0.3)
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, **kw)
+    seeds = np.arange(R, dtype=np.uint64) * np.uint64(977) + np.uint64(5)
+    rot = _engine(tab, cfg)
+    assert "wl=v3" in rot.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_ROTATE", "1")
+    plain = _engine(tab, cfg)
+    pick = np.array([0, 1023, 1024, 3071, 3072, 4095])
+    ora = orc.OracleMC(tab, capi.make_config(len(pick), capi.KERNEL_WANGLANDAU, capi.STEP_SWAP, **kw))
+    try:
+        rot.set_state(occ0, seeds)
+        plain.set_state(occ0, seeds)
+    except ValueError:
+        pytest.skip("a random start outside the window")
+    ora.set_state(occ0[pick], seeds[pick], 0.0)
+    for n in (700, 65, 1001):  # (1001 = 3 x 333 + 2: the remainder runs as one launch of all walkers)
+        monkeypatch.delenv("SMOLMC_NO_ROTATE", raising=False)
+        rot.run(n)
+        monkeypatch.setenv("SMOLMC_NO_ROTATE", "1")
+        plain.run(n)
+        ora.run(n)
+        a, b, o = rot.get_state(), plain.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"]) and np.array_equal(a["n_accepted"], b["n_accepted"])
+        assert np.array_equal(a["n_steps"], b["n_steps"])
+        assert np.array_equal(a["occupancy"][pick], o["occupancy"]) and np.array_equal(a["n_accepted"][pick], o["n_accepted"])
+        wa, wb, wo = rot.get_wl(), plain.get_wl(), ora.get_wl()
+        for k in ("histogram", "occurrences"):
+            assert np.array_equal(wa[k], wb[k]) and np.array_equal(wa[k][pick], wo[k])
+        np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=0, atol=0)
+        np.testing.assert_allclose(wa["entropy"][pick], wo["entropy"], rtol=0, atol=0)
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(wa["mean_features"][pick], wo["mean_features"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(wa["mod_factor"], wb["mod_factor"])
+
+
 def test_errors_surface_as_exceptions(monkeypatch):
     tab = tables_for("fcc_prim222_aliased", MODES["int"])
     eng = _engine(tab, capi.make_config(1))

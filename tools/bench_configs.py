@@ -39,7 +39,7 @@ def main():
     if a.mc:
         kw["mc"] = a.mc
     wl = workloads.BUILDERS[a.config](**kw)
-    if a.config in (4, 10):  # the window is centred on the starting enthalpy, evaluated on the engine
+    if a.config in (4, 10, 11):  # the window is centred on the starting enthalpy, evaluated on the engine
         probe = Engine(wl.tables, capi.make_config(1))
         h0 = float(probe.natural_parameters @ probe.eval_full(wl.occupancy[:1])[0])
         probe.close()

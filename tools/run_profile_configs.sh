@@ -7,14 +7,14 @@ set -x
 tag=${1:-r04}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFGS=${CFGS:-"3 9 4 5 10 d3 u2"}
+CFGS=${CFGS:-"3 9 4 5 10 11 12 13 d3 u2"}
 # config -> bench_configs arguments | kernel name fragment | replicas | steps per launch
 args_of() { case $1 in
   3) echo "--config 3";; 9) echo "--config 9";; 4) echo "--config 4 --mc 20000";; 5) echo "--config 5";;
-  10) echo "--config 10";; d3) echo "--config 3 --mc 500";; u2) echo "--config 2 --mc 2000";; esac; }
-kern_of() { case $1 in 3|9) echo "mc_lean_kernel";; 4|10) echo "mc_wl_kernel";; 5) echo "mc_table_kernel";; d3) echo "mc_kernel";; u2) echo "mc_univ_kernel";; esac; }
-reps_of() { case $1 in 4|10) echo 1024;; u2) echo 4096;; *) echo 2048;; esac; }
-mc_of() { case $1 in 3|9|10|u2) echo 2000;; 4) echo 20000;; 5) echo 3456;; d3) echo 500;; esac; }
+  10) echo "--config 10";; 11) echo "--config 11";; 12) echo "--config 12";; 13) echo "--config 13";; d3) echo "--config 3 --mc 500";; u2) echo "--config 2 --mc 2000";; esac; }
+kern_of() { case $1 in 3|9|12|13) echo "mc_lean_kernel";; 11) echo "mc_lean_multi_kernel";; 4|10) echo "mc_wl_kernel";; 5) echo "mc_table_kernel";; d3) echo "mc_kernel";; u2) echo "mc_univ_kernel";; esac; }
+reps_of() { case $1 in 4|10|11) echo 1024;; u2|12) echo 4096;; *) echo 2048;; esac; }
+mc_of() { case $1 in 3|9|10|11|13|u2) echo 2000;; 12) echo 10000;; 4) echo 20000;; 5) echo 3456;; d3) echo 500;; esac; }
 cd /tmp
 for k in $CFGS; do
   pre=""; [ $k = d3 ] && pre="SMOLMC_DENSE_EWALD=1"; [ $k = u2 ] && pre="SMOLMC_FORCE_UNIVERSAL=1"
