@@ -58,11 +58,14 @@ def local_tables_of(cluster_processor):
     return out
 
 
-def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=True):
+def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=False):
     """capi.TableSet (= smolmc_tables + the arrays it points at) of a smol.moca.Ensemble.
-    ``contiguous``: when restricted sites or sublattices split by species leave the active sites
-    scattered, relabel the sites (capi.TableSet.permute_sites; the Engine converts occupancies and
-    step records at its boundary) so that the specialised kernels still take the model."""
+    ``contiguous`` (default off, like ``moca.Ensemble.make_tables``): when restricted sites or sublattices
+    split by species leave the active sites scattered, relabel the sites (capi.TableSet.permute_sites) so that
+    the specialised kernels still take the model.  Only ``smol_amd.engine.Engine`` undoes the relabelling at its
+    boundary (occupancies and step records in the caller's numbering): any other consumer of the TableSet -- a
+    direct C-ABI client -- must apply ``tab.site_perm`` itself, so ``engine_from_sampler_arguments`` opts in and
+    nothing else does."""
     ce, ew = split_processor(ensemble.processor)
     sub = ce.cluster_subspace
     decomposition = hasattr(ce, "_interaction_tensors")
@@ -99,7 +102,7 @@ def engine_from_sampler_arguments(ensemble, nwalkers, kernel_type="metropolis", 
 
     kernels = {"metropolis": capi.KERNEL_METROPOLIS, "wanglandau": capi.KERNEL_WANGLANDAU}
     steps = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP, "table-flip": capi.STEP_TABLE_FLIP}
-    tables = tables_from_ensemble(ensemble)
+    tables = tables_from_ensemble(ensemble, contiguous=True)  # (the Engine converts at its boundary)
     cfg = capi.make_config(nwalkers, kernels[kernel_type.lower().replace("-", "")], steps[step_type],
                            device, **wl)
     return Engine(tables, cfg)

@@ -138,8 +138,8 @@ class Sublattice:
         """Split into one sublattice per partition of this one's species, by what occupies each
         site in ``occu`` (smol/moca/sublattice.py:109-186): partition p gets the sites holding
         one of its species (given as species or as codes), keeps those codes as its encoding, and a
-        single-species partition is restricted (inactive).  Sites are listed code by code in
-        ascending code order, as the reference lists them."""
+        single-species partition is restricted (inactive).  The ACTIVE sites are listed code by code in
+        ascending code order, as the reference lists them; ``sites`` is sorted (the constructor's np.unique)."""
         occu = np.asarray(occu)
         out = []
         for partition in species_in_partitions:
@@ -148,8 +148,9 @@ class Sublattice:
             sites = np.concatenate([self.sites[occu[self.sites] == c] for c in codes] + [np.zeros(0, np.int64)])
             actives = np.concatenate([self.active_sites[occu[self.active_sites] == c] for c in codes]
                                      + [np.zeros(0, np.int64)])
+            # (`sites` stays what the constructor makes of it -- sorted, np.unique, sublattice.py:57 -- only the
+            # ACTIVE sites are listed code by code, :176-178: reset_restricted_sites then restores sorted sites)
             part = Sublattice([self.species[i] for i in where], sites, [self.charges[i] for i in where])
-            part.sites = sites.astype(np.int64)
             part.active_sites = actives.astype(np.int64)
             part.encoding = np.array(codes, dtype=np.int32)
             if len(codes) == 1:

@@ -244,6 +244,9 @@ def config10(first=0, count=1024, dim=12, mc=2000, h0=None):
         sc, tab, kw, neutral_rocksalt_occupancy(sc, first, count), _seeds(first, count, 777), 0.0, 1, mc)
 
 
+_LNO_TABLES = {}
+
+
 def config11(first=0, count=1024, dim=8, mc=2000, h0=None, step=capi.STEP_SWAP, update_period=1):
     """(not in BASELINE.json) the model the reference ships -- LiNiO2 with Li+/vacancy and Ni3+/Ni4+ disorder and an
     Ewald term (docs/src/notebooks/data/basic_ce_ewald.mson, slimmed copy under tests/golden) -- in a dim^3 cell
@@ -253,9 +256,10 @@ def config11(first=0, count=1024, dim=8, mc=2000, h0=None, step=capi.STEP_SWAP, 
 
     from . import mson
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lno_ce_ewald.mson.json.gz")
-    ce = mson.load_mson(path)
-    tab = ce.tables(np.diag([dim] * 3))
+    if dim not in _LNO_TABLES:  # (10 s of table generation: bench.py builds the workload at three walker counts)
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lno_ce_ewald.mson.json.gz")
+        _LNO_TABLES[dim] = mson.load_mson(path).tables(np.diag([dim] * 3))
+    tab = _LNO_TABLES[dim]
     cell = tab.supercell
     P = cell.size
     occ = np.ones((count, cell.num_sites), dtype=np.int32)

@@ -91,6 +91,7 @@ def build_case(rng, profile="any"):
     big = profile == "big"  # cells of 2000-14000 sites: potential field in HBM, pending-update lists, gx tables
     lean = profile == "lean" or big or fast
     dims = ([int(rng.integers(9, 16)) for _ in range(3)] if big else
+            [int(rng.integers(4, 9)) for _ in range(3)] if fast else
             [int(rng.integers(4, 11)) for _ in range(3)] if lean else [int(rng.integers(2, 7)) for _ in range(3)])
     if not lean and rng.random() < 0.15:
         scm = np.diag(dims)
@@ -104,7 +105,7 @@ def build_case(rng, profile="any"):
     if sc.num_sites > (14000 if big else 2200 if lean else 600) or (big and sc.num_sites < 2000):
         return None
     coefs = synth.random_coefs(model, seed=int(rng.integers(1 << 30)))
-    ptype = pick(rng, ["decomposition", "decomposition", "decomposition", "expansion"] if lean else ["decomposition", "expansion"])
+    ptype = "decomposition" if fast else pick(rng, ["decomposition", "decomposition", "decomposition", "expansion"] if lean else ["decomposition", "expansion"])
     use_ewald = ionic and rng.random() < 0.6
     desc.update(processor=ptype, ewald=use_ewald)
     ens = moca.Ensemble.from_cluster_expansion(sc, coefs, processor_type=ptype,
@@ -175,8 +176,8 @@ def build_case(rng, profile="any"):
     if tab_engine.site_perm is not None:
         desc["relabelled"] = True
     bias = None
-    if kernel == "metropolis" and rng.random() < 0.35:
-        kind = pick(rng, ["fugacity", "square-charge", "square-hyperplane"])
+    if kernel == "metropolis" and rng.random() < 0.35 and not (fast and step == "table-flip"):
+        kind = pick(rng, ["fugacity", "square-charge"] if fast else ["fugacity", "square-charge", "square-hyperplane"])
         if kind == "fugacity":
             fr = []
             for s in ens.active_sublattices:

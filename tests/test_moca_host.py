@@ -295,9 +295,16 @@ def test_split_sublattice_by_species():
     assert p1.species == (names[1],) and p1.encoding.tolist() == [1] and not p1.is_active
     assert sorted(np.concatenate([p0.sites, p1.sites])) == sorted(sub.sites)
     assert np.all(np.isin(occu[p0.sites], [0, 2])) and np.all(occu[p1.sites] == 1)
-    # code by code in ascending code order, restricted sites carried over
-    n0 = int((occu[sub.sites] == 0).sum())
-    assert np.all(occu[p0.sites[:n0]] == 0) and np.all(occu[p0.sites[n0:]] == 2)
+    # the ACTIVE sites code by code in ascending code order (sublattice.py:176-178), restricted sites carried over;
+    # `sites` itself is what the constructor keeps: sorted (np.unique, sublattice.py:57)
+    n0 = int((occu[p0.active_sites] == 0).sum())
+    assert np.all(occu[p0.active_sites[:n0]] == 0) and np.all(occu[p0.active_sites[n0:]] == 2)
+    assert np.array_equal(p0.sites, np.sort(p0.sites)) and np.array_equal(p1.sites, np.sort(p1.sites))
+    back = parts[0]
+    keep = back.active_sites.copy()
+    back.reset_restricted_sites()
+    assert np.array_equal(back.active_sites, back.sites)  # sorted after a reset, as in the reference
+    back.active_sites = keep
     assert not np.isin(sub.sites[:2], np.concatenate([p0.active_sites, p1.active_sites])).any()
     with pytest.raises(ValueError):
         sub.split_by_species(occu, [[0, 7]])
