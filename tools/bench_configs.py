@@ -42,6 +42,8 @@ def main():
     if a.config in (4, 10, 11):  # the window is centred on the starting enthalpy, evaluated on the engine
         probe = Engine(wl.tables, capi.make_config(1))
         h0 = float(probe.natural_parameters @ probe.eval_full(wl.occupancy[:1])[0])
+        if a.config == 11:  # random starts with a long upper tail: the window's upper edge 30 eV above the highest
+            h0 = float((probe.eval_full(wl.occupancy) @ probe.natural_parameters).max()) + 30.0 - 95.63
         probe.close()
         wl = workloads.BUILDERS[a.config](h0=h0, **kw)
     eng = Engine(wl.tables, wl.make_config())

@@ -13,6 +13,11 @@ def dbs(path):
     return [path]
 
 
+def short(name, n=200):
+    """torch's elementwise kernels carry kilobytes of template arguments: keep the head"""
+    return name if len(name) <= n else name[:n] + "...>"
+
+
 def main():
     for arg in sys.argv[1:]:
         for db in dbs(arg):
@@ -24,7 +29,7 @@ def main():
                 ).fetchall()
                 print("KERNEL_STATS name | calls | total_ms | avg_ms | pct")
                 for r in rows:
-                    print(f"  {r[0]} | {r[1]} | {r[2]/1e3:.3f} | {r[3]/1e3:.3f} | {r[4]:.2f}")
+                    print(f"  {short(r[0])} | {r[1]} | {r[2]/1e3:.3f} | {r[3]/1e3:.3f} | {r[4]:.2f}")
             except sqlite3.Error as e:
                 print("  (no kernel stats)", e)
             try:
@@ -38,7 +43,7 @@ def main():
                     for r in rows:
                         if r[0].startswith("__amd"):
                             continue
-                        print(f"  {r[0]} | {r[1]} | {r[2]:.6g} | {r[3]} | {r[4]} | {r[5]} | {r[6]}")
+                        print(f"  {short(r[0])} | {r[1]} | {r[2]:.6g} | {r[3]} | {r[4]} | {r[5]} | {r[6]}")
             except sqlite3.Error:
                 pass
 
