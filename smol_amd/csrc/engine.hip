@@ -1,5 +1,7 @@
 // engine.hip -- C-ABI (include/smolmc.h), host-side table preparation and the evaluation kernels.
 #include <array>
+#include <map>
+#include <string>
 #include <thread>
 
 #include "smolmc_common.h"
@@ -1607,23 +1609,67 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 u.ratio = t->loc_ratio[r];
             }
             if (dev_upload(h, recs.data(), recs.size(), &up.recs)) return bail(1);
-            std::vector<long long> row_ptr((size_t)t->num_sites + 1, 0), row_off;
-            std::vector<int> row_rec;
+            // the cluster rows of every site, packed for the enthalpy pass (URow / URecE); equal records once
+            std::vector<URecE> rec_e;
+            std::vector<int32_t> rec_of((size_t)std::max<int64_t>(nloc, 1), 0);
+            std::map<std::string, int32_t> rec_index;
+            up.max_I = 1;
+            up.all_k1 = 1;
+            up.tens_len = 0;
+            uint64_t nrows = 0;
+            for (int64_t r = 0; r < nloc; ++r) {
+                const URec &u = recs[(size_t)r];
+                URecE e;
+                memset(&e, 0, sizeof(e));
+                for (int m = 0; m < u.I; ++m) e.st[m] = u.st[m];
+                e.K = u.K; e.Nt = u.Nt; e.feat = u.feat; e.scale = u.scale;
+                e.nat0 = (u.feat >= 0 && u.feat < h->F) ? h->natural[(size_t)u.feat] : 0.0;
+                // (offsets inside one tensor, k * Nt + index, stay below the total checked here)
+                if ((uint64_t)u.t_off + (uint64_t)u.K * (uint64_t)u.Nt > 0xffffffffull)
+                    return bail(fail("cluster tensors of more than 2^32 entries"));
+                e.t_off = (uint32_t)u.t_off;
+                up.tens_len = (int)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>((uint64_t)up.tens_len, (uint64_t)u.t_off + (uint64_t)u.K * (uint64_t)u.Nt));
+                up.max_I = std::max(up.max_I, (int)u.I);
+                if (u.K != 1) up.all_k1 = 0;
+                nrows += (uint64_t)u.J;
+                const std::string key((const char *)&e, sizeof(e));
+                auto it = rec_index.find(key);
+                if (it == rec_index.end()) {
+                    it = rec_index.emplace(key, (int32_t)rec_e.size()).first;
+                    rec_e.push_back(e);
+                }
+                rec_of[(size_t)r] = it->second;
+            }
+            if (rec_e.empty()) { URecE e; memset(&e, 0, sizeof(e)); rec_e.push_back(e); }
+            up.n_recs_e = (int)rec_e.size();
+            up.dict_lds = up.n_recs_e <= SMOLMC_UNIV_DICT_RECS && up.tens_len <= SMOLMC_UNIV_DICT_TENS && h->F <= SMOLMC_UNIV_DICT_NAT &&
+                          getenv("SMOLMC_UNIV_NO_DICT") == nullptr;
+            if (nloc > 0x7fffffffll || nrows > 0x7fffffffull) return bail(fail("more than 2^31 local cluster rows"));
+            std::vector<uint32_t> row_ptr((size_t)t->num_sites + 1, 0);
+            std::vector<URow> rows((size_t)std::max<uint64_t>(nrows, 1));
+            memset(rows.data(), 0, rows.size() * sizeof(URow));
+            size_t q = 0;
             for (int s = 0; s < t->num_sites; ++s) {
                 for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1]; ++r) {
                     const int I = t->orb_nsites[t->loc_orbit[r]];
                     for (int j = 0; j < t->loc_nrows[r]; ++j) {
-                        row_rec.push_back((int)r);
-                        row_off.push_back((long long)t->loc_off[r] + (long long)j * I);
+                        URow &w = rows[q++];
+                        const int32_t *m = t->loc_idx + t->loc_off[r] + (int64_t)j * I;
+                        for (int i = 0; i < SMOLMC_MAX_CLUSTER_SITES; ++i) w.x[i] = i < I ? m[i] : (I ? m[0] : s);
+                        w.rec = rec_of[(size_t)r];
                     }
                 }
-                row_ptr[(size_t)s + 1] = (long long)row_rec.size();
+                row_ptr[(size_t)s + 1] = (uint32_t)q;
             }
-            if (nloc > 0x7fffffffll) return bail(fail("more than 2^31 local records"));
+            up.rows_uniform = t->num_sites > 0 ? (int)row_ptr[1] : 0;
+            for (int s = 0; s < t->num_sites; ++s)
+                if (row_ptr[(size_t)s + 1] - row_ptr[(size_t)s] != (uint32_t)up.rows_uniform) up.rows_uniform = 0;
+            const URow *d_rows = nullptr;
             if (dev_upload(h, row_ptr.data(), row_ptr.size(), &up.row_ptr) ||
-                dev_upload(h, row_rec.data(), row_rec.size(), &up.row_rec) ||
-                dev_upload(h, row_off.data(), row_off.size(), &up.row_off))
+                dev_upload(h, rows.data(), rows.size(), &d_rows) ||
+                dev_upload(h, rec_e.data(), rec_e.size(), &up.recs_e))
                 return bail(1);
+            up.rows = (const uint4 *)d_rows;
         }
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)
@@ -1671,14 +1717,19 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             up.tf_d = d;
             up.tf_sw = t->swap_weight;
         }
-        // per-wave LDS: step scratch (flips, counts, weights: 928 B) + the occupancy when it fits
+        // per-wave LDS: step scratch (flips, counts, weights, a-priori factors: 1952 B) + the occupancy when it fits
         // (+ the step's feature deltas, one cell per cluster feature, while that stays small)
         up.dfeat_cells = (h->Fce <= 1024 && getenv("SMOLMC_UNIV_TWO_PASS") == nullptr) ? (h->Fce + 1) / 2 * 2 : 0;
-        const size_t scratch = 928 + (size_t)up.dfeat_cells * 8, with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
+        up.dfeat_shift = 0;
+        while (up.dfeat_cells && getenv("SMOLMC_UNIV_NO_COPIES") == nullptr && up.dfeat_shift < 3 && ((size_t)up.dfeat_cells << (up.dfeat_shift + 1)) <= 512) up.dfeat_shift++;
+        up.acc_cells = up.dfeat_cells ? (h->F + 1) / 2 * 2 : 0;
+        const size_t scratch = 1952 + (((size_t)up.dfeat_cells << up.dfeat_shift) + (size_t)up.acc_cells) * 8,
+                     with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
         up.occ_lds = with_occ <= 160 * 1024 - 256 && getenv("SMOLMC_UNIV_OCC_HBM") == nullptr;
         up.lds_per_wave = (int)(up.occ_lds ? with_occ : scratch);
+        up.lds_shared = up.dict_lds ? SMOLMC_UNIV_DICT_BYTES : 0;
         h->univ_wpb = 4;
-        while (h->univ_wpb > 1 && (size_t)up.lds_per_wave * h->univ_wpb > 64 * 1024) h->univ_wpb /= 2;
+        while (h->univ_wpb > 1 && (size_t)up.lds_shared + (size_t)up.lds_per_wave * h->univ_wpb > 64 * 1024) h->univ_wpb /= 2;
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         h->univ = !h->lean && (table || !h->general_ok);
     }
@@ -1880,7 +1931,7 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
     if (!h || !buf || n <= 0) return fail("null argument");
     if (h->univ)
         snprintf(buf, (size_t)n, "universal occ=%s field=%d lds=%zu (%s)", h->up.occ_lds ? "lds" : "hbm", h->kp.ew_field,
-                 (size_t)h->up.lds_per_wave * h->univ_wpb, h->general_ok ? "TableFlip outside the lean families" : h->general_reason.c_str());
+                 (size_t)h->up.lds_shared + (size_t)h->up.lds_per_wave * h->univ_wpb, h->general_ok ? "TableFlip outside the lean families" : h->general_reason.c_str());
     else if (h->lean)
         snprintf(buf, (size_t)n, "%s nslot=%d mm=%d field=%d lds=%zu%s", h->lean_multi ? "lean-multi" : "lean",
                  h->lean_nslot, h->lean_mm, h->lp.ew_field, h->lean_lds,

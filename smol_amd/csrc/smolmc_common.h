@@ -531,6 +531,28 @@ struct URec {
     double ratio;         // cluster_ratio (the feature pass divides like the reference: p / ratio / J)
 };
 
+// ... the part the enthalpy pass reads, one gather of 56 bytes per cluster row.  Records that agree in every
+// field are stored once (a translation-invariant model has one per orbit and site class, not one per site): the
+// table is then a few cache lines, or sits in LDS (UParams::dict_lds).
+struct URecE {
+    int32_t st[6];   // tensor strides of the members (0 beyond the cluster)
+    int32_t K, Nt;   // functions (1 in interaction mode), tensor length
+    int32_t feat;    // first feature index
+    uint32_t t_off;  // offset of the tensor(s) in corr_tensors / interaction_tensors
+    double scale;    // size / ratio / J
+    double nat0;     // natural parameter of feature `feat` (all a record of one function needs)
+};
+#define SMOLMC_UNIV_DICT_RECS 64    // dictionaries in LDS: at most this many distinct records,
+#define SMOLMC_UNIV_DICT_TENS 1024  // ... tensor entries (doubles)
+#define SMOLMC_UNIV_DICT_NAT 128    // ... and features
+#define SMOLMC_UNIV_DICT_BYTES (SMOLMC_UNIV_DICT_RECS * 56 + SMOLMC_UNIV_DICT_TENS * 8 + SMOLMC_UNIV_DICT_NAT * 8)
+// one cluster row of a site, packed (32 bytes, two 16-byte loads): the member sites (members beyond the
+// cluster repeat the first one: their stride is 0) and the local record
+struct URow {
+    int32_t x[6];
+    int32_t rec, pad;
+};
+
 // parameter block of the universal kernel (mc_univ.h)
 struct UParams {
     KParams K;   // walker state, sublattices, Ewald / mu / bias tables, Wang-Landau state, replay, samples
@@ -538,9 +560,15 @@ struct UParams {
     const double *natural; // [F] natural parameters
     const URec *recs;      // [n_loc] packed local records, indexed like loc_orbit
     // the cluster rows of every site flattened over its records (lane <-> row in the enthalpy pass):
-    const long long *row_ptr; // [N+1] rows of site s: row_ptr[s] .. row_ptr[s+1]
-    const int *row_rec;       // [nrows] local record of the row
-    const long long *row_off; // [nrows] offset of the row's first member in loc_idx
+    const uint32_t *row_ptr;  // [N+1] rows of site s: row_ptr[s] .. row_ptr[s+1]
+    const uint4 *rows;        // [nrows] URow
+    const URecE *recs_e;      // [n_recs_e] the enthalpy pass's part of recs, distinct ones
+    int n_recs_e;
+    int tens_len;             // entries of the feature mode's tensor array the records reach
+    int dict_lds;             // records, tensors and natural parameters are copied to LDS (workgroup-shared, SMOLMC_UNIV_DICT_BYTES)
+    int rows_uniform;         // > 0: every site has this many rows (row_ptr[s] = s * rows_uniform, not read)
+    int max_I;                // largest cluster of the model (sites)
+    int all_k1;               // every record has one function
     // TableFlip
     int tf_n, tf_d;          // flip vectors, dims (species over the active sublattices)
     const int *tf_table;     // [tf_n][tf_d]
@@ -551,7 +579,10 @@ struct UParams {
     int occ_lds;             // occupancy staged in LDS (else read / written in HBM)
     int dfeat_cells;         // > 0: per-wave LDS cells [dfeat_cells] take the step's feature deltas in the enthalpy
                              // pass (committed on acceptance); 0: features come from a second pass over the flips
+    int dfeat_shift;         // ... each cell exists 1 << dfeat_shift times (LDS atomics serialise per address)
+    int acc_cells;           // dfeat_cells > 0: F rounded up to even -- LDS cells of the feature changes accepted in this launch
     int lds_per_wave;
+    int lds_shared;          // bytes of workgroup-shared LDS in front of the per-wave blocks (the dictionaries)
     int wl;                  // Wang-Landau kernel
     // replay extras
     const double *rp_lp;     // [R][nsteps] a-priori factors (NaN = derive) or null

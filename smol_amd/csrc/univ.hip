@@ -3,8 +3,13 @@
 
 int smolmc_launch_univ(smolmc_handle *h, const UParams &up, int replay) {
     const int wpb = h->univ_wpb;
-    const size_t lds = (size_t)up.lds_per_wave * wpb;
-    auto kern = up.occ_lds ? mc_univ_kernel<true> : mc_univ_kernel<false>;
+    const size_t lds = (size_t)up.lds_shared + (size_t)up.lds_per_wave * wpb;
+    const bool table = up.K.step_type == SMOLMC_STEP_TABLE_FLIP, k1 = up.all_k1 != 0;
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+    const bool dense = (long long)h->R > 2ll * 4 * cus; // more than two walkers per SIMD
+    const int sel = (up.occ_lds ? 8 : 0) | (k1 ? 4 : 0) | (table ? 2 : 0) | (dense ? 1 : 0);
+    void (*kern)(const UParams, const int) = up.dict_lds ? smolmc_univ_kernel_dict(sel) : univ_select<false>(sel);
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
