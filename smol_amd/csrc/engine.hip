@@ -1717,19 +1717,34 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             up.tf_d = d;
             up.tf_sw = t->swap_weight;
         }
-        // per-wave LDS: step scratch (flips, counts, weights, a-priori factors: 1952 B) + the occupancy when it fits
+        // per-wave LDS: step scratch (flips, counts, weights, a-priori factors, running sums: 2464 B) + the occupancy when it fits
         // (+ the step's feature deltas, one cell per cluster feature, while that stays small)
         up.dfeat_cells = (h->Fce <= 1024 && getenv("SMOLMC_UNIV_TWO_PASS") == nullptr) ? (h->Fce + 1) / 2 * 2 : 0;
+        up.acc_cells = up.dfeat_cells ? (h->F + 1) / 2 * 2 : 0;
+        up.lds_shared = up.dict_lds ? SMOLMC_UNIV_DICT_BYTES : 0;
+        auto lay_out = [&]() {
+            const size_t scratch = (cfg->step_type == SMOLMC_STEP_TABLE_FLIP ? SMOLMC_UNIV_SCRATCH_TABLE : SMOLMC_UNIV_SCRATCH) +
+                                   (((size_t)up.dfeat_cells << up.dfeat_shift) + (size_t)up.acc_cells) * 8,
+                         with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
+            up.occ_lds = with_occ <= 160 * 1024 - 256 && getenv("SMOLMC_UNIV_OCC_HBM") == nullptr;
+            up.lds_per_wave = (int)(up.occ_lds ? with_occ : scratch);
+            h->univ_wpb = 4;
+            while (h->univ_wpb > 1 && (size_t)up.lds_shared + (size_t)up.lds_per_wave * h->univ_wpb > 64 * 1024) h->univ_wpb /= 2;
+        };
+        // shadow copies of the step's feature cells: as many as keep them within 4 KB -- and, for launches of more than
+        // twelve walkers per CU, the workgroup within a quarter of the CU's LDS (a workgroup of 40.1 KB halves the resident
+        // walkers of config 2: 1.3e9 -> 8.1e8 flips/s)
         up.dfeat_shift = 0;
         while (up.dfeat_cells && getenv("SMOLMC_UNIV_NO_COPIES") == nullptr && up.dfeat_shift < 3 && ((size_t)up.dfeat_cells << (up.dfeat_shift + 1)) <= 512) up.dfeat_shift++;
-        up.acc_cells = up.dfeat_cells ? (h->F + 1) / 2 * 2 : 0;
-        const size_t scratch = 1952 + (((size_t)up.dfeat_cells << up.dfeat_shift) + (size_t)up.acc_cells) * 8,
-                     with_occ = (scratch + (size_t)h->Npad + 15) & ~(size_t)15;
-        up.occ_lds = with_occ <= 160 * 1024 - 256 && getenv("SMOLMC_UNIV_OCC_HBM") == nullptr;
-        up.lds_per_wave = (int)(up.occ_lds ? with_occ : scratch);
-        up.lds_shared = up.dict_lds ? SMOLMC_UNIV_DICT_BYTES : 0;
-        h->univ_wpb = 4;
-        while (h->univ_wpb > 1 && (size_t)up.lds_shared + (size_t)up.lds_per_wave * h->univ_wpb > 64 * 1024) h->univ_wpb /= 2;
+        lay_out();
+        const bool crowded = (long long)cfg->n_replicas > 12ll * 256;
+        auto too_big = [&]() { return crowded && h->univ_wpb == 4 && (size_t)up.lds_shared + (size_t)up.lds_per_wave * 4 > 40 * 1024; };
+        while (too_big() && up.dfeat_shift > 0) { up.dfeat_shift--; lay_out(); }
+        if (too_big() && up.dict_lds) {
+            up.dict_lds = 0;
+            up.lds_shared = 0;
+            lay_out();
+        }
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         h->univ = !h->lean && (table || !h->general_ok);
     }

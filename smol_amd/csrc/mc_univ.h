@@ -70,7 +70,8 @@ __device__ __forceinline__ philox_out univ_block(unsigned long long step, uint32
 // flip j (vS, vC, vQ0, vCum); `total` rows.
 // dF (or null): LDS cells of the step's feature deltas; every row adds scale * (t_k[ind_f] - t_k[ind_i])
 // to the cell of its feature (committed to the walker's features when the step is accepted).
-template <bool OL, bool K1, bool DL>
+// MAXF: the most flips a step of this call has (2: flips and swaps without the loops over eight flips)
+template <bool OL, bool K1, bool DL, int MAXF>
 __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, const uint8_t *occ, const int lane, const int nfl,
                                                     const int vS, const int vC, const uint32_t vQ0, const uint32_t vCum,
                                                     const uint32_t total, double *dF, const int cshift) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, con
             fi[g] = 0; sm[g] = S0; cm[g] = C0;
             uint32_t qo = Q00;
 #pragma unroll
-            for (int j = 1; j < SMOLMC_MAX_STEP_FLIPS; ++j)
+            for (int j = 1; j < MAXF; ++j)
                 if (j < nfl) {
                     const uint32_t cj = rdlane(vCum, j);
                     const bool in = pp >= cj;
@@ -125,7 +126,7 @@ __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, con
             for (int i = 0; i < SMOLMC_MAX_CLUSTER_SITES; ++i)
                 if (i < Imax) v[i] = uocc_ld<OL>(occ, x[i]);
 #pragma unroll
-            for (int j = 0; j + 1 < SMOLMC_MAX_STEP_FLIPS; ++j)
+            for (int j = 0; j + 1 < MAXF; ++j)
                 if (j + 1 < nfl) { // flips before this row's own
                     const int sj = (int)rdlane((uint32_t)vS, j), cj = (int)rdlane((uint32_t)vC, j);
                     const bool before = j < fi[g];
@@ -264,6 +265,8 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
     double *s_mw = (double *)(s_col + 8); // [64] masked direction weights at the current counts
     double *s_mw2 = s_mw + 64;            // [64] ... at the counts after a direction (a-priori factor)
     double *s_lp = s_mw2 + 64;            // [64] a-priori factor of the directions at the current counts
+    double *s_cum = s_lp + 64;            // [64] running sums of the masked weights (direction order)
+    int last_feas = -1;                   // last direction with a weight
     bool head_valid = false;
     unsigned long long lp_valid = 0ull;
     double sumw_now = 0.0;
@@ -272,9 +275,10 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
     // the end of the launch (and where a sample / the Wang-Landau statistics read them) -- global atomics and a
     // wait for them on every accepted step otherwise
     const int dcells = Q0->dfeat_cells << Q0->dfeat_shift, cshift = Q0->dfeat_shift;
-    double *s_dF = Q0->dfeat_cells ? s_lp + 64 : nullptr;
+    // (the TableFlip scratch exists for TableFlip handles only: 4096 walkers need four workgroups per CU, 40 KB each)
+    double *s_dF = Q0->dfeat_cells ? (double *)(wp + (TABLE ? SMOLMC_UNIV_SCRATCH_TABLE : SMOLMC_UNIV_SCRATCH)) : nullptr;
     double *s_acc = Q0->dfeat_cells ? s_dF + dcells : nullptr;
-    uint8_t *occ = OL ? (uint8_t *)(s_lp + 64 + dcells + Q0->acc_cells) : Q0->K.occ + (size_t)r * Q0->K.Npad;
+    uint8_t *occ = OL ? (uint8_t *)(wp + (TABLE ? SMOLMC_UNIV_SCRATCH_TABLE : SMOLMC_UNIV_SCRATCH)) + (size_t)(dcells + Q0->acc_cells) * 8 : Q0->K.occ + (size_t)r * Q0->K.Npad;
     for (int i = lane; i < dcells + Q0->acc_cells; i += 64) s_dF[i] = 0.0;
     if (OL) {
         const uint4 *src = (const uint4 *)(Q0->K.occ + (size_t)r * Q0->K.Npad);
@@ -336,7 +340,6 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
     const uint32_t nact0 = (uint32_t)(Q0->K.sub_ptr[1] - Q0->K.sub_ptr[0]);
     // word j of block blk of the current step (TableFlip batches)
     auto tword = [&](const uint32_t blk, const uint32_t j) -> uint32_t {
-        const UParamsKernarg Q = univ_params();
         if (blk < 64u) {
             const uint32_t a = rdlane(W0, (int)blk), b = rdlane(W1, (int)blk), c = rdlane(W2, (int)blk), d = rdlane(W3, (int)blk);
             return j == 0 ? a : j == 1 ? b : j == 2 ? c : d;
@@ -400,6 +403,16 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
             sumw_now = masked_weights(-1, s_mw);
             head_valid = true;
             lp_valid = 0ull;
+            // the running sums choose_section_from_partition forms (math.py:870-893), added in its order: the
+            // per-step choice is then one compare + ballot
+            const int n2 = 2 * univ_params()->tf_n;
+            double cum = 0.0;
+            last_feas = -1;
+            for (int i = 0; i < n2; ++i) {
+                const double m = s_mw[i];
+                if (m > 0.0) { cum += m; last_feas = i; }
+                s_cum[i] = cum; // (every lane, same value)
+            }
         }
         return sumw_now;
     };
@@ -419,7 +432,6 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
     // are tried at once, one per lane.  wsrc: the lane of block 0 of this step in the batch.
     // Returns the number of flips (0: no site of another species, mcusher.py:197-199).
     auto propose_swap = [&](const int sl, const uint32_t w_site, const int wsrc, int &s1, int &c1, int &s2, int &c2) -> int {
-        const UParamsKernarg Q = univ_params();
         const uint32_t nact = nact_of(sl);
         const int site1 = uni(site_of(sl, __umulhi(w_site, nact)));
         const int sp1 = uni(uocc_ld<OL>(occ, site1));
@@ -603,17 +615,13 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
             } else {
                 // choose_section_from_partition (math.py:870-893)
                 const double target = (double)rdlane(W0, 1) * (1.0 / 4294967296.0) * sumw;
-                double cum = 0.0;
-                int idx = -1, last = -1;
-                for (int i = 0; i < 2 * Q->tf_n && idx < 0; ++i) {
-                    const double m = s_mw[i];
-                    if (m <= 0.0) continue;
-                    last = i;
-                    cum += m;
-                    if (target < cum) idx = i;
+                int idx;
+                {   // the first direction with a weight whose running sum exceeds the target, else the last one with a weight
+                    const bool in = lane < 2 * Q->tf_n;
+                    const double m = in ? s_mw[lane] : 0.0, c = in ? s_cum[lane] : 0.0;
+                    const unsigned long long hit = __ballot(in && m > 0.0 && target < c);
+                    idx = hit ? (int)__builtin_ctzll(hit) : last_feas;
                 }
-                if (idx < 0) idx = last;
-                idx = uni(idx);
                 const int d = Q->tf_d;
                 const int *row = Q->tf_table + (size_t)(idx >> 1) * d;
                 const int sgn = (idx & 1) ? -1 : 1;
@@ -701,41 +709,50 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
             const uint32_t q0 = ru ? (uint32_t)vS * ru : Q->row_ptr[vS], q1 = ru ? q0 + ru : Q->row_ptr[vS + 1];
             vQ0 = q0;
             const uint32_t len = lane < nfl ? q1 - q0 : 0u;
-#pragma unroll
-            for (int j = 0; j < SMOLMC_MAX_STEP_FLIPS; ++j)
-                if (j < nfl) {
-                    if (lane == j) vCum = total;
-                    total += rdlane(len, j);
-                    if (j + 1 < nfl) {
-                        const int sj = (int)rdlane((uint32_t)vS, j), cj = (int)rdlane((uint32_t)vC, j);
-                        if (lane > j && vS == sj) vOld = cj;
-                    }
+            for (int j = 0; j < nfl; ++j) {
+                if (lane == j) vCum = total;
+                total += rdlane(len, j);
+                if (j + 1 < nfl) {
+                    const int sj = (int)rdlane((uint32_t)vS, j), cj = (int)rdlane((uint32_t)vC, j);
+                    if (lane > j && vS == sj) vOld = cj;
                 }
+            }
         }
         auto S_ = [&](const int f) -> int { return (int)rdlane((uint32_t)vS, f); };
         auto C_ = [&](const int f) -> int { return (int)rdlane((uint32_t)vC, f); };
         auto OLD_ = [&](const int f) -> int { return (int)rdlane((uint32_t)vOld, f); };
         auto ORIG_ = [&](const int f) -> int { return (int)rdlane((uint32_t)vOrig, f); };
+        auto RD_ = [&](const double v, const int f) -> double { // lane f's value
+            return __hiloint2double((int)rdlane((uint32_t)__double2hiint(v), f), (int)rdlane((uint32_t)__double2loint(v), f));
+        };
         double e = 0.0, ew_part = 0.0, ew_uni = 0.0, dMu = 0.0;
-        if (total) e = univ_step_partial<OL, K1, DL>(smem, occ, lane, nfl, vS, vC, vQ0, vCum, total, s_dF, cshift);
+        double vdq = 0.0; // potential-field mode: lane f holds the charge change of flip f
+        if (total) {
+            if (nfl <= 2) e = univ_step_partial<OL, K1, DL, 2>(smem, occ, lane, nfl, vS, vC, vQ0, vCum, total, s_dF, cshift);
+            else e = univ_step_partial<OL, K1, DL, SMOLMC_MAX_STEP_FLIPS>(smem, occ, lane, nfl, vS, vC, vQ0, vCum, total, s_dF, cshift);
+        }
         if (has_ewald) {
             const int W = Q->K.ew_W;
             if (Q->K.ew_field) {
-                // O(1) per flip from the walker's potential field + the cross terms of the earlier flips
+                // O(1) per flip from the walker's potential field + the cross terms of the earlier flips; lane f works
+                // on flip f (one round trip for the whole step), the terms are added in flip order
                 const int ab = Q->K.ew_act_base, na = Q->K.ew_nact;
                 const double *phi = Q->K.ew_phi + (size_t)r * na;
-                for (int f = 0; f < nfl; ++f) {
-                    const int s = S_(f), newc = C_(f), oldc = OLD_(f);
-                    const double dq = Q->K.ew_qs[(size_t)s * W + newc] - Q->K.ew_qs[(size_t)s * W + oldc];
-                    double pot = __hip_atomic_load(&phi[s - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (int g = 0; g < f; ++g) {
+                const bool act = lane < nfl;
+                const int s = act ? vS : ab;
+                const double dq = act ? Q->K.ew_qs[(size_t)s * W + vC] - Q->K.ew_qs[(size_t)s * W + vOld] : 0.0;
+                double pot = __hip_atomic_load(&phi[s - ab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vdq = dq;
+#pragma unroll
+                for (int g = 0; g + 1 < SMOLMC_MAX_STEP_FLIPS; ++g)
+                    if (g + 1 < nfl) {
                         const int sg = S_(g);
-                        if (sg == s) continue;
-                        const double dqg = Q->K.ew_qs[(size_t)sg * W + C_(g)] - Q->K.ew_qs[(size_t)sg * W + OLD_(g)];
-                        pot = fma(dqg, Q->K.ew_G[(size_t)s * na + (sg - ab)], pot);
+                        const double dqg = RD_(dq, g);
+                        const double gg = Q->K.ew_G[(size_t)s * na + (sg - ab)];
+                        if (g < lane && sg != s) pot = fma(dqg, gg, pot);
                     }
-                    ew_uni += 2.0 * dq * pot + (Q->K.ew_dg[(size_t)s * W + newc] - Q->K.ew_dg[(size_t)s * W + oldc]);
-                }
+                const double term = act ? 2.0 * dq * pot + (Q->K.ew_dg[(size_t)s * W + vC] - Q->K.ew_dg[(size_t)s * W + vOld]) : 0.0;
+                for (int f = 0; f < nfl; ++f) ew_uni += RD_(term, f);
             } else {
                 for (int f = 0; f < nfl; ++f) {
                     const int s = S_(f), newc = C_(f), oldc = OLD_(f);
@@ -750,11 +767,10 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
                 }
             }
         }
-        if (has_mu)
-            for (int f = 0; f < nfl; ++f) {
-                const int s = S_(f);
-                dMu += Q->K.mu[(size_t)s * Q->K.mu_W + C_(f)] - Q->K.mu[(size_t)s * Q->K.mu_W + ORIG_(f)]; // ensemble.py:368-374
-            }
+        if (has_mu) {
+            const double term = lane < nfl ? Q->K.mu[(size_t)vS * Q->K.mu_W + vC] - Q->K.mu[(size_t)vS * Q->K.mu_W + vOrig] : 0.0; // ensemble.py:368-374
+            for (int f = 0; f < nfl; ++f) dMu += RD_(term, f);
+        }
         double dH = wave_sum(e);
         double dEw = 0.0;
         if (has_ewald) {
@@ -854,12 +870,12 @@ __global__ void __launch_bounds__(256, WPS) mc_univ_kernel(const UParams U_kerna
                 }
             }
             if (has_ewald && Q->K.ew_field) {
+                // (flip after flip through the tuned sweep: one fused pass over the field with the flips in an inner loop
+                // measured slower -- config 5 forced universal 73 -> 98 ms)
                 double *phi = Q->K.ew_phi + (size_t)r * Q->K.ew_nact;
-                const int W = Q->K.ew_W;
                 for (int f = 0; f < nfl; ++f) {
-                    const int s = S_(f);
-                    const double dq = Q->K.ew_qs[(size_t)s * W + C_(f)] - Q->K.ew_qs[(size_t)s * W + OLD_(f)];
-                    if (dq != 0.0) field_apply_global(Q->K, phi, lane, s, dq);
+                    const double dq = RD_(vdq, f);
+                    if (dq != 0.0) field_apply_global(Q->K, phi, lane, S_(f), dq);
                 }
             }
             if (TABLE && dir >= 0 && lane < Q->tf_d) {

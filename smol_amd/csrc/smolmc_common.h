@@ -542,6 +542,8 @@ struct URecE {
     double scale;    // size / ratio / J
     double nat0;     // natural parameter of feature `feat` (all a record of one function needs)
 };
+#define SMOLMC_UNIV_SCRATCH 128         // per-wave step scratch of the universal kernel: flips of a replayed step
+#define SMOLMC_UNIV_SCRATCH_TABLE 2464  // ... + TableFlip: counts, picks, masked weights (x2), a-priori factors, running sums
 #define SMOLMC_UNIV_DICT_RECS 64    // dictionaries in LDS: at most this many distinct records,
 #define SMOLMC_UNIV_DICT_TENS 1024  // ... tensor entries (doubles)
 #define SMOLMC_UNIV_DICT_NAT 128    // ... and features
