@@ -455,6 +455,16 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     for (int o = 0; o < t->n_orb; ++o) kmax = std::max(kmax, (int)t->orb_nfunc[o]);
     bool corr_kf = corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && class_rep.size() == 1;
     if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = corr_kf = false; // A/B switch (tests, profiling)
+    // (why a model does not get the lean tables, reported by smolmc_kernel_info: the first condition that fails)
+    h->lean_reason = class_rep.size() < 1 ? "no site with clusters"
+                     : class_rep.size() > 4 ? "more than 4 site classes"
+                     : aliased ? "aliased supercell (a cluster holds a site twice)"
+                     : (corr && !corr_k1 && !corr_kf) ? (class_rep.size() != 1 ? "several correlation functions per orbit on several site classes"
+                                                                               : "more than SMOLMC_LEAN_MAX_KF correlation functions per orbit")
+                     : N > 65535 ? "more than 65535 sites"
+                     : niter_max > 8 ? "more than 512 clusters per site"
+                     : need_mm > 3 ? "clusters of more than 4 sites"
+                     : num_ce_features(t) > 64 ? "more than 64 cluster features" : "";
     if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1 || corr_kf) && N <= 65535 &&
         niter_max <= 8 && need_mm <= 3 && num_ce_features(t) <= 64) {
         const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
@@ -630,7 +640,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.live = (uint32_t)K;
             L.w = corr_kf ? scale : t->ce_coefs[feat] * scale; // (KF: the coefficients are folded into the table)
             L.fs = scale;
-            if (dt.size() > 8000u) ok = false; // keep the LDS tables within budget
+            if (dt.size() > 8000u) { ok = false; h->lean_reason = "delta tables beyond 8000 entries (species^(cluster size - 1) x species^2 per distinct table)"; } // keep the LDS tables within budget
             double dmax = 0.0;
             {
                 const double *D = dt.data() + doff_of[key];
@@ -1402,6 +1412,15 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         const int wl_sum_mode = (cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
         const bool multi_wl_ok = !wl || (!table && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && cfg->wl_update_period < (1ll << 31) &&
                                          getenv("SMOLMC_NO_WL_MULTI") == nullptr);
+        // (why a model with lean tables runs neither lean family: the first condition that fails, for smolmc_kernel_info)
+        if (!lean && h->lean_tables)
+            h->lean_reason = h->lean_kf ? "several correlation functions per orbit with Wang-Landau, a bias, TableFlip, several sublattices or an Ewald term without field"
+                             : !multi_wl_ok ? "Wang-Landau with TableFlip or more than 63 features"
+                             : !multi_bias_ok ? "hyperplane bias, or a bias with TableFlip"
+                             : h->F > 64 ? "more than 64 features"
+                             : t->n_sublattices > 4 ? "more than 4 active sublattices"
+                             : (t->has_ewald && !kp.ew_field) ? "Ewald matrix that does not factorise into site charges (no potential field)"
+                             : (getenv("SMOLMC_FORCE_GENERAL") || getenv("SMOLMC_NO_LEAN_MULTI")) ? "environment override" : "";
         if (!lean && h->lean_tables && !h->lean_kf && multi_wl_ok && multi_bias_ok && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
@@ -1520,7 +1539,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             const size_t per_wave = base_wave + (phi_lds ? (size_t)kp.ew_nact * 8 : 0);
             int wpb = 0;
             layout(per_wave, wpb);
-            if (wpb == 0) ok = false;
+            if (wpb == 0 && ok) { ok = false; h->lean_reason = "walker state beyond the workgroup's LDS (multi-class layout)"; }
+            if (!ok && h->lean_reason.empty())
+                h->lean_reason = "sublattice layout (an active sublattice is not one site range of one class with codes 0..n-1, or per-site "
+                                 "chemical potentials / bias / charges differ inside a sublattice), or a flip table beyond 8 vectors / 16 dims";
             if (ok) {
                 if (t->has_mu && dev_upload(h, mu_rows.data(), 32, &lp.m_mu)) return bail(1);
                 if (t->has_ewald &&
@@ -1963,6 +1985,11 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
             snprintf(buf + used, (size_t)n - used, h->lean_multi_wl ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
         if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
             snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");
+        // why the model runs neither lean family (the first condition that failed at smolmc_create)
+        if (!h->lean && !h->lean_reason.empty() && strlen(buf) + h->lean_reason.size() + 16 < (size_t)n) {
+            strncat(buf, " | not lean: ", (size_t)n - strlen(buf) - 1);
+            strncat(buf, h->lean_reason.c_str(), (size_t)n - strlen(buf) - 1);
+        }
     }
     return 0;
 }

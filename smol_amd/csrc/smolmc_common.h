@@ -669,6 +669,7 @@ struct smolmc_handle {
     bool univ = false;
     bool general_ok = true;      // mc_kernel can run this model (else: why not)
     std::string general_reason;
+    std::string lean_reason;           // why the model runs neither lean family (first failing condition; empty: it does)
     int univ_wpb = 4;
     int max_step_flips = 2;      // most flips a native step of this handle makes (TableFlip: from the table)
 };

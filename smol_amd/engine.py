@@ -285,9 +285,10 @@ class Engine:
         return df, dh
 
     def kernel_info(self):
-        """Kernel family this handle dispatches to, e.g. 'lean nslot=2 mm=2 field=0 lds=19968'."""
-        buf = C.create_string_buffer(128)
-        self._chk(self._lib.smolmc_kernel_info(self._h, buf, 128))
+        """Kernel family this handle dispatches to, e.g. 'lean nslot=2 mm=2 field=0 lds=19968'; for a model on
+        ``mc_kernel`` / the universal kernel the string ends with ' | not lean: <the first condition that failed>'."""
+        buf = C.create_string_buffer(512)
+        self._chk(self._lib.smolmc_kernel_info(self._h, buf, 512))
         return buf.value.decode()
 
     def get_bias(self):

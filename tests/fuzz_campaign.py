@@ -6,7 +6,7 @@ dispatch overrides (auto / SMOLMC_FORCE_GENERAL / SMOLMC_FORCE_UNIVERSAL), each 
 engine and on the CPU oracle with the same Philox streams: occupancies, accept counters and
 Wang-Landau histograms bit-equal, enthalpies / features / bias / entropies to 1e-10.
 
-    python tests/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean|big|fast] [--out gpurun_out/fuzz.jsonl]
+    python tests/fuzz_campaign.py [--cases 200] [--seed 1] [--minutes 10] [--profile any|lean|big|fast|univ] [--out gpurun_out/fuzz.jsonl]
 
 The campaign itself is time-boxed and not collected by pytest (tests/test_gpu_fuzz_campaign.py runs a
 fixed handful of its cases); the oracle is the checker here, as everywhere under tests/.  A failing case
@@ -214,6 +214,8 @@ def build_case(rng, profile="any"):
         cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, st, **wl_kw)
         desc["update_period"] = up
     env = None if lean else pick(rng, [None, None, None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"])
+    if profile == "univ":  # the models of `any`, every one on the universal kernel (rewritten in round 5)
+        env = "SMOLMC_FORCE_UNIVERSAL"
     desc.update(walkers=R, sites=int(sc.num_sites), env=env)
     seeds = rng.integers(1, 2 ** 62, size=R).astype(np.uint64)
     temps = rng.uniform(400.0, 6000.0, size=R)
@@ -360,12 +362,12 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--profile", default="any", choices=["any", "lean", "big", "fast"])
+    ap.add_argument("--profile", default="any", choices=["any", "lean", "big", "fast", "univ"])
     args = ap.parse_args()
     seeds = [args.only] if args.only is not None else [args.seed * 1000003 + i for i in range(args.cases)]
     t0 = time.time()
     counts = {"ok": 0, "void": 0, "FAIL": 0}
-    kernels = {}
+    kernels, not_lean = {}, {}
     out = open(args.out, "w") if args.out else None
     for s in seeds:
         if time.time() - t0 > 60.0 * args.minutes:
@@ -380,12 +382,15 @@ def main():
             d = res["desc"]  # kernel family / step type (/ Wang-Landau): which kernels the campaign actually reached
             k = d["kernel_info"].split()[0] + "/" + d["step"] + ("/wl" if d["kernel"] == "wang-landau" else "")
             kernels[k] = kernels.get(k, 0) + 1
+            if " | not lean: " in d["kernel_info"] and not d.get("env"):  # (why the model left the lean families, unforced cases)
+                why = d["kernel_info"].split(" | not lean: ", 1)[1]
+                not_lean[why] = not_lean.get(why, 0) + 1
         if res["status"] == "FAIL" or args.only is not None:
             print(json.dumps(res, default=str), flush=True)
         if out:
             out.write(json.dumps(res, default=str) + "\n")
             out.flush()
-    summary = dict(cases=sum(counts.values()), **counts, kernels=kernels, seconds=round(time.time() - t0, 1),
+    summary = dict(cases=sum(counts.values()), **counts, kernels=kernels, not_lean=not_lean, seconds=round(time.time() - t0, 1),
                    first_seed=seeds[0])
     print(json.dumps(summary))
     if out:
