@@ -24,8 +24,9 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 // Ensemble.compute_feature_vector for one occupancy per block
 // (evaluator.pyx:121-209 x size; processor/ewald.py:128-145; ensemble.py:343-349)
+// ce_only: the cluster features alone (lazy cluster features: the scalar features are carried by the kernels)
 __global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const uint8_t *occ_all,
-                                                        double *out_all) {
+                                                        double *out_all, const int ce_only) {
     __shared__ double sh[8];
     const uint8_t *occ = occ_all + (size_t)blockIdx.x * T.Npad;
     double *out = out_all + (size_t)blockIdx.x * T.F;
@@ -52,6 +53,7 @@ __global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const
             }
         }
     }
+    if (ce_only) return;
     int f = T.Fce;
     if (T.has_ewald) {
         double s = 0;
@@ -453,20 +455,34 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     // tables follow it (mc_lean_kernel KF).
     int kmax = 1;
     for (int o = 0; o < t->n_orb; ++o) kmax = std::max(kmax, (int)t->orb_nfunc[o]);
-    bool corr_kf = corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && class_rep.size() == 1;
-    if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = corr_kf = false; // A/B switch (tests, profiling)
+    const bool cfg_wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
+    // (the KF instantiations are plain Metropolis flip / swap kernels of the single-class layout)
+    bool corr_kf = corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && class_rep.size() == 1 && !cfg_wl && !t->bias_type &&
+                   h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP && t->n_sublattices == 1 && niter_max <= 4 && num_ce_features(t) <= 64 &&
+                   getenv("SMOLMC_LAZY_FEATURES_ONLY") == nullptr;
+    // LAZY cluster features (round 5): every other Metropolis kernel of the lean families takes a model with several
+    // correlation functions per orbit as an interaction-mode model of the folded tensors E = sum_k coef_k ct_k --
+    // the decision needs nothing else -- and carries no cluster features at all: they are evaluated from the
+    // occupancy where somebody reads them (smolmc_get_state, sample rows; ensure_features / lazy_rows_kernel).
+    // Any number of functions per orbit and of cluster features; Wang-Landau needs the features on every step and
+    // stays on mc_kernel.
+    bool corr_lazy = corr && !corr_k1 && !corr_kf && !cfg_wl && getenv("SMOLMC_NO_LAZY_FEATURES") == nullptr;
+    if (getenv("SMOLMC_NO_LEAN_CORR")) corr_k1 = corr_kf = corr_lazy = false; // A/B switch (tests, profiling)
+    // ... and the same for models of more than 64 cluster features (the kernels' feature cells are one per lane)
+    const bool wide_lazy = !corr_lazy && !corr_kf && (!corr || corr_k1) && num_ce_features(t) > 64 && !cfg_wl &&
+                           getenv("SMOLMC_NO_LAZY_FEATURES") == nullptr;
+    const bool lazy_any = corr_lazy || wide_lazy;
     // (why a model does not get the lean tables, reported by smolmc_kernel_info: the first condition that fails)
     h->lean_reason = class_rep.size() < 1 ? "no site with clusters"
                      : class_rep.size() > 4 ? "more than 4 site classes"
                      : aliased ? "aliased supercell (a cluster holds a site twice)"
-                     : (corr && !corr_k1 && !corr_kf) ? (class_rep.size() != 1 ? "several correlation functions per orbit on several site classes"
-                                                                               : "more than SMOLMC_LEAN_MAX_KF correlation functions per orbit")
+                     : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? "several correlation functions per orbit under Wang-Landau"
                      : N > 65535 ? "more than 65535 sites"
                      : niter_max > 8 ? "more than 512 clusters per site"
                      : need_mm > 3 ? "clusters of more than 4 sites"
-                     : num_ce_features(t) > 64 ? "more than 64 cluster features" : "";
-    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1 || corr_kf) && N <= 65535 &&
-        niter_max <= 8 && need_mm <= 3 && num_ce_features(t) <= 64) {
+                     : (num_ce_features(t) > 64 && !lazy_any) ? "more than 64 cluster features (Wang-Landau or correlation functions on the KF kernels)" : "";
+    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1 || corr_kf || corr_lazy) && N <= 65535 &&
+        niter_max <= 8 && need_mm <= 3 && (num_ce_features(t) <= 64 || lazy_any)) {
         const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
         const int NCLS = (int)class_rep.size();
         const int MML = need_mm <= 2 ? 2 : 3;
@@ -569,10 +585,11 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                                    : t->interaction_tensors + t->orb_itensor_off[o];
             const int feat = corr ? t->orb_bit_id[o] : t->orb_id[o];
             const int K = corr_kf ? t->orb_nfunc[o] : 1;
-            std::vector<double> Efold; // KF: folded tensor sum_k coef_k ct_k (decision table source)
-            if (corr_kf) {
+            const int Kfold = (corr_kf || corr_lazy) ? t->orb_nfunc[o] : 1;
+            std::vector<double> Efold; // KF / lazy: folded tensor sum_k coef_k ct_k (decision table source)
+            if (corr_kf || corr_lazy) {
                 Efold.assign((size_t)Nt, 0.0);
-                for (int kk = 0; kk < K; ++kk)
+                for (int kk = 0; kk < Kfold; ++kk)
                     for (int i = 0; i < Nt; ++i) Efold[i] += t->ce_coefs[feat + kk] * T[(size_t)kk * Nt + i];
             }
             const int ss = st[k.p];
@@ -586,7 +603,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 int nb = 1;
                 for (int a = 0; a < I - 1; ++a) nb *= SMAX;
                 for (int tb = 0; tb < ntab; ++tb) {
-                const double *Tsrc = !corr_kf ? T : (tb == 0 ? Efold.data() : T + (size_t)(tb - 1) * Nt);
+                const double *Tsrc = corr_lazy ? Efold.data() : !corr_kf ? T : (tb == 0 ? Efold.data() : T + (size_t)(tb - 1) * Nt);
                 double *Dt = D.data() + (size_t)tb * tlen;
                 for (int b = 0; b < nb; ++b) {
                     // decode b into the species of the other members -> tensor base index
@@ -636,9 +653,9 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 uint32_t cs = 8u;
                 for (int m = 0; m < I - 1; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
             }
-            L.feat = (uint32_t)feat;
+            L.feat = lazy_any ? 0u : (uint32_t)feat; // (lazy: the kernels' feature cells are never read)
             L.live = (uint32_t)K;
-            L.w = corr_kf ? scale : t->ce_coefs[feat] * scale; // (KF: the coefficients are folded into the table)
+            L.w = (corr_kf || corr_lazy) ? scale : t->ce_coefs[feat] * scale; // (KF / lazy: the coefficients are folded into the table)
             L.fs = scale;
             if (dt.size() > 8000u) { ok = false; h->lean_reason = "delta tables beyond 8000 entries (species^(cluster size - 1) x species^2 per distinct table)"; } // keep the LDS tables within budget
             double dmax = 0.0;
@@ -656,6 +673,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         h->lp.fast_eps = 2.0 * sum_abs_max * ldexp(1.0, -19);
         h->lp.ktab8 = (uint32_t)tlen * 8u;
         h->lean_kf = corr_kf ? SMOLMC_LEAN_MAX_KF : 0;
+        h->lazy_tables = lazy_any;
         h->lp.nt8 = (uint32_t)NTP * 8u;
         h->lp.snt8 = (uint32_t)NTP * 8u * (uint32_t)SMAX;
         if (ok) {
@@ -1196,7 +1214,13 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     // lean-kernel eligibility (everything else runs mc_kernel)
     {
         // (lean Wang-Landau keeps per-bin feature SUMS: update_period 1 only, see WlParams)
-        bool lean = h->lean_tables && h->F <= 64 &&
+        // (lazy cluster features: the lean kernels see the scalar features only -- Ewald energy, chemical work)
+        const int nscal = (t->has_ewald ? 1 : 0) + (t->has_mu ? 1 : 0);
+        const int Fk = h->lazy_tables ? nscal : h->F;
+        if (h->lazy_tables) {
+            if (dev_alloc(h, (size_t)h->R * 2, &h->d_lazy_scal)) return bail(1);
+        }
+        bool lean = h->lean_tables && Fk <= 64 &&
                     (!wl || (cfg->wl_update_period == 1 && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
                              getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr && (getenv("SMOLMC_WL_PLAIN_ONLY") == nullptr || (!t->has_ewald && !t->has_mu)))) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
@@ -1260,7 +1284,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             if (const char *sc = getenv("SMOLMC_FAST_EPS_SCALE")) lp.fast_eps *= atof(sc);
             lp.occ = kp.occ;
             lp.enthalpy = kp.enthalpy;
-            lp.features = kp.features;
+            lp.features = h->lazy_tables ? h->d_lazy_scal : kp.features;
             lp.beta = kp.beta;
             lp.seeds = kp.seeds;
             lp.nsteps = kp.nsteps;
@@ -1269,8 +1293,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             lp.R = h->R;
             lp.N = h->N;
             lp.Npad = h->Npad;
-            lp.F = h->F;
-            lp.Fce = h->Fce;
+            lp.F = Fk;
+            lp.Fce = h->lazy_tables ? 0 : h->Fce;
             lp.sbase = sbase;
             lp.nact = nact;
             lp.ncodes = nc;
@@ -1417,11 +1441,11 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             h->lean_reason = h->lean_kf ? "several correlation functions per orbit with Wang-Landau, a bias, TableFlip, several sublattices or an Ewald term without field"
                              : !multi_wl_ok ? "Wang-Landau with TableFlip or more than 63 features"
                              : !multi_bias_ok ? "hyperplane bias, or a bias with TableFlip"
-                             : h->F > 64 ? "more than 64 features"
+                             : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
                              : (t->has_ewald && !kp.ew_field) ? "Ewald matrix that does not factorise into site charges (no potential field)"
                              : (getenv("SMOLMC_FORCE_GENERAL") || getenv("SMOLMC_NO_LEAN_MULTI")) ? "environment override" : "";
-        if (!lean && h->lean_tables && !h->lean_kf && multi_wl_ok && multi_bias_ok && h->F <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        if (!lean && h->lean_tables && !h->lean_kf && multi_wl_ok && multi_bias_ok && Fk <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
@@ -1570,9 +1594,9 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     lp.tf_sw = t->swap_weight;
                     lp.tf_ln_len = 0;
                 }
-                lp.occ = kp.occ; lp.enthalpy = kp.enthalpy; lp.features = kp.features; lp.beta = kp.beta;
+                lp.occ = kp.occ; lp.enthalpy = kp.enthalpy; lp.features = h->lazy_tables ? h->d_lazy_scal : kp.features; lp.beta = kp.beta;
                 lp.seeds = kp.seeds; lp.nsteps = kp.nsteps; lp.nacc = kp.nacc; lp.last_acc = kp.last_acc;
-                lp.R = h->R; lp.N = h->N; lp.Npad = h->Npad; lp.F = h->F; lp.Fce = h->Fce;
+                lp.R = h->R; lp.N = h->N; lp.Npad = h->Npad; lp.F = Fk; lp.Fce = h->lazy_tables ? 0 : h->Fce;
                 if (wl) {
                     lp.wl.L = h->L;
                     lp.wl.vmin = kp.wl_min; lp.wl.vmax = kp.wl_max; lp.wl.bin = kp.wl_bin;
@@ -1806,9 +1830,48 @@ extern "C" int smolmc_set_stream(smolmc_handle *h, void *stream) {
     return 0;
 }
 
-static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, double *d_out) {
-    hipLaunchKernelGGL(eval_full_kernel, dim3(nocc), dim3(256), 0, h->stream, h->rt, d_occ8, d_out);
+static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, double *d_out, int ce_only = 0) {
+    hipLaunchKernelGGL(eval_full_kernel, dim3(nocc), dim3(256), 0, h->stream, h->rt, d_occ8, d_out, ce_only);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- lazy cluster features (build_mc_tables) ---------------------------------------------------------------
+// The lean kernels of such a handle carry the scalar features only (d_lazy_scal, row stride nscal); the cluster
+// part of kp.features is evaluated from the occupancies where it is read.
+static bool is_lazy(const smolmc_handle *h) { return h->lazy_tables && h->lean; }
+static int lazy_nscal(const smolmc_handle *h) { return (h->rt.has_ewald ? 1 : 0) + (h->rt.has_mu ? 1 : 0); }
+// rows of full feature vectors [n][F] <-> rows of scalar features [n][nscal]
+__global__ void lazy_scalars_kernel(double *features, double *scal, size_t n, int F, int Fce, int nscal, int to_scal) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (size_t)nscal) return;
+    const size_t row = i / nscal;
+    const int j = (int)(i % nscal);
+    if (to_scal) scal[row * nscal + j] = features[row * F + Fce + j];
+    else features[row * F + Fce + j] = scal[row * nscal + j];
+}
+static int lazy_scalars(smolmc_handle *h, double *features, double *scal, size_t n, int to_scal) {
+    const int ns = lazy_nscal(h);
+    if (!ns || !n) return 0;
+    hipLaunchKernelGGL(lazy_scalars_kernel, dim3((unsigned)((n * ns + 255) / 256)), dim3(256), 0, h->stream, features, scal, n,
+                       h->F, h->Fce, ns, to_scal);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// kp.features current (before anybody reads them, and before a kernel that updates them incrementally -- mc_kernel /
+// the universal kernel replaying records the lean kernels do not take -- runs on a lazy handle)
+static int ensure_features(smolmc_handle *h) {
+    if (!is_lazy(h) || !h->ce_dirty) return 0;
+    TRY(launch_eval_full(h, h->kp.occ, h->R, h->kp.features, 1));
+    TRY(lazy_scalars(h, h->kp.features, h->d_lazy_scal, (size_t)h->R, 0));
+    h->ce_dirty = false;
+    return 0;
+}
+// ... and after such a kernel (or smolmc_set_state): the scalars the lean kernels continue from
+static int lazy_scalars_from_features(smolmc_handle *h) {
+    if (!is_lazy(h)) return 0;
+    TRY(lazy_scalars(h, h->kp.features, h->d_lazy_scal, (size_t)h->R, 1));
+    h->ce_dirty = false;
     return 0;
 }
 
@@ -1913,6 +1976,7 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
     hipLaunchKernelGGL(dot_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream,
                        kp.features, h->d_natural, kp.enthalpy, (int)R, h->F);
     HIPCHK(hipGetLastError());
+    TRY(lazy_scalars_from_features(h));
     if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && reset_aux) {
         const size_t RL = R * h->L;
         HIPCHK(hipMemsetAsync(kp.wl_entropy, 0, RL * 8, h->stream));
@@ -1983,6 +2047,7 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
                      h->ew_gx_dims[2]);
         else if (h->lean && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && used + 8 < (size_t)n)
             snprintf(buf + used, (size_t)n - used, h->lean_multi_wl ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
+        if (is_lazy(h) && strlen(buf) + 16 < (size_t)n) strncat(buf, " lazy-features", (size_t)n - strlen(buf) - 1);
         if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
             snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");
         // why the model runs neither lean family (the first condition that failed at smolmc_create)
@@ -2022,7 +2087,11 @@ extern "C" int smolmc_get_state(smolmc_handle *h, int32_t *occ, double *features
         hipFree(d32);
         if (e != hipSuccess) return fail(std::string("occupancy download: ") + hipGetErrorString(e));
     }
-    if (features) HIPCHK(hipMemcpy(features, kp.features, R * h->F * 8, hipMemcpyDeviceToHost));
+    if (features) {
+        TRY(ensure_features(h));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(features, kp.features, R * h->F * 8, hipMemcpyDeviceToHost));
+    }
     if (enthalpy) HIPCHK(hipMemcpy(enthalpy, kp.enthalpy, R * 8, hipMemcpyDeviceToHost));
     if (n_accepted) HIPCHK(hipMemcpy(n_accepted, kp.nacc, R * 8, hipMemcpyDeviceToHost));
     if (n_steps) HIPCHK(hipMemcpy(n_steps, kp.nsteps, R * 8, hipMemcpyDeviceToHost));
@@ -2242,13 +2311,14 @@ static int run_steps(smolmc_handle *h, int64_t nsteps, const SampleBufs &smp) {
             if (smp.every) {
                 const size_t rows = (size_t)(done / smp.every) * h->R;
                 lp.smp.H += rows;
-                lp.smp.feat += rows * h->F;
+                lp.smp.feat += rows * (size_t)lp.F; // (lazy cluster features: rows of the scalar features)
                 lp.smp.acc += rows;
                 if (lp.smp.occ) lp.smp.occ += rows * h->Npad;
             }
             if (int rc = launch_lean(h, lp, n)) return rc;
             done += n;
         }
+        if (is_lazy(h)) h->ce_dirty = true;
         return 0;
     }
     KParams kp = h->kp;
@@ -2345,6 +2415,16 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
         sl.o_wlf = take(rows * L * F * 8);
     }
     sl.o_occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? take(rows * h->Npad) : 0;
+    // lazy cluster features, rows recorded in-kernel: the kernels write rows of scalar features and the occupancy of
+    // every sample; the cluster features of the rows are evaluated from those when the launch is through.  What the
+    // caller did not ask for sits behind the part of the arena that is downloaded.
+    const bool lazy_rows = is_lazy(h) && !(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL));
+    size_t download = at, o_scal = 0, o_occ_int = sl.o_occ;
+    if (lazy_rows) {
+        download = at;
+        o_scal = take(rows * (size_t)std::max(1, lazy_nscal(h)) * 8);
+        if (!(flags & SMOLMC_SAMPLE_OCCUPANCY)) o_occ_int = take(rows * h->Npad);
+    }
     // the slot's previous block must have left the device (and its pinned mirror is about to be reused: a
     // block the caller never fetched is dropped here)
     if (sl.state != 0) HIPCHK(hipEventSynchronize(sl.copy_done));
@@ -2357,7 +2437,7 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
         HIPCHK(hipHostMalloc((void **)&sl.hst, at, hipHostMallocDefault));
         sl.cap = at;
     }
-    sl.used = at;
+    sl.used = lazy_rows ? download : at;
     sl.n = nsamples;
     sl.flags = flags;
     sl.state = 0;
@@ -2365,11 +2445,16 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
     memset(&smp, 0, sizeof(smp));
     smp.every = thin_by;
     smp.H = (double *)(sl.d + sl.o_H);
-    smp.feat = (double *)(sl.d + sl.o_feat);
+    smp.feat = (double *)(sl.d + (lazy_rows ? o_scal : sl.o_feat));
     smp.acc = sl.d + sl.o_acc;
-    smp.occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? sl.d + sl.o_occ : nullptr;
+    smp.occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) || lazy_rows ? sl.d + o_occ_int : nullptr;
     if (!(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL))) {
         TRY(run_steps(h, nsamples * thin_by, smp)); // the kernels record the rows themselves, one launch
+        if (lazy_rows) {
+            if (rows > 0x7fffffffull) return fail("lazy cluster features: more than 2^31 sample rows in one block");
+            TRY(launch_eval_full(h, sl.d + o_occ_int, (int)rows, (double *)(sl.d + sl.o_feat), 1));
+            TRY(lazy_scalars(h, (double *)(sl.d + sl.o_feat), (double *)(sl.d + o_scal), rows, 0));
+        }
     } else {
         SampleBufs none;
         memset(&none, 0, sizeof(none));
@@ -2388,6 +2473,7 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
         A.R = h->R; A.F = h->F; A.L = h->L; A.Npad = h->Npad;
         for (int64_t j = 0; j < nsamples; ++j) {
             TRY(run_steps(h, thin_by, none));
+            TRY(ensure_features(h)); // (lazy cluster features: the snapshot reads kp.features)
             A.mf_is_sums = h->wl_sums ? 1 : 0; // (the representation the launch left the per-bin statistics in)
             hipLaunchKernelGGL(sample_snapshot_kernel, dim3((unsigned)h->R), dim3(256), 0, h->stream, A, (long long)j);
             HIPCHK(hipGetLastError());
@@ -2599,6 +2685,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
         lp.rp_steps = d_steps; lp.rp_u = d_u; lp.rp_acc = d_acc; lp.rp_H = d_H; lp.rp_err = d_err;
         lp.rp_lp = d_lp; lp.rp_lp_out = d_lpo;
         if (!rc) rc = smolmc_launch_lean_replay(h, lp);
+        if (is_lazy(h)) h->ce_dirty = true;
         if (!rc) e = hipStreamSynchronize(h->stream);
         int bad = 0;
         if (!rc && e == hipSuccess) e = hipMemcpy(&bad, d_err, 4, hipMemcpyDeviceToHost);
@@ -2610,6 +2697,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
                               "the walkers have been advanced -- set the state again");
     } else if (e == hipSuccess && general_replay) {
         rc = wl_set_representation(h, h->kp.wl_sum_mode != 0);
+        if (!rc) rc = ensure_features(h); // (mc_kernel updates the features incrementally)
         KParams kp = h->kp;
         kp.steps_to_run = nsteps;
         kp.rp_steps = d_steps;
@@ -2617,15 +2705,18 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
         kp.rp_acc = d_acc;
         kp.rp_H = d_H;
         if (!rc) rc = launch_mc(h, kp, 1);
+        if (!rc) rc = lazy_scalars_from_features(h);
         if (!rc) e = hipStreamSynchronize(h->stream);
     } else if (e == hipSuccess) {
         rc = wl_set_representation(h, false);
+        if (!rc) rc = ensure_features(h); // (the universal kernel updates the features incrementally)
         UParams up = univ_block_of(h);
         up.K.steps_to_run = nsteps;
         memset(&up.K.smp, 0, sizeof(up.K.smp));
         up.K.rp_steps = d_steps; up.K.rp_u = d_u; up.K.rp_acc = d_acc; up.K.rp_H = d_H;
         up.rp_lp = d_lp; up.rp_lp_out = d_lpo; up.rp_err = d_err;
         if (!rc) rc = smolmc_launch_univ(h, up, 1);
+        if (!rc) rc = lazy_scalars_from_features(h);
         if (!rc) e = hipStreamSynchronize(h->stream);
         int bad = 0;
         if (!rc && e == hipSuccess) e = hipMemcpy(&bad, d_err, 4, hipMemcpyDeviceToHost);

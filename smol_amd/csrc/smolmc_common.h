@@ -669,6 +669,11 @@ struct smolmc_handle {
     bool univ = false;
     bool general_ok = true;      // mc_kernel can run this model (else: why not)
     std::string general_reason;
+    // lazy cluster features (engine.hip, build_mc_tables): the lean kernels of this handle carry the scalar features
+    // only (d_lazy_scal [R][2]: Ewald energy, chemical work); the cluster part of kp.features is evaluated from the
+    // occupancies when it is read
+    bool lazy_tables = false, lazy = false, ce_dirty = false;
+    double *d_lazy_scal = nullptr;
     std::string lean_reason;           // why the model runs neither lean family (first failing condition; empty: it does)
     int univ_wpb = 4;
     int max_step_flips = 2;      // most flips a native step of this handle makes (TableFlip: from the table)

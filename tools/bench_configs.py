@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--temperature", type=float, default=0.0)
     ap.add_argument("--ladder", default="", help="config 5: lowest,highest temperature of the exchange ladder")
+    ap.add_argument("--sampled", type=int, default=0, help="also time blocks of the device ring with this thin_by (wall clock, "
+                                                            "features recorded, no occupancies): what lazy cluster features cost")
     a = ap.parse_args()
     kw = {}
     if a.ladder:
@@ -70,12 +72,24 @@ def main():
     s1 = eng.get_state(occupancy=False)
     k_ms = float(np.mean(ms))
     steps = R * mc
+    sampled = None
+    if a.sampled:
+        import time
+
+        ns = max(1, mc // a.sampled)
+        eng.run_sampled(ns, a.sampled, occupancy=False)
+        t0 = time.perf_counter()
+        for _ in range(a.launches):
+            eng.run_sampled(ns, a.sampled, occupancy=False)
+        dt = (time.perf_counter() - t0) / a.launches
+        sampled = dict(thin_by=a.sampled, samples_per_block=ns, wall_ms=dt * 1e3, mc_steps_per_s=R * ns * a.sampled / dt)
     print(json.dumps(dict(
         config=wl.name, kernel=eng.kernel_info(), replicas=R, mc_steps_per_launch=mc, kernel_ms=k_ms,
         mc_steps_per_s=steps / (k_ms * 1e-3), flips_per_s=wl.flips_per_step * steps / (k_ms * 1e-3),
         us_per_step_per_walker=k_ms * 1e3 / mc,
         acceptance=float((s1["n_accepted"] - s0["n_accepted"]).sum()) / (a.launches * steps),
         exchange_acceptance_mean=None if rex is None else float(rex.acceptance.mean()),
+        sampled=sampled,
     )))
 
 
