@@ -26,34 +26,76 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // (evaluator.pyx:121-209 x size; processor/ewald.py:128-145; ensemble.py:343-349)
 // ce_only: the cluster features alone (lazy cluster features: the scalar features are carried by the kernels)
 __global__ void __launch_bounds__(256) eval_full_kernel(const RefTables T, const uint8_t *occ_all,
-                                                        double *out_all, const int ce_only) {
+                                                        double *out_all, const int ce_only, const int nocc, const int M) {
     __shared__ double sh[8];
-    const uint8_t *occ = occ_all + (size_t)blockIdx.x * T.Npad;
-    double *out = out_all + (size_t)blockIdx.x * T.F;
-    if (threadIdx.x == 0) out[0] = (T.corr_mode ? 1.0 : T.offset) * (double)T.P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char eval_smem[];
+    // Round 5 (this kernel is on the sampling path of handles with lazy cluster features): a block evaluates M <= 4
+    // occupancies at once -- the index rows of an orbit, 15 MB for config 2, are read once for the M of them -- from
+    // copies in LDS (M x Npad bytes of dynamic LDS; M = 0: one occupancy, read through the caches).
+    const int m_eff = M > 0 ? M : 1;
+    const int first = blockIdx.x * m_eff;
+    const uint8_t *gocc = occ_all + (size_t)first * T.Npad;
+    if (M > 0) {
+        for (int m = 0; m < M; ++m) {
+            const int q = first + m < nocc ? m : 0; // (blocks past the end repeat their first occupancy)
+            const uint4 *src = (const uint4 *)(gocc + (size_t)q * T.Npad);
+            uint4 *dst = (uint4 *)(eval_smem + (size_t)m * T.Npad);
+            for (int i = threadIdx.x; i < T.Npad / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    const uint8_t *occ = M > 0 ? (const uint8_t *)eval_smem : gocc;
+    const int ostr = M > 0 ? T.Npad : 0; // occupancy m at occ + m * ostr
+    if (threadIdx.x < m_eff && first + (int)threadIdx.x < nocc)
+        out_all[(size_t)(first + threadIdx.x) * T.F] = (T.corr_mode ? 1.0 : T.offset) * (double)T.P;
     for (int n = 0; n < T.n_orb; ++n) {
         const int I = T.orb_nsites[n], K = T.corr_mode ? T.orb_nfunc[n] : 1;
         const int Nt = T.orb_tensor_len[n];
         const int *st = T.tensor_indices + T.orb_stride_off[n];
         const int *ind = T.full_idx + T.full_off[n];
         const long long J = (T.full_off[n + 1] - T.full_off[n]) / I;
-        for (int k = 0; k < K; ++k) {
-            const double *t = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] + (size_t)k * Nt
-                                          : T.interaction_tensors + T.orb_itensor_off[n];
-            double p = 0;
+        const double *t0 = T.corr_mode ? T.corr_tensors + T.orb_ctensor_off[n] : T.interaction_tensors + T.orb_itensor_off[n];
+        // the tensor index of a cluster once for up to four functions (the sums of a function are those of the
+        // function-by-function loop: same clusters per thread, same order)
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            double p[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[m][k] = 0.0;
+            const int kn = K - k0 < 4 ? K - k0 : 4;
             for (long long j = threadIdx.x; j < J; j += blockDim.x) {
-                int index = 0;
-                for (int i = 0; i < I; ++i) index += st[i] * (int)occ[ind[j * I + i]];
-                p += t[index];
+                int index[4] = {0, 0, 0, 0};
+                for (int i = 0; i < I; ++i) {
+                    const int x = ind[j * I + i], sti = st[i];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (m < m_eff) index[m] += sti * (int)occ[(size_t)m * ostr + x];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (m < m_eff)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < kn) p[m][k] += t0[(size_t)(k0 + k) * Nt + index[m]];
             }
-            p = block_sum(p, sh);
-            if (threadIdx.x == 0) {
-                const int o = T.corr_mode ? T.orb_bit_id[n] + k : T.orb_id[n];
-                out[o] = p / (double)J * (double)T.P;
-            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (m < m_eff)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < kn) {
+                            const double v = block_sum(p[m][k], sh);
+                            if (threadIdx.x == 0 && first + m < nocc) {
+                                const int o = T.corr_mode ? T.orb_bit_id[n] + k0 + k : T.orb_id[n];
+                                out_all[(size_t)(first + m) * T.F + o] = v / (double)J * (double)T.P;
+                            }
+                        }
         }
     }
     if (ce_only) return;
+    // (the scalar features below: launches with one occupancy per block)
+    double *out = out_all + (size_t)first * T.F;
     int f = T.Fce;
     if (T.has_ewald) {
         double s = 0;
@@ -476,7 +518,8 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     h->lean_reason = class_rep.size() < 1 ? "no site with clusters"
                      : class_rep.size() > 4 ? "more than 4 site classes"
                      : aliased ? "aliased supercell (a cluster holds a site twice)"
-                     : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? "several correlation functions per orbit under Wang-Landau"
+                     : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? (cfg_wl ? "several correlation functions per orbit under Wang-Landau"
+                                                                                : "environment override (SMOLMC_NO_LEAN_CORR / SMOLMC_NO_LAZY_FEATURES)")
                      : N > 65535 ? "more than 65535 sites"
                      : niter_max > 8 ? "more than 512 clusters per site"
                      : need_mm > 3 ? "clusters of more than 4 sites"
@@ -1831,7 +1874,13 @@ extern "C" int smolmc_set_stream(smolmc_handle *h, void *stream) {
 }
 
 static int launch_eval_full(smolmc_handle *h, const uint8_t *d_occ8, int nocc, double *d_out, int ce_only = 0) {
-    hipLaunchKernelGGL(eval_full_kernel, dim3(nocc), dim3(256), 0, h->stream, h->rt, d_occ8, d_out, ce_only);
+    // occupancies per block (see the kernel): four when the copies fit 60 KB of LDS and only the cluster features are
+    // wanted, one with the scalar features (their loops take one occupancy), none staged beyond 60 KB
+    int M = h->Npad <= 60 * 1024 ? 1 : 0;
+    if (ce_only && M && nocc >= 8) M = std::min(4, (60 * 1024) / h->Npad);
+    const int per = M > 0 ? M : 1;
+    hipLaunchKernelGGL(eval_full_kernel, dim3((unsigned)((nocc + per - 1) / per)), dim3(256), (size_t)M * h->Npad, h->stream, h->rt, d_occ8,
+                       d_out, ce_only, nocc, M);
     HIPCHK(hipGetLastError());
     return 0;
 }
