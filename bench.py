@@ -525,6 +525,25 @@ def _time_other_configs(device, rank, world, red_dev, out):
             out.append(dict(config="config11: LiNiO2 under Wang-Landau", error=f"{type(e).__name__}: {e}"[:300]))
 
     if world == 1:
+        # the backstop kernel on the headline workload (round-5 review item 6) and the lazy-feature path on config 13
+        for env, build, key, note in (
+            ("SMOLMC_FORCE_UNIVERSAL", lambda: workloads.config2(mc=2000), "config2_universal",
+             "config 2 forced onto mc_univ_kernel (the backstop: TableFlip x Wang-Landau / biases, any cluster and class count, "
+             "HBM-resident occupancies); VALU-bound at four waves per SIMD (DESIGN.md 4.8)"),
+            ("SMOLMC_LAZY_FEATURES_ONLY", lambda: workloads.config13(mc=3456), "config13_lazy",
+             "config 13 with lazy cluster features (DESIGN.md 4.9): decisions from the folded tensors on the plain lean kernel, "
+             "correlation functions evaluated where the trace is read; kernel-only figure"),
+        ):
+            os.environ[env] = "1"
+            try:
+                wlx = build()
+                info, first, _ = _engine_run(Engine, wlx, device, clock, 5, wlx.mc_per_launch)
+            finally:
+                del os.environ[env]
+            wlx.name = key + ": " + wlx.name
+            record(wlx, info, first, None, issue_roof(key, note), wlx.n_walkers, launches=5)
+
+    if world == 1:
         # config 3 on the LITERAL formulation of ewald.pyx:38-58 (two rows of the 382 MB matrix gathered per
         # proposal; what a matrix that does not factorise takes): the one HBM-bound kernel of the engine
         os.environ["SMOLMC_DENSE_EWALD"] = "1"
