@@ -1287,8 +1287,10 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 for (int c = 0; c < nc; ++c)
                     if (t->mu_table[(size_t)(sbase + i) * t->mu_width + c] != mu_row[c]) lean = false;
         }
-        std::vector<double> bias_pair(64, 0.0);
-        if (lean && t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE) lean = false; // general kernel
+        // (pair tables of the bias: [row][old * 8 + new], one row for Fugacity / SquareCharge, bias_rows rows for
+        // SquareHyperplaneBias -- on the lean kernels since round 5)
+        const int brows_l = t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE ? t->bias_rows : 1;
+        std::vector<double> bias_pair((size_t)64 * SMOLMC_MAX_BIAS_ROWS, 0.0);
         // the table kernels are Metropolis kernels of at most 8 flip vectors: Wang-Landau TableFlip
         // and larger tables take the universal kernel
         if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP && (wl || t->n_flip_vectors > 8)) lean = false;
@@ -1297,15 +1299,18 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         if (lean && t->bias_type) {
             // the bias row must be the same on every active site (it is defined per sublattice)
             const int W = t->bias_width;
-            for (int i = 0; lean && i < nact; ++i)
-                for (int c = 0; c < nc; ++c)
-                    if (h->bias_host[(size_t)(sbase + i) * W + c] != h->bias_host[(size_t)sbase * W + c]) lean = false;
+            for (int k = 0; k < brows_l; ++k) {
+                const double *tabk = h->bias_host.data() + (size_t)k * t->num_sites * W;
+                for (int i = 0; lean && i < nact; ++i)
+                    for (int c = 0; c < nc; ++c)
+                        if (tabk[(size_t)(sbase + i) * W + c] != tabk[(size_t)sbase * W + c]) lean = false;
+                for (int o = 0; lean && o < nc; ++o)
+                    for (int n = 0; n < nc; ++n) {
+                        const double a = tabk[(size_t)sbase * W + n], b = tabk[(size_t)sbase * W + o];
+                        bias_pair[(size_t)k * 64 + o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
+                    }
+            }
             if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) lean = false;
-            for (int o = 0; lean && o < nc; ++o)
-                for (int n = 0; n < nc; ++n) {
-                    const double a = h->bias_host[(size_t)sbase * W + n], b = h->bias_host[(size_t)sbase * W + o];
-                    bias_pair[o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
-                }
         }
         if (lean) {
             LeanParams &lp = h->lp;
@@ -1316,6 +1321,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 lp.bias_pen = t->bias_penalty;
                 lp.bias = kp.bias;
                 lp.charge = kp.charge;
+                lp.bias_rows = brows_l;
+                lp.bias_row_stride = 64;
             }
             if (t->has_mu) { // the mu delta of a step joins the float32 sum (<= 2 flips * 2 |mu|)
                 double mmax = 0.0;
@@ -1471,8 +1478,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         // (MCBias: Fugacity / SquareCharge with flips or swaps; the hyperplane bias and biased
         // TableFlip take the general kernel)
-        const bool multi_bias_ok = !t->bias_type || (t->bias_type != SMOLMC_BIAS_SQUARE_HYPERPLANE &&
-                                                     cfg->step_type != SMOLMC_STEP_TABLE_FLIP);
+        const bool multi_bias_ok = !t->bias_type || cfg->step_type != SMOLMC_STEP_TABLE_FLIP;
         // Wang-Landau on this layout (round 5; mc_lean_multi_kernel<..., WLK>): any number of classes the
         // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves; the
         // Wang-Landau TableFlip stays on the universal kernel.  SMOLMC_NO_WL_MULTI: A/B switch.
@@ -1483,7 +1489,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
         if (!lean && h->lean_tables)
             h->lean_reason = h->lean_kf ? "several correlation functions per orbit with Wang-Landau, a bias, TableFlip, several sublattices or an Ewald term without field"
                              : !multi_wl_ok ? "Wang-Landau with TableFlip or more than 63 features"
-                             : !multi_bias_ok ? "hyperplane bias, or a bias with TableFlip"
+                             : !multi_bias_ok ? "a bias term with TableFlip"
                              : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
                              : (t->has_ewald && !kp.ew_field) ? "Ewald matrix that does not factorise into site charges (no potential field)"
@@ -1493,21 +1499,22 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
             bool ok = true;
-            std::vector<double> mu_rows(32, 0.0), q_rows(32, 0.0), dg_rows(32, 0.0), bias_pairs(256, 0.0);
+            std::vector<double> mu_rows(32, 0.0), q_rows(32, 0.0), dg_rows(32, 0.0), bias_pairs((size_t)256 * SMOLMC_MAX_BIAS_ROWS, 0.0);
             double cum = 0.0, mmax = 0.0;
             for (int k = 0; k < ns && ok; ++k) {
                 const int64_t a0 = t->sub_site_ptr[k], a1 = t->sub_site_ptr[k + 1];
                 const int na = (int)(a1 - a0), ncod = (int)(t->sub_code_ptr[k + 1] - t->sub_code_ptr[k]);
                 const int sb = t->sub_active_sites[a0];
-                if (na <= 0 || ncod < 2 || ncod > 8) ok = false;
+                auto no = [&](const char *why) { if (ok) h->lean_reason = why; ok = false; };
+                if (na <= 0 || ncod < 2 || ncod > 8) no("an active sublattice of fewer than 2 or more than 8 species");
                 for (int i = 0; ok && i < na; ++i)
-                    if (t->sub_active_sites[a0 + i] != sb + i) ok = false;
+                    if (t->sub_active_sites[a0 + i] != sb + i) no("the active sites of a sublattice are not one site range (Ensemble.make_tables(contiguous=True) relabels them)");
                 for (int c = 0; ok && c < ncod; ++c)
-                    if (t->sub_codes[t->sub_code_ptr[k] + c] != c) ok = false;
+                    if (t->sub_codes[t->sub_code_ptr[k] + c] != c) no("a sublattice whose species codes are not 0 .. n-1 (split by species)");
                 const int cls = ok ? h->site_class_host[sb] : 255;
-                if (cls == 255) ok = false;
+                if (ok && cls == 255) no("an active sublattice without clusters");
                 for (int i = 0; ok && i < na; ++i)
-                    if (h->site_class_host[sb + i] != cls) ok = false; // classes == sublattices
+                    if (h->site_class_host[sb + i] != cls) no("sites of one sublattice in different site classes (cluster environments)"); // classes == sublattices
                 if (!ok) break;
                 lp.m_sbase[k] = sb; lp.m_nact[k] = na; lp.m_ncodes[k] = ncod; lp.m_cls[k] = cls;
                 cum += t->sub_probs[k];
@@ -1525,14 +1532,17 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                 if (t->bias_type) { // one bias row per sublattice (it is defined per sublattice)
                     const int W = t->bias_width;
                     if (W < ncod) ok = false;
-                    for (int i = 0; ok && i < na; ++i)
-                        for (int c = 0; c < ncod; ++c)
-                            if (h->bias_host[(size_t)(sb + i) * W + c] != h->bias_host[(size_t)sb * W + c]) ok = false;
-                    for (int o = 0; ok && o < ncod; ++o)
-                        for (int n = 0; n < ncod; ++n) {
-                            const double a = h->bias_host[(size_t)sb * W + n], b = h->bias_host[(size_t)sb * W + o];
-                            bias_pairs[k * 64 + o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
-                        }
+                    for (int rw = 0; rw < brows_l; ++rw) { // (rows of a hyperplane bias: [row][sublattice][old * 8 + new])
+                        const double *tabk = h->bias_host.data() + (size_t)rw * t->num_sites * W;
+                        for (int i = 0; ok && i < na; ++i)
+                            for (int c = 0; c < ncod; ++c)
+                                if (tabk[(size_t)(sb + i) * W + c] != tabk[(size_t)sb * W + c]) ok = false;
+                        for (int o = 0; ok && o < ncod; ++o)
+                            for (int n = 0; n < ncod; ++n) {
+                                const double a = tabk[(size_t)sb * W + n], b = tabk[(size_t)sb * W + o];
+                                bias_pairs[(size_t)rw * 256 + k * 64 + o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
+                            }
+                    }
                 }
                 if (t->has_ewald) {
                     if (kp.ew_W > 8 || sb < kp.ew_act_base || sb + na > kp.ew_act_base + kp.ew_nact) ok = false;
@@ -1617,6 +1627,8 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                     return bail(1);
                 if (t->bias_type) {
                     if (dev_upload(h, bias_pairs.data(), bias_pairs.size(), &lp.bias_pair)) return bail(1);
+                    lp.bias_rows = brows_l;
+                    lp.bias_row_stride = 256;
                     lp.bias_type = t->bias_type;
                     lp.bias_pen = t->bias_penalty;
                     lp.bias = kp.bias;

@@ -548,7 +548,12 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     // MCBias (separate instantiations, lean_bias_n*.hip: even a never-taken runtime branch costs
     // the unbiased kernel 10 %): biased walkers always take the exact decision path
     const int btype = BIAS ? P.bias_type : 0;
-    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
+    // running sums of the quadratic biases: the net charge (SquareChargeBias) / A_k . n - b_k of every hyperplane
+    // (SquareHyperplaneBias, bias.py:290-366: up to SMOLMC_MAX_BIAS_ROWS rows, on the lean kernels since round 5)
+    const int brows = (btype && btype != SMOLMC_BIAS_FUGACITY) ? P.bias_rows : 0;
+    double bias_acc = 0.0, chg[SMOLMC_MAX_BIAS_ROWS];
+#pragma unroll
+    for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) chg[k] = k < brows ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] : 0.0;
     // Metropolis without Ewald: the accept decision is pre-tested on a float32 wave sum of
     // the lane partials against thresholds widened by a rigorous error bound (P.fast_eps);
     // only the rare undecided step pays for the float64 reduction, so decisions are exactly
@@ -957,16 +962,25 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
         double dH = 0.0, dEw = 0.0;
         double wl_nbq = 0.0; // WL: bin coordinate of the proposed enthalpy
         // compute_bias_change against the original occupancy (kernel/base.py:307-311; bias.py)
-        double dB = 0.0, dQ = 0.0;
+        double dB = 0.0, dQ[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
         if (btype && nfl >= 1) {
-            double x = P.bias_pair[o1 * 8 + n1];
-            if (nfl == 2) x += P.bias_pair[o2 * 8 + n2];
             if (btype == SMOLMC_BIAS_FUGACITY) {
-                dB = x;
+                dB = P.bias_pair[o1 * 8 + n1];
+                if (nfl == 2) dB += P.bias_pair[o2 * 8 + n2];
             } else {
-                dQ = x;
-                const double cn = charge + dQ;
-                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+                double sq_new = 0.0, sq_old = 0.0;
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                    if (k < brows) {
+                        const double *bp = P.bias_pair + k * P.bias_row_stride;
+                        double x = bp[o1 * 8 + n1];
+                        if (nfl == 2) x += bp[o2 * 8 + n2];
+                        dQ[k] = x;
+                        const double cn = chg[k] + x;
+                        sq_old += chg[k] * chg[k];
+                        sq_new += cn * cn;
+                    }
+                dB = -P.bias_pen * sq_new - (-P.bias_pen * sq_old);
             }
         }
 #ifdef SMOLMC_EXP_F32TAB
@@ -1089,7 +1103,8 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
             acc_mu += dMu;
             acc_ew += dEw;
             bias_acc += dB;
-            charge += dQ;
+#pragma unroll
+            for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) chg[k] += dQ[k];
             if (!FAST) H += dH;
             if (!SELACC) nacc_add++;
         };
@@ -1285,7 +1300,9 @@ __launch_bounds__(256) mc_lean_kernel(const LeanParams P) {
     }
     if (btype && lane == 0) {
         P.bias[r] += bias_acc;
-        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
+#pragma unroll
+        for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+            if (k < brows) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] = chg[k];
     }
     if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
     if (lane == 0) {

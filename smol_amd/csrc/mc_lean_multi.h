@@ -167,7 +167,11 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     double acc_mu = 0.0, acc_ew = 0.0;
     constexpr bool FAST = !HAS_EW && !BIAS && !WLK; // float32 accept pre-test (Ewald / biased / Wang-Landau variants take the exact path)
     const int btype = BIAS ? P.bias_type : 0;
-    double bias_acc = 0.0, charge = btype == SMOLMC_BIAS_SQUARE_CHARGE ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] : 0.0;
+    // (running sums of the quadratic biases, one per row: see mc_lean_kernel)
+    const int brows = (btype && btype != SMOLMC_BIAS_FUGACITY) ? P.bias_rows : 0;
+    double bias_acc = 0.0, chg[SMOLMC_MAX_BIAS_ROWS];
+#pragma unroll
+    for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) chg[k] = k < brows ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] : 0.0;
     float thr_lo = 0.0f, thr_hi = 0.0f;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
@@ -622,17 +626,26 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         if (!ONE) __builtin_amdgcn_s_setprio(3);
 #endif
         // compute_bias_change against the original occupancy (kernel/base.py:307-311; bias.py)
-        double dB = 0.0, dQ = 0.0;
+        double dB = 0.0, dQ[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
         if (BIAS && nfl >= 1) {
-            const double *bp = P.bias_pair + sub1 * 64;
-            double x = bp[o1 * 8 + n1];
-            if (nfl == 2) x += bp[o2 * 8 + n2];
             if (btype == SMOLMC_BIAS_FUGACITY) {
-                dB = x;
+                const double *bp = P.bias_pair + sub1 * 64;
+                dB = bp[o1 * 8 + n1];
+                if (nfl == 2) dB += bp[o2 * 8 + n2];
             } else {
-                dQ = x;
-                const double cn = charge + dQ;
-                dB = -P.bias_pen * (cn * cn) - (-P.bias_pen * (charge * charge));
+                double sq_new = 0.0, sq_old = 0.0;
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                    if (k < brows) {
+                        const double *bp = P.bias_pair + k * P.bias_row_stride + sub1 * 64;
+                        double x = bp[o1 * 8 + n1];
+                        if (nfl == 2) x += bp[o2 * 8 + n2];
+                        dQ[k] = x;
+                        const double cn = chg[k] + x;
+                        sq_old += chg[k] * chg[k];
+                        sq_new += cn * cn;
+                    }
+                dB = -P.bias_pen * sq_new - (-P.bias_pen * sq_old);
             }
         }
         double dH = 0.0, dEw = HAS_EW ? ew_uni : 0.0;
@@ -677,7 +690,8 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         MULTI_PHASE(2)
         if (accepted) {
             bias_acc += dB;
-            charge += dQ;
+#pragma unroll
+            for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) chg[k] += dQ[k];
             if (WLK) {
                 // the state (bin, features) ends here: its post-steps go to the bin's row (sums)
                 if (wl_sum_mode) wl_flush_run();
@@ -877,7 +891,9 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     }
     if (btype && lane == 0) {
         P.bias[r] += bias_acc;
-        if (btype == SMOLMC_BIAS_SQUARE_CHARGE) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS] = charge;
+#pragma unroll
+        for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+            if (k < brows) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] = chg[k];
     }
     if (lane == 0) {
         if (HAS_EW && !WLK) featp[P.Fce] += acc_ew;

@@ -435,6 +435,7 @@ struct LeanParams {
     int bias_type;
     const double *bias_pair;
     double bias_pen;
+    int bias_rows, bias_row_stride; // SquareHyperplaneBias: bias_rows pair tables, bias_row_stride doubles apart (one row otherwise)
     double *bias, *charge;
     uint8_t *occ;
     double *enthalpy, *features;

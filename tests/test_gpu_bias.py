@@ -190,12 +190,18 @@ def test_table_flip_without_table_uses_composition_space():
     assert len({int((o == 2).sum()) for o in occs.reshape(-1, P)}) > 1  # composition moved
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["auto", "general-kernel"])
 @pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
-def test_square_hyperplane_bias_matches_oracle(rocksalt, step):
+def test_square_hyperplane_bias_matches_oracle(rocksalt, step, general, monkeypatch):
     """SquareHyperplaneBias (bias.py:290-366, two hyperplanes) on the engine == oracle, running
-    bias == recomputation from the species counts, through the smol-shaped Sampler as well."""
+    bias == recomputation from the species counts, through the smol-shaped Sampler as well.  On the biased lean
+    kernel since round 5 (one running sum per hyperplane), and on mc_kernel as before."""
     from oracle import oracle as orc
 
+    if general:
+        monkeypatch.setenv("SMOLMC_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
     model, sc, coefs = rocksalt
     ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.2)
     A, b = [[0, 1, 0, 0], [1, 0, -1, 0]], [sc.size // 3, 1]
@@ -208,7 +214,7 @@ def test_square_hyperplane_bias_matches_oracle(rocksalt, step):
     seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(977)
     temps = np.linspace(600.0, 5000.0, R)
     eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
-    assert eng.kernel_info().startswith("general")  # a rarely used term: general kernel only
+    assert eng.kernel_info().startswith("general" if general else "lean"), eng.kernel_info()  # both paths are pinned
     eng.set_state(occ0, seeds, temps)
     ora.set_state(occ0, seeds, temps)
     np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in occ0], rtol=RTOL, atol=ATOL)
@@ -228,3 +234,46 @@ def test_square_hyperplane_bias_matches_oracle(rocksalt, step):
     occs = sampler.samples.get_occupancies(flat=False)
     got = sampler.samples.get_trace_value("bias", flat=False)[..., 0]
     np.testing.assert_allclose(got, [[bias.compute_bias(o) for o in row] for row in occs], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
+def test_square_hyperplane_bias_two_sublattices(oxyfluoride, step, monkeypatch):
+    """Three hyperplanes over the species of two active sublattices on the multi-sublattice lean kernel: the oracle's
+    chain, the running bias a recomputation, the rows of the device ring with the bias column."""
+    from oracle import oracle as orc
+
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    model, sc, coefs = oxyfluoride
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.15)
+    ndim = sum(len(sl.species) for sl in ens.active_sublattices)
+    rng = np.random.default_rng(31)
+    A = rng.integers(-1, 2, size=(3, ndim)).tolist()
+    b = [sc.size // 4, 0, -2]
+    bias = moca.SquareHyperplaneBias(ens.sublattices, A, b, penalty=0.02)
+    tab = ens.make_tables().set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=bias.intercepts)
+    R = 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, step)
+    occ0 = np.zeros((R, sc.num_sites), dtype=np.int32)
+    occ0[:, : sc.size] = rng.integers(0, 3, size=(R, sc.size))
+    occ0[:, sc.size:] = rng.integers(0, 2, size=(R, sc.num_sites - sc.size))
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(613)
+    temps = np.linspace(800.0, 5000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean-multi"), eng.kernel_info()
+    eng.set_state(occ0, seeds, temps)
+    ora.set_state(occ0, seeds, temps)
+    for chunk in (1, 16, 400):
+        eng.run(chunk)
+        ora.run(chunk)
+        a, b_ = eng.get_state(), ora.get_state()
+        assert np.array_equal(a["occupancy"], b_["occupancy"])
+        assert np.array_equal(a["n_accepted"], b_["n_accepted"])
+        np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in a["occupancy"]], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    smp = eng.run_sampled(3, 20, bias=True)
+    for j in range(3):
+        ora.run(20)
+        assert np.array_equal(smp["occupancy"][j], ora.get_state()["occupancy"])
+        np.testing.assert_allclose(smp["bias"][j], ora.get_bias(), rtol=RTOL, atol=ATOL)
+    eng.close()
