@@ -502,6 +502,10 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     bool corr_kf = corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && class_rep.size() == 1 && !cfg_wl && !t->bias_type &&
                    h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP && t->n_sublattices == 1 && niter_max <= 4 && num_ce_features(t) <= 64 &&
                    getenv("SMOLMC_LAZY_FEATURES_ONLY") == nullptr;
+    // ... and the Wang-Landau kernel of the multi-class layout (KFW, round 5): any number of classes the layout takes
+    if (corr && !corr_k1 && kmax <= SMOLMC_LEAN_MAX_KF && cfg_wl && !t->bias_type && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP &&
+        num_ce_features(t) <= 61 && getenv("SMOLMC_NO_WL_KF") == nullptr)
+        corr_kf = true;
     // LAZY cluster features (round 5): every other Metropolis kernel of the lean families takes a model with several
     // correlation functions per orbit as an interaction-mode model of the folded tensors E = sum_k coef_k ct_k --
     // the decision needs nothing else -- and carries no cluster features at all: they are evaluated from the
@@ -518,7 +522,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     h->lean_reason = class_rep.size() < 1 ? "no site with clusters"
                      : class_rep.size() > 4 ? "more than 4 site classes"
                      : aliased ? "aliased supercell (a cluster holds a site twice)"
-                     : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? (cfg_wl ? "several correlation functions per orbit under Wang-Landau"
+                     : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? (cfg_wl ? "Wang-Landau with more than SMOLMC_LEAN_MAX_KF correlation functions per orbit, more than 61 of them, or TableFlip"
                                                                                 : "environment override (SMOLMC_NO_LEAN_CORR / SMOLMC_NO_LAZY_FEATURES)")
                      : N > 65535 ? "more than 65535 sites"
                      : niter_max > 8 ? "more than 512 clusters per site"
@@ -1487,14 +1491,14 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
                                          getenv("SMOLMC_NO_WL_MULTI") == nullptr);
         // (why a model with lean tables runs neither lean family: the first condition that fails, for smolmc_kernel_info)
         if (!lean && h->lean_tables)
-            h->lean_reason = h->lean_kf ? "several correlation functions per orbit with Wang-Landau, a bias, TableFlip, several sublattices or an Ewald term without field"
+            h->lean_reason = (h->lean_kf && !wl) ? "several correlation functions per orbit (KF kernel) on a model outside the single-class lean shape"
                              : !multi_wl_ok ? "Wang-Landau with TableFlip or more than 63 features"
                              : !multi_bias_ok ? "a bias term with TableFlip"
                              : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
                              : (t->has_ewald && !kp.ew_field) ? "Ewald matrix that does not factorise into site charges (no potential field)"
                              : (getenv("SMOLMC_FORCE_GENERAL") || getenv("SMOLMC_NO_LEAN_MULTI")) ? "environment override" : "";
-        if (!lean && h->lean_tables && !h->lean_kf && multi_wl_ok && multi_bias_ok && Fk <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
+        if (!lean && h->lean_tables && (!h->lean_kf || wl) && multi_wl_ok && multi_bias_ok && Fk <= 64 && t->n_sublattices <= 4 && (!t->has_ewald || kp.ew_field) &&
             getenv("SMOLMC_FORCE_GENERAL") == nullptr && getenv("SMOLMC_NO_LEAN_MULTI") == nullptr) {
             LeanParams &lp = h->lp;
             const int ns = t->n_sublattices;
@@ -2301,6 +2305,9 @@ static int update_walker_order(smolmc_handle *h, LeanParams &lp) {
 static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     lp.steps = nsteps;
     TRY(update_walker_order(h, lp));
+    if (h->lean_multi_wl && h->lean_kf) // several correlation functions per orbit (KFW)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_wl_kf_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_kf_4(h, lp) : smolmc_launch_multi_wl_kf_8(h, lp));
     if (h->lean_multi_wl)
         return h->lean_nslot == 2 ? smolmc_launch_multi_wl_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_4(h, lp) : smolmc_launch_multi_wl_8(h, lp));
@@ -2634,6 +2641,7 @@ extern "C" int smolmc_get_samples_ex(smolmc_handle *h, double *enthalpy, double 
 // Wang-Landau; TableFlip handles have their own (smolmc_table_replay_available)
 static bool smolmc_lean_replay_takes(const smolmc_handle *h) {
     if (h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) return false;
+    if (h->lean_multi_wl && h->lean_kf) return false; // (no replay instantiation of the KFW kernel: mc_kernel / the universal kernel)
     if (h->lp.bias_type) return SMOLMC_HAVE_BIAS_REPLAY != 0;
     return true;
 }

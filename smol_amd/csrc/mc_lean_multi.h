@@ -78,10 +78,14 @@ __device__ __noinline__ void wl_multi_row_swap(double *grows, double *crow, int 
 // index-row fetches, see mc_lean.h).
 // REPLAY: proposals and uniforms from the host in the reference's draw order (see mc_lean_kernel;
 // instantiated in multi_replay_n*.hip).
-// WLK: the Wang-Landau kernel on this layout (see above; multi_wl_n*.hip).
-template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false, bool WLK = false>
+// WLK: the Wang-Landau kernel on this layout (see above; multi_wl_n*.hip).  WLK == 2 (KFW, multi_wl_kf_n*.hip): ... with
+// several correlation functions per orbit (evaluator.pyx:211-265): the decision reads the slot's FOLDED table
+// E = sum_k coef_k ct_k as every other slot does; an accepted step reads the slot's K function tables (global memory,
+// LeanParams::dtk, at the table index the decision computed) and adds K feature deltas.
+template <int NSLOT, int MM, int STEP, bool HAS_MU, int EWM, bool ONE = false, bool BIAS = false, bool REPLAY = false, int WLK = 0>
 __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) {
     static_assert(!(WLK && BIAS), "Cannot apply bias to Wang-Landau simulation (wanglandau.py:127-128)");
+    constexpr bool KFW = WLK == 2;
     constexpr bool HAS_EW = EWM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         s_rec[i] = rec;
         if (WLK) {
             s_fs[i] = sl.live ? sl.fs : 0.0;
-            s_ft[i] = sl.feat;
+            s_ft[i] = KFW ? (sl.feat | (sl.live << 16)) : sl.feat; // (KFW: + the number of functions of the slot's orbit)
         }
     }
     const bool live = r < P.R;
@@ -580,6 +584,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         // -------- enthalpy delta: slot records of the site's class from LDS ------------------
         const MultiRec *rec1 = s_rec + ((size_t)cls1 * NSLOT) * 64 + lane;
         double e = 0.0, d1[NSLOT], d2[NSLOT];
+        uint32_t ad1[KFW ? NSLOT : 1], ad2[KFW ? NSLOT : 1]; // KFW: byte offsets of the two decision reads
         {
             const uint32_t pair1 = (uint32_t)o1 * snt8 + (uint32_t)n1 * nt8;
 #pragma unroll
@@ -589,6 +594,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row1, it * MM + m)]);
                 d1[it] = *(const double *)((const unsigned char *)s_dt + (a + pair1));
+                if (KFW) ad1[KFW ? it : 0] = a + pair1;
                 e = fma(rc.w, d1[it], e);
             }
         }
@@ -609,6 +615,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
 #pragma unroll
                 for (int m = 0; m < MM; ++m) a += __umul24(rc.st8[m], (uint32_t)occ[row_entry<NW>(row2, it * MM + m)]);
                 d2[it] = *(const double *)((const unsigned char *)s_dt + (a + pair2));
+                if (KFW) ad2[KFW ? it : 0] = a + pair2;
                 e = fma(rc.w, d2[it], e);
             }
             if (HAS_EW) {
@@ -699,11 +706,34 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                 // _do_accept_step (wanglandau.py:204-220): features and enthalpy follow the step
                 const double *fsp = s_fs + ((size_t)cls1 * NSLOT) * 64 + lane;
                 const uint32_t *ftp = s_ft + ((size_t)cls1 * NSLOT) * 64 + lane;
+                if (KFW) {
+                    // K function deltas per slot from the function tables of the slot's group, which starts at
+                    // doff8 * SMOLMC_LEAN_MAX_KF in LeanParams::dtk (as mc_lean_kernel's KF variant, mc_lean.h)
+                    const unsigned char *dtk = (const unsigned char *)P.dtk;
+                    const uint32_t ktab8 = P.ktab8;
+#pragma unroll
+                    for (int it = 0; it < NSLOT; ++it) {
+                        const uint32_t ft = ftp[it * 64], K = ft >> 16, f0 = ft & 0xffffu;
+                        const uint32_t doff8 = (ONE ? rcs[ONE ? it : 0] : rec1[it * 64]).doff8;
+                        const uint32_t g1 = doff8 * (uint32_t)(SMOLMC_LEAN_MAX_KF - 1) + ad1[KFW ? it : 0];
+                        const uint32_t g2 = doff8 * (uint32_t)(SMOLMC_LEAN_MAX_KF - 1) + ad2[KFW ? it : 0];
+                        const double fsc = fsp[it * 64];
+#pragma unroll
+                        for (int k = 0; k < SMOLMC_LEAN_MAX_KF; ++k) {
+                            const bool on = (uint32_t)k < K;
+                            double dk = *(const double *)(dtk + (g1 + (on ? (uint32_t)k * ktab8 : 0u)));
+                            if (STEP == SMOLMC_STEP_SWAP) dk += *(const double *)(dtk + (g2 + (on ? (uint32_t)k * ktab8 : 0u)));
+                            __hip_atomic_fetch_add(&s_feat[f0 + (on ? (uint32_t)k : 0u) + wl_shadow], on ? fsc * dk : 0.0, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) {
                     const double d = STEP == SMOLMC_STEP_SWAP ? d1[it] + d2[it] : d1[it];
                     __hip_atomic_fetch_add(&s_feat[ftp[it * 64] + wl_shadow], fsp[it * 64] * d, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
                 }
                 double df = 0.0;
 #pragma unroll
@@ -906,7 +936,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
     if (REPLAY && lane == 0 && rp_bad) atomicOr(P.rp_err, 1);
 }
 
-template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false, bool REPLAY = false, bool WLK = false>
+template <int NSLOT, int MM, int STEP, bool MU, int EW, bool BIAS = false, bool REPLAY = false, int WLK = 0>
 static int launch_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
@@ -935,20 +965,20 @@ template <int NSLOT, int MM, bool BIAS = false> static int launch_multi_nm(smolm
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_multi_me<NSLOT, MM, SMOLMC_STEP_SWAP, BIAS>(h, lp);
     return launch_multi_me<NSLOT, MM, SMOLMC_STEP_FLIP, BIAS>(h, lp);
 }
-// Wang-Landau variants (multi_wl_n*.hip, multi_wl_replay_n*.hip)
-template <int NSLOT, int MM, int STEP, bool REPLAY> static int launch_multi_wl_me(smolmc_handle *h, const LeanParams &lp) {
+// Wang-Landau variants (multi_wl_n*.hip, multi_wl_replay_n*.hip; W = 2: several correlation functions per orbit, multi_wl_kf_n*.hip)
+template <int NSLOT, int MM, int STEP, bool REPLAY, int W> static int launch_multi_wl_me(smolmc_handle *h, const LeanParams &lp) {
     const bool mu = lp.m_mu != nullptr;
     if (lp.ew_field == 1)
-        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, false, REPLAY, true>(h, lp);
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 1, false, REPLAY, W>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 1, false, REPLAY, W>(h, lp);
     if (lp.ew_field == 2)
-        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, false, REPLAY, true>(h, lp);
-    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, false, REPLAY, true>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, false, REPLAY, true>(h, lp);
+        return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 2, false, REPLAY, W>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 2, false, REPLAY, W>(h, lp);
+    return mu ? launch_multi_inst<NSLOT, MM, STEP, true, 0, false, REPLAY, W>(h, lp) : launch_multi_inst<NSLOT, MM, STEP, false, 0, false, REPLAY, W>(h, lp);
 }
-template <int NSLOT, bool REPLAY = false> static int launch_multi_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, bool REPLAY = false, int W = 1> static int launch_multi_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
     const bool swap = h->cfg.step_type == SMOLMC_STEP_SWAP;
     if (h->lean_mm == 2)
-        return swap ? launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_SWAP, REPLAY>(h, lp) : launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_FLIP, REPLAY>(h, lp);
-    return swap ? launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_SWAP, REPLAY>(h, lp) : launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_FLIP, REPLAY>(h, lp);
+        return swap ? launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_SWAP, REPLAY, W>(h, lp) : launch_multi_wl_me<NSLOT, 2, SMOLMC_STEP_FLIP, REPLAY, W>(h, lp);
+    return swap ? launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_SWAP, REPLAY, W>(h, lp) : launch_multi_wl_me<NSLOT, 3, SMOLMC_STEP_FLIP, REPLAY, W>(h, lp);
 }
 // replay variants (multi_replay_n*.hip)
 template <int NSLOT, int MM, int STEP> static int launch_multi_replay_me(smolmc_handle *h, const LeanParams &lp) {

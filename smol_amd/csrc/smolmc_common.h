@@ -777,6 +777,9 @@ int smolmc_launch_multi_8(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_kf_2(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_kf_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_wl_kf_8(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_replay_2(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_replay_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_wl_replay_8(smolmc_handle *h, const LeanParams &lp);

@@ -802,10 +802,10 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("rocksalt444_ewald", "corr", capi.STEP_FLIP, "mu3", "metropolis", "lean"),       # K = 3 / 4 / 6 functions per orbit
     ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),
     ("fcc3_indicator_skew", "corr", capi.STEP_FLIP, "mu3", "metropolis", "lean"),
-    ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "wang-landau", "general"),    # WL keeps K > 1 on mc_kernel
+    ("rocksalt444_ewald", "corr", capi.STEP_SWAP, None, "wang-landau", "lean-multi"), # WL with K > 1: the KFW kernel (round 5)
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "wang-landau", "lean-multi"),   # WL + two sublattices (round 5)
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "wang-landau", "lean-multi"),
-    ("rocksalt333_two_sublattices", "corr", capi.STEP_FLIP, "muG", "wang-landau", "general"),     # K > 1 of a multi-class model
+    ("rocksalt333_two_sublattices", "corr", capi.STEP_FLIP, "muG", "wang-landau", "lean-multi"),  # K > 1 of a multi-class model
     ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
@@ -827,6 +827,8 @@ def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, e
     assert info.startswith(expected), info
     if name == "rocksalt444_ewald" and kernel == "metropolis":
         assert "field=1" in info
+    if mode == "corr" and expected == "lean-multi" and kernel == "wang-landau":
+        assert "kf=1" in info, info
     if mode == "corr" and expected == "lean":
         assert ("kf=1" in info) == (name != "fcc_prim666_triplets" and name != "fcc_conv444_pairs")
 

@@ -87,7 +87,7 @@ def _mu_two(c):
 @pytest.mark.parametrize("phi", ["lds", "hbm"])
 @pytest.mark.parametrize("update_period", [1, 3])
 @pytest.mark.parametrize("step", [capi.STEP_SWAP, capi.STEP_FLIP], ids=["swap", "flip"])
-@pytest.mark.parametrize("mode", ["int"])  # (three cation species: K > 1 correlation features of a multi-class model stay on mc_kernel)
+@pytest.mark.parametrize("mode", ["int", "corr"])  # (corr: three cation species, K = 3 / 4 / 6 functions per orbit -- the KFW instantiations)
 def test_two_sublattices_with_ewald(mode, step, update_period, phi, monkeypatch):
     """Disorder on the cation AND the anion sublattice + Ewald term (+ one mu row per sublattice for the
     semigrand flips): narrow bins (many bin changes, the row cache of 32 bins evicts), a check period
@@ -106,6 +106,7 @@ def test_two_sublattices_with_ewald(mode, step, update_period, phi, monkeypatch)
     info = eng.kernel_info()
     assert info.startswith("lean-multi") and ("wl=multi" in info) and (("wl=multi-mean" in info) == (update_period != 1)), info
     assert f"field={1 if phi == 'lds' else 2}" in info, info
+    assert ("kf=1" in info) == (mode == "corr"), info
     a, x = _same_chain(eng, ora, (1, 2, 13, 64, 400, 1500))
     assert a["n_accepted"].sum() > 200
     assert (x["occurrences"] > 0).sum(axis=1).max() > 32  # more visited bins than cached rows
