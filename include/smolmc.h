@@ -191,7 +191,14 @@ int smolmc_abi_version(void);
 
 /* Which kernel family this handle dispatches to, as a short text ("lean nslot=2 mm=2 field=1" /
  * "general nslot=8 mm=2 field=1"): lets callers and tests assert that the intended path runs
- * (no reference counterpart). Writes at most n bytes including the terminator. */
+ * (no reference counterpart). Writes at most n bytes including the terminator (give it 512).
+ * A handle on mc_kernel / the universal kernel appends " | not lean: <the first condition of
+ * smolmc_create that kept the model off the specialised kernels>".  "lazy-features" marks a handle
+ * whose kernels carry the scalar features only (Ewald energy, chemical work) and whose cluster
+ * features -- several correlation functions per orbit, evaluator.pyx:211-265, or more than 64 of
+ * them -- are evaluated from the occupancies wherever this interface returns them
+ * (smolmc_get_state, smolmc_get_samples*): same values, to rounding, as the step-by-step trace
+ * of sampler/sampler.py:204-207. */
 int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n);
 
 /* ---- sizes -------------------------------------------------------------- */

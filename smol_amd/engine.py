@@ -291,6 +291,12 @@ class Engine:
         self._chk(self._lib.smolmc_kernel_info(self._h, buf, 512))
         return buf.value.decode()
 
+    def not_lean_reason(self):
+        """Why the model runs on ``mc_kernel`` / the universal kernel instead of a lean family: the first condition that
+        failed at ``smolmc_create`` (None on a lean handle)."""
+        info = self.kernel_info()
+        return info.split(" | not lean: ", 1)[1] if " | not lean: " in info else None
+
     def get_bias(self):
         """trace.bias of every walker (models created with an MCBias term)."""
         b = np.zeros(self.R)
