@@ -340,12 +340,12 @@ def issue_roof(key, note):
     launch the same passes counted.  No modelled byte rate: these kernels keep their working set in
     LDS / L2."""
     def roof(rec):
-        from smol_amd.engine import source_digest
+        from smol_amd import codeobj
 
         pmc = pmc_constants().get(key, {})
         out = dict(bound="issue", unit="fraction of issue cycles", note=note,
                    pmc_source=pmc.get("source", "no PMC pass for this configuration"),
-                   pmc_stale=bool(pmc) and pmc.get("csrc_sha256") != source_digest())
+                   pmc_stale=codeobj.isa_stale(pmc))
         for k in ("valu_issue_frac", "lds_issue_frac", "valu_per_step", "salu_per_step", "lds_per_step", "vmem_per_step",
                   "wave_cycles_per_step", "waves_per_simd", "lds_bank_conflict_per_step", "hbm_bytes_per_launch"):
             if k in pmc:
@@ -555,7 +555,7 @@ def _time_other_configs(device, rank, world, red_dev, out):
         A_EW = 2.0 * wl3d.sc.num_sites * 8.0 + wl3d.sc.num_sites  # 58 752 B per flip at N = 3456
 
         def dense_roof(rec):
-            from smol_amd.engine import source_digest
+            from smol_amd import codeobj
 
             pmc = pmc_constants().get("config3_dense_ewald", {})
             a = rec["flips_per_s"] * A_EW / 1e9
@@ -563,7 +563,7 @@ def _time_other_configs(device, rank, world, red_dev, out):
                         algorithmic_bytes_per_flip=A_EW, traffic=pmc.get("hbm_bytes_per_launch"),
                         traffic_unit="bytes per launch of 2048 x 500 flips (rocprofv3 FETCH_SIZE + WRITE_SIZE passes)",
                         pmc_source=pmc.get("source", "none"),
-                        pmc_stale=bool(pmc) and pmc.get("csrc_sha256") != source_digest(),
+                        pmc_stale=codeobj.isa_stale(pmc),
                         note="dense Ewald rows (SMOLMC_DENSE_EWALD): streaming gather, eight sites per lane in flight")
 
         wl3d.name = "config3 with the dense Ewald rows (ewald.pyx:38-58 literally)"
@@ -877,10 +877,10 @@ def main():
         flips_per_launch = 2.0 * args.mc_per_step * R
         achieved = flips_per_launch * ALGO_BYTES_PER_FLIP / (k_ms * 1e-3) / 1e9
         pmc = pmc_constants().get(f"{R}x{args.mc_per_step}", {}) if args.features == "interactions" else {}
-        from smol_amd.engine import source_digest
+        from smol_amd import codeobj
 
-        # the counters were collected on the build whose source digest the file carries
-        pmc_stale = bool(pmc) and pmc.get("csrc_sha256") != source_digest()
+        # the counters were collected on the kernel whose machine-code digest the entry carries (codeobj.py)
+        pmc_stale = codeobj.isa_stale(pmc)
         probe = measure_hbm_peak()
         measured_peak = max(probe.values()) if probe else HBM_MEASURED_FALLBACK_GBS
         roof = {

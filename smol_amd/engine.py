@@ -55,17 +55,20 @@ SYMBOLS = {
 }
 
 
-def source_digest():
+def source_digest(root=None):
     """sha256 over the kernel sources (smol_amd/csrc/*.h, *.hip, Makefile and include/smolmc.h, by
-    sorted name): profiles/pmc_constants.json carries the digest of the build its counters were
-    collected on, and bench.py flags the constants as stale when the sources have moved on."""
+    sorted name) of the repository at ``root`` (default: this one).  profiles/pmc_constants.json
+    carries the digest of the tree its counters were collected on, next to the per-kernel machine-code
+    digest (codeobj.py) that bench.py compares: this one names the tree, that one says whether the
+    kernel an entry was measured on is still the kernel that runs."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    src = os.path.join(_HERE, "csrc")
+    here = _HERE if root is None else os.path.join(root, "smol_amd")
+    src = os.path.join(here, "csrc")
     files = sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.hip")))
-    files += [os.path.join(src, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "smolmc.h")]
+    files += [os.path.join(src, "Makefile"), os.path.join(os.path.dirname(here), "include", "smolmc.h")]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:

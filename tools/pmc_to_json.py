@@ -19,6 +19,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smol_amd import codeobj  # noqa: E402
 from smol_amd.engine import source_digest  # noqa: E402
 
 
@@ -33,7 +34,7 @@ def main():
     ap.add_argument("--key", default=None, help='entry name (default "<replicas>x<mc>"; other configurations: "config3" ...)')
     ap.add_argument("--waves-per-simd", type=float, default=0.0, help="resident waves per SIMD (default replicas / 1024)")
     a = ap.parse_args()
-    tot = {}
+    by_name = {}
     for p in a.paths:
         for db in (sorted(glob.glob(os.path.join(p, "**", "*.db"), recursive=True)) if os.path.isdir(p) else [p]):
             con = sqlite3.connect(db)
@@ -45,9 +46,13 @@ def main():
                 continue
             for name, ctr, val, n in rows:
                 if a.kernel in name:
-                    tot[ctr] = (float(val), int(n))
-    if not tot:
+                    by_name.setdefault(name, {})[ctr] = (float(val), int(n))
+    if not by_name:
         raise SystemExit("no counters for kernel " + a.kernel)
+    # several instantiations may match the fragment (a replay or set-up kernel of the same family): the
+    # entry is the one the passes spent their waves in
+    full_name = max(by_name, key=lambda k: max(v for v, _ in by_name[k].values()))
+    tot = by_name[full_name]
     waves_per_simd = a.waves_per_simd if a.waves_per_simd > 0 else max(1, a.replicas // 1024)
 
     def per_step(c):
@@ -60,8 +65,14 @@ def main():
 
     # the digest of the kernel sources these counters were collected on: bench.py compares it with
     # the tree it runs from and prints "pmc_stale": true when they differ
+    # ... and the kernel's full name with the digest of its machine code in the library of this tree
+    # (smol_amd/codeobj.py): bench.py's "pmc_stale" compares THAT, so an entry goes stale when its kernel's
+    # instruction stream moves and not when a comment does
     rec = {"source": a.source, "kernel": a.kernel, "waves_per_simd": waves_per_simd,
            "csrc_sha256": source_digest()}
+    hit = codeobj.find_kernel(full_name)
+    if hit is not None:
+        rec["kernel_symbol"], rec["isa_sha256"] = hit
     for c, k in (("SQ_INSTS_VALU", "valu_per_step"), ("SQ_INSTS_SALU", "salu_per_step"),
                  ("SQ_INSTS_LDS", "lds_per_step"), ("SQ_INSTS_VMEM_RD", "vmem_per_step")):
         if c in tot:
