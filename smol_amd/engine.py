@@ -121,6 +121,7 @@ class Engine:
         self._lib = load_library()
         self.tables, self.config = tables, config
         self._h = _HP()
+        self._pending = []  # blocks queued on the device ring and not fetched yet: (nsamples, flags)
         rc = self._lib.smolmc_create(C.byref(tables.struct), C.byref(config), C.byref(self._h))
         if rc:
             self._h = None
@@ -331,14 +332,13 @@ class Engine:
         flags = ((capi.SAMPLE_OCCUPANCY if occupancy else 0) | (capi.SAMPLE_BIAS if bias else 0) |
                  (capi.SAMPLE_WL if wl else 0))
         self._chk(self._lib.smolmc_run_sampled(self._h, int(nsamples), int(thin_by), flags))
-        self._pending = getattr(self, "_pending", [])
         self._pending.append((int(nsamples), flags))
         del self._pending[:-2]  # (a third block drops the oldest, as the C side does)
 
     def fetch_samples(self, packed=False):
         """The oldest block queued with ``run_sampled_async`` that was not fetched yet (waits for ITS
         download only)."""
-        if not getattr(self, "_pending", None):
+        if not self._pending:
             raise EngineError("no samples recorded: call run_sampled_async first")
         ns, flags = self._pending.pop(0)
         H = np.empty((ns, self.R))
