@@ -1535,9 +1535,23 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     // cached between accepted table steps: feasible directions at the current counts, their weight
     // sum, and (lane dir of vlp, bit dir of lp_valid) the log a-priori factor of direction dir
     bool head_valid = false;
-    unsigned feas_now = 0, lp_valid = 0;
+    unsigned feas_now = 0;
+    unsigned long long lp_valid = 0ull;
     double sumw = 0.0, vlp = 0.0, vcum = 0.0;
     int last_feas = -1;
+    // One flip vector (the usual charge-neutral exchange): the counts live on a line, count = start + kpos * u,
+    // and the factor of a direction is a function of kpos alone -- that of the reverse direction one position
+    // further its negative: f(k, -u) = -f(k - 1, +u) (the count terms swap sides, p_next / p_now inverts).
+    // vlp then holds F(k) = f(k, +u) for the positions around kpos, lane k & 63 (bit k & 63 of lp_valid), and an
+    // accepted table step invalidates nothing: a hot walker wanders back and forth over a few positions and
+    // recomputed both factors (a table read from L2 + a wave reduction each) after every accepted table step.
+    // Several vectors: lane d / bit d hold direction d at the current counts, dropped when the counts change.
+#ifdef SMOLMC_NO_LP_LINE // A/B switch
+    const bool lp_line = false;
+#else
+    const bool lp_line = P.tf_n == 1;
+#endif
+    int kpos = 0;
     // Proposal batch: the proposals of 64 consecutive steps computed at once, lane l <-> step
     // (step & ~63) + l, all on the vector unit (the step-at-a-time proposal below is a chain of
     // dependent scalar instructions -- ballot, find-first, readlane, compare -- of one wave:
@@ -1566,7 +1580,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         feas_now = feasible(vcnt, tfn, na);
         sumw = masked_sum(feas_now, tfn);
         head_valid = true;
-        lp_valid = 0u;
+        lp_valid = 0ull;
         // running sums of the feasible weights, lane idx <-> direction idx, added in the
         // order choose_section_from_partition adds them: the per-step choice below is then
         // one compare + ballot instead of a loop of readlanes and float64 adds
@@ -1765,6 +1779,17 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         // on some paths only).
         RowWords<NW> rows[4];
         double vG = 0.0;
+        // G[si][sj] for the lanes that hold a flip pair: a random 8-byte read from the rows of the site kernel (24 MB
+        // for config 5) every step.  Timing without it (-DSMOLMC_EXP_NOVG, wrong results): -8 % per sweep; the same
+        // value through the translation-compressed tables (E8 / S8, then gx: two dependent L2 reads) measured level on
+        // the hot ladder and 4 % slower on the cold one -- the dependent chain is what costs, not where it ends.
+        auto cross_G = [&](const uint32_t si, const uint32_t sj, const bool want) -> double {
+            double g = 0.0;
+#ifndef SMOLMC_EXP_NOVG // timing experiment only when defined (wrong results)
+            if (want) g = P.ew_G[(size_t)(si * ew_na_v) + (sj - (uint32_t)sbase)];
+#endif
+            return g;
+        };
         auto fetch_rows = [&]() {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -1772,7 +1797,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             if (has_ew && ew_field) {
                 const int pi = lane >> 3, pj = lane & 7;
                 const int si = __shfl(vsite, pi), sj = __shfl(vsite, pj);
-                if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)((uint32_t)si * ew_na_v) + (uint32_t)(sj - sbase)];
+                vG = cross_G((uint32_t)si, (uint32_t)sj, pj < pi && pi < nfl);
             }
         };
 
@@ -1788,7 +1813,11 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         };
         // compute_log_priori_factor (mcusher.py:656-711), cached per direction (lane d of vlp)
         auto priori_of = [&](const int d) {
-            if (__builtin_expect(!((lp_valid >> d) & 1u), 0)) {
+            // where the factor of direction d lives: lane d, or on the line the position of the +u step it is
+            // (the negative of) -- see lp_line
+            const int slot = lp_line ? ((kpos - (d & 1)) & 63) : d;
+            const bool flip_sign = lp_line && (d & 1);
+            if (__builtin_expect(!((lp_valid >> slot) & 1ull), 0)) {
                 const LeanParamsKernarg Q = rare_params();
                 const int tfn = Q->tf_n, na = Q->nact, lnlen = Q->tf_ln_len;
                 const double tsw = Q->tf_sw;
@@ -1807,11 +1836,12 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 }
                 lf += table_log_count_ratio(lnlen ? s_ln : lng, vu, vcnt, nc);
                 lf = uni_d(lf);
-                if (lane == d) vlp = lf;
-                lp_valid |= 1u << d;
+                if (lane == slot) vlp = flip_sign ? -lf : lf;
+                lp_valid |= 1ull << slot;
             }
-            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), d),
-                                          (int)rdlane((uint32_t)__double2loint(vlp), d));
+            log_priori = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vlp), slot),
+                                          (int)rdlane((uint32_t)__double2loint(vlp), slot));
+            if (flip_sign) log_priori = -log_priori;
         };
         if (covered) {
             // the batch's proposal of this step (see propose_batch)
@@ -1834,7 +1864,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 if (has_ew && ew_field) {
                     const int pi = lane >> 3, pj = lane & 7;
                     const uint32_t si = pi == 1 ? s1 : pi == 2 ? s2 : s3, sj = pj == 0 ? s0 : pj == 1 ? s1 : s2;
-                    if (pj < pi && pi < nfl) vG = P.ew_G[(size_t)(si * ew_na_v) + (sj - (uint32_t)sbase)];
+                    vG = cross_G(si, sj, pj < pi && pi < nfl);
                 }
             }
 #ifdef SMOLMC_EXP_PHASES
@@ -2227,7 +2257,14 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 const bool was_all = all_feasible(vcnt);
                 vcnt += vu;
 #ifndef SMOLMC_EXP_NOPRIORI // timing experiment only when defined (wrong results)
-                lp_valid = 0u;
+                if (lp_line) {
+                    // one position along the line; the two lanes whose positions leave the window of 62 around
+                    // kpos are dropped (their residues now belong to positions on the other side)
+                    kpos += (dir & 1) ? -1 : 1;
+                    lp_valid &= ~((1ull << ((kpos + 32) & 63)) | (1ull << ((kpos + 33) & 63)));
+                } else {
+                    lp_valid = 0ull;
+                }
 #endif
                 if (!(was_all && all_feasible(vcnt))) head_valid = false;
             }
@@ -2235,20 +2272,11 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             if (!REPLAY) {
                 // batch lanes whose scan examined a site that has just changed are stale (all 32
                 // kept sites against every flipped site; unused slots hold 0xffff, no site)
-                uint32_t hit = 0u;
-                for (int f = 0; f < nfl; ++f) {
-                    const uint32_t sf = rdlane((uint32_t)vsite, f);
-                    const uint32_t pat = sf | (sf << 16);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const uint32_t dd = q_c[i] ^ pat; // a zero half-word <=> that kept site is sf
-                        hit |= (dd - 0x00010001u) & ~dd & 0x80008000u;
-                    }
-                }
+                const bool hit = batch_lane_examined(q_c, vsite, nfl);
 #ifdef SMOLMC_EXP_STALEIGN // timing experiment only when defined (wrong results): the marking is computed and dropped
-                if (__ballot(hit != 0u) == 0x123456789abcull) q_stale = ~0ull;
+                if (__ballot(hit) == 0x123456789abcull) q_stale = ~0ull;
 #else
-                q_stale |= __ballot(hit != 0u);
+                q_stale |= __ballot(hit);
 #endif
             }
 #endif

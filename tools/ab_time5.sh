@@ -1,0 +1,11 @@
+# timing-only A/B of mc_table_kernel variants (smol_amd/exp/libsmolmc_t*.so) on config 5 -> gpurun_out/ab_time5.txt
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+out=gpurun_out/ab_time5.txt; : > $out
+for f in smol_amd/exp/libsmolmc_t*.so; do
+  for a in "" "--ladder 400,2000"; do
+    SMOLMC_LIB=$PWD/$f python tools/bench_configs.py --config 5 $a --launches ${LAUNCHES:-3} > /tmp/o.txt 2>/dev/null
+    echo "$(basename $f) config5 $a: $(tail -1 /tmp/o.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['kernel_ms'],3), round(d['acceptance'],4))")" >> $out
+    grep -a "phases\|batch:\|proposal:" /tmp/o.txt | tail -6 >> $out
+  done
+done
+cat $out
