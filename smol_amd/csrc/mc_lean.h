@@ -1736,6 +1736,13 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_cov[3] = {0, 0, 0}, ph_bat = 0, ph_prop[4] = {0, 0, 0, 0};
     long long ph_t = clock64();
 #endif
+#ifdef SMOLMC_EXP_VGPREF // experiment, MEASURED SLOWER (not in the build): the cross terms of the NEXT step fetched a step ahead, at
+    // the end of this step (=1) or before its decision (=2).  Config 5 hot / cold ladder 10.23 / 6.47 ms per sweep -> 11.0 / 7.4
+    // either way: two more live VGPRs across the sweep (spills 4 -> 8) and three readlanes per step cost more than the read
+    // that -DSMOLMC_EXP_NOVG prices at 8 %.  Kept as a documented negative result, like wave_sum_mfma.
+    double vG_pref = 0.0;
+    uint32_t vG_tag = ~0u; // low word of the step vG_pref belongs to
+#endif
     for (uint32_t steps_left = (uint32_t)P.steps; steps_left != 0u; --steps_left, ++step) {
         // feasibility mask, weight sums of the directions: recomputed (here only: one copy of the
         // code) after the species counts changed; the batch's directions assume the old mask
@@ -1801,6 +1808,24 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             }
         };
 
+#ifdef SMOLMC_EXP_VGPREF
+        auto prefetch_next_G = [&]() {
+        // the batch knows the sites of the next step; if that step stays covered (this step's marking is done) it takes
+        // the value from here instead of waiting for the read in its own evaluation
+        if (!REPLAY && has_ew && ew_field && l6 < 63) {
+            const uint32_t qn = rdlane(q_meta, l6 + 1);
+            const int nfn = (int)((qn >> 2) & 7u);
+            if ((qn & 1u) && !((q_stale >> (l6 + 1)) & 1ull) && nfn >= 2) {
+                const uint32_t b01 = rdlane(q_s01, l6 + 1), b23 = rdlane(q_s23, l6 + 1);
+                const uint32_t t0 = b01 & 0xffffu, t1 = b01 >> 16, t2 = nfn > 2 ? b23 & 0xffffu : t0, t3 = nfn > 3 ? b23 >> 16 : t0;
+                const int pi = lane >> 3, pj = lane & 7;
+                const uint32_t si = pi == 1 ? t1 : pi == 2 ? t2 : t3, sj = pj == 0 ? t0 : pj == 1 ? t1 : t2;
+                vG_pref = cross_G(si, sj, pj < pi && pi < nfn);
+                vG_tag = (uint32_t)step + 1u;
+            }
+        }
+        };
+#endif
         int vu = 0; // table step: lane c holds the change of the count of species c
         double log_priori = 0.0;
         // count changes (lane c: species c) of table direction d
@@ -1864,6 +1889,10 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 if (has_ew && ew_field) {
                     const int pi = lane >> 3, pj = lane & 7;
                     const uint32_t si = pi == 1 ? s1 : pi == 2 ? s2 : s3, sj = pj == 0 ? s0 : pj == 1 ? s1 : s2;
+#ifdef SMOLMC_EXP_VGPREF
+                    if (vG_tag == (uint32_t)step) vG = vG_pref;
+                    else
+#endif
                     vG = cross_G(si, sj, pj < pi && pi < nfl);
                 }
             }
@@ -2239,6 +2268,9 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[4] += tn - ph_t; ph_t = tn; }
 #endif
+#if defined(SMOLMC_EXP_VGPREF) && SMOLMC_EXP_VGPREF == 2
+        prefetch_next_G(); // (before the decision: more cover, but an accepted step's sweep queues behind it)
+#endif
         double dH = wave_sum_all(e);
         double dEw = 0.0;
         if (has_ew) {
@@ -2306,6 +2338,9 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             Q->rp_H[krec] = H;
             if (Q->rp_lp_out) Q->rp_lp_out[krec] = log_priori;
         }
+#if defined(SMOLMC_EXP_VGPREF) && SMOLMC_EXP_VGPREF != 2
+        prefetch_next_G(); // (at the end of the step)
+#endif
 
         if (--smp_countdown == 0) {
             const LeanParamsKernarg Q = rare_params(); // (sampling parameters: see rare_params)
