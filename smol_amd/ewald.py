@@ -170,7 +170,10 @@ def supercell_ewald(sc, eta=None, acc=12.0, use_term="total"):
             if k >= 0:
                 qs[k] = prim.charges[sc.site_b[s]][code]
                 site_of[k] = s
-    mat = g_full[np.ix_(site_of, site_of)] * np.outer(qs, qs)
+    mat = g_full[np.ix_(site_of, site_of)]
+    del g_full
+    for a0 in range(0, M, 512):  # mat[a, b] *= q_a q_b in row blocks: no second M x M array (ewald_matrix_pmg)
+        mat[a0:a0 + 512] *= np.outer(qs[a0:a0 + 512], qs)
     # two species on the same site never coexist; keep kernel value (as the
     # reference's overlapping-site structure would) but the self term only on diag
     if with_point:
@@ -313,7 +316,12 @@ def ewald_matrix_pmg(lattice, frac, site_of, charges, eta=None, real_space_cut=N
             for t1 in range(P):  # site (b1, t1) sees (b2, t2) like (b1, 0) sees (b2, t2 - t1)
                 g[b1 * P + t1] = row[:, translation_index[t1]].reshape(-1)
     g = 0.5 * (g + g.T)
-    mat = g[np.ix_(site_of, site_of)] * np.outer(q, q)
+    mat = g[np.ix_(site_of, site_of)]
+    del g
+    # mat[a, b] *= q_a q_b in row blocks: the same products as `* np.outer(q, q)` without a second M x M array
+    # (M = 10 368 for the reference's LiNiO2 model in a 12^3 cell: 860 MB each)
+    for a0 in range(0, len(q), 512):
+        mat[a0:a0 + 512] *= np.outer(q[a0:a0 + 512], q)
     if with_point:
         mat[np.diag_indices_from(mat)] += point * q * q
     mat *= CONV_FACT

@@ -222,3 +222,27 @@ def test_ewald_use_term_parts_add_up_and_are_honoured_by_the_importer(lno):
     tot = ewald.supercell_ewald(sc)[1]
     np.testing.assert_allclose(sum(ewald.supercell_ewald(sc, use_term=t)[1] for t in ("real", "reciprocal", "point")),
                                tot, rtol=1e-12, atol=1e-12)
+
+
+def test_periodic_tree_matching_equals_the_all_pairs_definition(lno):
+    """mson._pbc_match (periodic k-d tree) against the all-pairs comparison it replaced: cluster index tables
+    of diagonal and sheared supercells, and points that sit on / just below a cell face."""
+    ce, _ = lno
+    for scm in ([[2, 0, 0], [0, 3, 0], [0, 0, 2]], [[2, 1, 0], [0, 2, 0], [0, 1, 3]], [[1, -1, 0], [1, 1, 0], [0, 0, 2]]):
+        scm = np.array(scm)
+        sub = ce.subspace
+        cell = sub.supercell(scm)
+        inv = np.linalg.inv(scm.astype(np.float64))
+        pts = mson.lattice_points_in_supercell(scm)
+        for orb in sub.orbits:
+            t = (np.array(orb.clusters) @ inv)[:, None, :, :] + pts[None, :, None, :]
+            a = mson._pbc_match(t.reshape(-1, 3), cell.frac_coords)
+            b = mson._pbc_match_all_pairs(t.reshape(-1, 3), cell.frac_coords)
+            assert np.array_equal(a, b)
+    rng = np.random.default_rng(5)
+    targets = np.vstack([rng.random((50, 3)), [[0.0, 0.5, 0.25], [0.5, 0.0, 1.0 - 1e-13]]])
+    points = targets + rng.integers(-3, 4, targets.shape) + rng.uniform(-4e-6, 4e-6, targets.shape)
+    assert np.array_equal(mson._pbc_match(points, targets, atol=1e-5), np.arange(len(targets)))
+    assert np.array_equal(mson._pbc_match_all_pairs(points, targets, atol=1e-5), np.arange(len(targets)))
+    with pytest.raises(ValueError):
+        mson._pbc_match(np.array([[0.123, 0.456, 0.789]]), targets[:5], atol=1e-5)
