@@ -141,29 +141,42 @@ def lattice_points_in_supercell(scmatrix):
     return pts
 
 
-def _pbc_match(points, targets, atol=SITE_TOL):
-    """Index into ``targets`` of every row of ``points`` modulo lattice translations
-    (what pymatgen's coord_list_mapping_pbc does: every fractional coordinate within ``atol`` of the
-    target's, modulo 1); raises if a point has no image.  A periodic k-d tree over the wrapped targets
-    (maximum norm on the unit torus -- the same criterion) instead of all point x target differences:
-    the cluster tables of an 8^3 LiNiO2 supercell 34 s -> 0.3 s, entry for entry the same
+def _wrap01(x):
+    w = x - np.floor(x)
+    w[w >= 1.0] = 0.0  # (x = -1e-17 wraps to 1.0 in float64; the tree wants [0, 1))
+    return w
+
+
+class _PbcMatcher:
+    """Matches points to ``targets`` modulo lattice translations (what pymatgen's coord_list_mapping_pbc does:
+    every fractional coordinate within ``atol`` of the target's, modulo 1).  A periodic k-d tree over the wrapped
+    targets (maximum norm on the unit torus -- the same criterion) instead of all point x target differences: the
+    cluster tables of an 8^3 LiNiO2 supercell 34 s -> 0.3 s, entry for entry the same
     (tests/test_mson_golden.py regenerates the reference's cached tables with it)."""
-    points, targets = np.asarray(points, dtype=np.float64), np.asarray(targets, dtype=np.float64)
-    try:
-        from scipy.spatial import cKDTree
-    except ImportError:  # (no scipy: the all-pairs comparison)
-        return _pbc_match_all_pairs(points, targets, atol)
 
-    def wrap(x):
-        w = x - np.floor(x)
-        w[w >= 1.0] = 0.0  # (x = -1e-17 wraps to 1.0 in float64; the tree wants [0, 1))
-        return w
+    def __init__(self, targets, atol=SITE_TOL):
+        self.targets, self.atol = np.asarray(targets, dtype=np.float64), atol
+        try:
+            from scipy.spatial import cKDTree
 
-    tree = cKDTree(wrap(targets), boxsize=1.0)
-    dist, idx = tree.query(wrap(points), k=1, p=np.inf, distance_upper_bound=atol)
-    if not np.all(np.isfinite(dist)):
-        raise ValueError("a cluster site has no image in the supercell")
-    return idx.astype(np.int64)
+            self.tree = cKDTree(_wrap01(self.targets), boxsize=1.0)
+        except ImportError:  # (no scipy: the all-pairs comparison)
+            self.tree = None
+
+    def match(self, points):
+        """Index into the targets of every row of ``points``; raises if a point has no image."""
+        points = np.asarray(points, dtype=np.float64)
+        if self.tree is None:
+            return _pbc_match_all_pairs(points, self.targets, self.atol)
+        dist, idx = self.tree.query(_wrap01(points), k=1, p=np.inf, distance_upper_bound=self.atol,
+                                    workers=-1 if len(points) > 100000 else 1)
+        if not np.all(np.isfinite(dist)):
+            raise ValueError("a cluster site has no image in the supercell")
+        return idx.astype(np.int64)
+
+
+def _pbc_match(points, targets, atol=SITE_TOL):
+    return _PbcMatcher(targets, atol).match(points)
 
 
 def _pbc_match_all_pairs(points, targets, atol=SITE_TOL):
@@ -343,11 +356,12 @@ class MsonSubspace:
         if supercell_frac is None:
             supercell_frac = self.supercell(scm).frac_coords
         out = []
+        matcher = _PbcMatcher(supercell_frac)
         for orb in self.orbits:
             prim = np.array(orb.clusters)  # (mult, I, 3)
             fc = prim @ inv
             t = fc[:, None, :, :] + pts[None, :, None, :]
-            rows = _pbc_match(t.reshape(-1, 3), supercell_frac).reshape(-1, orb.num_sites)
+            rows = matcher.match(t.reshape(-1, 3)).reshape(-1, orb.num_sites)
             out.append(np.ascontiguousarray(rows, dtype=np.int32))
         return tuple(out)
 
@@ -448,8 +462,9 @@ class MsonSupercell:
             # site (b, 0) is the representative row of prim site b)
             pts = self.lattice_points
             trans = np.empty((self.size, self.size), dtype=np.int64)
+            matcher = _PbcMatcher(pts)
             for t1 in range(self.size):
-                trans[t1] = _pbc_match(pts - pts[t1], pts)
+                trans[t1] = matcher.match(pts - pts[t1])
             if not np.allclose(pts[0], 0.0):
                 trans = None
         mat = ewald_mod.ewald_matrix_pmg(self.lattice, self.frac_coords, site_of, q, eta=eta,
@@ -465,9 +480,19 @@ def local_tables(full_indices, num_sites):
     for pos, rows in enumerate(full_indices):
         if rows.size == 0:
             continue
-        for site in np.unique(rows):
-            sel = np.any(rows == site, axis=-1)
-            out.setdefault(int(site), []).append((pos, np.ascontiguousarray(rows[sel]), len(rows) / float(sel.sum())))
+        # the rows that contain a site, for every site at once: (site, row) pairs sorted by site then row, a row
+        # that names a site twice (aliased tiny supercells) counted once -- the same lists, in the same order, as
+        # `rows[np.any(rows == site, axis=-1)]` site by site
+        nr, width = rows.shape
+        flat, rid = rows.ravel(), np.repeat(np.arange(nr), width)
+        order = np.lexsort((rid, flat))
+        fs, fr = flat[order], rid[order]
+        keep = np.ones(len(fs), dtype=bool)
+        keep[1:] = (fs[1:] != fs[:-1]) | (fr[1:] != fr[:-1])
+        fs, fr = fs[keep], fr[keep]
+        cut = np.flatnonzero(np.concatenate(([True], fs[1:] != fs[:-1], [True])))
+        for a, b in zip(cut[:-1], cut[1:]):
+            out.setdefault(int(fs[a]), []).append((pos, np.ascontiguousarray(rows[fr[a:b]]), nr / float(b - a)))
     return out
 
 
