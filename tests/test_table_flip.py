@@ -131,3 +131,32 @@ def test_table_flip_trace_consistency():
         np.testing.assert_allclose(st["features"][r], f, rtol=1e-10, atol=1e-8)
         np.testing.assert_allclose(st["enthalpy"][r], nat @ f, rtol=1e-10, atol=1e-8)
     assert 0 < st["n_accepted"].sum() < st["n_steps"].sum()
+
+
+def test_composition_line_cache_never_serves_another_position():
+    """The bookkeeping of mc_table_kernel's a-priori factors for a single flip vector (mc_lean.h, lp_line), restated:
+    lane (k & 63) holds F(k) = f(k, +u), direction d reads slot (kpos - (d & 1)) & 63 with the sign of d, and an accepted
+    step moves kpos by one and drops the residues (kpos + 32) & 63 and (kpos + 33) & 63.  Over long random walks --
+    drifting, oscillating, reversing after 31 / 32 / 33 steps -- a slot that is marked valid always holds the factor of
+    the position it is read for."""
+    rng = np.random.default_rng(11)
+
+    def walk(moves):
+        kpos, valid, held = 0, 0, [None] * 64  # (Python ints) held[lane] = the position whose factor the lane holds
+        for mv in moves:
+            for d in (0, 1):  # both directions are looked up at every position
+                want = kpos - (d & 1)
+                slot = want & 63
+                if (valid >> slot) & 1:
+                    assert held[slot] == want  # served from the cache: it must be THIS position's factor
+                else:
+                    held[slot], valid = want, valid | (1 << slot)
+            kpos += int(mv)
+            valid &= ~((1 << ((kpos + 32) & 63)) | (1 << ((kpos + 33) & 63)))
+        return kpos
+
+    walk(rng.choice([-1, 1], size=20000))                      # diffusive
+    walk(rng.choice([-1, 1], size=20000, p=[0.3, 0.7]))        # drifting up (wraps the window many times)
+    walk(rng.choice([-1, 1], size=20000, p=[0.7, 0.3]))        # drifting down
+    for span in (30, 31, 32, 33, 34, 63, 64, 65):              # sawtooth around the window size
+        walk(np.tile(np.concatenate([np.ones(span, int), -np.ones(span, int)]), 20))
