@@ -34,7 +34,12 @@
 extern "C" {
 #endif
 
-#define SMOLMC_ABI_VERSION 7
+#define SMOLMC_ABI_VERSION 8
+
+/* Status codes: 0 = ok; SMOLMC_ERR (1) = any failure, message in smolmc_last_error(); the codes below name failures a
+ * caller may want to handle without parsing the message (the message is set for them too). */
+#define SMOLMC_ERR 1
+#define SMOLMC_ERR_RING_FULL 2 /* smolmc_run_sampled: both ring slots hold blocks that were not fetched */
 
 #define SMOLMC_BIAS_NONE 0
 #define SMOLMC_BIAS_FUGACITY 1
@@ -270,12 +275,25 @@ int smolmc_sync(smolmc_handle *h);
  *     run_sampled(0); run_sampled(1); get_samples -> block 0; run_sampled(2); get_samples -> block 1; ...
  * smolmc_get_samples* deliver the OLDEST block not yet delivered (waiting for its copy only, not for
  * younger launches); with none pending they deliver the newest block again.  A third
- * smolmc_run_sampled while two blocks are pending drops the older one.  Nothing is allocated per call
- * once the slots have grown to the block size. */
+ * smolmc_run_sampled while two blocks are pending is REFUSED with SMOLMC_ERR_RING_FULL and changes nothing
+ * (ABI 8; ABI 7 silently dropped the older block) -- fetch or smolmc_discard_samples first.  A call that fails
+ * for any other reason (arguments, an allocation, a launch) leaves the ring as it was: the slot is taken only
+ * when every launch of the block has been queued.  Nothing is allocated per call once the slots have grown
+ * to the block size. */
 #define SMOLMC_SAMPLE_OCCUPANCY 1 /* flags bit 0 */
 #define SMOLMC_SAMPLE_BIAS 2      /* flags bit 1: trace.bias (error without an MCBias term) */
 #define SMOLMC_SAMPLE_WL 4        /* flags bit 2: the Wang-Landau trace (error on a Metropolis handle) */
 int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t thin_by, int flags);
+/* The ring as the next smolmc_get_samples* call sees it (ABI 8): *n_pending = blocks queued and not fetched
+ * (0..2), *nsamples / *flags = sample count and SMOLMC_SAMPLE_* flags of the block that call would deliver
+ * (0 / 0 when the ring is empty) -- get_samples takes no array lengths, a caller that did not queue the
+ * block itself sizes its arrays from here (container.py:409-413 allocates from nsamples the same way).
+ * Any pointer may be NULL. */
+int smolmc_pending_samples(smolmc_handle *h, int *n_pending, int64_t *nsamples, int *flags);
+/* Forget every block of the ring, fetched or not: what a sampling loop that is abandoned half way
+ * (an exception between two blocks, sampler/sampler.py:195-210 left early) calls so that the next loop
+ * does not receive its blocks.  The walkers keep the state the queued launches leave them in. */
+int smolmc_discard_samples(smolmc_handle *h);
 /* [nsamples x R (x F | x N)], NULLs allowed */
 int smolmc_get_samples(smolmc_handle *h, double *enthalpy, double *features,
                        uint8_t *accepted, int32_t *occupancy);

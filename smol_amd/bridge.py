@@ -58,14 +58,11 @@ def local_tables_of(cluster_processor):
     return out
 
 
-def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=False):
-    """capi.TableSet (= smolmc_tables + the arrays it points at) of a smol.moca.Ensemble.
-    ``contiguous`` (default off, like ``moca.Ensemble.make_tables``): when restricted sites or sublattices
-    split by species leave the active sites scattered, relabel the sites (capi.TableSet.permute_sites) so that
-    the specialised kernels still take the model.  Only ``smol_amd.engine.Engine`` undoes the relabelling at its
-    boundary (occupancies and step records in the caller's numbering): any other consumer of the TableSet -- a
-    direct C-ABI client -- must apply ``tab.site_perm`` itself, so ``engine_from_sampler_arguments`` opts in and
-    nothing else does."""
+def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weight=0.1):
+    """capi.TableSet (= smolmc_tables + the arrays it points at) of a smol.moca.Ensemble, in smol's own site
+    numbering.  Restricted sites and sublattices split by species (sublattice.py:84-186) leave the active sites of a
+    sublattice scattered; ``smolmc_create`` renumbers the sites internally then (ABI 8) and every entry point keeps
+    speaking the caller's numbering, so neither this function nor any C-ABI client has anything to translate."""
     ce, ew = split_processor(ensemble.processor)
     sub = ce.cluster_subspace
     decomposition = hasattr(ce, "_interaction_tensors")
@@ -87,11 +84,6 @@ def tables_from_ensemble(ensemble, flip_table=None, flip_weights=None, swap_weig
         [dict(active_sites=s.active_sites, codes=s.encoding) for s in ensemble.active_sublattices],
         **kwargs,
     )
-    if contiguous and getattr(ensemble, "sublattices", None) is not None:
-        new_of = capi.contiguous_relabelling(ce.num_sites, [(s.active_sites, s.restricted_sites)
-                                                            for s in ensemble.sublattices])
-        if new_of is not None:
-            tab.permute_sites(new_of)
     return tab
 
 
@@ -102,7 +94,7 @@ def engine_from_sampler_arguments(ensemble, nwalkers, kernel_type="metropolis", 
 
     kernels = {"metropolis": capi.KERNEL_METROPOLIS, "wanglandau": capi.KERNEL_WANGLANDAU}
     steps = {"flip": capi.STEP_FLIP, "swap": capi.STEP_SWAP, "table-flip": capi.STEP_TABLE_FLIP}
-    tables = tables_from_ensemble(ensemble, contiguous=True)  # (the Engine converts at its boundary)
+    tables = tables_from_ensemble(ensemble)
     cfg = capi.make_config(nwalkers, kernels[kernel_type.lower().replace("-", "")], steps[step_type],
                            device, **wl)
     return Engine(tables, cfg)

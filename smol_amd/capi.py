@@ -23,7 +23,8 @@ STEP_FLIP = 0
 STEP_SWAP = 1
 STEP_TABLE_FLIP = 2
 BIAS_NONE, BIAS_FUGACITY, BIAS_SQUARE_CHARGE, BIAS_SQUARE_HYPERPLANE = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
+ERR_RING_FULL = 2  # SMOLMC_ERR_RING_FULL
 SAMPLE_OCCUPANCY, SAMPLE_BIAS, SAMPLE_WL = 1, 2, 4  # SMOLMC_SAMPLE_* flags of smolmc_run_sampled
 MAX_STEP_FLIPS = 8              # SMOLMC_MAX_STEP_FLIPS
 STEP_ROW = 2 * MAX_STEP_FLIPS   # SMOLMC_STEP_ROW: int32 per step record (site, code) x 8, -1 = no flip
@@ -362,49 +363,6 @@ class TableSet:
             p.append(-1.0)
         return np.array(p)
 
-    site_perm = None  # (new_of, old_of) once permute_sites relabelled the sites
-
-    def _repoint(self):
-        for name, ctype in smolmc_tables._fields_:
-            if name in self._keep:
-                setattr(self.struct, name, _ptr(self._keep[name], ctype._type_))
-
-    def permute_sites(self, new_of):
-        """Relabel the sites in place: site p becomes site ``new_of[p]`` in every table (cluster-site
-        rows, per-site record ranges, Ewald index rows, chemical-potential and bias rows, the active
-        site lists, which keep their ORDER -- so a walker draws the same physical sites from the
-        same random words).  The model is the same model; an `Engine` built from these tables
-        converts occupancies and step records at its boundary (``site_perm``), callers keep their own
-        numbering.  Used by the host API to make every active sublattice a contiguous site range --
-        restricted sites, sublattices split by species -- which is what the specialised kernels index."""
-        new_of = np.asarray(new_of, dtype=np.int64)
-        N = self.struct.num_sites
-        if new_of.shape != (N,) or not np.array_equal(np.sort(new_of), np.arange(N)):
-            raise ValueError("new_of must be a permutation of the sites")
-        old_of = np.argsort(new_of)
-        k = self._keep
-        for name in ("full_idx", "loc_idx", "sub_active_sites"):
-            k[name] = new_of[k[name]].astype(np.int32)
-        sp = k["site_ptr"]
-        order = (np.concatenate([np.arange(sp[p], sp[p + 1]) for p in old_of]) if len(k["loc_orbit"])
-                 else np.zeros(0, np.int64)).astype(np.int64)
-        for name in ("loc_orbit", "loc_ratio", "loc_nrows", "loc_off"):
-            k[name] = np.ascontiguousarray(k[name][order])
-        k["site_ptr"] = np.concatenate(([0], np.cumsum(np.diff(sp)[old_of]))).astype(np.int64)
-        for name in ("ewald_inds", "mu_table"):
-            if name in k:
-                k[name] = np.ascontiguousarray(k[name][old_of])
-        if "bias_table" in k:
-            k["bias_table"] = np.ascontiguousarray(np.take(k["bias_table"], old_of, axis=-2))
-        if self.nspecies_per_site is not None:
-            self.nspecies_per_site = np.ascontiguousarray(self.nspecies_per_site[old_of])
-        self._repoint()
-        if self.site_perm is not None:  # compose with an earlier relabelling
-            new_of = new_of[self.site_perm[0]]
-            old_of = np.argsort(new_of)
-        self.site_perm = (new_of, old_of)
-        return self
-
     def set_bias(self, bias_type, table=None, penalty=0.0, intercepts=None):
         """Attach (or clear) an MCBias term (smol/moca/kernel/bias.py): ``table`` is the
         reference's per-(site, species code) table -- fugacity fractions (BIAS_FUGACITY,
@@ -439,8 +397,6 @@ class TableSet:
             raise ValueError("fugacity fractions must be positive")
         if bias_type != BIAS_FUGACITY and not penalty > 0:
             raise ValueError("Penalty factor should be > 0!")  # bias.py:250-251, :328-329
-        if self.site_perm is not None:  # the table comes in the caller's site numbering
-            tb = np.take(tb, self.site_perm[1], axis=-2)
         tb = np.ascontiguousarray(tb)
         self._keep["bias_table"] = tb
         t.bias_type, t.bias_width, t.bias_penalty = int(bias_type), shape[1], float(penalty)
@@ -561,22 +517,6 @@ def step_rows(steps, *lead):
     out = np.full(a.shape[:-1] + (STEP_ROW,), -1, dtype=np.int32)
     out[..., :w] = a
     return np.ascontiguousarray(out)
-
-
-def contiguous_relabelling(num_sites, sublattices):
-    """Site relabelling (``new_of`` for TableSet.permute_sites) that makes every sublattice one site
-    range with its active sites first, in the order of their list: ``sublattices`` = (active_sites,
-    restricted_sites) of ALL sublattices of the ensemble, in order.  None when the sites already are
-    numbered that way (or the sublattices do not partition the sites)."""
-    order = [np.asarray(x, dtype=np.int64) for pair in sublattices for x in pair]
-    old_of = np.concatenate(order) if order else np.zeros(0, np.int64)
-    if len(old_of) != num_sites or not np.array_equal(np.sort(old_of), np.arange(num_sites)):
-        return None
-    if np.array_equal(old_of, np.arange(num_sites)):
-        return None
-    new_of = np.empty(num_sites, dtype=np.int64)
-    new_of[old_of] = np.arange(num_sites)
-    return new_of
 
 
 def make_config(

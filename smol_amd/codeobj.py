@@ -73,6 +73,13 @@ def _demangle(names):
     return dem if len(dem) == len(names) else list(names)
 
 
+def _merge_copies(copies):
+    """{mangled name: set of digests of its copies} -> one digest per name: the copy's own when all copies are
+    byte-identical, else a digest over all of them (order-free)."""
+    return {n: (next(iter(c)) if len(c) == 1 else hashlib.sha256("".join(sorted(c)).encode()).hexdigest())
+            for n, c in copies.items()}
+
+
 def kernel_digests(path=None):
     """{demangled kernel name: sha256 over its machine code and its kernel descriptor} for every
     kernel of the library (default: the library engine.load_library would load)."""
@@ -85,7 +92,11 @@ def kernel_digests(path=None):
         return _CACHE[key]
     with open(path, "rb") as fh:
         blob = fh.read()
-    raw = {}
+    # A kernel defined in a shared header (the static __global__ helpers of smolmc_common.h) is emitted by several
+    # translation units under ONE mangled name: every copy is digested, and a name whose copies differ gets the
+    # digest of all of them together (sorted) -- it changes when ANY copy changes, so `isa_stale` cannot compare an
+    # entry with the wrong translation unit's copy.
+    copies = {}
     for elf in _code_objects(blob):
         syms, read = _elf_symbols(elf)
         if read is None:
@@ -97,7 +108,8 @@ def kernel_digests(path=None):
             h = hashlib.sha256()
             h.update(read(sh, v, sz))
             h.update(read(*kd[n]))
-            raw[n] = h.hexdigest()
+            copies.setdefault(n, set()).add(h.hexdigest())
+    raw = _merge_copies(copies)
     names = sorted(raw)
     out = {d: raw[m] for m, d in zip(names, _demangle(names))}
     _CACHE[key] = out

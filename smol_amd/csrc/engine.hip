@@ -1033,9 +1033,156 @@ static int build_compact_ewald(smolmc_handle *h, const smolmc_tables *t) {
 extern "C" int smolmc_abi_version(void) { return SMOLMC_ABI_VERSION; }
 extern "C" const char *smolmc_last_error(void) { return smolmc_g_err.c_str(); }
 
+// ---- site relabelling behind the boundary (ABI 8) -------------------------------------------------------------
+// The lean kernel families index an active sublattice as ONE site range (site = base + mulhi(word, n_active)).
+// Ensemble.restrict_sites and split_sublattice_by_species (smol/moca/sublattice.py:84-186, ensemble.py:288-321)
+// leave the active sites of a sublattice scattered.  smolmc_create then renumbers the sites ITSELF: the active sites
+// of every sublattice first, in the order of their lists (so a walker draws the same physical site from the same
+// random word), then the other sites whose species can differ between occupancies (restricted sites: the Ewald
+// potential field covers one block of changeable sites), then the rest, each group in the caller's order.  The handle
+// is built from the renumbered tables; occupancies, step records and sample rows cross every entry point in the
+// CALLER's numbering (set_state / get_state / get_samples* / replay / eval_full / eval_delta).  Rounds 4-5 did this in
+// the Python binding only (capi.TableSet.permute_sites), so a C client of this header got mc_kernel.
+struct RelabelledTables {
+    smolmc_tables t;
+    std::vector<int32_t> full_idx, loc_idx, sub_active_sites, loc_orbit, loc_nrows, ewald_inds;
+    std::vector<int64_t> site_ptr, loc_off;
+    std::vector<double> loc_ratio, mu_table, bias_table;
+};
+
+// new_of (caller's site -> engine's site) when a relabelling is needed and possible, else empty
+static std::vector<int32_t> plan_relabelling(const smolmc_tables *t) {
+    std::vector<int32_t> none;
+    const int N = t->num_sites, ns = t->n_sublattices;
+    if (N <= 0 || ns <= 0 || !t->sub_site_ptr || !t->sub_active_sites || getenv("SMOLMC_NO_SITE_RELABEL")) return none;
+    bool needed = false;
+    std::vector<char> taken((size_t)N, 0);
+    std::vector<int32_t> order;
+    order.reserve((size_t)N);
+    for (int k = 0; k < ns; ++k) {
+        const int64_t a = t->sub_site_ptr[k], b = t->sub_site_ptr[k + 1];
+        for (int64_t i = a; i < b; ++i) {
+            const int st = t->sub_active_sites[i];
+            if (st < 0 || st >= N || taken[st]) return none; // (malformed lists: smolmc_create reports them)
+            taken[st] = 1;
+            order.push_back(st);
+            if (st != t->sub_active_sites[a] + (int)(i - a)) needed = true;
+        }
+    }
+    if (!needed) return none;
+    // sites outside the active lists: changeable ones (more than one Ewald species, or a vacancy: what
+    // build_compact_ewald does not fold into the frozen-site constants) before the single-species ones
+    auto frozen = [&](int s) {
+        if (!t->has_ewald || !t->ewald_inds) return true;
+        int nvalid = 0;
+        for (int c = 0; c < t->ewald_width; ++c) nvalid += t->ewald_inds[(size_t)s * t->ewald_width + c] >= 0;
+        return nvalid == 1 && t->ewald_inds[(size_t)s * t->ewald_width] >= 0;
+    };
+    for (int pass = 0; pass < 2; ++pass)
+        for (int s = 0; s < N; ++s)
+            if (!taken[s] && frozen(s) == (pass == 1)) order.push_back(s);
+    if ((int)order.size() != N) return none;
+    std::vector<int32_t> new_of((size_t)N);
+    for (int p = 0; p < N; ++p) new_of[order[p]] = p;
+    return new_of;
+}
+
+// the caller's tables with site p renamed new_of[p] in every site-indexed array (validate_tables has passed)
+static void relabel_tables(const smolmc_tables *t, const std::vector<int32_t> &new_of, const std::vector<int32_t> &old_of,
+                           RelabelledTables &rt) {
+    const int N = t->num_sites;
+    rt.t = *t;
+    const int64_t nfull = t->full_off[t->n_orb], nrec = t->site_ptr[N];
+    rt.full_idx.resize((size_t)nfull);
+    for (int64_t i = 0; i < nfull; ++i) rt.full_idx[i] = new_of[t->full_idx[i]];
+    int64_t nloc = 0;
+    for (int64_t r = 0; r < nrec; ++r)
+        nloc = std::max<int64_t>(nloc, t->loc_off[r] + (int64_t)t->loc_nrows[r] * t->orb_nsites[t->loc_orbit[r]]);
+    rt.loc_idx.resize((size_t)nloc);
+    for (int64_t i = 0; i < nloc; ++i) {
+        const int v = t->loc_idx[i];
+        rt.loc_idx[i] = (v >= 0 && v < N) ? new_of[v] : v; // (entries between records, if any, are never read)
+    }
+    // the record range of engine site p is that of the caller's site old_of[p]
+    rt.site_ptr.assign((size_t)N + 1, 0);
+    rt.loc_orbit.reserve((size_t)nrec); rt.loc_nrows.reserve((size_t)nrec);
+    rt.loc_off.reserve((size_t)nrec); rt.loc_ratio.reserve((size_t)nrec);
+    for (int p = 0; p < N; ++p) {
+        const int q = old_of[p];
+        for (int64_t r = t->site_ptr[q]; r < t->site_ptr[q + 1]; ++r) {
+            rt.loc_orbit.push_back(t->loc_orbit[r]);
+            rt.loc_nrows.push_back(t->loc_nrows[r]);
+            rt.loc_off.push_back(t->loc_off[r]);
+            rt.loc_ratio.push_back(t->loc_ratio[r]);
+        }
+        rt.site_ptr[(size_t)p + 1] = (int64_t)rt.loc_orbit.size();
+    }
+    const int64_t nact = t->sub_site_ptr[t->n_sublattices];
+    rt.sub_active_sites.resize((size_t)nact);
+    for (int64_t i = 0; i < nact; ++i) rt.sub_active_sites[i] = new_of[t->sub_active_sites[i]];
+    auto rows = [&](const auto *src, int width, int blocks, auto &dst) {
+        dst.resize((size_t)blocks * N * width);
+        for (int b = 0; b < blocks; ++b)
+            for (int p = 0; p < N; ++p)
+                std::copy(src + ((size_t)b * N + old_of[p]) * width, src + ((size_t)b * N + old_of[p] + 1) * width,
+                          dst.begin() + ((size_t)b * N + p) * width);
+    };
+    rt.t.full_idx = rt.full_idx.data();
+    rt.t.loc_idx = rt.loc_idx.data();
+    rt.t.site_ptr = rt.site_ptr.data();
+    rt.t.loc_orbit = rt.loc_orbit.data();
+    rt.t.loc_nrows = rt.loc_nrows.data();
+    rt.t.loc_off = rt.loc_off.data();
+    rt.t.loc_ratio = rt.loc_ratio.data();
+    rt.t.sub_active_sites = rt.sub_active_sites.data();
+    if (t->has_ewald && t->ewald_inds) {
+        rows(t->ewald_inds, t->ewald_width, 1, rt.ewald_inds);
+        rt.t.ewald_inds = rt.ewald_inds.data();
+    }
+    if (t->has_mu && t->mu_table) {
+        rows(t->mu_table, t->mu_width, 1, rt.mu_table);
+        rt.t.mu_table = rt.mu_table.data();
+    }
+    if (t->bias_type && t->bias_table && t->bias_width > 0) {
+        const int brows = t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE ? std::max(1, std::min(t->bias_rows, SMOLMC_MAX_BIAS_ROWS)) : 1;
+        rows(t->bias_table, t->bias_width, brows, rt.bias_table);
+        rt.t.bias_table = rt.bias_table.data();
+    }
+}
+
+static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_handle **out, std::vector<int32_t> *new_of);
+
+// Test hooks, NOT part of the C-ABI (not in include/smolmc.h): the renumbering smolmc_create would apply to these
+// tables, as a heap copy whose first member is the renumbered smolmc_tables (NULL: none needed / possible), and the
+// map caller's site -> engine's site.  Host code only: tests/test_relabel_host.py runs the CPU oracle on both table
+// sets without a GPU.
+extern "C" void *smolmc_debug_relabel(const smolmc_tables *t, int32_t *new_of_out) {
+    if (!t || validate_tables(t)) return nullptr;
+    std::vector<int32_t> new_of = plan_relabelling(t);
+    if (new_of.empty()) return nullptr;
+    std::vector<int32_t> old_of(new_of.size());
+    for (size_t p = 0; p < new_of.size(); ++p) old_of[new_of[p]] = (int32_t)p;
+    RelabelledTables *rt = new RelabelledTables();
+    relabel_tables(t, new_of, old_of, *rt);
+    if (new_of_out) std::copy(new_of.begin(), new_of.end(), new_of_out);
+    return rt;
+}
+extern "C" void smolmc_debug_relabel_free(void *p) { delete (RelabelledTables *)p; }
+
 extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, smolmc_handle **out) {
     if (!t || !cfg || !out) return fail("null argument");
     if (cfg->n_replicas <= 0) return fail("n_replicas must be positive");
+    if (int rc = validate_tables(t)) return rc; // (in the caller's numbering, before anything is renamed)
+    std::vector<int32_t> new_of = plan_relabelling(t);
+    if (new_of.empty()) return create_impl(t, cfg, out, nullptr);
+    std::vector<int32_t> old_of(new_of.size());
+    for (size_t p = 0; p < new_of.size(); ++p) old_of[new_of[p]] = (int32_t)p;
+    RelabelledTables rt;
+    relabel_tables(t, new_of, old_of, rt);
+    return create_impl(&rt.t, cfg, out, &new_of); // (the engine copies every table at create: rt may go)
+}
+
+static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_handle **out, std::vector<int32_t> *new_of) {
     if (t->max_species > 255) return fail("more than 255 species codes per site");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1045,6 +1192,12 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     smolmc_handle *h = new smolmc_handle();
     h->cfg = *cfg;
     h->device = cfg->device;
+    if (new_of) {
+        h->relabelled = true;
+        h->new_of = *new_of;
+        h->old_of.resize(new_of->size());
+        for (size_t p = 0; p < new_of->size(); ++p) h->old_of[(*new_of)[p]] = (int32_t)p;
+    }
     auto bail = [&](int rc) {
         smolmc_destroy(h);
         return rc;
@@ -1075,7 +1228,7 @@ extern "C" int smolmc_create(const smolmc_tables *t, const smolmc_config *cfg, s
     }
     memset(&h->kp, 0, sizeof(KParams));
     KParams &kp = h->kp;
-    if (int rc = validate_tables(t)) return bail(rc);
+    // (validate_tables(t) has passed: smolmc_create runs it on the caller's tables before any renaming)
     // species codes a site may carry: max_species by default, the largest sublattice code + 1 on
     // the sites of an active sublattice
     h->site_ncodes.assign((size_t)t->num_sites, (uint8_t)std::min(255, std::max(1, t->max_species)));
@@ -1940,6 +2093,46 @@ static int lazy_scalars_from_features(smolmc_handle *h) {
     return 0;
 }
 
+// ---- the boundary of a relabelled handle (see plan_relabelling): caller's numbering <-> engine's ----------------
+// rows of occupancies in the caller's numbering -> the engine's (a copy; the caller's array on a plain handle)
+static const int32_t *occ_in(const smolmc_handle *h, const int32_t *occ, size_t rows, std::vector<int32_t> &tmp) {
+    if (!h->relabelled) return occ;
+    const size_t N = (size_t)h->N;
+    tmp.resize(rows * N);
+    const int32_t *old_of = h->old_of.data();
+    for (size_t r = 0; r < rows; ++r) {
+        const int32_t *src = occ + r * N;
+        int32_t *dst = tmp.data() + r * N;
+        for (size_t p = 0; p < N; ++p) dst[p] = src[old_of[p]];
+    }
+    return tmp.data();
+}
+// ... and back, in place
+static void occ_out(const smolmc_handle *h, int32_t *occ, size_t rows) {
+    if (!h->relabelled) return;
+    const size_t N = (size_t)h->N;
+    std::vector<int32_t> row(N);
+    const int32_t *new_of = h->new_of.data();
+    for (size_t r = 0; r < rows; ++r) {
+        int32_t *o = occ + r * N;
+        std::copy(o, o + N, row.begin());
+        for (size_t p = 0; p < N; ++p) o[p] = row[new_of[p]];
+    }
+}
+// step records (site, code) x SMOLMC_MAX_STEP_FLIPS: the sites renamed; a site outside the cell is left as it is --
+// the range checks of the entry point reject it (renaming it would turn it into a step nobody asked for)
+static const int32_t *steps_in(const smolmc_handle *h, const int32_t *steps, size_t nrec, std::vector<int32_t> &tmp) {
+    if (!h->relabelled) return steps;
+    tmp.assign(steps, steps + nrec * SMOLMC_STEP_ROW);
+    for (size_t i = 0; i < nrec; ++i)
+        for (int f = 0; f < SMOLMC_MAX_STEP_FLIPS; ++f) {
+            int32_t &site = tmp[i * SMOLMC_STEP_ROW + 2 * f];
+            if (site < 0) break;
+            if (site < h->N) site = h->new_of[site];
+        }
+    return tmp.data();
+}
+
 static int upload_occ(smolmc_handle *h, const int32_t *occ, size_t nocc, uint8_t *d_occ8) {
     const size_t n32 = nocc * h->N;
     // every code must exist on its site: a larger one would index past the tensors / tables on the
@@ -1949,8 +2142,8 @@ static int upload_occ(smolmc_handle *h, const int32_t *occ, size_t nocc, uint8_t
     for (size_t i = 0, s = 0; i < n32; ++i, s = (s + 1 == N ? 0 : s + 1))
         if (occ[i] < 0 || occ[i] >= (int)lim[s]) {
             char msg[160];
-            snprintf(msg, sizeof msg, "occupancy code %d out of range on site %zu (%d species codes there)", occ[i], s,
-                     (int)lim[s]);
+            snprintf(msg, sizeof msg, "occupancy code %d out of range on site %zu (%d species codes there)", occ[i],
+                     h->relabelled ? (size_t)h->old_of[s] : s, (int)lim[s]); // (the site in the caller's numbering)
             return fail(msg);
         }
     int *d32 = nullptr;
@@ -1982,6 +2175,8 @@ extern "C" int smolmc_set_state(smolmc_handle *h, const int32_t *occ, const uint
     HIPCHK(hipSetDevice(h->device));
     KParams &kp = h->kp;
     const size_t R = h->R;
+    std::vector<int32_t> occ_engine;
+    occ = occ_in(h, occ, R, occ_engine);
     TRY(upload_occ(h, occ, R, kp.occ));
     std::vector<double> beta;
     set_betas(h, temperature, beta);
@@ -2115,6 +2310,7 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
         if (is_lazy(h) && strlen(buf) + 16 < (size_t)n) strncat(buf, " lazy-features", (size_t)n - strlen(buf) - 1);
         if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
             snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");
+        if (h->relabelled && strlen(buf) + 16 < (size_t)n) strncat(buf, " relabelled=1", (size_t)n - strlen(buf) - 1);
         // why the model runs neither lean family (the first condition that failed at smolmc_create)
         if (!h->lean && !h->lean_reason.empty() && strlen(buf) + h->lean_reason.size() + 16 < (size_t)n) {
             strncat(buf, " | not lean: ", (size_t)n - strlen(buf) - 1);
@@ -2151,6 +2347,7 @@ extern "C" int smolmc_get_state(smolmc_handle *h, int32_t *occ, double *features
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         hipFree(d32);
         if (e != hipSuccess) return fail(std::string("occupancy download: ") + hipGetErrorString(e));
+        occ_out(h, occ, R);
     }
     if (features) {
         TRY(ensure_features(h));
@@ -2459,69 +2656,85 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
     const bool wl = h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU;
     if ((flags & SMOLMC_SAMPLE_BIAS) && !h->kp.bias_type) return fail("the model has no bias term");
     if ((flags & SMOLMC_SAMPLE_WL) && !wl) return fail("handle is not a Wang-Landau kernel");
+    if (thin_by > ((int64_t)1 << 30) && h->lean && getenv("SMOLMC_LAUNCH_CHUNK") == nullptr)
+        return fail("thin_by must be <= 2^30 steps"); // (before a slot is touched: run_steps would refuse it)
     if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    // The slot this block goes to is the older one.  When it still holds a block nobody fetched, so does the other
+    // (it is younger): the ring is full and the call is refused -- ABI 7 dropped the older block here without a word.
     SampleSlot &sl = h->slots[h->next_slot];
-    h->next_slot ^= 1;
+    if (sl.state == 1) {
+        fail("sample ring full: both slots hold blocks that were not fetched (call smolmc_get_samples* or "
+             "smolmc_discard_samples first)");
+        return SMOLMC_ERR_RING_FULL;
+    }
     if (!sl.kernel_done) {
         HIPCHK(hipEventCreateWithFlags(&sl.kernel_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.copy_done, hipEventDisableTiming));
     }
-    // layout of the block inside the slot's arenas
+    // layout of the block inside the slot's arenas: worked out on a COPY of the slot record, which replaces the
+    // record only when every launch of the block has been queued -- a call that fails on the way (an allocation, a
+    // launch) leaves the ring as it was: the slot keeps its delivered block, next_slot does not move
+    SampleSlot w = sl;
     const size_t rows = (size_t)nsamples * h->R, F = (size_t)h->F, L = (size_t)h->L;
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at += up256(bytes); return o; };
-    sl.o_H = take(rows * 8);
-    sl.o_feat = take(rows * F * 8);
-    sl.o_acc = take(rows);
-    sl.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? take(rows * 8) : 0;
-    sl.o_wlm = sl.o_wlS = sl.o_wlh = sl.o_wlo = sl.o_wlf = 0;
+    w.o_H = take(rows * 8);
+    w.o_feat = take(rows * F * 8);
+    w.o_acc = take(rows);
+    w.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? take(rows * 8) : 0;
+    w.o_wlm = w.o_wlS = w.o_wlh = w.o_wlo = w.o_wlf = 0;
     if (flags & SMOLMC_SAMPLE_WL) {
-        sl.o_wlm = take(rows * 8);
-        sl.o_wlS = take(rows * L * 8);
-        sl.o_wlh = take(rows * L * 8);
-        sl.o_wlo = take(rows * L * 8);
-        sl.o_wlf = take(rows * L * F * 8);
+        w.o_wlm = take(rows * 8);
+        w.o_wlS = take(rows * L * 8);
+        w.o_wlh = take(rows * L * 8);
+        w.o_wlo = take(rows * L * 8);
+        w.o_wlf = take(rows * L * F * 8);
     }
-    sl.o_occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? take(rows * h->Npad) : 0;
+    w.o_occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) ? take(rows * h->Npad) : 0;
     // lazy cluster features, rows recorded in-kernel: the kernels write rows of scalar features and the occupancy of
     // every sample; the cluster features of the rows are evaluated from those when the launch is through.  What the
     // caller did not ask for sits behind the part of the arena that is downloaded.
     const bool lazy_rows = is_lazy(h) && !(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL));
-    size_t download = at, o_scal = 0, o_occ_int = sl.o_occ;
+    size_t download = at, o_scal = 0, o_occ_int = w.o_occ;
     if (lazy_rows) {
         download = at;
         o_scal = take(rows * (size_t)std::max(1, lazy_nscal(h)) * 8);
         if (!(flags & SMOLMC_SAMPLE_OCCUPANCY)) o_occ_int = take(rows * h->Npad);
     }
-    // the slot's previous block must have left the device (and its pinned mirror is about to be reused: a
-    // block the caller never fetched is dropped here)
+    if (lazy_rows && rows > 0x7fffffffull) return fail("lazy cluster features: more than 2^31 sample rows in one block");
+    // the slot's previous block (delivered, or none) must have left the device before its arenas are reused
     if (sl.state != 0) HIPCHK(hipEventSynchronize(sl.copy_done));
     if (at > sl.cap) {
+        // (growing frees the delivered block's mirror: the slot is empty from here on, whatever happens next)
+        sl.state = 0;
         if (sl.d) hipFree(sl.d);
         if (sl.hst) hipHostFree(sl.hst);
         sl.d = sl.hst = nullptr;
         sl.cap = 0;
         HIPCHK(hipMalloc((void **)&sl.d, at));
-        HIPCHK(hipHostMalloc((void **)&sl.hst, at, hipHostMallocDefault));
+        if (hipHostMalloc((void **)&sl.hst, at, hipHostMallocDefault) != hipSuccess) {
+            hipFree(sl.d);
+            sl.d = nullptr;
+            return fail("hipHostMalloc failed (pinned mirror of the sample ring)");
+        }
         sl.cap = at;
+        w.d = sl.d; w.hst = sl.hst; w.cap = sl.cap;
     }
-    sl.used = lazy_rows ? download : at;
-    sl.n = nsamples;
-    sl.flags = flags;
-    sl.state = 0;
+    w.used = lazy_rows ? download : at;
+    w.n = nsamples;
+    w.flags = flags;
     SampleBufs smp;
     memset(&smp, 0, sizeof(smp));
     smp.every = thin_by;
-    smp.H = (double *)(sl.d + sl.o_H);
-    smp.feat = (double *)(sl.d + (lazy_rows ? o_scal : sl.o_feat));
-    smp.acc = sl.d + sl.o_acc;
+    smp.H = (double *)(sl.d + w.o_H);
+    smp.feat = (double *)(sl.d + (lazy_rows ? o_scal : w.o_feat));
+    smp.acc = sl.d + w.o_acc;
     smp.occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) || lazy_rows ? sl.d + o_occ_int : nullptr;
     if (!(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL))) {
         TRY(run_steps(h, nsamples * thin_by, smp)); // the kernels record the rows themselves, one launch
         if (lazy_rows) {
-            if (rows > 0x7fffffffull) return fail("lazy cluster features: more than 2^31 sample rows in one block");
-            TRY(launch_eval_full(h, sl.d + o_occ_int, (int)rows, (double *)(sl.d + sl.o_feat), 1));
-            TRY(lazy_scalars(h, (double *)(sl.d + sl.o_feat), (double *)(sl.d + o_scal), rows, 0));
+            TRY(launch_eval_full(h, sl.d + o_occ_int, (int)rows, (double *)(sl.d + w.o_feat), 1));
+            TRY(lazy_scalars(h, (double *)(sl.d + w.o_feat), (double *)(sl.d + o_scal), rows, 0));
         }
     } else {
         SampleBufs none;
@@ -2532,11 +2745,11 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
         A.occ = kp.occ; A.features = kp.features; A.enthalpy = kp.enthalpy; A.last_acc = kp.last_acc; A.bias = kp.bias;
         A.wl_S = kp.wl_entropy; A.wl_hist = kp.wl_hist; A.wl_occ = kp.wl_occur; A.wl_mf = kp.wl_meanf; A.wl_m = kp.wl_m;
         A.o_occ = smp.occ; A.o_feat = smp.feat; A.o_H = smp.H; A.o_acc = smp.acc;
-        A.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? (double *)(sl.d + sl.o_bias) : nullptr;
+        A.o_bias = (flags & SMOLMC_SAMPLE_BIAS) ? (double *)(sl.d + w.o_bias) : nullptr;
         if (flags & SMOLMC_SAMPLE_WL) {
-            A.o_wlm = (double *)(sl.d + sl.o_wlm); A.o_wlS = (double *)(sl.d + sl.o_wlS);
-            A.o_wlh = (long long *)(sl.d + sl.o_wlh); A.o_wlo = (long long *)(sl.d + sl.o_wlo);
-            A.o_wlf = (double *)(sl.d + sl.o_wlf);
+            A.o_wlm = (double *)(sl.d + w.o_wlm); A.o_wlS = (double *)(sl.d + w.o_wlS);
+            A.o_wlh = (long long *)(sl.d + w.o_wlh); A.o_wlo = (long long *)(sl.d + w.o_wlo);
+            A.o_wlf = (double *)(sl.d + w.o_wlf);
         }
         A.R = h->R; A.F = h->F; A.L = h->L; A.Npad = h->Npad;
         for (int64_t j = 0; j < nsamples; ++j) {
@@ -2548,13 +2761,51 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
         }
     }
     // download on the copy stream as soon as the block is complete; the next block's launches do not wait for it
+    // (the mirror is about to be overwritten: from here the slot no longer holds its old block)
+    sl.state = 0;
     HIPCHK(hipEventRecord(sl.kernel_done, h->stream));
     HIPCHK(hipStreamWaitEvent(h->copy_stream, sl.kernel_done, 0));
-    HIPCHK(hipMemcpyAsync(sl.hst, sl.d, sl.used, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipMemcpyAsync(sl.hst, sl.d, w.used, hipMemcpyDeviceToHost, h->copy_stream));
     HIPCHK(hipEventRecord(sl.copy_done, h->copy_stream));
     // (the next writer of this slot's arenas -- the call after next -- waits for copy_done above)
-    sl.state = 1;
-    sl.seq = ++h->slot_seq;
+    // every launch is queued: the block takes the slot
+    w.state = 1;
+    w.seq = ++h->slot_seq;
+    sl = w;
+    h->next_slot ^= 1;
+    return 0;
+}
+
+// The block the next smolmc_get_samples* call delivers (ABI 8): its sample count and flags, so that a caller can size
+// its arrays from the ring itself -- get_samples takes no lengths -- and the number of blocks queued and not fetched.
+static SampleSlot *next_delivery(smolmc_handle *h) {
+    SampleSlot *sl = nullptr;
+    for (SampleSlot &c : h->slots)
+        if (c.state == 1 && (!sl || c.seq < sl->seq)) sl = &c;
+    if (!sl)
+        for (SampleSlot &c : h->slots)
+            if (c.state == 2 && (!sl || c.seq > sl->seq)) sl = &c;
+    return sl;
+}
+extern "C" int smolmc_pending_samples(smolmc_handle *h, int *n_pending, int64_t *nsamples, int *flags) {
+    if (!h) return fail("null handle");
+    int np = 0;
+    for (SampleSlot &c : h->slots) np += c.state == 1;
+    const SampleSlot *sl = next_delivery(h);
+    if (n_pending) *n_pending = np;
+    if (nsamples) *nsamples = sl ? (int64_t)sl->n : 0;
+    if (flags) *flags = sl ? sl->flags : 0;
+    return 0;
+}
+// Forget every block of the ring, fetched or not (a sampling loop that was abandoned half way: the blocks it queued
+// must not be delivered to the next one).  The walkers keep the state the queued launches leave them in.
+extern "C" int smolmc_discard_samples(smolmc_handle *h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    for (SampleSlot &c : h->slots) {
+        if (c.state != 0 && c.copy_done) HIPCHK(hipEventSynchronize(c.copy_done));
+        c.state = 0;
+    }
     return 0;
 }
 
@@ -2573,12 +2824,14 @@ static void host_copy(void *dst, const void *src, size_t bytes) {
     for (int k = 0; k < nt; ++k) th[k].join();
 }
 // occupancy rows: Npad bytes apart in the ring, N bytes (uint8) or N int32 in the caller's array
-template <typename T> static void host_copy_occ(T *dst, const uint8_t *src, size_t rows, int N, int Npad) {
+// (new_of != nullptr: a relabelled handle -- column p of the caller's row is byte new_of[p] of the ring's)
+template <typename T> static void host_copy_occ(T *dst, const uint8_t *src, size_t rows, int N, int Npad, const int32_t *new_of) {
     auto work = [=](size_t r0, size_t r1) {
         for (size_t r = r0; r < r1; ++r) {
             const uint8_t *s = src + r * Npad;
             T *d = dst + r * (size_t)N;
-            if (sizeof(T) == 1) memcpy(d, s, (size_t)N);
+            if (new_of) for (int i = 0; i < N; ++i) d[i] = (T)s[new_of[i]];
+            else if (sizeof(T) == 1) memcpy(d, s, (size_t)N);
             else for (int i = 0; i < N; ++i) d[i] = (T)s[i];
         }
     };
@@ -2594,12 +2847,7 @@ static int get_samples_impl(smolmc_handle *h, double *enthalpy, double *features
                             int64_t *wl_occ, double *wl_mf, double *wl_m) {
     if (!h) return fail("null handle");
     // the oldest block not yet delivered; with none pending, the newest delivered one again
-    SampleSlot *sl = nullptr;
-    for (SampleSlot &c : h->slots)
-        if (c.state == 1 && (!sl || c.seq < sl->seq)) sl = &c;
-    if (!sl)
-        for (SampleSlot &c : h->slots)
-            if (c.state == 2 && (!sl || c.seq > sl->seq)) sl = &c;
+    SampleSlot *sl = next_delivery(h);
     if (!sl) return fail("no samples recorded: call smolmc_run_sampled first");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventSynchronize(sl->copy_done));
@@ -2617,8 +2865,9 @@ static int get_samples_impl(smolmc_handle *h, double *enthalpy, double *features
     if (wl_hist) host_copy(wl_hist, sl->hst + sl->o_wlh, rows * L * 8);
     if (wl_occ) host_copy(wl_occ, sl->hst + sl->o_wlo, rows * L * 8);
     if (wl_mf) host_copy(wl_mf, sl->hst + sl->o_wlf, rows * L * F * 8);
-    if (occ8) host_copy_occ<uint8_t>(occ8, sl->hst + sl->o_occ, rows, h->N, h->Npad);
-    if (occ32) host_copy_occ<int32_t>(occ32, sl->hst + sl->o_occ, rows, h->N, h->Npad);
+    const int32_t *new_of = h->relabelled ? h->new_of.data() : nullptr;
+    if (occ8) host_copy_occ<uint8_t>(occ8, sl->hst + sl->o_occ, rows, h->N, h->Npad, new_of);
+    if (occ32) host_copy_occ<int32_t>(occ32, sl->hst + sl->o_occ, rows, h->N, h->Npad, new_of);
     sl->state = 2;
     return 0;
 }
@@ -2681,6 +2930,8 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     if (nsteps <= 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     const size_t n = (size_t)h->R * nsteps;
+    std::vector<int32_t> steps_engine;
+    steps = steps_in(h, steps, n, steps_engine);
     // every flip: a changeable site of an active sublattice (the lean kernels index their tables
     // relative to the active range; a code beyond the site's species would index past its tensors)
     int max_flips = 0;
@@ -2834,6 +3085,8 @@ extern "C" int smolmc_eval_full(smolmc_handle *h, const int32_t *occ, int nocc, 
     if (nocc <= 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     TRY(ensure_eval_occ(h, nocc));
+    std::vector<int32_t> occ_engine;
+    occ = occ_in(h, occ, (size_t)nocc, occ_engine);
     TRY(upload_occ(h, occ, nocc, h->d_eval_occ));
     double *d_out = nullptr;
     HIPCHK(hipMalloc((void **)&d_out, (size_t)nocc * h->F * 8));
@@ -2851,6 +3104,9 @@ extern "C" int smolmc_eval_delta(smolmc_handle *h, const int32_t *occ, const int
     if (!h || !occ || !flips || !dfeatures) return fail("null argument");
     if (nstep <= 0) return 0;
     HIPCHK(hipSetDevice(h->device));
+    std::vector<int32_t> occ_engine, flips_engine;
+    occ = occ_in(h, occ, 1, occ_engine);
+    flips = steps_in(h, flips, (size_t)nstep, flips_engine);
     for (int i = 0; i < nstep; ++i)
         for (int f = 0; f < SMOLMC_MAX_STEP_FLIPS; ++f) {
             const int s = flips[(size_t)i * SMOLMC_STEP_ROW + 2 * f], c = flips[(size_t)i * SMOLMC_STEP_ROW + 2 * f + 1];

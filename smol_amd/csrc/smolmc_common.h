@@ -695,6 +695,10 @@ struct smolmc_handle {
     std::string lean_reason;           // why the model runs neither lean family (first failing condition; empty: it does)
     int univ_wpb = 4;
     int max_step_flips = 2;      // most flips a native step of this handle makes (TableFlip: from the table)
+    // site relabelling behind the boundary (engine.hip, plan_relabelling): the tables this handle was built from are
+    // the caller's with the sites renumbered; occupancies and step records are translated at every entry point
+    bool relabelled = false;
+    std::vector<int32_t> new_of, old_of; // caller's site -> engine's site, and back
 };
 
 static void free_samples(smolmc_handle *h);

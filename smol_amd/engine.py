@@ -42,6 +42,8 @@ SYMBOLS = {
     "smolmc_run": (C.c_int, [_HP, C.c_int64]),
     "smolmc_sync": (C.c_int, [_HP]),
     "smolmc_run_sampled": (C.c_int, [_HP, C.c_int64, C.c_int64, C.c_int]),
+    "smolmc_pending_samples": (C.c_int, [_HP, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "smolmc_discard_samples": (C.c_int, [_HP]),
     "smolmc_get_samples": (C.c_int, [_HP, _f64p, _f64p, _u8p, _i32p]),
     "smolmc_get_samples_u8": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p]),
     "smolmc_get_samples_ex": (C.c_int, [_HP, _f64p, _f64p, _u8p, _u8p, _f64p, _f64p, _i64p, _i64p, _f64p, _f64p]),
@@ -114,6 +116,10 @@ class EngineError(RuntimeError):
     pass
 
 
+class RingFullError(EngineError):
+    """smolmc_run_sampled refused a block: both ring slots hold blocks that were not fetched."""
+
+
 class Engine:
     """One engine handle = R walkers of one ensemble on one GPU."""
 
@@ -121,15 +127,13 @@ class Engine:
         self._lib = load_library()
         self.tables, self.config = tables, config
         self._h = _HP()
-        self._pending = []  # blocks queued on the device ring and not fetched yet: (nsamples, flags)
         rc = self._lib.smolmc_create(C.byref(tables.struct), C.byref(config), C.byref(self._h))
         if rc:
             self._h = None
             self._chk(rc)
-        # tables whose sites were relabelled (capi.TableSet.permute_sites): occupancies and step
-        # records cross this boundary in the CALLER's numbering
-        perm = getattr(tables, "site_perm", None)
-        self._new_of, self._old_of = (None, None) if perm is None else (perm[0].copy(), perm[1].copy())
+        # (scattered active sites -- restricted sites, sublattices split by species -- are renumbered INSIDE
+        # smolmc_create since ABI 8, `kernel_info` says "relabelled=1": occupancies and step records cross the C-ABI
+        # in the caller's numbering, nothing is translated here)
         self.R = config.n_replicas
         self.N = tables.struct.num_sites
         self.F = self._lib.smolmc_num_features(self._h)
@@ -149,6 +153,8 @@ class Engine:
     def _chk(self, rc):
         if rc:
             msg = self._lib.smolmc_last_error().decode()
+            if rc == capi.ERR_RING_FULL:
+                raise RingFullError(msg)
             # argument problems are ValueErrors like the reference's (expansion.py:97-103,
             # wanglandau.py:80-88); device problems are RuntimeErrors
             if any(k in msg for k in ("enthalpy", "mod_factor", "range", "must be", "larger")):
@@ -166,23 +172,6 @@ class Engine:
             occ = occ.astype(np.int32)
         return np.ascontiguousarray(occ).reshape(shape)
 
-    def _occ_in(self, occ):
-        return occ if self._old_of is None else np.ascontiguousarray(occ[..., self._old_of])
-
-    def _occ_out(self, occ):
-        return occ if (self._new_of is None or occ is None) else np.ascontiguousarray(occ[..., self._new_of])
-
-    def _steps_in(self, steps):
-        if self._new_of is None:
-            return steps
-        steps = steps.copy()
-        sites = steps[..., 0::2]
-        # (a site beyond the cell is left as it is: the C side rejects it -- mapping it through the
-        # relabelling would turn it into a valid site and evaluate a step nobody asked for)
-        ok = (sites >= 0) & (sites < self.N)
-        steps[..., 0::2] = np.where(ok, self._new_of[np.where(ok, sites, 0)], sites)
-        return steps
-
     # ---- state ----------------------------------------------------------------
     @property
     def natural_parameters(self):
@@ -191,7 +180,7 @@ class Engine:
         return out
 
     def set_state(self, occupancies, seeds=None, temperature=None, reset_aux=True):
-        occ = self._occ_in(self._occ32(occupancies, (self.R, self.N)))
+        occ = self._occ32(occupancies, (self.R, self.N))
         seeds = (
             np.arange(self.R, dtype=np.uint64)
             if seeds is None
@@ -225,7 +214,7 @@ class Engine:
                 _p(na, C.c_uint64), _p(ns, C.c_uint64), _p(la, C.c_uint8),
             )
         )
-        return dict(occupancy=self._occ_out(occ), features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
+        return dict(occupancy=occ, features=feat, enthalpy=H, n_accepted=na, n_steps=ns,
                     accepted=la.astype(bool))
 
     def get_enthalpy(self):
@@ -332,15 +321,24 @@ class Engine:
         flags = ((capi.SAMPLE_OCCUPANCY if occupancy else 0) | (capi.SAMPLE_BIAS if bias else 0) |
                  (capi.SAMPLE_WL if wl else 0))
         self._chk(self._lib.smolmc_run_sampled(self._h, int(nsamples), int(thin_by), flags))
-        self._pending.append((int(nsamples), flags))
-        del self._pending[:-2]  # (a third block drops the oldest, as the C side does)
+
+    def pending_samples(self):
+        """(blocks queued and not fetched, nsamples and flags of the block ``fetch_samples`` would deliver): the
+        ring's own bookkeeping (smolmc_pending_samples) -- the arrays of a fetch are sized from it."""
+        npend, ns, flags = C.c_int(), C.c_int64(), C.c_int()
+        self._chk(self._lib.smolmc_pending_samples(self._h, C.byref(npend), C.byref(ns), C.byref(flags)))
+        return int(npend.value), int(ns.value), int(flags.value)
+
+    def discard_samples(self):
+        """Forget every block of the ring (a sampling loop left half way must not hand its blocks to the next)."""
+        self._chk(self._lib.smolmc_discard_samples(self._h))
 
     def fetch_samples(self, packed=False):
         """The oldest block queued with ``run_sampled_async`` that was not fetched yet (waits for ITS
         download only)."""
-        if not self._pending:
+        npend, ns, flags = self.pending_samples()
+        if npend == 0:
             raise EngineError("no samples recorded: call run_sampled_async first")
-        ns, flags = self._pending.pop(0)
         H = np.empty((ns, self.R))
         feat = np.empty((ns, self.R, self.F))
         acc = np.empty((ns, self.R), dtype=np.uint8)
@@ -365,7 +363,7 @@ class Engine:
             occ = np.empty((ns, self.R, self.N), dtype=np.int32) if with_occ else None
             self._chk(self._lib.smolmc_get_samples(self._h, _p(H, C.c_double), _p(feat, C.c_double),
                                                    _p(acc, C.c_uint8), _p(occ, C.c_int32)))
-        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=self._occ_out(occ), **extra)
+        return dict(enthalpy=H, features=feat, accepted=acc.astype(bool), occupancy=occ, **extra)
 
     def last_kernel_ms(self):
         ms = C.c_float()
@@ -378,7 +376,7 @@ class Engine:
         smolmc_replay) -> (accepted (R,n) bool, H (R,n)[, log_priori used (R,n)])."""
         uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.R, -1)
         n = uniforms.shape[1]
-        steps = self._steps_in(capi.step_rows(steps, self.R, n))
+        steps = capi.step_rows(steps, self.R, n)
         lp = None if log_priori is None else np.ascontiguousarray(log_priori, dtype=np.float64).reshape(self.R, n)
         acc = np.zeros((self.R, n), dtype=np.uint8)
         H = np.zeros((self.R, n))
@@ -393,23 +391,34 @@ class Engine:
 
     # ---- evaluator level --------------------------------------------------------
     def eval_full(self, occupancies):
-        occ = self._occ_in(self._occ32(occupancies, (-1, self.N)))
+        occ = self._occ32(occupancies, (-1, self.N))
         out = np.zeros((len(occ), self.F))
         self._chk(self._lib.smolmc_eval_full(self._h, _p(occ, C.c_int32), len(occ), _p(out, C.c_double)))
         return out
 
-    def eval_delta(self, occupancy, steps):
-        """steps: an ndarray of (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}), k <= 8,
-        -1 = absent -- n steps, exactly what capi.step_rows makes of it (an (n, 2) array is n single
-        flips); a flat record is one step.  ONE step may also be given the way the reference's ushers
-        return it, as a Python list of (site, code) tuples (mcusher.py:104-116)."""
-        occ = self._occ_in(self._occ32(occupancy, (self.N,)))
+    def eval_delta(self, occupancy, steps, single_step=None):
+        """Feature changes of steps applied to ``occupancy`` (each step on its own, not chained), (n, F).
+
+        ``steps`` as records: an ndarray of (n, 2k) int32 rows (site_0, code_0, ..., site_{k-1}, code_{k-1}),
+        k <= 8, -1 = absent -- n steps, exactly what capi.step_rows makes of it; a flat record is one step.
+        ``steps`` the way the reference's ushers return ONE step: a Python list of (site, code) tuples
+        (mcusher.py:104-116).  An (n, 2) ndarray with n > 1 could be read either way -- n single flips or one step
+        of n flips, and it silently changed meaning between rounds -- so it is refused unless ``single_step`` says
+        which: True = one step of n flips, False = n steps of one flip.  ``single_step`` also overrides the default
+        reading of the other spellings."""
+        occ = self._occ32(occupancy, (self.N,))
         as_pairs = isinstance(steps, (list, tuple)) and len(steps) > 0 and all(
             isinstance(f, (list, tuple)) and len(f) == 2 for f in steps)
         a = np.asarray(steps, dtype=np.int32)
-        if a.ndim == 1 or as_pairs:
-            a = a.reshape(1, -1)  # one step: flat record or a list of (site, code) tuples
-        steps = self._steps_in(capi.step_rows(a))
+        if single_step is None:
+            if isinstance(steps, np.ndarray) and a.ndim == 2 and a.shape[1] == 2 and a.shape[0] > 1:
+                raise ValueError(
+                    f"an ({a.shape[0]}, 2) array is ambiguous: {a.shape[0]} single-flip steps (single_step=False) or "
+                    f"one step of {a.shape[0]} flips (single_step=True)?")
+            single_step = a.ndim == 1 or as_pairs
+        if single_step:
+            a = a.reshape(1, -1)  # one step: flat record, a list of (site, code) tuples, or pair rows
+        steps = capi.step_rows(a)
         out = np.zeros((len(steps), self.F))
         self._chk(
             self._lib.smolmc_eval_delta(

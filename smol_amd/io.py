@@ -40,8 +40,6 @@ def save_tables(path, tab: capi.TableSet):
         out[name] = np.array(getattr(t, name), dtype=np.float64)
     for name, arr in tab._keep.items():
         out["arr_" + name] = arr
-    if tab.site_perm is not None:  # relabelled sites (TableSet.permute_sites): the Engine needs the map
-        out["site_new_of"] = np.asarray(tab.site_perm[0], dtype=np.int64)
     np.savez_compressed(path, **out)
 
 
@@ -102,7 +100,8 @@ def load_tables(path) -> capi.TableSet:
     if "bias_table" in A:  # MCBias term (files written before it was persisted have none)
         tab.set_bias(int(d["bias_type"]), A["bias_table"], float(d["bias_penalty"]),
                      intercepts=A.get("bias_intercepts"))
-    if "site_new_of" in d.files:  # (after set_bias: the stored bias table is in the relabelled numbering)
-        new_of = d["site_new_of"].astype(np.int64)
-        tab.site_perm = (new_of, np.argsort(new_of))
+    if "site_new_of" in d.files:
+        # (files of rounds 4-5 could hold tables the Python binding had renumbered; the map was only ever applied by
+        # that binding, which no longer exists -- smolmc_create renumbers internally)
+        raise ValueError("this file holds site-relabelled tables (site_new_of) of an older smol_amd: export it again")
     return tab

@@ -624,19 +624,13 @@ class Ensemble:
                                 table_ergodic=table_ergodic)
 
     # -- tables for the engine -----------------------------------------------------
-    def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1, contiguous=False):
-        """Flattened tables of this ensemble.  ``contiguous``: relabel the sites (capi.TableSet.permute_sites;
-        the Engine converts at its boundary) so that every sublattice is one site range with its active
-        sites first -- restricted sites and sublattices split by species otherwise leave the active
-        sites scattered, which only the general kernels take."""
+    def make_tables(self, flip_table=None, flip_weights=None, swap_weight=0.1):
+        """Flattened tables of this ensemble, in its own site numbering (restricted sites and sublattices split by
+        species leave active sites scattered: smolmc_create renumbers them behind the C-ABI, ``kernel_info`` then
+        says "relabelled=1", and callers never see it)."""
         tab = self._processor._make_tables(mu_table=self._mu_table, sublattices=self._sublattices)
         if flip_table is not None:
             tab = self._with_flip_table(tab, flip_table, flip_weights, swap_weight)
-        if contiguous:
-            new_of = capi.contiguous_relabelling(self.num_sites, [(s.active_sites, s.restricted_sites)
-                                                                  for s in self._sublattices])
-            if new_of is not None:
-                tab.permute_sites(new_of)
         return tab
 
     def _with_flip_table(self, tab, flip_table, flip_weights, swap_weight):
@@ -1620,7 +1614,7 @@ class Sampler:
         ens = k0.ensemble
         key = self._model_key()
         if self._engine is None or self._engine_key != key:
-            tables = ens.make_tables(**k0.usher_kwargs, contiguous=os.environ.get("SMOLMC_NO_SITE_RELABEL") is None)
+            tables = ens.make_tables(**k0.usher_kwargs)
             if k0.bias is not None:
                 tables.set_bias(k0.bias.bias_type, k0.bias._table, k0.bias.penalty,
                                 intercepts=getattr(k0.bias, "intercepts", None))
@@ -1712,7 +1706,7 @@ class Sampler:
 
     def _sample_blocks(self, nsteps, initial_occupancies, thin_by, max_block=0, state_loaded=False):
         """Generator over blocks of thinned samples, dict name -> (n, nwalkers, ...): the unit
-        the device ring delivers (``smolmc_run_sampled``, ABI 7): the samples of a block are recorded on
+        the device ring delivers (``smolmc_run_sampled``): the samples of a block are recorded on
         the device -- inside one launch for Metropolis kernels, as launch + snapshot pairs queued without
         a host round trip for biased and Wang-Landau kernels (trace.bias; the per-walker L and L x F
         arrays of the Wang-Landau trace) -- and the block's download overlaps the next block's kernel."""
@@ -1757,6 +1751,18 @@ class Sampler:
         def queue(n):
             eng.run_sampled_async(n, thin_by, occupancy=True, bias=has_bias, wl=is_wl)
 
+        # Block i + 1 is queued before block i is handed out, so a consumer that stops early -- a `break` out of
+        # Sampler.sample(), an exception in run() between two blocks -- leaves a block on the (cached) engine's ring.
+        # The ring is emptied when this generator starts and when it ends, however it ends: the next run's first
+        # fetch is its own first block.
+        eng.discard_samples()
+        try:
+            yield from self._ring_blocks(eng, sizes, queue, temps, nw, k0, has_bias, is_wl)
+        finally:
+            eng.discard_samples()
+
+    @staticmethod
+    def _ring_blocks(eng, sizes, queue, temps, nw, k0, has_bias, is_wl):
         if sizes:
             queue(sizes[0])
         for i, n in enumerate(sizes):

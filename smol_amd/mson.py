@@ -168,7 +168,9 @@ class _PbcMatcher:
         points = np.asarray(points, dtype=np.float64)
         if self.tree is None:
             return _pbc_match_all_pairs(points, self.targets, self.atol)
-        dist, idx = self.tree.query(_wrap01(points), k=1, p=np.inf, distance_upper_bound=self.atol,
+        # (cKDTree's bound is a strict `<`; the all-pairs definition and pymatgen's coord_list_mapping_pbc accept a
+        # difference of exactly atol: one ulp above it makes the two agree at the tolerance boundary)
+        dist, idx = self.tree.query(_wrap01(points), k=1, p=np.inf, distance_upper_bound=np.nextafter(self.atol, np.inf),
                                     workers=-1 if len(points) > 100000 else 1)
         if not np.all(np.isfinite(dist)):
             raise ValueError("a cluster site has no image in the supercell")
@@ -187,7 +189,7 @@ def _pbc_match_all_pairs(points, targets, atol=SITE_TOL):
         p = points[start:start + 4096]
         d = p[:, None, :] - t[None, :, :]
         d -= np.round(d)
-        hit = np.all(np.abs(d) < atol, axis=-1)
+        hit = np.all(np.abs(d) <= atol, axis=-1)
         if not np.all(hit.any(axis=1)):
             raise ValueError("a cluster site has no image in the supercell")
         out[start:start + 4096] = hit.argmax(axis=1)

@@ -123,18 +123,23 @@ def _rocksalt(dim, cutoffs=None, prim=None):
     return out
 
 
-def _mu_rows(sc, scale):
+def _mu_rows(sc, scale, values=None):
+    """Chemical potentials of the three cation species on every cation site: SURVEY 8d's U(-scale, scale) draw
+    with seed 7, or the three ``values`` given (tools/equil_sweep.py's mu axis)."""
     mu = np.zeros((sc.num_sites, 3))
-    mu[: sc.size] = np.random.default_rng(7).uniform(-scale, scale, 3)[None, :]
+    mu[: sc.size] = (np.random.default_rng(7).uniform(-scale, scale, 3) if values is None
+                     else np.asarray(values, dtype=float))[None, :]
     return mu
 
 
-def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=None, feature_mode=capi.FEATURES_INTERACTIONS):
-    """BASELINE configs[2]: ternary rocksalt dim^3, triplet CE + Ewald, semigrand flip."""
+def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=None, feature_mode=capi.FEATURES_INTERACTIONS,
+            ewald_coef=0.1, mu_values=None):
+    """BASELINE configs[2]: ternary rocksalt dim^3, triplet CE + Ewald, semigrand flip.  ``ewald_coef`` (1 / epsilon,
+    SURVEY 8d: epsilon = 10) and ``mu_values`` are the axes of tools/equil_sweep.py."""
     model, sc, ew = _rocksalt(dim)
     temperature = CONFIG3_T if temperature is None else temperature
-    mu = _mu_rows(sc, CONFIG3_MU if mu_scale is None else mu_scale)
-    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=0.1, mu_table=mu,
+    mu = _mu_rows(sc, CONFIG3_MU if mu_scale is None else mu_scale, mu_values)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=ewald_coef, mu_table=mu,
                                    feature_mode=feature_mode)
     return Workload(
         3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip",

@@ -170,11 +170,12 @@ def build_case(rng, profile="any"):
         if rng.random() < 0.3:
             usher["flip_weights"] = rng.uniform(0.5, 2.0, len(usher["flip_table"]))
     tab = ens.make_tables(**usher)
-    # the engine's tables: the same model with the sites relabelled so that every active sublattice is
-    # one site range (what the Sampler hands to the engine); the oracle keeps the original numbering
-    tab_engine = ens.make_tables(**usher, contiguous=True) if (lean or rng.random() < 0.5) else tab
-    if tab_engine.site_perm is not None:
-        desc["relabelled"] = True
+    # engine and oracle get the SAME tables in the caller's numbering: where restricted sites / a split sublattice
+    # scatter the active sites, smolmc_create renumbers them behind the C-ABI (kernel_info: "relabelled=1")
+    # (half of the unforced cases switch the renumbering off: scattered layouts on mc_kernel / the universal kernel)
+    tab_engine = tab
+    if not (lean or rng.random() < 0.5):
+        desc["no_relabel"] = True
     bias = None
     if kernel == "metropolis" and rng.random() < 0.35 and not (fast and step == "table-flip"):
         kind = pick(rng, ["fugacity", "square-charge"] if fast else ["fugacity", "square-charge", "square-hyperplane"])
@@ -245,13 +246,17 @@ def _run_case(case_seed, case, rng):
         os.environ.pop(name, None)
     if case["env"]:
         os.environ[case["env"]] = "1"
+    if desc.get("no_relabel"):
+        os.environ["SMOLMC_NO_SITE_RELABEL"] = "1"
     try:
         eng = Engine(case["tab_engine"], case["cfg"])
     finally:
-        for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"):
+        for name in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL", "SMOLMC_NO_SITE_RELABEL"):
             os.environ.pop(name, None)
     ora = orc.OracleMC(case["tab"], case["cfg"])
     desc["kernel_info"] = eng.kernel_info()
+    if "relabelled=1" in desc["kernel_info"]:
+        desc["relabelled"] = True
     try:
         eng.set_state(case["occ"], case["seeds"], case["temps"])
     except Exception as e:

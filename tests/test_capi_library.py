@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(engine.SYMBOLS), declared ^ set(engine.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.smolmc_abi_version() == capi.ABI_VERSION == 7
+    assert lib.smolmc_abi_version() == capi.ABI_VERSION == 8
 
 
 def test_struct_layout_matches_header():

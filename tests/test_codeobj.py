@@ -45,3 +45,13 @@ def test_isa_stale_follows_the_machine_code_not_the_comments():
     # entries from before the per-kernel stamp: the digest over the source tree decides
     assert not codeobj.isa_stale(dict(csrc_sha256=engine.source_digest()))
     assert codeobj.isa_stale(dict(csrc_sha256="0" * 64))
+
+
+def test_a_name_emitted_by_several_translation_units_changes_when_any_copy_does():
+    """Static __global__ helpers of a shared header appear once per translation unit under one mangled name: equal
+    copies keep the copy's digest, differing copies get one over all of them -- not "whichever bundle came last"."""
+    a, b, c = "a" * 64, "b" * 64, "c" * 64
+    m = codeobj._merge_copies({"k1": {a}, "k2": {a, b}, "k3": {b, a}})
+    assert m["k1"] == a
+    assert m["k2"] == m["k3"] and m["k2"] not in (a, b) and len(m["k2"]) == 64
+    assert codeobj._merge_copies({"k2": {a, c}})["k2"] != m["k2"]

@@ -437,6 +437,42 @@ def test_processor_change_of_a_whole_table_step(rocksalt):
                                    rtol=1e-9, atol=1e-8)
 
 
+def test_eval_delta_spellings_are_explicit(rocksalt):
+    """Engine.eval_delta: a list of (site, code) tuples is ONE step (the ushers' form, mcusher.py:104-116), rows of
+    records are one step each, and the (n, 2) ndarray that can be read both ways is refused until `single_step` says
+    which (round 4 read it as one step, round 5 as n steps: same call, other numbers, no error)."""
+    from smol_amd.engine import Engine
+
+    model, sc, coefs = rocksalt
+    tab = capi.TableSet.from_synth(sc, coefs)
+    eng = Engine(tab, capi.make_config(1))
+    rng = np.random.default_rng(4)
+    occ = np.zeros(sc.num_sites, dtype=np.int32)
+    occ[: sc.size] = rng.integers(0, 3, sc.size)
+    s0, s1 = (int(x) for x in rng.choice(sc.size, 2, replace=False))
+    pairs = [(s0, int((occ[s0] + 1) % 3)), (s1, int((occ[s1] + 2) % 3))]
+    arr = np.array(pairs, dtype=np.int32)
+    new = occ.copy()
+    for s, c in pairs:
+        new[s] = c
+    step = eng.eval_full(new[None])[0] - eng.eval_full(occ[None])[0]
+    one = eng.eval_delta(occ, pairs)  # list of tuples: one two-flip step
+    assert one.shape == (1, eng.F)
+    np.testing.assert_allclose(one[0], step, rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(eng.eval_delta(occ, arr.ravel())[0], one[0], rtol=0, atol=0)  # a flat record: the same step
+    np.testing.assert_allclose(eng.eval_delta(occ, arr, single_step=True)[0], one[0], rtol=0, atol=0)
+    with pytest.raises(ValueError, match="ambiguous"):
+        eng.eval_delta(occ, arr)
+    two = eng.eval_delta(occ, arr, single_step=False)  # two single-flip steps, each against `occ`
+    assert two.shape == (2, eng.F)
+    for k, (s, c) in enumerate(pairs):
+        x = occ.copy()
+        x[s] = c
+        np.testing.assert_allclose(two[k], eng.eval_full(x[None])[0] - eng.eval_full(occ[None])[0], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(eng.eval_delta(occ, pairs, single_step=False), two, rtol=0, atol=0)
+    eng.close()
+
+
 def test_kernel_single_step_walks_the_sampler_chain(fcc):
     """MCKernel.single_step / compute_initial_trace / set_aux_state / trace (kernel/base.py:145-166,
     287-289,345-366; tests/test_moca/test_kernel.py test_single_step): a kernel stepped one step at
@@ -549,9 +585,9 @@ def test_split_sublattice_sampling_matches_the_oracle(rocksalt, step):
 
 @pytest.mark.parametrize("step", ["swap", "flip", "table-flip"])
 def test_restricted_sites_stay_on_the_specialised_kernels(rocksalt, step):
-    """Ensemble.restrict_sites (sublattice.py:84-107) scatters the active sites; the Sampler relabels the
-    sites (capi.TableSet.permute_sites) so that the lean kernels still take the model.  Checked against
-    the oracle on the UNRELABELLED tables: the restricted sites never change, the chain is the same."""
+    """Ensemble.restrict_sites (sublattice.py:84-107) scatters the active sites; smolmc_create renumbers the
+    sites behind the C-ABI (ABI 8) so that the lean kernels still take the model.  Checked against the oracle on
+    the same tables in the caller's numbering: the restricted sites never change, the chain is the same."""
     from oracle import oracle as orc
 
     model, sc, coefs = rocksalt
@@ -569,7 +605,7 @@ def test_restricted_sites_stay_on_the_specialised_kernels(rocksalt, step):
     sampler = moca.Sampler.from_ensemble(ens, temperature=4000.0, step_type=step, nwalkers=nw, seeds=seeds, **kw)
     sampler.run(600, occ, thin_by=150)
     assert sampler.engine.kernel_info().startswith("lean"), sampler.engine.kernel_info()
-    assert sampler.engine.tables.site_perm is not None
+    assert "relabelled=1" in sampler.engine.kernel_info()
     occs = sampler.samples.get_occupancies(flat=False)
     assert np.all(occs[:, :, frozen] == occ[None, :, frozen]) and len(np.unique(occs[:, 0], axis=0)) > 1
     ukw = {k: v for k, v in kw.items()}

@@ -116,10 +116,14 @@ def test_wang_landau_trace_of_the_ring(which, monkeypatch):
     eng.close()
 
 
-def test_two_slots_deliver_in_order_and_drop_the_oldest(monkeypatch):
+def test_two_slots_deliver_in_order_and_a_full_ring_refuses(monkeypatch):
     """run_sampled_async x 2, then fetch x 2: blocks come back oldest first, each the chain's continuation;
-    a third block queued before any fetch drops the first (smolmc.h); fetching with nothing pending
-    delivers the newest block again; sizes may change from block to block (the slots grow)."""
+    a third block queued before any fetch is REFUSED (SMOLMC_ERR_RING_FULL, ABI 8: nothing is dropped, the
+    walkers do not move); a call that fails leaves the ring as it was; smolmc_discard_samples empties it;
+    fetching with nothing pending delivers the newest block again (C level); sizes may change from block to
+    block (the slots grow)."""
+    from smol_amd.engine import EngineError, RingFullError
+
     for k in ENV:
         monkeypatch.delenv(k, raising=False)
     name = "fcc_prim666_triplets"
@@ -142,19 +146,42 @@ def test_two_slots_deliver_in_order_and_drop_the_oldest(monkeypatch):
     assert d["occupancy"] is None and d["enthalpy"].shape == (2, R)
     ora.run(80)
     np.testing.assert_allclose(d["enthalpy"][-1], ora.get_state()["enthalpy"], rtol=1e-10, atol=1e-8)
-    # three blocks without a fetch: the oldest is dropped, the other two arrive in order
+    # three blocks without a fetch: the third is refused, nothing is dropped, the walkers stay where block 2 left them
+    assert eng.pending_samples() == (0, 2, 0)  # (nothing pending; a fetch would repeat block d: 2 samples, no flags)
     eng.run_sampled_async(1, 5)
     eng.run_sampled_async(2, 5)
-    eng.run_sampled_async(3, 5)
-    ora.run(5)
+    assert eng.pending_samples() == (2, 1, capi.SAMPLE_OCCUPANCY)
+    with pytest.raises(RingFullError, match="sample ring full"):
+        eng.run_sampled_async(3, 5)
+    assert eng._lib.smolmc_run_sampled(eng._h, 3, 5, 1) == capi.ERR_RING_FULL  # (the status code a C client sees)
+    # ... and a call that fails on its arguments does not take a slot either
+    with pytest.raises((EngineError, ValueError)):
+        eng.run_sampled_async(1, 5, bias=True)  # (the model has no bias term)
+    assert eng.pending_samples() == (2, 1, capi.SAMPLE_OCCUPANCY)
     x = eng.fetch_samples()
-    assert x["enthalpy"].shape == (2, R)
+    assert x["enthalpy"].shape == (1, R)
     _check_rows(x, ora, 5)
+    eng.run_sampled_async(3, 5)  # (a slot is free again)
+    y = eng.fetch_samples()
+    assert y["enthalpy"].shape == (2, R)
+    _check_rows(y, ora, 5)
     y = eng.fetch_samples()
     assert y["enthalpy"].shape == (3, R)
     _check_rows(y, ora, 5)
     st = eng.get_state()
     assert np.array_equal(st["occupancy"], ora.get_state()["occupancy"])
+    # an abandoned loop: two blocks queued, discarded; the next block is the next loop's own
+    eng.run_sampled_async(4, 3)
+    eng.run_sampled_async(4, 3)
+    eng.discard_samples()
+    assert eng.pending_samples() == (0, 0, 0)
+    with pytest.raises(EngineError, match="no samples recorded"):
+        eng.fetch_samples()
+    ora.run(24)
+    eng.run_sampled_async(3, 5)
+    y = eng.fetch_samples()
+    assert y["enthalpy"].shape == (3, R)
+    _check_rows(y, ora, 5)
     # C level: nothing pending -> the newest block again
     H = np.zeros((3, R))
     import ctypes as C

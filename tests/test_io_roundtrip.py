@@ -71,34 +71,15 @@ def test_unknown_arrays_are_refused(tmp_path):
         io.load_tables(path)
 
 
-def test_relabelled_tables_survive_the_roundtrip(tmp_path):
-    """TableSet.permute_sites: the site map travels with the file, every array as relabelled."""
-    from tests.cases import load_case
-
-    c = load_case("rocksalt444_ewald")
-    tab = capi.TableSet.from_synth(c["sc"], c["coefs"], ewald=c["ewald"], ewald_coef=0.1)
-    N = tab.num_sites
-    charges = np.zeros((N, 3))
-    charges[: c["sc"].size] = [1.0, 3.0, 4.0]
-    tab.set_bias(capi.BIAS_SQUARE_CHARGE, charges, penalty=0.75)
-    new_of = np.random.default_rng(0).permutation(N)
-    before = tab._keep["sub_active_sites"].copy()
-    tab.permute_sites(new_of)
-    np.testing.assert_array_equal(tab._keep["sub_active_sites"], new_of[before])
-    np.testing.assert_array_equal(tab._keep["bias_table"][new_of], charges)
-    path = str(tmp_path / "perm.npz")
+def test_files_with_python_side_relabelling_are_refused(tmp_path):
+    """Rounds 4-5 could write tables the Python binding had renumbered (`site_new_of`); that binding-side translation
+    is gone (smolmc_create renumbers internally, ABI 8), so such a file is refused instead of silently running with
+    the wrong numbering at the boundary."""
+    tab = tables_for("fcc_conv444_pairs", capi.FEATURES_INTERACTIONS)
+    path = str(tmp_path / "m.npz")
     io.save_tables(path, tab)
-    back = io.load_tables(path)
-    np.testing.assert_array_equal(back.site_perm[0], new_of)
-    np.testing.assert_array_equal(back.site_perm[1], np.argsort(new_of))
-    for name in ("full_idx", "site_ptr", "loc_orbit", "loc_nrows", "ewald_inds", "bias_table", "sub_active_sites"):
-        np.testing.assert_array_equal(back._keep[name], tab._keep[name])
-
-    def rows(t, r):  # (the loader packs the local rows in site order: same rows, other offsets)
-        n = int(t._keep["loc_nrows"][r]) * int(t._keep["orb_nsites"][t._keep["loc_orbit"][r]])
-        return t._keep["loc_idx"][int(t._keep["loc_off"][r]):int(t._keep["loc_off"][r]) + n]
-
-    for r in range(len(tab._keep["loc_orbit"])):
-        np.testing.assert_array_equal(rows(back, r), rows(tab, r))
-    with pytest.raises(ValueError, match="permutation"):
-        tab.permute_sites(np.zeros(N, dtype=int))
+    d = dict(np.load(path))
+    d["site_new_of"] = np.arange(tab.num_sites)
+    np.savez(path, **d)
+    with pytest.raises(ValueError, match="site-relabelled"):
+        io.load_tables(path)

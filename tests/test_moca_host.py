@@ -390,49 +390,6 @@ def test_encode_decode_occupancy():  # processor/base.py:228-243
         moca.Sampler.from_ensemble(ens, temperature=300).samples.to_hdf5("x.h5")
 
 
-@pytest.mark.parametrize("step", ["flip", "swap"])
-def test_relabelled_sites_are_the_same_model(step):
-    """capi.TableSet.permute_sites (Ensemble.make_tables(contiguous=True)): with restricted sites the
-    active sites are scattered; relabelling makes every active sublattice one site range and changes
-    nothing else -- the oracle walks the same chain on both sets of tables (occupancies mapped through
-    the permutation), with Ewald term, chemical potentials and a bias."""
-    from oracle import oracle as orc
-    from smol_amd import capi
-
-    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 5.0, 3: 3.5})
-    sc = synth.build_supercell(model, [3, 3, 2])
-    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=2), ewald_coefficient=0.2)
-    ens.chemical_potentials = {sp: 0.05 * i for i, sp in enumerate(ens.species)}
-    rng = np.random.default_rng(0)
-    act = np.concatenate([s.active_sites for s in ens.active_sublattices])
-    assert ens.make_tables(contiguous=True).site_perm is None  # nothing to do without restrictions
-    ens.restrict_sites(rng.choice(act, 7, replace=False))
-    nsp = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
-    R = 3
-    occ = (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
-    a, b = ens.make_tables(), ens.make_tables(contiguous=True)
-    new_of, old_of = b.site_perm
-    for sites in np.split(b._keep["sub_active_sites"], b._keep["sub_site_ptr"][1:-1]):
-        assert np.array_equal(sites, sites[0] + np.arange(len(sites)))  # contiguous, list order kept
-    bias = moca.SquareChargeBias(ens.sublattices, penalty=0.05)
-    for t in (a, b):
-        t.set_bias(bias.bias_type, bias._table, bias.penalty)
-    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, moca.STEP_TYPES[step])
-    oa, ob = orc.OracleMC(a, cfg), orc.OracleMC(b, cfg)
-    seeds = np.arange(R, dtype=np.uint64) + 5
-    oa.set_state(occ, seeds, 3000.0)
-    ob.set_state(occ[:, old_of], seeds, 3000.0)
-    for n in (1, 50, 300):
-        oa.run(n)
-        ob.run(n)
-        sa, sb = oa.get_state(), ob.get_state()
-        assert np.array_equal(sa["occupancy"], sb["occupancy"][:, new_of])
-        np.testing.assert_allclose(sa["enthalpy"], sb["enthalpy"], rtol=1e-10, atol=1e-9)
-        np.testing.assert_allclose(sa["features"], sb["features"], rtol=1e-10, atol=1e-9)
-        np.testing.assert_allclose(oa.get_bias(), ob.get_bias(), rtol=1e-10, atol=1e-9)
-    assert 0 < sa["n_accepted"].sum()
-
-
 def test_get_sampled_species():  # container.py:144-181 without pymatgen
     sc, ens = _rocksalt_ensemble()
     s = moca.Sampler.from_ensemble(ens, temperature=500, nwalkers=2)

@@ -47,14 +47,18 @@ def main():
     ap.add_argument("--replicas", type=int, default=2048)
     ap.add_argument("--mc", type=int, default=0)
     ap.add_argument("--penalty", nargs="+", type=float, default=[None], help="config 9: SquareChargeBias penalties")
+    ap.add_argument("--ewald-coef", nargs="+", type=float, default=[0.1], help="config 3: 1 / epsilon of the Ewald term")
+    ap.add_argument("--mu-values", nargs="+", default=[None],
+                    help="config 3: 'a,b,c' chemical potentials of Li+ / Mn3+ / Ti4+ instead of the seeded draw")
     a = ap.parse_args()
-    for mu, pen in ((m, p) for m in a.mu for p in a.penalty):
+    for mu, pen, ewc, muv in ((m, p, e, v) for m in a.mu for p in a.penalty for e in a.ewald_coef for v in a.mu_values):
         for T in a.T:
             kw = dict(count=a.replicas, mu_scale=mu)
             if a.mc:
                 kw["mc"] = a.mc
             if a.config == 3:
-                wl = workloads.config3(temperature=float(T), **kw)
+                mv = None if muv in (None, "none") else [float(x) for x in muv.split(",")]
+                wl = workloads.config3(temperature=float(T), ewald_coef=ewc, mu_values=mv, **kw)
             elif a.config == 9:
                 wl = workloads.config9(temperature=float(T), penalty=pen, **kw)
             else:
@@ -77,7 +81,7 @@ def main():
             st = eng.get_state(occupancy=True)
             nact = wl.sc.size
             comp = [float((st["occupancy"][:, :nact] == c).mean()) for c in range(3)]
-            print(json.dumps(dict(config=a.config, T=T, mu_scale=mu, penalty=pen, kernel=eng.kernel_info(), equil_steps=done,
+            print(json.dumps(dict(config=a.config, T=T, mu_scale=mu, penalty=pen, ewald_coef=ewc, mu_values=muv, kernel=eng.kernel_info(), equil_steps=done,
                                   transient=first, steady=steady, composition=comp,
                                   exchange_acceptance=None if rex is None else float(rex.acceptance.mean()))),
                   flush=True)
