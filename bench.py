@@ -474,15 +474,19 @@ def _time_other_configs(device, rank, world, red_dev, out):
                       "HBM (measured fetch 22 MB per launch); the dense two-row formulation of SURVEY 8d (58752 B/flip) is the "
                       "SMOLMC_DENSE_EWALD path: pmc entry config3_dense_ewald")
 
-        # (the transient of round 2's bench: launches 2-11 of 2000 steps from the random start; config 3
-        # as specified has no mixed steady state -- its Ewald energy without the charged-cell term is
-        # concave in the net charge, unconstrained flips run to a pure composition -- so the steady
-        # figure is the cost of REJECTED proposals; config 9 below is the well-posed variant)
+        # Config 3 at its frozen temperature (round 6: 40000 K, steady-state acceptance 0.38 -- workloads.CONFIG3_T):
+        # the transient window (launches 2-11 of 2000 steps from the random start) and the equilibrated figure.
         info, first, steady = _engine_run(Engine, wl3, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
         record(wl3, info, first, steady, issue_roof("config3", ewald_note), wl3.n_walkers, launches=10)
-        # (the headline figure of this entry is the cost of REJECTED proposals: say so where a reader looks first)
-        out[-1]["state"] = "reject-path only (no mixed steady state exists, acceptance ~ 0: see `transient` and config 9)"
+        # ... and the point rounds 2-5 quoted (3000 K): there the unconstrained flips run to a pure composition and the
+        # steady figure is the cost of REJECTED proposals
+        wl3r = workloads.config3(temperature=workloads.CONFIG3_T_REJECT)
+        wl3r.name = wl3r.name.replace("config3:", "config3_reject_path:")
+        info, first, steady = _engine_run(Engine, wl3r, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
+                                          transient_mc=2000)
+        record(wl3r, info, first, steady, issue_roof("config3_reject_path", ewald_note), wl3r.n_walkers, launches=10)
+        out[-1]["state"] = "reject-path only (3000 K: the chain runs to a pure composition, acceptance ~ 0)"
         wl9 = workloads.config9()
         info, first, steady = _engine_run(Engine, wl9, device, clock, 10, 20_000, equil=EQUIL_STEPS[3],
                                           transient_mc=2000)
@@ -503,7 +507,7 @@ def _time_other_configs(device, rank, world, red_dev, out):
                issue_roof("config13", "H1 (correlation trace), K = 3 / 4 / 6 functions per orbit: decision from one folded "
                                       "table per slot, the K function tables read on accepted steps only (DESIGN.md 4.1a)"),
                wl13.n_walkers, launches=10)
-        out[-1]["state"] = "reject-path only (config 3's lattice: see config 3 above); the transient window is the figure"
+        # (config 13 follows config 3 to its frozen temperature: a genuine steady state now)
         # the reference's own model (LiNiO2, two active sublattices, Ewald) under Wang-Landau: mc_lean_multi_kernel<..., WLK>
         try:
             # (the window must hold EVERY walker's random start: the Ewald term gives the starting enthalpies a long

@@ -69,8 +69,15 @@ def neutral_rocksalt_occupancy(sc, first, count, seed=5):
 
 
 HEADLINE_T = 2500.0  # acceptance ~0.38 on the config-2 Hamiltonian (tuned once and frozen)
-# configs 3 and 5: temperature / chemical-potential scale (round 2 values; see tools/equil_sweep.py)
-CONFIG3_T, CONFIG3_MU = 3000.0, 0.5
+# configs 3 and 5: temperature / chemical-potential scale (see tools/equil_sweep.py).
+# Config 3 (round 6): tuned once and frozen like the headline's T.  SURVEY 8d fixes the lattice, epsilon = 10 and the seeded
+# mu draw, not the temperature.  Unconstrained semigrand flips on an Ewald energy without the charged-cell term run to one
+# pure composition below ~2e4 K (acceptance 1e-6 at rounds 2-5's 3000 K: their sweeps stopped at 12000 K and concluded that
+# no mixed steady state exists); at 40000 K the chain is stationary -- acceptance 0.380 after 4e5 AND after 2e6 steps per
+# walker, cations Li / Mn / Ti = 0.045 / 0.29 / 0.665 (profiles/r06_equil_sweep.jsonl).  CONFIG3_T_REJECT keeps the old
+# point as `config3_reject_path`.
+CONFIG3_T, CONFIG3_MU = 40000.0, 0.5
+CONFIG3_T_REJECT = 3000.0
 # (round 3: config 5's ladder moved from SURVEY's 400-2000 K, where the equilibrated walkers accept
 # 0.1 % of their steps, to 2500-12500 K: steady-state acceptance 0.17, profiles/r03_equil_sweep.jsonl)
 CONFIG5_T, CONFIG5_MU = (2500.0, 12500.0), 0.5
@@ -142,7 +149,7 @@ def config3(first=0, count=2048, dim=12, mc=2000, temperature=None, mu_scale=Non
     tab = capi.TableSet.from_synth(sc, synth.random_coefs(model), ewald=ew, ewald_coef=ewald_coef, mu_table=mu,
                                    feature_mode=feature_mode)
     return Workload(
-        3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip",
+        3, f"config3: ternary rocksalt {dim}^3 ({sc.num_sites} sites), triplet CE + Ewald, semigrand flip, T={temperature:g}K",
         sc, tab, dict(kernel=capi.KERNEL_METROPOLIS, step=capi.STEP_FLIP),
         random_codes(sc, first, count, 3), _seeds(first, count, 777), temperature, 1, mc)
 

@@ -79,6 +79,54 @@ def test_table_flip_proposal_batch_matches_oracle_over_many_blocks(dim, ewald):
     eng.close()
 
 
+@pytest.mark.parametrize("dims", [(3, 12, 12), (4, 11, 12), (5, 9, 14), (3, 3, 6), (12, 12, 12)], ids=lambda d: "x".join(map(str, d)))
+def test_table_flip_field_sweep_on_other_cell_shapes(dims, monkeypatch):
+    """The three-flip potential-field sweep of an accepted TableFlip step (field_sweep_gx_multi<3>: chunks of batches
+    of nine groups, a shifted tail batch for swaps only, group-by-group and ragged tails) on cells that are not cubes
+    -- fields of 432, 528, 630 and 54 entries besides BASELINE config 5's 1728: the same chain as the oracle (dense
+    Ewald rows, ewald.pyx:38-58) at temperatures where a third of the steps is accepted, in launches that start and
+    end inside the 64-step proposal blocks; the field has not drifted from the occupancies (running trace ==
+    from-scratch evaluation); SMOLMC_NO_EWALD_GX (rows of the full site kernel instead of the translation-compressed
+    tables): the same chain again.  (Round 6 built two other sweeps on these cases -- a periodic 13.8 KB table walked
+    plane by plane, and two entries per lane and gather with the offsets in LDS -- both bit-identical and both
+    SLOWER on config 5: NOTES.md.)"""
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    monkeypatch.delenv("SMOLMC_NO_EWALD_GX", raising=False)
+    sc, tab = _model(dims, coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=True)
+    P = sc.size
+    R = 4 if P > 1000 else 6
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    rng = np.random.default_rng(7)
+    occ = np.array([_neutral_occ(sc, (P & 1) + 2 * (P // 14 + r), rng) for r in range(R)])
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(900)
+    temps = np.linspace(5000.0, 20000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean") and "gx=1x" + "x".join(map(str, dims)) in eng.kernel_info(), eng.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_EWALD_GX", "1")
+    rows = Engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_EWALD_GX")
+    assert "gx=" not in rows.kernel_info() and "field=1" in rows.kernel_info(), rows.kernel_info()
+    for e in (eng, ora, rows):
+        e.set_state(occ, seeds, temps)
+    for chunk in (1, 62, 3, 400) if P > 1000 else (1, 62, 3, 700, 129, 1105):
+        for e in (eng, ora, rows):
+            e.run(chunk)
+        a, b, c = eng.get_state(), ora.get_state(), rows.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+        assert np.array_equal(a["occupancy"], c["occupancy"])
+        np.testing.assert_allclose(a["enthalpy"], c["enthalpy"], rtol=1e-11, atol=1e-9)
+    acc = a["n_accepted"].sum() / a["n_steps"].sum()
+    assert 0.1 < acc < 0.9, acc
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-7)
+    eng.close()
+    rows.close()
+
+
 def test_launch_order_of_a_ladder_does_not_change_any_walker(monkeypatch):
     """On an exchange ladder the engine deals the walkers to launch slots hottest-with-coldest
     (engine.hip, update_walker_order); which slot runs a walker must not matter."""

@@ -24,7 +24,7 @@ def _model(dim, coef_scale=0.0, mu=None, ewald=False):
     from smol_amd import ewald as ew
 
     model = synth.build_cluster_model(synth.rocksalt_prim(), {2: 3.5})
-    sc = synth.build_supercell(model, [dim] * 3)
+    sc = synth.build_supercell(model, [dim] * 3 if np.isscalar(dim) else list(dim))
     coefs = synth.random_coefs(model, seed=5, scale=coef_scale)
     mu_table = None
     if mu is not None:
