@@ -362,7 +362,7 @@ def hbm_ce(rec):  # 56 algorithmic bytes per CE flip
                 note="CE flip, occupancy LDS-resident: nominal HBM fraction (56 B/flip)")
 
 
-def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None, transient_mc=None):
+def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None, transient_mc=None, device_decide=False):
     """transient (first `launches` launches of `transient_mc` steps after one warm-up launch of the
     same length) and, after `equil` more untimed steps per walker, steady-state figures (launches of
     `mc` steps) of one workload on this rank's walkers; with `rex` every launch is followed by one
@@ -378,7 +378,7 @@ def _engine_run(Engine, wl, device, clock, launches, mc, equil=0, rex=None, tran
             for _ in range(n):
                 eng.run(steps)
         else:
-            parallel.run_replica_exchange(eng, rex, n, steps)
+            parallel.run_replica_exchange(eng, rex, n, steps, device_decide=device_decide)
 
     def measure(mc=mc):
         launch(1, mc)
@@ -592,8 +592,11 @@ def _time_other_configs(device, rank, world, red_dev, out):
     per = 2048
     wl5 = workloads.config5(first=rank * per, count=per, total=per * world)
     rex = parallel.ReplicaExchange(wl5.extras["ladder"], per, rank, world, seed=11)
+    # N ranks on RCCL: the swap decisions are taken by a kernel on the all-gathered device tensor (smolmc_exchange_dev,
+    # round 6) -- the host NumPy decisions were the serial section of the loop; SMOLMC_REX_DEVICE_DECIDE=0 switches back
+    dev_decide = world > 1 and red_dev == "cuda" and os.environ.get("SMOLMC_REX_DEVICE_DECIDE", "1") != "0"
     info, first, steady = _engine_run(Engine, wl5, device, clock, 30, wl5.mc_per_launch,
-                                      equil=EQUIL_STEPS[5], rex=rex)
+                                      equil=EQUIL_STEPS[5], rex=rex, device_decide=dev_decide)
     record(wl5, info, first, steady,
            issue_roof("config5", "TableFlip step (three flips + proposal + a-priori factor) at two waves per SIMD: "
                                  "instruction-issue / latency bound (DESIGN.md section 5); mc_steps_per_s is wall time "
@@ -601,7 +604,8 @@ def _time_other_configs(device, rank, world, red_dev, out):
            per * world, launches=30, exchange_every_steps=wl5.mc_per_launch,
            exchange_acceptance_mean=float(rex.acceptance.mean()),
            exchange_latency_ms_per_sweep=float(clock.max([rex.exchange_seconds / max(rex.exchange_timed, 1) * 1e3])[0]),
-           exchange_path="collective (all-gather over %d ranks)" % world if world > 1 else "single rank (direct read-back)")
+           exchange_path="collective (all-gather over %d ranks)" % world if world > 1 else "single rank (direct read-back)",
+           exchange_decisions="device kernel (smolmc_exchange_dev)" if dev_decide else "host (NumPy)")
     if world == 1:
         # BASELINE's own ladder for config 5 (400-2000 K): equilibrated it accepts 0.1 % of its steps
         # (why the default ladder above is hotter), so only the window rounds 1-2 quoted is timed

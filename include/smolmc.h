@@ -356,6 +356,21 @@ int smolmc_set_stream(smolmc_handle *h, void *hip_stream);
 int smolmc_export_enthalpy_dev(smolmc_handle *h, double *dst_dev);
 /* Permute per-walker temperatures from a DEVICE or host array after an exchange */
 int smolmc_import_temperature_dev(smolmc_handle *h, const double *src_dev);
+/* One exchange attempt of a replica-exchange temperature ladder decided on the device (ABI 8; no reference
+ * counterpart: SURVEY 8e, BASELINE configs[4]).  n_total walkers over all ranks, this handle holds walkers
+ * first .. first + R - 1 of them.  All arrays are DEVICE arrays of this handle's GPU:
+ *   enthalpy_all_dev [n_total]   the all-gathered enthalpies, global walker order
+ *   ladder_dev       [n_total]   temperature of every rung
+ *   log_u_dev        [>= n_total / 2]  log of the acceptance uniform of the p-th pair of this attempt (the caller's
+ *                                counter-based stream: identical on every rank)
+ *   rung_of_dev      [n_total]   in / out: walker -> rung
+ *   stats_dev        [2 (n_total - 1)] in / out, may be NULL: attempts | acceptances per neighbouring pair of rungs
+ * parity 0 / 1: pairs (0,1),(2,3),... / (1,2),(3,4),...  Accepts with min(1, exp((beta_k - beta_k+1)(H_a - H_b))),
+ * moves the rung assignment and sets THIS handle's temperatures to ladder[rung_of[first + r]]; asynchronous on the
+ * handle's stream (the inputs must be complete when it is called).  Every rank that calls it with the same inputs
+ * takes the same decisions; only temperatures move, occupancies never leave their GPU. */
+int smolmc_exchange_dev(smolmc_handle *h, int n_total, int first, int parity, const double *enthalpy_all_dev,
+                        const double *ladder_dev, const double *log_u_dev, int32_t *rung_of_dev, int64_t *stats_dev);
 
 #ifdef __cplusplus
 }

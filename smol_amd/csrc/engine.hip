@@ -3146,6 +3146,50 @@ __global__ void beta_from_T_kernel(const double *T, double *beta, int R, double 
     if (r < R) beta[r] = 1.0 / (kB * T[r]);
 }
 
+// One exchange attempt of a temperature ladder decided on the device: the serial section of the N-rank config-5 loop
+// (host NumPy over the all-gathered enthalpies until round 5: parallel.ReplicaExchange.decide).  One workgroup; the
+// rung -> walker map lives in LDS.  Every operation is the NumPy path's own (beta = 1 / (kB T), the product of the two
+// differences, the comparison with the host-made log u): the same decisions bit for bit.
+__global__ void __launch_bounds__(1024) rex_decide_kernel(const int n, const int first, const int parity, const double *H,
+                                                          const double *ladder, const double *log_u, int *rung_of,
+                                                          long long *stats, double *beta_out, const int R, const double kB) {
+    extern __shared__ int walker_at[]; // [n] rung -> walker
+    for (int g = threadIdx.x; g < n; g += blockDim.x) walker_at[rung_of[g]] = g;
+    __syncthreads();
+    const int npairs = (n - 1 - parity + 1) / 2; // pairs (k, k + 1), k = parity, parity + 2, ... < n - 1
+    for (int p = threadIdx.x; p < npairs; p += blockDim.x) {
+        const int k = parity + 2 * p;
+        const int a = walker_at[k], b = walker_at[k + 1];
+        const double bk = 1.0 / (kB * ladder[k]), bk1 = 1.0 / (kB * ladder[k + 1]);
+        const double expo = (bk - bk1) * (H[a] - H[b]);
+        const bool acc = expo >= 0.0 || log_u[p] < expo;
+        if (stats) {
+            stats[k] += 1;                          // attempted
+            if (acc) stats[(n - 1) + k] += 1;       // accepted
+        }
+        if (acc) { rung_of[a] = k + 1; rung_of[b] = k; } // (the pairs of one parity are disjoint)
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) beta_out[r] = 1.0 / (kB * ladder[rung_of[first + r]]);
+}
+
+extern "C" int smolmc_exchange_dev(smolmc_handle *h, int n_total, int first, int parity, const double *enthalpy_all_dev,
+                                   const double *ladder_dev, const double *log_u_dev, int32_t *rung_of_dev,
+                                   int64_t *stats_dev) {
+    if (!h || !enthalpy_all_dev || !ladder_dev || !log_u_dev || !rung_of_dev) return fail("null argument");
+    if (n_total < 2 || n_total > 16384) return fail("exchange ladder must hold 2 .. 16384 walkers (the rung map lives in LDS)");
+    if (first < 0 || first + h->R > n_total) return fail("this handle's walkers are out of range of the ladder");
+    if (parity != 0 && parity != 1) return fail("parity must be 0 or 1");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(rex_decide_kernel, dim3(1), dim3(1024), (size_t)n_total * sizeof(int), h->stream, n_total, first, parity,
+                       enthalpy_all_dev, ladder_dev, log_u_dev, (int *)rung_of_dev, (long long *)stats_dev, h->d_beta, h->R,
+                       SMOLMC_KB);
+    HIPCHK(hipGetLastError());
+    h->order_dirty = true; // (the launch order of the TableFlip kernels follows the temperatures)
+    return 0;
+}
+
 extern "C" int smolmc_import_temperature_dev(smolmc_handle *h, const double *src_dev) {
     if (!h || !src_dev) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));

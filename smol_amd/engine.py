@@ -54,6 +54,7 @@ SYMBOLS = {
     "smolmc_set_stream": (C.c_int, [_HP, C.c_void_p]),
     "smolmc_export_enthalpy_dev": (C.c_int, [_HP, C.c_void_p]),
     "smolmc_import_temperature_dev": (C.c_int, [_HP, C.c_void_p]),
+    "smolmc_exchange_dev": (C.c_int, [_HP, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -436,3 +437,10 @@ class Engine:
 
     def import_temperature(self, dev_ptr):
         self._chk(self._lib.smolmc_import_temperature_dev(self._h, C.c_void_p(int(dev_ptr))))
+
+    def exchange_dev(self, n_total, first, parity, enthalpy_all_ptr, ladder_ptr, log_u_ptr, rung_of_ptr, stats_ptr=0):
+        """One exchange attempt of a temperature ladder decided on the device (smolmc_exchange_dev): device
+        pointers in, this handle's temperatures follow the new rung assignment; asynchronous."""
+        self._chk(self._lib.smolmc_exchange_dev(
+            self._h, int(n_total), int(first), int(parity), C.c_void_p(int(enthalpy_all_ptr)), C.c_void_p(int(ladder_ptr)),
+            C.c_void_p(int(log_u_ptr)), C.c_void_p(int(rung_of_ptr)), C.c_void_p(int(stats_ptr)) if stats_ptr else None))

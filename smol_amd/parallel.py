@@ -120,10 +120,26 @@ class ReplicaExchange:
         self.attempted = np.zeros(self.n - 1, dtype=np.int64)
         self.accepted = np.zeros(self.n - 1, dtype=np.int64)
 
+    # rung_of / attempted / accepted: host arrays; after `decide_on_device` attempts the current values live on the
+    # GPU and every read brings them back first (sync_from_device), so no reader ever sees a stale ladder
+    def _synced(name):
+        def get(self):
+            self.sync_from_device()
+            return getattr(self, "_" + name)
+
+        def put(self, value):
+            setattr(self, "_" + name, value)
+
+        return property(get, put)
+
+    rung_of, attempted, accepted = _synced("rung_of"), _synced("attempted"), _synced("accepted")
+    del _synced
+
     # ------------------------------------------------------------------------------
     @property
     def temperatures(self):
         """Temperature of every global walker."""
+        self.sync_from_device()
         return self.ladder[self.rung_of]
 
     def local_temperatures(self):
@@ -148,6 +164,9 @@ class ReplicaExchange:
     def decide(self, enthalpy):
         """Swap decisions from the gathered enthalpies: pure function of (state, enthalpy),
         identical on every rank.  Returns the list of accepted rung pairs (k, k+1)."""
+        self.sync_from_device()
+        if getattr(self, "_dev", None) is not None:
+            self._dev = None  # (host decisions from here on: the device copies would go stale)
         parity = self.calls & 1
         walker_at = np.empty(self.n, dtype=np.int64)  # rung -> walker
         walker_at[self.rung_of] = np.arange(self.n)
@@ -168,6 +187,69 @@ class ReplicaExchange:
         self.calls += 1
         return [(int(k), int(k + 1)) for k in won]
 
+    # ---- decisions on the device (smolmc_exchange_dev) ---------------------------------------------
+    # The same attempt without the host in the loop: the all-gathered enthalpies stay on the GPU, one small kernel
+    # takes the decisions of `decide` -- same arithmetic, same counter-based uniforms (their logs are made on the
+    # host, a block of attempts ahead of time, and uploaded once per block) -- moves the rung assignment and sets the
+    # engine's temperatures.  rung_of / attempted / accepted live in device tensors meanwhile; `sync_from_device`
+    # (called by every reader below) brings them back.
+    LOG_U_BLOCK = 64  # attempts whose log-uniforms are uploaded together
+
+    def _device_state(self, device):
+        import torch
+
+        if getattr(self, "_dev", None) is None or self._dev["device"] != device:
+            self._dev = dict(
+                device=device,
+                ladder=torch.from_numpy(self.ladder).to(device),
+                rung_of=torch.from_numpy(self.rung_of.astype(np.int32)).to(device),
+                stats=torch.from_numpy(np.concatenate([self.attempted, self.accepted]).astype(np.int64)).to(device),
+                log_u=None, log_u_first=-1,
+            )
+            # (the uploads ran on torch's stream, the decision kernel runs on the engine's: they must have landed)
+            torch.cuda.synchronize(device)
+            self._dev_dirty = False
+        return self._dev
+
+    def _log_u_row(self, st):
+        """Device row of log(u) for attempt `self.calls` (uploaded LOG_U_BLOCK attempts at a time)."""
+        import torch
+
+        if st["log_u"] is None or not (st["log_u_first"] <= self.calls < st["log_u_first"] + self.LOG_U_BLOCK):
+            half = max(self.n // 2, 1)
+            rows = np.zeros((self.LOG_U_BLOCK, half))
+            for i in range(self.LOG_U_BLOCK):
+                c = self.calls + i
+                npairs = len(range(c & 1, self.n - 1, 2))
+                with np.errstate(divide="ignore"):  # (the draws `decide` makes for attempt c, in its order)
+                    rows[i, :npairs] = np.log(_philox_uniforms(self.seed, c, max(npairs, 1))[:npairs])
+            st["log_u"] = torch.from_numpy(rows).to(st["device"])
+            torch.cuda.synchronize(st["device"])  # (as above: another stream reads it)
+            st["log_u_first"] = self.calls
+        return st["log_u"][self.calls - st["log_u_first"]]
+
+    def decide_on_device(self, engine, enthalpy_all_dev):
+        """One attempt decided by `engine`'s GPU from the device tensor of ALL walkers' enthalpies (float64, global
+        order); the engine's temperatures are set by the same kernel.  Identical decisions to `decide`."""
+        st = self._device_state(enthalpy_all_dev.device)
+        lu = self._log_u_row(st)
+        engine.exchange_dev(self.n, self.rank * self.per_rank, self.calls & 1, enthalpy_all_dev.data_ptr(),
+                            st["ladder"].data_ptr(), lu.data_ptr(), st["rung_of"].data_ptr(), st["stats"].data_ptr())
+        self.calls += 1
+        self._dev_dirty = True
+
+    def sync_from_device(self):
+        """Bring rung_of / attempted / accepted back from the device after `decide_on_device` attempts."""
+        if getattr(self, "_dev_dirty", False):
+            import torch
+
+            self._dev_dirty = False  # (first: the assignments below go through the syncing properties)
+            torch.cuda.synchronize(self._dev["device"])
+            self.rung_of = self._dev["rung_of"].cpu().numpy().astype(np.int64)
+            stats = self._dev["stats"].cpu().numpy()
+            self.attempted, self.accepted = stats[: self.n - 1].copy(), stats[self.n - 1:].copy()
+        return self
+
     def exchange(self, local_enthalpy, force_collective=False):
         """gather + decide; returns this rank's new temperatures (NumPy, len per_rank)."""
         self.decide(self.gather(local_enthalpy, force_collective))
@@ -175,6 +257,7 @@ class ReplicaExchange:
 
     @property
     def acceptance(self):
+        self.sync_from_device()
         return self.accepted / np.maximum(self.attempted, 1)
 
 
@@ -183,7 +266,7 @@ def geometric_ladder(t_min, t_max, n):
     return np.geomspace(t_min, t_max, n)
 
 
-def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, collective=None):
+def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, collective=None, device_decide=None):
     """Alternate ``steps_between`` MC steps on every walker with one exchange attempt.
 
     ``engine`` is a smol_amd.engine.Engine holding this rank's ``rex.per_rank`` walkers.
@@ -195,14 +278,22 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
     tests, ``bench.py --oversubscribe`` / ``--dry-run``): the same all-gather over host tensors.
     Single rank (default): no collective is needed, the enthalpies are read back directly and
     the temperatures uploaded with set_temperature.  All paths take the same decisions
-    (tests/test_gpu_device_plumbing.py, tests/test_parallel_gloo.py)."""
+    (tests/test_gpu_device_plumbing.py, tests/test_parallel_gloo.py).
+    ``device_decide`` (default: SMOLMC_REX_DEVICE_DECIDE=1 in the environment; collective device path only): the swap
+    decisions are taken by a kernel on the all-gathered device tensor (smolmc_exchange_dev) instead of NumPy on a
+    host copy -- no device-to-host copy, no host arithmetic and no temperature upload per attempt; `rex.rung_of` /
+    `attempted` / `accepted` are brought back when read (`rex.sync_from_device()`)."""
+    import os
+
+    if device_decide is None:
+        device_decide = os.environ.get("SMOLMC_REX_DEVICE_DECIDE") == "1"
     dist = _dist()
     ready = dist.is_available() and dist.is_initialized()
     multi = ready and (rex.world > 1 if collective is None else bool(collective))
     if collective and not ready:
         raise RuntimeError("collective=True needs an initialised torch.distributed process group")
     on_device = multi and (device is not None or collective_device() == "cuda")
-    buf = tbuf = None
+    buf = tbuf = allbuf = None
     if multi:
         import torch
     if on_device:
@@ -217,7 +308,17 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
         if hasattr(engine, "sync"):
             engine.sync()  # (the exchange needs the launch's enthalpies anyway; timed from here: its own latency)
         t_ex = time.perf_counter()
-        if on_device:
+        if on_device and device_decide:
+            engine.export_enthalpy(buf.data_ptr())
+            if allbuf is None:
+                allbuf = torch.empty(rex.n, dtype=torch.float64, device=dev)
+            if rex.world > 1 or collective:
+                dist.all_gather_into_tensor(allbuf, buf, group=rex.group)
+            else:
+                allbuf.copy_(buf)
+            torch.cuda.current_stream().synchronize()  # (the kernel runs on the engine's stream)
+            rex.decide_on_device(engine, allbuf)
+        elif on_device:
             engine.export_enthalpy(buf.data_ptr())
             new_t = rex.exchange(buf, force_collective=True)
             tbuf.copy_(torch.from_numpy(new_t))
@@ -231,4 +332,6 @@ def run_replica_exchange(engine, rex, n_exchanges, steps_between, device=None, c
             engine.set_temperature(rex.local_temperatures())
         rex.exchange_seconds += time.perf_counter() - t_ex
         rex.exchange_timed += 1
+    if on_device and device_decide and hasattr(engine, "sync"):
+        engine.sync()  # (the last attempt's temperatures are in place when this returns)
     return rex

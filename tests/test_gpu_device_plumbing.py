@@ -124,6 +124,66 @@ def test_collective_exchange_branch_equals_direct_branch(nccl_world1):
     np.testing.assert_array_equal(sa["enthalpy"], sb["enthalpy"])
 
 
+@pytest.mark.parametrize("R", [64, 65, 2], ids=["even", "odd", "two"])
+def test_exchange_decided_on_the_device_equals_the_numpy_decisions(nccl_world1, R):
+    """smolmc_exchange_dev (round 6): export_enthalpy_dev -> all_gather_into_tensor (RCCL, world size 1) -> ONE kernel
+    that takes the swap decisions from the device tensor, moves the rung assignment and sets the temperatures --
+    against the host path (NumPy over a host copy, upload of the new temperatures): the same rung assignment after
+    every block of attempts, the same acceptance counters, identical walkers.  Ladders of even and odd length (the
+    odd-parity attempt has one pair fewer) and of two walkers (the odd attempt has none); more attempts than one
+    uploaded block of log-uniforms; a host-side attempt in between (`decide`) drops the device copies and a later
+    device attempt starts from the host state again."""
+    ladder = parallel.geometric_ladder(400.0, 2400.0, R)
+    out = []
+    for dev in (True, False):
+        eng, occ, seeds = _engine(R)
+        eng.set_state(occ, seeds, ladder)
+        rex = parallel.ReplicaExchange(ladder, R, rank=0, world=1, seed=5)
+        trace = []
+        for n_ex in (1, 7, parallel.ReplicaExchange.LOG_U_BLOCK + 3):
+            parallel.run_replica_exchange(eng, rex, n_ex, 54, collective=True, device_decide=dev)
+            trace.append((rex.temperatures.copy(), rex.attempted.copy(), rex.accepted.copy()))
+        rex.decide(eng.get_enthalpy())  # (a host attempt in the middle of either run)
+        eng.set_temperature(rex.local_temperatures())
+        parallel.run_replica_exchange(eng, rex, 5, 54, collective=True, device_decide=dev)
+        out.append((eng.get_state(), rex.rung_of.copy(), rex.accepted.copy(), rex.attempted.copy(), trace, rex.calls))
+    (sa, ra, aa, ta, tra, ca), (sb, rb, ab, tb, trb, cb) = out
+    assert ca == cb == 1 + 7 + parallel.ReplicaExchange.LOG_U_BLOCK + 3 + 1 + 5
+    for (t1, at1, ac1), (t2, at2, ac2) in zip(tra, trb):
+        np.testing.assert_array_equal(t1, t2)
+        assert np.array_equal(at1, at2) and np.array_equal(ac1, ac2)
+    assert np.array_equal(ra, rb) and np.array_equal(aa, ab) and np.array_equal(ta, tb)
+    assert sorted(ra) == list(range(R)) and ta.sum() > 0
+    if R > 2:
+        assert aa.sum() > 0
+    assert np.array_equal(sa["occupancy"], sb["occupancy"])
+    np.testing.assert_array_equal(sa["enthalpy"], sb["enthalpy"])
+
+
+def test_exchange_dev_argument_checks(nccl_world1):
+    import torch
+
+    from smol_amd.engine import EngineError
+
+    eng, occ, seeds = _engine(8)
+    eng.set_state(occ, seeds, 1000.0)
+    H = torch.zeros(8, dtype=torch.float64, device="cuda")
+    lad = torch.full((8,), 1000.0, dtype=torch.float64, device="cuda")
+    lu = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ro = torch.arange(8, dtype=torch.int32, device="cuda")
+    with pytest.raises((EngineError, ValueError), match="out of range"):
+        eng.exchange_dev(8, 1, 0, H.data_ptr(), lad.data_ptr(), lu.data_ptr(), ro.data_ptr())
+    with pytest.raises((EngineError, ValueError), match="parity"):
+        eng.exchange_dev(8, 0, 2, H.data_ptr(), lad.data_ptr(), lu.data_ptr(), ro.data_ptr())
+    with pytest.raises((EngineError, ValueError), match="16384"):
+        eng.exchange_dev(20000, 0, 0, H.data_ptr(), lad.data_ptr(), lu.data_ptr(), ro.data_ptr())
+    eng.exchange_dev(8, 0, 0, H.data_ptr(), lad.data_ptr(), lu.data_ptr(), ro.data_ptr())  # (stats may be omitted)
+    eng.sync()
+    # equal enthalpies: exponent 0 >= 0, every pair of the even attempt swaps
+    assert ro.cpu().tolist() == [1, 0, 3, 2, 5, 4, 7, 6]
+    eng.close()
+
+
 def test_global_sums_over_nccl(nccl_world1):
     import torch
 
