@@ -483,6 +483,55 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
 
     // ---- lean tables (see mc_lean_kernel) ------------------------------------------
     memset(&h->lp, 0, sizeof(LeanParams));
+    // The lean families' view of a site's clusters: one slot per local row, the flipped site's OWN positions in the row
+    // folded into the slot's table (selfmask), the other members gathered.  On an unaliased cell a row holds the site
+    // once (selfmask = 1 << p): exactly the slots above.  On an ALIASED cell -- a supercell shorter than a cluster, so
+    // that a row holds a site twice; the reference keeps such rows (clusterspace.py:1353-1359) and its evaluator flips
+    // every position of the site at once (evaluator.pyx:258-259 read occu_f / occu_i through the whole row) -- the
+    // delta table of the slot does the same: D[(old, new)][b] = T[base(b) + (sum of the self strides) new] - T[... old]
+    // (round 6; until then such cells ran on mc_kernel's GENERIC rows).  Order inside a record: by first self position,
+    // then by mask -- the order of the reference's rows (equivalent cluster major) at equal positions, which is the same
+    // on every site of a translation class; the classes are verified slot by slot below.
+    struct LSlot {
+        int orbit, pfirst, nother;
+        uint32_t selfmask;
+        int64_t rec;
+        const int32_t *row;
+    };
+    std::vector<std::vector<LSlot>> lslots(N);
+    int lean_need_mm = 1;
+    for (int s = 0; s < N; ++s) {
+        std::vector<LSlot> &sl = lslots[s];
+        for (int64_t r = t->site_ptr[s]; r < t->site_ptr[s + 1]; ++r) {
+            const int o = t->loc_orbit[r], I = t->orb_nsites[o], J = t->loc_nrows[r];
+            const int32_t *rows = t->loc_idx + t->loc_off[r];
+            std::vector<LSlot> rec;
+            for (int j = 0; j < J; ++j) {
+                uint32_t mask = 0;
+                for (int a = 0; a < I; ++a)
+                    if (rows[j * I + a] == s) mask |= 1u << a;
+                const int pf = mask ? __builtin_ctz(mask) : 0;
+                rec.push_back(LSlot{o, pf, I - __builtin_popcount(mask), mask, r, rows + (size_t)j * I});
+            }
+            std::stable_sort(rec.begin(), rec.end(), [](const LSlot &a, const LSlot &b) {
+                return a.pfirst != b.pfirst ? a.pfirst < b.pfirst : a.selfmask < b.selfmask;
+            });
+            sl.insert(sl.end(), rec.begin(), rec.end());
+        }
+        std::stable_sort(sl.begin(), sl.end(), [](const LSlot &a, const LSlot &b) { return a.nother > b.nother; });
+        for (const LSlot &q : sl) lean_need_mm = std::max(lean_need_mm, q.nother);
+    }
+    // aliased cells: every site of a class must list the same slots as the class's representative
+    bool lean_slots_ok = true;
+    if (aliased)
+        for (int s = 0; s < N && lean_slots_ok; ++s) {
+            if (site_class[s] == 255) continue;
+            const std::vector<LSlot> &a = lslots[s], &b = lslots[class_rep[site_class[s]]];
+            lean_slots_ok = a.size() == b.size();
+            for (size_t q = 0; q < a.size() && lean_slots_ok; ++q)
+                lean_slots_ok = a[q].orbit == b[q].orbit && a[q].selfmask == b[q].selfmask && a[q].selfmask != 0;
+        }
+    const bool lean_aliased_ok = !aliased || (lean_slots_ok && getenv("SMOLMC_NO_LEAN_ALIASED") == nullptr);
     // one site class: mc_lean_kernel (NSLOT <= 4); up to four classes or up to 512 clusters per
     // site: mc_lean_multi_kernel (per-class slot records in LDS)
     // Correlation features (ClusterExpansionProcessor, evaluator.pyx:211-265): when every orbit
@@ -521,30 +570,30 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
     // (why a model does not get the lean tables, reported by smolmc_kernel_info: the first condition that fails)
     h->lean_reason = class_rep.size() < 1 ? "no site with clusters"
                      : class_rep.size() > 4 ? "more than 4 site classes"
-                     : aliased ? "aliased supercell (a cluster holds a site twice)"
+                     : !lean_aliased_ok ? "aliased supercell (a cluster holds a site twice) whose sites do not list their clusters alike"
                      : (corr && !corr_k1 && !corr_kf && !corr_lazy) ? (cfg_wl ? "Wang-Landau with more than SMOLMC_LEAN_MAX_KF correlation functions per orbit, more than 61 of them, or TableFlip"
                                                                                 : "environment override (SMOLMC_NO_LEAN_CORR / SMOLMC_NO_LAZY_FEATURES)")
                      : N > 65535 ? "more than 65535 sites"
                      : niter_max > 8 ? "more than 512 clusters per site"
-                     : need_mm > 3 ? "clusters of more than 4 sites"
+                     : lean_need_mm > 3 ? "clusters of more than 4 sites"
                      : (num_ce_features(t) > 64 && !lazy_any) ? "more than 64 cluster features (Wang-Landau or correlation functions on the KF kernels)" : "";
-    if (class_rep.size() >= 1 && class_rep.size() <= 4 && !aliased && (!corr || corr_k1 || corr_kf || corr_lazy) && N <= 65535 &&
-        niter_max <= 8 && need_mm <= 3 && (num_ce_features(t) <= 64 || lazy_any)) {
+    if (class_rep.size() >= 1 && class_rep.size() <= 4 && lean_aliased_ok && (!corr || corr_k1 || corr_kf || corr_lazy) && N <= 65535 &&
+        niter_max <= 8 && lean_need_mm <= 3 && (num_ce_features(t) <= 64 || lazy_any)) {
         const int NSL = niter_max <= 2 ? 2 : (niter_max <= 4 ? 4 : 8);
         const int NCLS = (int)class_rep.size();
-        const int MML = need_mm <= 2 ? 2 : 3;
+        const int MML = lean_need_mm <= 2 ? 2 : 3;
         const int ROW = NSL * MML;
         std::vector<uint16_t> lidx((size_t)N * 64 * ROW);
         for (int s = 0; s < N; ++s) {
             for (int q = 0; q < 64 * ROW; ++q) lidx[(size_t)s * 64 * ROW + q] = (uint16_t)s;
-            const std::vector<Slot> &sl = slots[s];
+            const std::vector<LSlot> &sl = lslots[s];
             for (size_t q = 0; q < sl.size(); ++q) {
-                const Slot &k = sl[q];
+                const LSlot &k = sl[q];
                 const int I = t->orb_nsites[k.orbit];
                 const int it = (int)(q / 64), ln = (int)(q % 64);
                 int m = 0;
                 for (int a = 0; a < I; ++a) {
-                    if (a == k.p) continue;
+                    if ((k.selfmask >> a) & 1u) continue; // (the site's own positions are folded into the slot's table)
                     lidx[(((size_t)s * 64 + ln) * NSL + it) * MML + m] = (uint16_t)k.row[a];
                     m++;
                 }
@@ -563,7 +612,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 const int nsamp = std::min(N, 48);
                 for (int k = 0; k < nsamp; ++k) {
                     const int s = (int)(((long long)k * 2654435761ll) % N);
-                    if (slots[s].empty()) continue;
+                    if (lslots[s].empty()) continue;
                     for (int q = 0; q < ROW; ++q)
                         for (int g = 0; g < 2; ++g) {
                             int cnt[32] = {0};
@@ -622,10 +671,10 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         bool ok = true;
         double sum_abs_max = 0.0;
         for (int cls = 0; cls < NCLS && ok; ++cls) {
-        const std::vector<Slot> &sl = slots[class_rep[cls]];
+        const std::vector<LSlot> &sl = lslots[class_rep[cls]];
         double sum_abs = 0.0;
         for (size_t q = 0; q < sl.size() && ok; ++q) {
-            const Slot &k = sl[q];
+            const LSlot &k = sl[q];
             const int o = k.orbit, I = t->orb_nsites[o], Nt = t->orb_tensor_len[o];
             const int32_t *st = t->tensor_indices + t->orb_stride_off[o];
             const double *T = corr ? t->corr_tensors + t->orb_ctensor_off[o] // K == 1: the one function
@@ -639,16 +688,21 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                 for (int kk = 0; kk < Kfold; ++kk)
                     for (int i = 0; i < Nt; ++i) Efold[i] += t->ce_coefs[feat + kk] * T[(size_t)kk * Nt + i];
             }
-            const int ss = st[k.p];
-            const int Sself = k.p == 0 ? Nt / st[0] : st[k.p - 1] / st[k.p];
-            const auto key = std::make_pair(o, k.p);
+            // the site's own positions: their strides add up (one position on an unaliased cell), its site space is
+            // that of the first of them
+            int ss = 0;
+            for (int a = 0; a < I; ++a)
+                if ((k.selfmask >> a) & 1u) ss += st[a];
+            const int Sself = k.pfirst == 0 ? Nt / st[0] : st[k.pfirst - 1] / st[k.pfirst];
+            const int nother = k.nother;
+            const auto key = std::make_pair(o, (int)k.selfmask);
             if (!doff_of.count(key)) {
                 // tables of the slot: the decision table (LDS) and, in KF mode, K correlation-function
                 // tables (global memory, read on accepted steps only)
                 const int ntab = corr_kf ? 1 + K : 1;
                 std::vector<double> D((size_t)ntab * tlen, 0.0);
                 int nb = 1;
-                for (int a = 0; a < I - 1; ++a) nb *= SMAX;
+                for (int a = 0; a < nother; ++a) nb *= SMAX;
                 for (int tb = 0; tb < ntab; ++tb) {
                 const double *Tsrc = corr_lazy ? Efold.data() : !corr_kf ? T : (tb == 0 ? Efold.data() : T + (size_t)(tb - 1) * Nt);
                 double *Dt = D.data() + (size_t)tb * tlen;
@@ -658,7 +712,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
                     int rem = b;
                     bool valid = true;
                     for (int a = 0; a < I; ++a) {
-                        if (a == k.p) continue;
+                        if ((k.selfmask >> a) & 1u) continue;
                         const int v = rem % SMAX;
                         rem /= SMAX;
                         const int Sa = a == 0 ? Nt / st[0] : st[a - 1] / st[a];
@@ -698,7 +752,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.doff8 = doff_of[key] * 8u;
             {
                 uint32_t cs = 8u;
-                for (int m = 0; m < I - 1; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
+                for (int m = 0; m < nother; ++m, cs *= (uint32_t)SMAX) L.stride8[m] = cs;
             }
             L.feat = lazy_any ? 0u : (uint32_t)feat; // (lazy: the kernels' feature cells are never read)
             L.live = (uint32_t)K;

@@ -303,6 +303,29 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         npend++;
     };
 
+    // Wang-Landau with the Ewald field in LDS on a field of exactly 16 groups (the reference's LiNiO2 model in an 8^3
+    // cell, config 11): three steps of four are accepted there and every accepted step swept the field in three
+    // dependent round trips -- S8 / E8, then two batches of gathers -- on a wave that has its SIMD to itself.  The E8
+    // offsets of a lane's 16 entries are constants of the launch: kept in registers (round 6; the kernel runs one or two
+    // waves per SIMD, registers are not what it is short of), the S8 offsets of a step's sites come with the proposal
+    // batch, and ALL gathers of the sweep are issued at once: one round trip.
+#ifdef SMOLMC_NO_WL_E16 // A/B switch (tools/build_variant.sh)
+    constexpr bool WLE16 = false;
+#else
+    constexpr bool WLE16 = WLK != 0 && EWM == 1 && !REPLAY; // (EWM 1: the field in LDS)
+#endif
+    uint32_t e0w[16]; // (dead -- and removed by the compiler -- in the instantiations that do not take this sweep)
+    bool have_e0w = false;
+    uint32_t vS8s = 0, vS8c[4] = {0, 0, 0, 0}; // per batch: S8 of the lane's site / swap candidates
+    if (WLE16 && phi_lds) {
+        const LeanParamsKernarg Q = rare_params();
+        if (Q->ew_gx != nullptr && Q->ew_nact == 1024) {
+            const uint32_t *pE8 = Q->ew_E8;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e0w[u] = pE8[64 * u + lane];
+            have_e0w = true;
+        }
+    }
     MultiRec rcs[ONE ? NSLOT : 1];
     if (ONE) {
 #pragma unroll
@@ -385,14 +408,22 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
                     if (gxq != nullptr) {
                         const uint32_t *qS8 = Q->ew_S8;
                         const uint32_t e1 = Q->ew_E8[vsite - abase];
+                        uint32_t s8c[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) vGc[j] = *(const double *)(gxq + (size_t)(e1 + qS8[cand[j] - abase]));
+                        for (int j = 0; j < 4; ++j) s8c[j] = qS8[cand[j] - abase];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vGc[j] = *(const double *)(gxq + (size_t)(e1 + s8c[j]));
+                        if (WLE16) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) vS8c[j] = s8c[j];
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) vGc[j] = P.ew_G[(size_t)cand[j] * P.ew_nact + (vsite - abase)];
                     }
                 }
             }
+            if (WLE16 && have_e0w) vS8s = rare_params()->ew_S8[vsite - abase];
             if (pend_on) {
                 const uint32_t *pE8 = rare_params()->ew_E8;
                 vE8s = pE8[vsite - abase];
@@ -456,6 +487,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         double cross_b = 0.0;  // cross term G[s2][s1] of a partner that came from the batch's candidates
         bool have_cross = false;
         uint32_t e8_2 = 0xffffffffu; // E8 of the swap partner when it came from the batch's candidates
+        uint32_t s8_2 = 0xffffffffu; // ... and its S8 (WLE16)
         if (STEP != SMOLMC_STEP_SWAP) { s2 = s1; a2 = a1; }
         if (REPLAY) { // the recorded proposal
             if (STEP == SMOLMC_STEP_FLIP) {
@@ -494,6 +526,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
         a2 = (int)rdlane((uint32_t)canda[J], b);                                                   \
         o2 = (int)rdlane((uint32_t)v##J, b);                                                       \
         if (PEND) e8_2 = rdlane(vE8c[J], b);                                                       \
+        if (WLE16) s8_2 = rdlane(vS8c[J], b);                                                      \
         if (HAS_EW) {                                                                              \
             cross_b = __hiloint2double((int)rdlane((uint32_t)__double2hiint(vGc[J]), b),           \
                                        (int)rdlane((uint32_t)__double2loint(vGc[J]), b));          \
@@ -754,7 +787,31 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             if (STEP == SMOLMC_STEP_SWAP) occ[a2] = (uint8_t)n2;
             MULTI_PHASE(3)
             if (HAS_EW) {
-                if (phi_lds) {
+                bool swept = false;
+                if constexpr (WLE16) {
+                  if (have_e0w) {
+                    swept = true;
+                    // all 16 groups in one batch: the E8 offsets from registers, S8 from the proposal batch (a swap partner
+                    // that did not come from the batch's candidates -- rare -- reads its own)
+                    const LeanParamsKernarg Q = rare_params();
+                    const unsigned char *gxa = (const unsigned char *)Q->ew_gx;
+                    const uint32_t s8a = rdlane(vS8s, l4);
+                    if (STEP == SMOLMC_STEP_SWAP) {
+                        if (dq1 != 0.0 || dq2 != 0.0) {
+                            const uint32_t s8b = s8_2 != 0xffffffffu ? s8_2 : Q->ew_S8[s2 - abase];
+                            const uint32_t s8[2] = {s8a, s8b};
+                            const double dq[2] = {dq1, dq2};
+                            field_sweep_gx_groups<2, 16>(phi + lane, e0w, gxa, s8, dq, 0);
+                        }
+                    } else if (dq1 != 0.0) {
+                        const uint32_t s8[1] = {s8a};
+                        const double dq[1] = {dq1};
+                        field_sweep_gx_groups<1, 16>(phi + lane, e0w, gxa, s8, dq, 0);
+                    }
+                  }
+                }
+                if (swept) {
+                } else if (phi_lds) {
                     if (STEP == SMOLMC_STEP_SWAP) {
                         if (dq1 != 0.0 || dq2 != 0.0) field_apply2<1>(P, phi, lane, s1, dq1, s2, dq2);
                     } else if (dq1 != 0.0) {

@@ -89,8 +89,14 @@ def build_case(rng, profile="any"):
         desc.update(lattice="fcc", nspecies=S)
     desc["cutoffs"] = cut
     big = profile == "big"  # cells of 2000-14000 sites: potential field in HBM, pending-update lists, gx tables
-    lean = profile == "lean" or big or fast
+    # round 6: "aliased" -- cells of two or three primitive cells per direction, shorter than their clusters (a cluster
+    # row holds a site twice): the lean families with the site's own positions folded into the slot tables;
+    # "relabel" -- restricted sites / a sublattice split by species on every case: the site renumbering behind the
+    # C-ABI.  Both on the handle's own kernel only.
+    aliased_p, relabel_p = profile == "aliased", profile == "relabel"
+    lean = profile == "lean" or big or fast or relabel_p
     dims = ([int(rng.integers(9, 16)) for _ in range(3)] if big else
+            [int(rng.integers(2, 4)) for _ in range(3)] if aliased_p else
             [int(rng.integers(4, 9)) for _ in range(3)] if fast else
             [int(rng.integers(4, 11)) for _ in range(3)] if lean else [int(rng.integers(2, 7)) for _ in range(3)])
     if not lean and rng.random() < 0.15:
@@ -132,7 +138,7 @@ def build_case(rng, profile="any"):
         occ = (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
     # split the first active sublattice by species (ensemble.py:288-321): every walker must then
     # share the partition, so the walkers permute walker 0's species inside it
-    if step != "table-flip" and rng.random() < 0.12:
+    if step != "table-flip" and rng.random() < (0.4 if relabel_p else 0.12):
         sub_id = next(i for i, s in enumerate(ens.sublattices) if s.is_active)
         sub = ens.sublattices[sub_id]
         if len(sub.species) >= 3:
@@ -151,7 +157,7 @@ def build_case(rng, profile="any"):
     if step == "flip" or rng.random() < 0.2:
         ens.chemical_potentials = {sp: float(rng.uniform(-0.3, 0.3)) for sp in ens.species}
         desc["mu"] = True
-    if rng.random() < (0.1 if fast else 0.3 if lean else 0.25):
+    if rng.random() < (1.0 if relabel_p and "split" not in desc else 0.1 if fast else 0.3 if lean else 0.25):
         act = np.concatenate([s.active_sites for s in ens.active_sublattices])
         ens.restrict_sites(rng.choice(act, size=max(1, len(act) // 10), replace=False))
         desc["restricted"] = True
@@ -174,7 +180,7 @@ def build_case(rng, profile="any"):
     # scatter the active sites, smolmc_create renumbers them behind the C-ABI (kernel_info: "relabelled=1")
     # (half of the unforced cases switch the renumbering off: scattered layouts on mc_kernel / the universal kernel)
     tab_engine = tab
-    if not (lean or rng.random() < 0.5):
+    if not (lean or aliased_p or rng.random() < 0.5):
         desc["no_relabel"] = True
     bias = None
     if kernel == "metropolis" and rng.random() < 0.35 and not (fast and step == "table-flip"):
@@ -214,7 +220,7 @@ def build_case(rng, profile="any"):
                      update_period=up, flatness=float(pick(rng, [0.8, 0.3])))
         cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, st, **wl_kw)
         desc["update_period"] = up
-    env = None if lean else pick(rng, [None, None, None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"])
+    env = None if (lean or aliased_p) else pick(rng, [None, None, None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"])
     if profile == "univ":  # the models of `any`, every one on the universal kernel (rewritten in round 5)
         env = "SMOLMC_FORCE_UNIVERSAL"
     desc.update(walkers=R, sites=int(sc.num_sites), env=env)
@@ -367,12 +373,13 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--profile", default="any", choices=["any", "lean", "big", "fast", "univ"])
+    ap.add_argument("--profile", default="any", choices=["any", "lean", "big", "fast", "univ", "aliased", "relabel"])
     args = ap.parse_args()
     seeds = [args.only] if args.only is not None else [args.seed * 1000003 + i for i in range(args.cases)]
     t0 = time.time()
     counts = {"ok": 0, "void": 0, "FAIL": 0}
     kernels, not_lean = {}, {}
+    unforced = {"lean": 0, "other": 0, "relabelled": 0}  # cases on the handle's own kernel (no SMOLMC_FORCE_*, renumbering on)
     out = open(args.out, "w") if args.out else None
     for s in seeds:
         if time.time() - t0 > 60.0 * args.minutes:
@@ -387,6 +394,9 @@ def main():
             d = res["desc"]  # kernel family / step type (/ Wang-Landau): which kernels the campaign actually reached
             k = d["kernel_info"].split()[0] + "/" + d["step"] + ("/wl" if d["kernel"] == "wang-landau" else "")
             kernels[k] = kernels.get(k, 0) + 1
+            if not d.get("env") and not d.get("no_relabel"):
+                unforced["lean" if d["kernel_info"].startswith("lean") else "other"] += 1
+                unforced["relabelled"] += int(bool(d.get("relabelled")))
             if " | not lean: " in d["kernel_info"] and not d.get("env"):  # (why the model left the lean families, unforced cases)
                 why = d["kernel_info"].split(" | not lean: ", 1)[1]
                 not_lean[why] = not_lean.get(why, 0) + 1
@@ -395,8 +405,10 @@ def main():
         if out:
             out.write(json.dumps(res, default=str) + "\n")
             out.flush()
-    summary = dict(cases=sum(counts.values()), **counts, kernels=kernels, not_lean=not_lean, seconds=round(time.time() - t0, 1),
-                   first_seed=seeds[0])
+    nun = unforced["lean"] + unforced["other"]
+    summary = dict(cases=sum(counts.values()), **counts, kernels=kernels, not_lean=not_lean,
+                   unforced=dict(unforced, lean_share=round(unforced["lean"] / nun, 3) if nun else None),
+                   seconds=round(time.time() - t0, 1), first_seed=seeds[0])
     print(json.dumps(summary))
     if out:
         out.write(json.dumps(dict(summary=summary)) + "\n")

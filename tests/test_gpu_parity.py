@@ -803,7 +803,9 @@ def test_more_than_65535_sites_uses_32bit_rows():
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "wang-landau", "lean-multi"),   # WL + two sublattices (round 5)
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "wang-landau", "lean-multi"),
     ("rocksalt333_two_sublattices", "corr", capi.STEP_FLIP, "muG", "wang-landau", "lean-multi"),  # K > 1 of a multi-class model
-    ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "general"),   # aliased cell
+    ("fcc_prim222_aliased", "int", capi.STEP_FLIP, "mu2", "metropolis", "lean"),      # aliased cell: the site's own positions folded into the slot's table (round 6)
+    ("fcc_prim222_aliased", "corr", capi.STEP_SWAP, None, "metropolis", "lean"),
+    ("fcc_prim222_aliased", "int", capi.STEP_SWAP, None, "wang-landau", "lean"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_SWAP, None, "metropolis", "lean-multi"),
     ("rocksalt333_two_sublattices", "int", capi.STEP_FLIP, "muG", "metropolis", "lean-multi"),
     ("rocksalt444_ewald", "int", capi.STEP_SWAP, None, "wang-landau", "lean"),        # WL + Ewald: field in LDS (round 4)
@@ -827,7 +829,7 @@ def test_dispatch_goes_where_the_design_says(name, mode, step, mukind, kernel, e
     if mode == "corr" and expected == "lean-multi" and kernel == "wang-landau":
         assert "kf=1" in info, info
     if mode == "corr" and expected == "lean":
-        assert ("kf=1" in info) == (name != "fcc_prim666_triplets" and name != "fcc_conv444_pairs")
+        assert ("kf=1" in info) == (name not in ("fcc_prim666_triplets", "fcc_conv444_pairs", "fcc_prim222_aliased"))  # (binary: K = 1)
 
 
 @pytest.mark.parametrize("name,step,mukind", [("fcc_prim666_triplets", capi.STEP_SWAP, None),
@@ -1039,3 +1041,89 @@ def test_lean_multi_kernel_many_clusters(step):
     assert np.array_equal(a["occupancy"], o["occupancy"])
     np.testing.assert_allclose(a["enthalpy"], o["enthalpy"], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(a["features"], o["features"], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("what", ["fcc222", "fcc234", "fcc233-ternary", "rocksalt222-ewald", "fcc222-wl", "rocksalt322-two-sublattices",
+                                  "fcc223-corr-k3"])
+def test_aliased_cells_on_the_lean_kernels(what, monkeypatch):
+    """Supercells shorter than their clusters: a cluster row holds a site twice (the reference keeps such rows,
+    clusterspace.py:1353-1359, and flips every position of the site at once, evaluator.pyx:258-259).  Round 6: the
+    lean families fold the flipped site's own positions into the slot's delta table (engine.hip, `LSlot`); until
+    then these cells ran on mc_kernel's GENERIC rows.  Same chains as the oracle: binary / ternary fcc, rocksalt with
+    the Ewald term (field in LDS), Wang-Landau, two active sublattices (mc_lean_multi_kernel), several correlation
+    functions per orbit (lazy features); SMOLMC_NO_LEAN_ALIASED puts the cell back on mc_kernel: the same chain."""
+    from oracle import oracle as orc
+    from smol_amd import ewald as ew
+    from smol_amd import synth
+
+    monkeypatch.delenv("SMOLMC_NO_LEAN_ALIASED", raising=False)
+    monkeypatch.delenv("SMOLMC_FORCE_GENERAL", raising=False)
+    kw, kernel, step, mode = {}, capi.KERNEL_METROPOLIS, capi.STEP_SWAP, MODES["int"]
+    if what.startswith("fcc"):
+        nsp = 3 if "ternary" in what or "k3" in what else 2
+        model = synth.build_cluster_model(synth.fcc_prim(nspecies=nsp), {2: 6.0, 3: 5.0})
+        dims = {"fcc222": [2, 2, 2], "fcc234": [2, 3, 4], "fcc233": [2, 3, 3], "fcc223": [2, 2, 3]}[what.split("-")[0]]
+        sc = synth.build_supercell(model, dims)
+        if "ternary" in what:
+            step = capi.STEP_FLIP
+            mu = np.zeros((sc.num_sites, 3))
+            mu[:] = [0.0, 0.05, -0.04]
+            kw["mu_table"] = mu
+        if "corr" in what:
+            mode = MODES["corr"]
+    else:
+        two = "two" in what
+        prim = synth.rocksalt_prim(anion_charges=(-2.0, -1.0)) if two else synth.rocksalt_prim()
+        model = synth.build_cluster_model(prim, {2: 6.0, 3: 4.5})
+        sc = synth.build_supercell(model, [3, 2, 2] if two else [2, 2, 2])
+        if "ewald" in what:
+            kw.update(ewald=ew.supercell_ewald(sc), ewald_coef=0.1)
+    tab = capi.TableSet.from_synth(sc, synth.random_coefs(model, seed=11, scale=0.03), feature_mode=mode, **kw)
+    R = 6
+    rng = np.random.default_rng(5)
+    nspc = np.array([sc.model.prim.nspecies[b] for b in sc.site_b])
+    occ = (rng.random((R, sc.num_sites)) * nspc).astype(np.int32)
+    cfgkw = {}
+    if what.endswith("-wl"):
+        kernel = capi.KERNEL_WANGLANDAU
+        ev = orc.OracleEvaluator(tab)
+        h0 = np.array([ev.feature_vector(o) @ ev.natural_parameters() for o in occ])
+        cfgkw = dict(min_enthalpy=h0.min() - 3.37, max_enthalpy=h0.max() + 3.11, bin_size=0.25, check_period=40, flatness=0.3)
+    cfg = capi.make_config(R, kernel, step, **cfgkw)
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(300)
+    temps = np.linspace(1500.0, 6000.0, R)
+    eng, ora = _engine(tab, cfg), orc.OracleMC(tab, cfg)
+    info = eng.kernel_info()
+    assert info.startswith("lean"), info
+    if "two" in what:
+        assert info.startswith("lean-multi"), info
+    if "k3" in what:
+        assert "lazy-features" in info or "kf=1" in info, info
+    monkeypatch.setenv("SMOLMC_NO_LEAN_ALIASED", "1")
+    old = _engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_LEAN_ALIASED")
+    assert old.kernel_info().startswith("general") and "aliased" in old.kernel_info(), old.kernel_info()
+    for e in (eng, ora, old):
+        e.set_state(occ, seeds, temps)
+    for n in (1, 17, 64, 300):
+        for e in (eng, ora, old):
+            e.run(n)
+        a, b, c = eng.get_state(), ora.get_state(), old.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"]), (what, n)
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=1e-10, atol=1e-8)
+        assert np.array_equal(a["occupancy"], c["occupancy"])
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-8)
+    if kernel == capi.KERNEL_WANGLANDAU:
+        wa, wb = eng.get_wl(), ora.get_wl()
+        assert np.array_equal(wa["histogram"], wb["histogram"]) and np.array_equal(wa["occurrences"], wb["occurrences"])
+        np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=0, atol=0)
+        np.testing.assert_allclose(wa["mean_features"], wb["mean_features"], rtol=1e-10, atol=1e-9)
+    # a device-sampled block on the same handle
+    if kernel == capi.KERNEL_METROPOLIS:
+        s = eng.run_sampled(3, 20, occupancy=True)
+        for j in range(3):
+            ora.run(20)
+            assert np.array_equal(s["occupancy"][j], ora.get_state()["occupancy"])
