@@ -1521,7 +1521,8 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
                         bias_pair[(size_t)k * 64 + o * 8 + n] = t->bias_type == SMOLMC_BIAS_FUGACITY ? std::log(a / b) : a - b;
                     }
             }
-            if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) lean = false;
+            // (TableFlip with a bias: mc_table_kernel<..., BIAS> since round 6; SMOLMC_NO_TABLE_BIAS: A/B switch)
+            if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP && getenv("SMOLMC_NO_TABLE_BIAS") != nullptr) lean = false;
         }
         if (lean) {
             LeanParams &lp = h->lp;
@@ -2570,6 +2571,8 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_4(h, lp) : smolmc_launch_multi_8(h, lp));
     if (lp.bias_type && h->cfg.step_type != SMOLMC_STEP_TABLE_FLIP)
         return h->lean_nslot == 2 ? smolmc_launch_lean_bias_2(h, lp) : smolmc_launch_lean_bias_4(h, lp);
+    if (lp.bias_type) // TableFlip with an MCBias term (single-class layout)
+        return h->lean_nslot == 2 ? smolmc_launch_table_bias_2(h, lp) : smolmc_launch_table_bias_4(h, lp);
     if (h->lean_kf) return h->lean_nslot == 2 ? smolmc_launch_lean_corr_2(h, lp) : smolmc_launch_lean_corr_4(h, lp);
     // Wang-Landau: the dedicated kernel (mc_wl.h); SMOLMC_WL_V2 keeps round 2's variant of
     // mc_lean_kernel reachable for A/B runs
@@ -3014,7 +3017,9 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     const bool want_general = getenv("SMOLMC_REPLAY_GENERAL") != nullptr && two_flip_ok && h->general_ok;
     // (the lean TableFlip replay kernels pick sites without replacement like the usher: a record with a repeated
     // site -- valid for the boundary -- takes the universal kernel, which evaluates it flip by flip)
-    const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30) && !repeated_site;
+    // (a biased TableFlip handle has no REPLAY instantiation: the universal kernel replays its records)
+    const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30) && !repeated_site &&
+                                   !(h->lp.bias_type && !h->lean_multi);
     // (a Flip handle's own kernel takes single flips: records of two flips go to mc_kernel / the universal kernel)
     const bool lean_shape_ok = two_flip_ok && (h->cfg.step_type != SMOLMC_STEP_FLIP || max_flips <= 1);
     const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&

@@ -1367,7 +1367,11 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // record from its count changes (_get_flip_id, mcusher.py:641-654), evaluates the a-priori factor with
 // the code of the native path (or takes the given one) and reports accept flag, enthalpy and factor
 // per step.
-template <int NSLOT, int MM, int EWM, bool REPLAY = false>
+// BIAS (round 6; table_bias_n*.hip): an MCBias term in the exponent (metropolis.py:43-44) -- the reference composes any
+// usher with any bias (kernel/base.py:192-239) and until now TableFlip with a bias ran on the universal kernel.  The
+// pair tables of the biased lean kernels (bias_pair[row][old * 8 + new]) are read lane-parallel, lane f = flip f; the
+// flips of a table step touch distinct sites, so "the last flip of a site counts" (bias.py:75-93) is every flip.
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false>
 __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // (four or eight walkers per workgroup, two waves per SIMD)
     constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1504,6 +1508,13 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     const double nbeta = -P.beta[r];
     unsigned long long step = P.nsteps[r];
     uint32_t nacc_add = 0; // accepted steps of this launch (< 2^30 steps per launch)
+    // MCBias: running bias and, for the square biases, the running A_k . n - b_k of every hyperplane (one for
+    // SquareChargeBias: the net charge)
+    const int tb_type = BIAS ? P.bias_type : 0;
+    const int tb_rows = (tb_type && tb_type != SMOLMC_BIAS_FUGACITY) ? P.bias_rows : 0;
+    double tb_acc = 0.0, tb_chg[SMOLMC_MAX_BIAS_ROWS];
+#pragma unroll
+    for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] = (BIAS && k < tb_rows) ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] : 0.0;
     const uint32_t key0_ = (uint32_t)P.seeds[r], key1_ = (uint32_t)(P.seeds[r] >> 32);
     // The ten Philox round keys (key + i * Weyl constant) are loop invariant and the compiler
     // parks all twenty of them in SGPRs across the step loop, which then spills; the keys are
@@ -2278,9 +2289,42 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             dH += ew_coef_v * dEw;
         }
         if (has_mu) dH -= dMu;
-        const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+        // compute_bias_change of the step against the occupancy before it (kernel/base.py:307-311, bias.py:75-93)
+        double dB = 0.0, dQ[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
+        if (BIAS && tb_type && nfl >= 1) {
+            const LeanParamsKernarg Q = rare_params();
+            const uint32_t pidx = lane < nfl ? (uint32_t)(vold * 8 + vnew) : 0u; // lane f: the species pair of flip f
+            if (tb_type == SMOLMC_BIAS_FUGACITY) {
+                const double x = Q->bias_pair[pidx];
+                for (int f = 0; f < nfl; ++f) // (in the order of the flips, as the reference adds them)
+                    dB += __hiloint2double((int)rdlane((uint32_t)__double2hiint(x), f), (int)rdlane((uint32_t)__double2loint(x), f));
+            } else {
+                double sq_new = 0.0, sq_old = 0.0;
+                const double pen = Q->bias_pen;
+                const int stride = Q->bias_row_stride;
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                    if (k < tb_rows) {
+                        const double x = Q->bias_pair[(size_t)k * stride + pidx];
+                        double xs = 0.0;
+                        for (int f = 0; f < nfl; ++f)
+                            xs += __hiloint2double((int)rdlane((uint32_t)__double2hiint(x), f), (int)rdlane((uint32_t)__double2loint(x), f));
+                        dQ[k] = xs;
+                        const double cn = tb_chg[k] + xs;
+                        sq_old += tb_chg[k] * tb_chg[k];
+                        sq_new += cn * cn;
+                    }
+                dB = -pen * sq_new - (-pen * sq_old);
+            }
+        }
+        const double exponent = nbeta * dH + log_priori + dB; // metropolis.py:41-44
         const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
         if (accepted) {
+            if (BIAS) {
+                tb_acc += dB;
+#pragma unroll
+                for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] += dQ[k];
+            }
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
             if (dir >= 0) {
@@ -2404,6 +2448,12 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
         P.last_acc[r] = (uint8_t)last_acc;
+        if (BIAS && tb_type) {
+            P.bias[r] += tb_acc;
+#pragma unroll
+            for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                if (k < tb_rows) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] = tb_chg[k];
+        }
     }
 }
 
@@ -2447,12 +2497,12 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
     return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
-template <int NSLOT, int MM, int EWM, bool REPLAY = false>
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false>
 static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
     const int wpb = h->lean_wpb;
     const size_t lds = wpb == 8 ? h->lean_lds_wpb8 : h->lean_lds;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = mc_table_kernel<NSLOT, MM, EWM, REPLAY>;
+    auto kern = mc_table_kernel<NSLOT, MM, EWM, REPLAY, BIAS>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -2464,10 +2514,14 @@ static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
 }
 
 
-template <int NSLOT, int MM, bool REPLAY = false>
+template <int NSLOT, int MM, bool REPLAY = false, bool BIAS = false>
 static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
-    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0, REPLAY>(h, lp);
-    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2, REPLAY>(h, lp) : launch_table_ewm<NSLOT, MM, 1, REPLAY>(h, lp);
+    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0, REPLAY, BIAS>(h, lp);
+    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2, REPLAY, BIAS>(h, lp) : launch_table_ewm<NSLOT, MM, 1, REPLAY, BIAS>(h, lp);
+}
+// (instantiated in table_bias_n*.hip only)
+template <int NSLOT> static int launch_table_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_inst<NSLOT, 2, false, true>(h, lp) : launch_table_inst<NSLOT, 3, false, true>(h, lp);
 }
 // (instantiated in table_replay_n*.hip only)
 template <int NSLOT> static int launch_table_replay_nslot(smolmc_handle *h, const LeanParams &lp) {

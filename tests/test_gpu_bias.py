@@ -277,3 +277,79 @@ def test_square_hyperplane_bias_two_sublattices(oxyfluoride, step, monkeypatch):
         assert np.array_equal(smp["occupancy"][j], ora.get_state()["occupancy"])
         np.testing.assert_allclose(smp["bias"][j], ora.get_bias(), rtol=RTOL, atol=ATOL)
     eng.close()
+
+
+@pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
+@pytest.mark.parametrize("kind", ["fugacity", "square-charge", "square-hyperplane"])
+def test_table_flip_with_a_bias_on_the_lean_table_kernel(rocksalt, kind, ewald, monkeypatch):
+    """TableFlip composed with an MCBias term (the reference composes any usher with any bias, kernel/base.py:192-239;
+    its charge-balanced recipes are the TableFlip usher and the square-charge bias): mc_table_kernel<..., BIAS> since
+    round 6 -- the universal kernel until then (SMOLMC_NO_TABLE_BIAS: the A/B switch, same chain).  Same chain as the
+    oracle on identical Philox streams; the running trace.bias equals a recomputation; the bias column of the device
+    ring; a replayed record of the biased handle (the universal kernel replays it)."""
+    from oracle import oracle as orc
+
+    for k in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL", "SMOLMC_NO_TABLE_BIAS"):
+        monkeypatch.delenv(k, raising=False)
+    model, sc, coefs = rocksalt
+    ens = moca.Ensemble.from_cluster_expansion(sc, coefs, ewald_coefficient=0.2 if ewald else None)
+    names = ens.active_sublattices[0].species
+    if kind == "fugacity":
+        bias = moca.FugacityBias(ens.sublattices, [{names[0]: 0.15, names[1]: 0.25, names[2]: 0.6}])
+    elif kind == "square-charge":
+        bias = moca.SquareChargeBias(ens.sublattices, penalty=0.05)
+    else:
+        bias = moca.SquareHyperplaneBias(ens.sublattices, [[0, 1, 0, 0], [1, 0, -1, 0]], [sc.size // 3, 1], penalty=0.05)
+    tab = ens.make_tables(flip_table=[[1, -3, 2, 0]], swap_weight=0.2)
+    tab.set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=getattr(bias, "intercepts", None))
+    R = 6
+    P = sc.size
+    rng = np.random.default_rng(31)
+    occ0 = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # charge neutral: 2 n_Mn + 3 n_Ti = P
+        n_ti = 1 + 2 * (r % 3)
+        n_mn = (P - 3 * n_ti) // 2
+        perm = rng.permutation(P)
+        occ0[r, perm[:n_mn]] = 1
+        occ0[r, perm[n_mn:n_mn + n_ti]] = 2
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(7919)
+    temps = np.linspace(1500.0, 9000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean "), eng.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_TABLE_BIAS", "1")
+    univ = Engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_TABLE_BIAS")
+    assert univ.kernel_info().startswith("universal"), univ.kernel_info()
+    for e in (eng, ora, univ):
+        e.set_state(occ0, seeds, temps)
+    np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    for chunk in (1, 16, 62, 400):
+        for e in (eng, ora, univ):
+            e.run(chunk)
+        a, b, c = eng.get_state(), ora.get_state(), univ.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+        assert np.array_equal(a["occupancy"], c["occupancy"])
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in a["occupancy"]], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    # the device ring with the bias column (launch + snapshot per sample)
+    s = eng.run_sampled(3, 40, occupancy=True, bias=True)
+    for j in range(3):
+        ora.run(40)
+        assert np.array_equal(s["occupancy"][j], ora.get_state()["occupancy"])
+        np.testing.assert_allclose(s["bias"][j], ora.get_bias(), rtol=RTOL, atol=ATOL)
+    # an empty replayed record: the biased handle has no REPLAY instantiation of its own, the universal kernel takes it
+    st = np.full((R, 1, capi.STEP_ROW), -1, dtype=np.int32)
+    acc_r, H_r = eng.replay(st, np.full((R, 1), 0.5))
+    acc_o, H_o = ora.replay(st, np.full((R, 1), 0.5))  # (a replayed step advances the walker's step counter)
+    assert np.array_equal(acc_r, acc_o)
+    np.testing.assert_allclose(H_r, H_o, rtol=RTOL, atol=1e-8)
+    eng.run(50)
+    ora.run(50)
+    assert np.array_equal(eng.get_state()["occupancy"], ora.get_state()["occupancy"])
+    np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    eng.close()
+    univ.close()
