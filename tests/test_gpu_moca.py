@@ -406,7 +406,7 @@ def test_any_usher_with_any_kernel_through_the_sampler(rocksalt):
                                      flip_table=table, swap_weight=0.2, bias_type="fugacity",
                                      bias_kwargs={"fugacity_fractions": [{"Li+": 0.2, "Mn3+": 0.3, "Ti4+": 0.5}]})
     fug.run(2000, occ, thin_by=500)
-    assert fug._engine.kernel_info().startswith("universal")
+    assert fug._engine.kernel_info().startswith("lean ")  # (TableFlip + bias: mc_table_kernel<..., BIAS> since round 6)
     c = fug.samples
     b = c.get_trace_value("bias", flat=False)
     bias = fug.mckernels[0].bias
