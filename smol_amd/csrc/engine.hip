@@ -2751,7 +2751,14 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
     // lazy cluster features, rows recorded in-kernel: the kernels write rows of scalar features and the occupancy of
     // every sample; the cluster features of the rows are evaluated from those when the launch is through.  What the
     // caller did not ask for sits behind the part of the arena that is downloaded.
-    const bool lazy_rows = is_lazy(h) && !(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL));
+    // Biased Metropolis handles on the lean families record their rows in-kernel like the unbiased ones (round 6: the
+    // running bias is a scalar the kernel carries anyway; LeanParams::smp_bias_off tells it where the column is).  The
+    // snapshot path -- one launch + one snapshot kernel per sample -- is left to Wang-Landau (per-walker L and L x F
+    // arrays) and to biased handles on mc_kernel / the universal kernel.  SMOLMC_NO_INKERNEL_BIAS: A/B switch.
+    const bool inkernel_bias = (flags & SMOLMC_SAMPLE_BIAS) && !(flags & SMOLMC_SAMPLE_WL) && h->lean && !h->univ &&
+                               h->lp.bias_type && getenv("SMOLMC_NO_INKERNEL_BIAS") == nullptr;
+    const bool snapshot_path = (flags & SMOLMC_SAMPLE_WL) || ((flags & SMOLMC_SAMPLE_BIAS) && !inkernel_bias);
+    const bool lazy_rows = is_lazy(h) && !snapshot_path;
     size_t download = at, o_scal = 0, o_occ_int = w.o_occ;
     if (lazy_rows) {
         download = at;
@@ -2787,8 +2794,14 @@ extern "C" int smolmc_run_sampled(smolmc_handle *h, int64_t nsamples, int64_t th
     smp.feat = (double *)(sl.d + (lazy_rows ? o_scal : w.o_feat));
     smp.acc = sl.d + w.o_acc;
     smp.occ = (flags & SMOLMC_SAMPLE_OCCUPANCY) || lazy_rows ? sl.d + o_occ_int : nullptr;
-    if (!(flags & (SMOLMC_SAMPLE_BIAS | SMOLMC_SAMPLE_WL))) {
-        TRY(run_steps(h, nsamples * thin_by, smp)); // the kernels record the rows themselves, one launch
+    if (!snapshot_path) {
+        if (inkernel_bias) {
+            if ((w.o_bias - w.o_H) / 8 > 0xffffffffull) return fail("sample block too large for the in-kernel bias column");
+            h->lp.smp_bias_off = (uint32_t)((w.o_bias - w.o_H) / 8);
+        }
+        const int rc_run = run_steps(h, nsamples * thin_by, smp); // the kernels record the rows themselves, one launch
+        h->lp.smp_bias_off = 0;
+        if (rc_run) return rc_run;
         if (lazy_rows) {
             TRY(launch_eval_full(h, sl.d + o_occ_int, (int)rows, (double *)(sl.d + w.o_feat), 1));
             TRY(lazy_scalars(h, (double *)(sl.d + w.o_feat), (double *)(sl.d + o_scal), rows, 0));

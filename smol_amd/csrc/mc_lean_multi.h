@@ -914,6 +914,7 @@ __global__ void __launch_bounds__(512) mc_lean_multi_kernel(const LeanParams P) 
             if (lane == 0) {
                 Q->smp.H[row] = Hnow;
                 Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+                if (BIAS && Q->smp_bias_off) (Q->smp.H + Q->smp_bias_off)[row] = Q->bias[r] + bias_acc; // trace.bias (kernel/base.py:307-311)
             }
             if (Q->smp.occ) {
                 const int qNpad = Q->Npad;

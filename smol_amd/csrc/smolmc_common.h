@@ -450,6 +450,10 @@ struct LeanParams {
     // (FugacityBias) or q_new - q_old (SquareChargeBias); running bias / net charge per walker.
     // mc_lean_multi_kernel: one such table per sublattice, bias_pair[sub * 64 + old * 8 + new].
     int bias_type;
+    // (in the padding behind bias_type: no other offset of this block moves) device ring of a BIASED handle: the bias
+    // column of the block starts this many doubles behind smp.H (both live in one arena); 0: the kernel records no
+    // bias column (the snapshot path does).  Round 6: biased Metropolis handles record their rows in-kernel.
+    uint32_t smp_bias_off;
     const double *bias_pair;
     double bias_pen;
     int bias_rows, bias_row_stride; // SquareHyperplaneBias: bias_rows pair tables, bias_row_stride doubles apart (one row otherwise)

@@ -45,13 +45,17 @@ def _check_rows(smp, ora, thin, bias=False, wl=False):
             np.testing.assert_allclose(smp["mod_factor"][i], y["mod_factor"])
 
 
-@pytest.mark.parametrize("force", [None, "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"], ids=["auto", "general", "universal"])
+@pytest.mark.parametrize("force", [None, "SMOLMC_NO_INKERNEL_BIAS", "SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL"],
+                         ids=["auto", "snapshot", "general", "universal"])
 @pytest.mark.parametrize("tag", ["BC_fug_flip_int", "BC_sqc_flip_corr", "BG_hyp_flip_int", "BG_sqc_swap_int"])
 def test_bias_column_of_the_ring(tag, force, monkeypatch):
     """Biased Metropolis handles (Fugacity, SquareCharge, SquareHyperplane; lean, lean-multi, general and
-    universal kernels): `bias` of every sample = the oracle's trace.bias at that step."""
+    universal kernels): `bias` of every sample = the oracle's trace.bias at that step.  "auto": the lean families
+    record the column in-kernel (round 6: one launch per block); "snapshot": the same handles through the launch +
+    snapshot pairs that mc_kernel / the universal kernel and Wang-Landau keep."""
     for k in ENV:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("SMOLMC_NO_INKERNEL_BIAS", raising=False)
     if force:
         monkeypatch.setenv(force, "1")
     R = 4
