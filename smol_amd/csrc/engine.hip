@@ -1487,9 +1487,20 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             sbase = t->sub_active_sites[0];
             for (int i = 0; i < nact; ++i)
                 if (t->sub_active_sites[i] != sbase + i) lean = false;
-            for (int c = 0; c < nc; ++c)
-                if (t->sub_codes[c] != c) lean = false;
+            // Species codes 0 .. n-1, or -- canonical swaps only, which never draw a code: they exchange the two sites'
+            // own -- any code list (a sublattice split by species, sublattice.py:109-186, keeps the site space's codes:
+            // {1, 2} of three); the per-code rows (mu, charges, bias pairs) then run up to the largest code.
+            bool default_codes = true;
+            int top = 0;
+            for (int c = 0; c < nc; ++c) {
+                default_codes = default_codes && t->sub_codes[c] == c;
+                top = std::max(top, (int)t->sub_codes[c]);
+            }
             if (nc < 2 || nc > 8) lean = false;
+            if (!default_codes) {
+                if (cfg->step_type == SMOLMC_STEP_SWAP && top < 8 && getenv("SMOLMC_NO_SWAP_ANY_CODES") == nullptr) nc = top + 1;
+                else lean = false;
+            }
         }
         if (lean && t->has_mu) {
             if (t->mu_width < nc) lean = false;
@@ -1715,14 +1726,25 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             double cum = 0.0, mmax = 0.0;
             for (int k = 0; k < ns && ok; ++k) {
                 const int64_t a0 = t->sub_site_ptr[k], a1 = t->sub_site_ptr[k + 1];
-                const int na = (int)(a1 - a0), ncod = (int)(t->sub_code_ptr[k + 1] - t->sub_code_ptr[k]);
+                const int na = (int)(a1 - a0);
+                int ncod = (int)(t->sub_code_ptr[k + 1] - t->sub_code_ptr[k]);
                 const int sb = t->sub_active_sites[a0];
                 auto no = [&](const char *why) { if (ok) h->lean_reason = why; ok = false; };
                 if (na <= 0 || ncod < 2 || ncod > 8) no("an active sublattice of fewer than 2 or more than 8 species");
                 for (int i = 0; ok && i < na; ++i)
                     if (t->sub_active_sites[a0 + i] != sb + i) no("the active sites of a sublattice are not one site range (Ensemble.make_tables(contiguous=True) relabels them)");
-                for (int c = 0; ok && c < ncod; ++c)
-                    if (t->sub_codes[t->sub_code_ptr[k] + c] != c) no("a sublattice whose species codes are not 0 .. n-1 (split by species)");
+                {   // (codes other than 0 .. n-1 -- a sublattice split by species -- under canonical swaps only: see the single-class path)
+                    bool default_codes = true;
+                    int top = 0;
+                    for (int c = 0; c < ncod; ++c) {
+                        default_codes = default_codes && t->sub_codes[t->sub_code_ptr[k] + c] == c;
+                        top = std::max(top, (int)t->sub_codes[t->sub_code_ptr[k] + c]);
+                    }
+                    if (ok && !default_codes) {
+                        if (cfg->step_type == SMOLMC_STEP_SWAP && top < 8 && ncod >= 2 && getenv("SMOLMC_NO_SWAP_ANY_CODES") == nullptr) ncod = top + 1;
+                        else no("a sublattice whose species codes are not 0 .. n-1 (split by species) under a step type that draws codes");
+                    }
+                }
                 const int cls = ok ? h->site_class_host[sb] : 255;
                 if (ok && cls == 255) no("an active sublattice without clusters");
                 for (int i = 0; ok && i < na; ++i)
