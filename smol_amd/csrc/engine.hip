@@ -2000,11 +2000,24 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             for (int s = 0; s < t->num_sites; ++s)
                 if (row_ptr[(size_t)s + 1] - row_ptr[(size_t)s] != (uint32_t)up.rows_uniform) up.rows_uniform = 0;
             const URow *d_rows = nullptr;
+            const URow16 *d_rows16 = nullptr;
+            // (opt-in, SMOLMC_UNIV_ROWS16=1: measured on config 2 forced onto this kernel, the 16-byte rows cut the
+            // fetched bytes 25.0 -> 8.7 GB per launch of 4096 x 2000 swap steps and COST 4 % of the rate -- 11 % on config
+            // 8 -- because the kernel is VALU-bound and the unpacking is six more vector instructions per row)
+            up.rows16 = (t->num_sites <= 65535 && getenv("SMOLMC_UNIV_ROWS16") != nullptr) ? 1 : 0;
+            if (up.rows16) {
+                std::vector<URow16> r16(rows.size());
+                for (size_t i = 0; i < rows.size(); ++i) {
+                    for (int k = 0; k < SMOLMC_MAX_CLUSTER_SITES; ++k) r16[i].x[k] = (uint16_t)rows[i].x[k];
+                    r16[i].rec_lo = (uint16_t)((uint32_t)rows[i].rec & 0xffffu);
+                    r16[i].rec_hi = (uint16_t)((uint32_t)rows[i].rec >> 16);
+                }
+                if (dev_upload(h, r16.data(), r16.size(), &d_rows16)) return bail(1);
+            } else if (dev_upload(h, rows.data(), rows.size(), &d_rows)) return bail(1);
             if (dev_upload(h, row_ptr.data(), row_ptr.size(), &up.row_ptr) ||
-                dev_upload(h, rows.data(), rows.size(), &d_rows) ||
                 dev_upload(h, rec_e.data(), rec_e.size(), &up.recs_e))
                 return bail(1);
-            up.rows = (const uint4 *)d_rows;
+            up.rows = up.rows16 ? (const uint4 *)d_rows16 : (const uint4 *)d_rows;
         }
         if (cfg->step_type == SMOLMC_STEP_TABLE_FLIP) {
             if (t->n_flip_vectors <= 0 || !t->flip_table || !t->flip_weights)

@@ -81,6 +81,7 @@ __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, con
                             : (Q->T.corr_mode ? Q->T.corr_tensors : Q->T.interaction_tensors);
     const int Imax = Q->max_I;
     const uint4 *rows = Q->rows;
+    const bool rows16 = Q->rows16 != 0; // (uniform: one 16-byte record per row instead of two)
     const URecE *recs_e = DL ? (const URecE *)sh : Q->recs_e;
     const double *natural = DL ? (const double *)(sh + SMOLMC_UNIV_DICT_RECS * sizeof(URecE) + SMOLMC_UNIV_DICT_TENS * 8) : Q->natural;
     // (LDS atomics serialise per address for the whole CU: the cells of a feature exist 1 << cshift times, the
@@ -111,9 +112,15 @@ __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, con
                     cm[g] = in ? (int)rdlane((uint32_t)vC, j) : cm[g];
                     qo = in ? rdlane(vQ0, j) - cj : qo;
                 }
-            const uint4 *rp = rows + 2u * (size_t)(qo + pp);
-            ra[g] = rp[0];
-            rb[g] = rp[1];
+            if (rows16) {
+                const uint4 w = rows[(size_t)(qo + pp)];
+                ra[g] = make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
+                rb[g] = make_uint4(w.z & 0xffffu, w.z >> 16, w.w, 0u);
+            } else {
+                const uint4 *rp = rows + 2u * (size_t)(qo + pp);
+                ra[g] = rp[0];
+                rb[g] = rp[1];
+            }
         }
         URecE R[G];
 #pragma unroll

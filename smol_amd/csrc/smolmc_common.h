@@ -576,6 +576,15 @@ struct URow {
     int32_t x[6];
     int32_t rec, pad;
 };
+// ... and in 16 bytes (round 6) for cells of at most 65535 sites: six u16 member sites + the record.  The rows are what
+// the kernel streams -- 230 of them per swap step of config 2, a 15 MB table against 4 MB of L2 per XCD: 3.0 KB of
+// Infinity-Cache / HBM fetches per step (round 5's PMC passes).  Measured: 25.0 -> 8.7 GB per launch (the 7.5 MB table
+// hits L2 more often), and 4-11 % SLOWER: the kernel is VALU-bound (0.65-0.68 issue) and the unpacking adds ~23 vector
+// instructions per step.  Opt-in (SMOLMC_UNIV_ROWS16=1), the 32-byte rows stay the default.
+struct URow16 {
+    uint16_t x[6];
+    uint16_t rec_lo, rec_hi;
+};
 
 // parameter block of the universal kernel (mc_univ.h)
 struct UParams {
@@ -608,6 +617,7 @@ struct UParams {
     int lds_per_wave;
     int lds_shared;          // bytes of workgroup-shared LDS in front of the per-wave blocks (the dictionaries)
     int wl;                  // Wang-Landau kernel
+    int rows16;              // rows are packed 16-byte records (u16 member sites: cells of <= 65535 sites) instead of URow
     // replay extras
     const double *rp_lp;     // [R][nsteps] a-priori factors (NaN = derive) or null
     double *rp_lp_out;       // [R][nsteps] or null
