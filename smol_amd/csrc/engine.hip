@@ -2001,10 +2001,14 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
                 if (row_ptr[(size_t)s + 1] - row_ptr[(size_t)s] != (uint32_t)up.rows_uniform) up.rows_uniform = 0;
             const URow *d_rows = nullptr;
             const URow16 *d_rows16 = nullptr;
-            // (opt-in, SMOLMC_UNIV_ROWS16=1: measured on config 2 forced onto this kernel, the 16-byte rows cut the
+            // (experiment build + SMOLMC_UNIV_ROWS16=1: measured on config 2 forced onto this kernel, the 16-byte rows cut the
             // fetched bytes 25.0 -> 8.7 GB per launch of 4096 x 2000 swap steps and COST 4 % of the rate -- 11 % on config
             // 8 -- because the kernel is VALU-bound and the unpacking is six more vector instructions per row)
+#ifdef SMOLMC_UNIV_ROWS16
             up.rows16 = (t->num_sites <= 65535 && getenv("SMOLMC_UNIV_ROWS16") != nullptr) ? 1 : 0;
+#else
+            up.rows16 = 0; // (the kernels of the default build do not read 16-byte rows: make EXTRA=-DSMOLMC_UNIV_ROWS16)
+#endif
             if (up.rows16) {
                 std::vector<URow16> r16(rows.size());
                 for (size_t i = 0; i < rows.size(); ++i) {

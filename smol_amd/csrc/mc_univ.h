@@ -81,7 +81,11 @@ __device__ __forceinline__ double univ_step_partial(const unsigned char *sh, con
                             : (Q->T.corr_mode ? Q->T.corr_tensors : Q->T.interaction_tensors);
     const int Imax = Q->max_I;
     const uint4 *rows = Q->rows;
-    const bool rows16 = Q->rows16 != 0; // (uniform: one 16-byte record per row instead of two)
+#ifdef SMOLMC_UNIV_ROWS16 // experiment build (make EXTRA=-DSMOLMC_UNIV_ROWS16; see URow16): one 16-byte record per row instead of two
+    const bool rows16 = uni(Q->rows16) != 0;
+#else
+    constexpr bool rows16 = false; // (even a never-taken uniform branch here cost the default path 3-4 %)
+#endif
     const URecE *recs_e = DL ? (const URecE *)sh : Q->recs_e;
     const double *natural = DL ? (const double *)(sh + SMOLMC_UNIV_DICT_RECS * sizeof(URecE) + SMOLMC_UNIV_DICT_TENS * 8) : Q->natural;
     // (LDS atomics serialise per address for the whole CU: the cells of a feature exist 1 << cshift times, the

@@ -580,7 +580,8 @@ struct URow {
 // the kernel streams -- 230 of them per swap step of config 2, a 15 MB table against 4 MB of L2 per XCD: 3.0 KB of
 // Infinity-Cache / HBM fetches per step (round 5's PMC passes).  Measured: 25.0 -> 8.7 GB per launch (the 7.5 MB table
 // hits L2 more often), and 4-11 % SLOWER: the kernel is VALU-bound (0.65-0.68 issue) and the unpacking adds ~23 vector
-// instructions per step.  Opt-in (SMOLMC_UNIV_ROWS16=1), the 32-byte rows stay the default.
+// instructions per step.  Behind -DSMOLMC_UNIV_ROWS16 (make EXTRA=..., then SMOLMC_UNIV_ROWS16=1): the default build has the
+// 32-byte rows only -- a never-taken uniform branch in the row loads cost the default path 3-4 %.
 struct URow16 {
     uint16_t x[6];
     uint16_t rec_lo, rec_hi;

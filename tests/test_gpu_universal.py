@@ -51,19 +51,14 @@ def _rand_occ(sc, rng, R):
     return (rng.random((R, sc.num_sites)) * nsp).astype(np.int32)
 
 
-@pytest.mark.parametrize("occ_mem", ["lds", "hbm", "lds-rows16"])
+@pytest.mark.parametrize("occ_mem", ["lds", "hbm"])
 @pytest.mark.parametrize("step", [capi.STEP_FLIP, capi.STEP_SWAP], ids=["flip", "swap"])
 @pytest.mark.parametrize("mode", ["int", "corr"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_flip_and_swap_chains_on_the_universal_kernel(name, mode, step, occ_mem, monkeypatch):
     """Every golden model (pairs, triplets, ternary indicator basis on a skew cell, aliased 2x2x2,
-    vacancies, two active sublattices, Ewald): the universal kernel runs the oracle's chain.  "rows16": the opt-in
-    16-byte cluster rows (SMOLMC_UNIV_ROWS16, round 6: a third of the fetched bytes, 4-11 % slower)."""
+    vacancies, two active sublattices, Ewald): the universal kernel runs the oracle's chain."""
     monkeypatch.setenv("SMOLMC_FORCE_UNIVERSAL", "1")
-    monkeypatch.delenv("SMOLMC_UNIV_ROWS16", raising=False)
-    if occ_mem.endswith("rows16"):
-        monkeypatch.setenv("SMOLMC_UNIV_ROWS16", "1")
-        occ_mem = "lds"
     if occ_mem == "hbm":
         monkeypatch.setenv("SMOLMC_UNIV_OCC_HBM", "1")
     else:
