@@ -1513,9 +1513,11 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         // SquareHyperplaneBias -- on the lean kernels since round 5)
         const int brows_l = t->bias_type == SMOLMC_BIAS_SQUARE_HYPERPLANE ? t->bias_rows : 1;
         std::vector<double> bias_pair((size_t)64 * SMOLMC_MAX_BIAS_ROWS, 0.0);
-        // the table kernels are Metropolis kernels of at most 8 flip vectors: Wang-Landau TableFlip
-        // and larger tables take the universal kernel
-        if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP && (wl || t->n_flip_vectors > 8)) lean = false;
+        // the table kernels take at most 8 flip vectors: larger tables run on the universal kernel
+        // (Wang-Landau TableFlip: mc_table_kernel<..., WLT> since round 6; SMOLMC_NO_TABLE_WL: A/B switch)
+        const bool table_wl = wl && cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
+        if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP && (t->n_flip_vectors > 8 || (wl && getenv("SMOLMC_NO_TABLE_WL") != nullptr)))
+            lean = false;
         // several correlation functions per orbit: plain Metropolis flip / swap variants only
         if (lean && h->lean_kf && (wl || t->bias_type || cfg->step_type == SMOLMC_STEP_TABLE_FLIP)) lean = false;
         if (lean && t->bias_type) {
@@ -1602,10 +1604,11 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             // (Wang-Landau: per-bin records and the cached rows of per-bin feature sums, mc_wl.h)
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 +
-                                       (wl ? std::max(wl_lean_bins_bytes(h->L) + (size_t)SMOLMC_WL_ROWS * h->F * 8,
-                                                      // (round 2's variant inside mc_lean_kernel, A/B switch: 24-byte records)
-                                                      getenv("SMOLMC_WL_V2") ? (size_t)h->L * 24 : (size_t)0)
-                                           : 0));
+                                       (table_wl ? wl_multi_wave_bytes(h->L, h->F, 1) // (mc_table_kernel<..., WLT>: the multi-class kernel's state)
+                                        : wl     ? std::max(wl_lean_bins_bytes(h->L) + (size_t)SMOLMC_WL_ROWS * h->F * 8,
+                                                            // (round 2's variant inside mc_lean_kernel, A/B switch: 24-byte records)
+                                                            getenv("SMOLMC_WL_V2") ? (size_t)h->L * 24 : (size_t)0)
+                                                 : 0));
             if (h->lean_lds > 150 * 1024) lean = false;
             // Ewald potential field in LDS when the changeable sites are the active
             // sublattice and it fits beside the occupancies
@@ -1639,7 +1642,7 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             // Wang-Landau with the Ewald term: mc_wl_kernel takes it from the field in LDS only
             // (also what the round-2 kernel SMOLMC_WL_V2 cannot do: no Ewald, no mu)
             if (lean && wl && t->has_ewald && !lp.ew_field) lean = false;
-            if (lean && wl && (t->has_ewald || t->has_mu) && getenv("SMOLMC_WL_V2") != nullptr) lean = false;
+            if (lean && wl && (t->has_ewald || t->has_mu || table_wl) && getenv("SMOLMC_WL_V2") != nullptr) lean = false;
             // one wave per workgroup (occupancy at LDS address 0, 32-bit index rows, a private
             // copy of the tables): Metropolis flips / swaps without Ewald term or bias, when 16
             // such workgroups still fit a CU
@@ -1688,7 +1691,7 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
                     h->lean_wpb = 4;
                     int cus = 0; // (fewer walkers than 8 per CU: four-walker workgroups spread over more CUs)
                     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
-                    if (lds8 <= 160 * 1024 && h->lean_lds > 40 * 1024 && cfg->n_replicas % 8 == 0 &&
+                    if (!wl && lds8 <= 160 * 1024 && h->lean_lds > 40 * 1024 && cfg->n_replicas % 8 == 0 &&
                         (long)cfg->n_replicas >= 8L * cus && getenv("SMOLMC_TABLE_WPB4") == nullptr) {
                         h->lean_wpb = 8;
                         h->lean_lds_wpb8 = lds8;
@@ -1703,15 +1706,17 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         // TableFlip take the general kernel)
         const bool multi_bias_ok = !t->bias_type || cfg->step_type != SMOLMC_STEP_TABLE_FLIP;
         // Wang-Landau on this layout (round 5; mc_lean_multi_kernel<..., WLK>): any number of classes the
-        // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves; the
-        // Wang-Landau TableFlip stays on the universal kernel.  SMOLMC_NO_WL_MULTI: A/B switch.
+        // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves.  The
+        // Wang-Landau TableFlip: mc_table_multi_kernel<..., WLT> (round 6) with update_period 1 and one correlation
+        // function per orbit, the universal kernel otherwise.  SMOLMC_NO_WL_MULTI, SMOLMC_NO_TABLE_WL: A/B switches.
         const int wl_sum_mode = (cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
-        const bool multi_wl_ok = !wl || (!table && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && cfg->wl_update_period < (1ll << 31) &&
-                                         getenv("SMOLMC_NO_WL_MULTI") == nullptr);
+        const bool multi_table_wl_ok = wl_sum_mode && !h->lean_kf && getenv("SMOLMC_NO_TABLE_WL") == nullptr;
+        const bool multi_wl_ok = !wl || ((!table || multi_table_wl_ok) && h->F <= 63 && cfg->wl_check_period < (1ll << 31) &&
+                                         cfg->wl_update_period < (1ll << 31) && getenv("SMOLMC_NO_WL_MULTI") == nullptr);
         // (why a model with lean tables runs neither lean family: the first condition that fails, for smolmc_kernel_info)
         if (!lean && h->lean_tables)
             h->lean_reason = (h->lean_kf && !wl) ? "several correlation functions per orbit (KF kernel) on a model outside the single-class lean shape"
-                             : !multi_wl_ok ? "Wang-Landau with TableFlip or more than 63 features"
+                             : !multi_wl_ok ? "Wang-Landau with more than 63 features, or with TableFlip and update_period > 1 / several correlation functions per orbit"
                              : !multi_bias_ok ? "a bias term with TableFlip"
                              : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
@@ -1829,7 +1834,8 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             // canonical swaps whenever it fits; else the HBM copy is used in place (ew_field 2).  SMOLMC_MULTI_PHI_HBM / _LDS force either (test hooks).
             // (Wang-Landau: entropies, step counts and cached rows instead of the accumulator cells)
             const size_t base_wave = (size_t)lp.Nlds + 64 + 64 * 8 +
-                                     (wl ? wl_multi_wave_bytes(h->L, h->F, wl_sum_mode) : nrec * (table ? 16 : 8));
+                                     (wl ? wl_multi_wave_bytes(h->L, h->F, wl_sum_mode) + (table ? nrec * 8 : 0) // (table: + pending cells)
+                                         : nrec * (table ? 16 : 8));
             bool phi_lds = t->has_ewald && (size_t)kp.ew_nact * 8 <= base_wave / 2;
             if (t->has_ewald && !phi_lds) {
                 int cus = 0, w = 0;
@@ -2400,7 +2406,10 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
             snprintf(buf + used, (size_t)n - used, " gx=%dx%dx%dx%d", h->ew_gx_blocks, h->ew_gx_dims[0], h->ew_gx_dims[1],
                      h->ew_gx_dims[2]);
         else if (h->lean && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && used + 8 < (size_t)n)
-            snprintf(buf + used, (size_t)n - used, h->lean_multi_wl ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
+            snprintf(buf + used, (size_t)n - used, (h->lean_multi_wl || h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
+        if (h->lean && !h->lean_multi && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP &&
+            strlen(buf) + 16 < (size_t)n) // (mc_table_kernel<..., WLT>)
+            strncat(buf, " wl=table", (size_t)n - strlen(buf) - 1);
         if (is_lazy(h) && strlen(buf) + 16 < (size_t)n) strncat(buf, " lazy-features", (size_t)n - strlen(buf) - 1);
         if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
             snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");
@@ -2599,6 +2608,9 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     if (h->lean_multi_wl && h->lean_kf) // several correlation functions per orbit (KFW)
         return h->lean_nslot == 2 ? smolmc_launch_multi_wl_kf_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_kf_4(h, lp) : smolmc_launch_multi_wl_kf_8(h, lp));
+    if (h->lean_multi_wl && h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_table_wl_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_table_wl_4(h, lp) : smolmc_launch_multi_table_wl_8(h, lp));
     if (h->lean_multi_wl)
         return h->lean_nslot == 2 ? smolmc_launch_multi_wl_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_4(h, lp) : smolmc_launch_multi_wl_8(h, lp));
@@ -2612,6 +2624,8 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
         return h->lean_nslot == 2 ? smolmc_launch_lean_bias_2(h, lp) : smolmc_launch_lean_bias_4(h, lp);
     if (lp.bias_type) // TableFlip with an MCBias term (single-class layout)
         return h->lean_nslot == 2 ? smolmc_launch_table_bias_2(h, lp) : smolmc_launch_table_bias_4(h, lp);
+    if (h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) // (single-class layout)
+        return h->lean_nslot == 2 ? smolmc_launch_table_wl_2(h, lp) : smolmc_launch_table_wl_4(h, lp);
     if (h->lean_kf) return h->lean_nslot == 2 ? smolmc_launch_lean_corr_2(h, lp) : smolmc_launch_lean_corr_4(h, lp);
     // Wang-Landau: the dedicated kernel (mc_wl.h); SMOLMC_WL_V2 keeps round 2's variant of
     // mc_lean_kernel reachable for A/B runs
@@ -3069,9 +3083,9 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     const bool want_general = getenv("SMOLMC_REPLAY_GENERAL") != nullptr && two_flip_ok && h->general_ok;
     // (the lean TableFlip replay kernels pick sites without replacement like the usher: a record with a repeated
     // site -- valid for the boundary -- takes the universal kernel, which evaluates it flip by flip)
-    // (a biased TableFlip handle has no REPLAY instantiation: the universal kernel replays its records)
+    // (a biased or Wang-Landau TableFlip handle has no REPLAY instantiation: the universal kernel replays its records)
     const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30) && !repeated_site &&
-                                   !(h->lp.bias_type && !h->lean_multi);
+                                   !(h->lp.bias_type && !h->lean_multi) && h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU;
     // (a Flip handle's own kernel takes single flips: records of two flips go to mc_kernel / the universal kernel)
     const bool lean_shape_ok = two_flip_ok && (h->cfg.step_type != SMOLMC_STEP_FLIP || max_flips <= 1);
     const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&

@@ -1372,8 +1372,16 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // usher with any bias (kernel/base.py:192-239) and until now TableFlip with a bias ran on the universal kernel.  The
 // pair tables of the biased lean kernels (bias_pair[row][old * 8 + new]) are read lane-parallel, lane f = flip f; the
 // flips of a table step touch distinct sites, so "the last flip of a site counts" (bias.py:75-93) is every flip.
-template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false>
+// WLT (round 6; table_wl_n*.hip): the Wang-Landau kernel (kernel/wanglandau.py:175-266, update_period 1) with TableFlip
+// proposals -- the reference composes any usher with any kernel and until now this pair ran on the universal kernel.
+// The accept rule is S[bin] - S[new bin] + the a-priori factor of the step (wanglandau.py:197-198); the per-walker
+// state (entropies, counted steps, the log of finished runs) is mc_lean_multi_kernel's (mc_lean_multi.h: WLK) behind
+// the potential field in LDS; the current feature vector lives in the lanes of one register and the enthalpy is
+// carried as the reference carries it (:216-218).
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false, bool WLT = false>
 __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // (four or eight walkers per workgroup, two waves per SIMD)
+    static_assert(!(WLT && BIAS), "Cannot apply bias to Wang-Landau simulation (wanglandau.py:127-128)");
+    static_assert(!(WLT && REPLAY), "Wang-Landau TableFlip replays take the universal kernel");
     constexpr bool has_ew = EWM != 0, ew_field = EWM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1384,7 +1392,8 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     const int r = (P.order != nullptr && slot < P.R) ? uni(P.order[slot]) : slot;
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
-    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (ew_field ? (size_t)P.ew_nact * 8 : 0);
+    const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (ew_field ? (size_t)P.ew_nact * 8 : 0) +
+                            (WLT ? wl_multi_wave_bytes(P.wl.L, P.F, 1) : 0);
     double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
     // block-shared copies of the flip table (<= 8 vectors x 8 codes), its weights and ln(k)
     double *s_tfw = s_mu + 24;
@@ -1395,6 +1404,10 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     double *s_feat = (double *)(wbase + P.Nlds);
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
     double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64); // Ewald potential field [ew_nact]
+    // WLT: S f64 [L] | counted steps u32 [L] | log of SMOLMC_WLM_LOG finished runs [F] (wl_multi_wave_bytes)
+    double *wl_S = phi + (ew_field ? P.ew_nact : 0);
+    uint32_t *wl_cnt = (uint32_t *)(wl_S + (WLT ? P.wl.L : 0));
+    double *s_rows = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     const bool has_mu = P.mu_row != nullptr;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -1415,6 +1428,11 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         if (lane < 16) s_cnt[lane] = 0;
         if (ew_field)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
+        if (WLT)
+            for (int i = lane; i < P.wl.L; i += 64) {
+                wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+                wl_cnt[i] = 0u;
+            }
     }
     __syncthreads();
     if (!live) return;
@@ -1527,6 +1545,48 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     int last_acc = 1;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    // ---- Wang-Landau state (WLT; as mc_lean_multi_kernel's WLK with update_period 1) ----
+    double fcur = base_feat;  // lane f < F: the walker's current feature vector (_current_features); H is _current_enthalpy
+    double wl_m = WLT ? P.wl.m[r] : 0.0;
+    int wb = 0;               // current bin (walkers start inside the window: smolmc_set_state)
+    if (WLT) wb = min(max(uni((int)floordiv_exact(H - P.wl.vmin, P.wl.bin)), 0), P.wl.L - 1);
+    const long long wl_counter0 = WLT ? P.wl.counter[r] : 0;
+    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u;
+    // (check period 0 = no device-side check: the remainder starts at 1 and cannot wrap to 0 inside a launch of < 2^30 steps)
+    uint32_t wl_rem_check = (WLT && wl_check) ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_check)) : 1u;
+    uint32_t wl_run_n = 0;    // post-steps of the current (bin, features) state not yet in its row
+    int vtag = -1;            // lane i < SMOLMC_WLM_LOG: the bin of log entry i
+    int wl_nlog = 0;
+    // shadow copies of the feature cells for the accepted steps' deltas (see mc_wl.h): lane l adds into copy l % wl_k,
+    // a reader sums the copies; cell 63 is never written (the address of "no copy")
+    const int wl_F = WLT ? P.F : 1;
+    const int wl_k = max(1, min(8, 63 / max(wl_F, 1)));
+    const uint32_t wl_shadow = (uint32_t)((lane % wl_k) * wl_F);
+    const int wl_rd0 = lane < wl_F ? lane : 63, wl_rdstep = lane < wl_F ? wl_F : 0; // copy k of feature `lane`: cell wl_rd0 + k wl_rdstep
+    const bool wl_zero_lane = lane < wl_k * wl_F;
+    // finished runs {bin, run_n * features} are logged in LDS and go to the rows of per-bin feature sums in HBM in one
+    // burst of fire-and-forget atomics (64 / F entries per instruction; the rows of a walker are touched by its own wave only)
+    const int wl_epi = max(1, 64 / max(wl_F, 1)), wl_lane_e = lane / max(wl_F, 1), wl_lane_f = lane - wl_lane_e * wl_F;
+    auto wl_log_flush = [&]() {
+        const LeanParamsKernarg Q = rare_params();
+        double *grows = Q->wl.meanf + (size_t)r * Q->wl.L * Q->F;
+        const int qF = Q->F;
+        for (int base = 0; base < wl_nlog; base += wl_epi) {
+            const int e = base + wl_lane_e;
+            const int bin = __shfl(vtag, e & 63); // (uniform control flow: ds_bpermute reads switched-off lanes otherwise)
+            if (wl_lane_e < wl_epi && e < wl_nlog)
+                unsafeAtomicAdd(grows + (size_t)bin * qF + wl_lane_f, s_rows[(uint32_t)base * (uint32_t)qF + lane]);
+        }
+        wl_nlog = 0;
+    };
+    auto wl_flush_run = [&]() {
+        if (wl_run_n != 0u) {
+            if (lane < wl_F) s_rows[(uint32_t)wl_nlog * (uint32_t)wl_F + lane] = (double)wl_run_n * fcur;
+            vtag = lane == wl_nlog ? wb : vtag;
+            wl_run_n = 0u;
+            if (++wl_nlog == SMOLMC_WLM_LOG) wl_log_flush();
+        }
+    };
     // 32-bit loop state (the host splits launches at 2^30 steps): the kernel is short of SGPRs
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu, smp_index = 0; // (no sampling: never reaches zero)
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
@@ -2318,13 +2378,43 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
                 dB = -pen * sq_new - (-pen * sq_old);
             }
         }
-        const double exponent = nbeta * dH + log_priori + dB; // metropolis.py:41-44
-        const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        bool accepted;
+        int wnb = wb;
+        if (WLT) { // WangLandau._accept_step (wanglandau.py:186-202): exact float64 delta, exact floor division
+            const LeanParamsKernarg Q = rare_params();
+            const double new_h = H + dH, vmin = Q->wl.vmin;
+            accepted = false;
+            if (__ballot(!(new_h < vmin || new_h >= Q->wl.vmax)) != 0ull) {
+                wnb = uni((int)floordiv_exact(new_h - vmin, Q->wl.bin));
+                const double ex = wl_S[wb] - wl_S[wnb] + log_priori; // (:197-198)
+                accepted = __ballot((ex >= 0.0) || (ex > lu)) != 0ull;
+            }
+        } else {
+            const double exponent = nbeta * dH + log_priori + dB; // metropolis.py:41-44
+            accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        }
         if (accepted) {
             if (BIAS) {
                 tb_acc += dB;
 #pragma unroll
                 for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] += dQ[k];
+            }
+            if (WLT) {
+                // the state (bin, features) ends here: its post-steps go to the bin's row; then features and bin follow
+                // the step (_do_accept_step, wanglandau.py:204-220; the enthalpy below with the Metropolis kernels')
+                wl_flush_run();
+#pragma unroll
+                for (int it = 0; it < NSLOT; ++it)
+                    __hip_atomic_fetch_add(&s_feat[sfeat[it] + wl_shadow], sfs[it] * pend[it], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                double df = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) df += s_feat[k < wl_k ? wl_rd0 + k * wl_rdstep : 63];
+                if (wl_zero_lane) s_feat[lane] = 0.0;
+                if (has_ew) df += lane == P.Fce ? dEw : 0.0;
+                if (has_mu) df += lane == P.Fce + (has_ew ? 1 : 0) ? dMu : 0.0;
+                fcur += df;
+                wb = wnb;
             }
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it) acc[it] += pend[it];
@@ -2373,6 +2463,20 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         { const long long tn = clock64(); ph_acc[5] += tn - ph_t; ph_t = tn; }
 #endif
         last_acc = accepted ? 1 : 0;
+        if (WLT) { // WangLandau._do_post_step (wanglandau.py:222-266), accepted or not
+            wl_run_n++;
+            if (lane == 0) { // entropy, histogram and occurrences of the bin (:241-245, update_period 1)
+                __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (++wl_rem_check == wl_check) wl_rem_check = 0u;
+            if (wl_rem_check == 0u) {
+                const LeanParamsKernarg Q = rare_params();
+                const size_t o = (size_t)r * Q->wl.L;
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, nullptr, Q->wl.hist + o, Q->wl.occur + o, Q->wl.L, Q->wl.flat,
+                                               Q->wl.div, wl_m, lane);
+            }
+        }
 #ifndef SMOLMC_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -2394,6 +2498,9 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             smp_countdown = (uint32_t)Q->smp.every;
             const size_t rowi = (size_t)smp_index * Q->R + r;
             smp_index++;
+            if (WLT) {
+                if (lane < qF) q_feat[rowi * qF + lane] = fcur;
+            } else {
             s_feat[lane] = 0.0;
 #pragma unroll
             for (int it = 0; it < NSLOT; ++it)
@@ -2402,6 +2509,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             if (lane < qFce) q_feat[rowi * qF + lane] = base_feat + s_feat[lane];
             if (has_ew && lane == qFce) q_feat[rowi * qF + lane] = base_feat + acc_ew;
             if (has_mu && lane == qFce + (has_ew ? 1 : 0)) q_feat[rowi * qF + lane] = base_feat + acc_mu;
+            }
             if (lane == 0) {
                 Q->smp.H[rowi] = H;
                 Q->smp.acc[rowi] = (uint8_t)last_acc;
@@ -2437,15 +2545,31 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         for (int i = lane; i < P.Npad / 4; i += 64)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
+    if (WLT) {
+        wl_flush_run(); // the unfinished run of the current state
+        wl_log_flush();
+        for (int i = lane; i < P.wl.L; i += 64) {
+            const size_t o = (size_t)r * P.wl.L + i;
+            P.wl.entropy[o] = wl_S[i];
+            P.wl.hist[o] += (long long)wl_cnt[i];
+            P.wl.occur[o] += (long long)wl_cnt[i];
+        }
+        if (lane < P.F) featp[lane] = fcur;
+        if (lane == 0) {
+            P.wl.m[r] = wl_m;
+            P.wl.counter[r] = wl_counter0 + (long long)(uint32_t)P.steps;
+        }
+    } else {
     s_feat[lane] = 0.0;
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it)
         __hip_atomic_fetch_add(&s_feat[sfeat[it]], sfs[it] * acc[it], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
+    }
     if (lane == 0) {
-        if (has_ew) featp[P.Fce] += acc_ew;
-        if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
+        if (has_ew && !WLT) featp[P.Fce] += acc_ew;
+        if (has_mu && !WLT) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
@@ -2499,12 +2623,12 @@ static int launch_lean_nm(smolmc_handle *h, const LeanParams &lp) {
     if (h->cfg.step_type == SMOLMC_STEP_SWAP) return launch_lean_me<NSLOT, MM, SMOLMC_STEP_SWAP>(h, lp);
     return launch_lean_me<NSLOT, MM, SMOLMC_STEP_FLIP>(h, lp);
 }
-template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false>
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool BIAS = false, bool WLT = false>
 static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
     const int wpb = h->lean_wpb;
     const size_t lds = wpb == 8 ? h->lean_lds_wpb8 : h->lean_lds;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = mc_table_kernel<NSLOT, MM, EWM, REPLAY, BIAS>;
+    auto kern = mc_table_kernel<NSLOT, MM, EWM, REPLAY, BIAS, WLT>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -2516,10 +2640,15 @@ static int launch_table_ewm(smolmc_handle *h, const LeanParams &lp) {
 }
 
 
-template <int NSLOT, int MM, bool REPLAY = false, bool BIAS = false>
+template <int NSLOT, int MM, bool REPLAY = false, bool BIAS = false, bool WLT = false>
 static int launch_table_inst(smolmc_handle *h, const LeanParams &lp) {
-    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0, REPLAY, BIAS>(h, lp);
-    return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2, REPLAY, BIAS>(h, lp) : launch_table_ewm<NSLOT, MM, 1, REPLAY, BIAS>(h, lp);
+    if (lp.ew_G == nullptr) return launch_table_ewm<NSLOT, MM, 0, REPLAY, BIAS, WLT>(h, lp);
+    if constexpr (WLT) return launch_table_ewm<NSLOT, MM, 2, REPLAY, BIAS, WLT>(h, lp); // (Wang-Landau: the Ewald term from the field only)
+    else return lp.ew_field ? launch_table_ewm<NSLOT, MM, 2, REPLAY, BIAS>(h, lp) : launch_table_ewm<NSLOT, MM, 1, REPLAY, BIAS>(h, lp);
+}
+// (instantiated in table_wl_n*.hip only)
+template <int NSLOT> static int launch_table_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_inst<NSLOT, 2, false, false, true>(h, lp) : launch_table_inst<NSLOT, 3, false, false, true>(h, lp);
 }
 // (instantiated in table_bias_n*.hip only)
 template <int NSLOT> static int launch_table_bias_nslot(smolmc_handle *h, const LeanParams &lp) {

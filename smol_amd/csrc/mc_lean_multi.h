@@ -1085,8 +1085,12 @@ template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const 
 // ----------------------------------------------------------------------------
 // EWM: 0 = no Ewald term, 1 = potential field in LDS, 2 = in HBM (compile time, see mc_lean_multi_kernel)
 // REPLAY: host-provided step records (see mc_table_kernel)
-template <int NSLOT, int MM, int EWM, bool REPLAY = false>
+// WLT (round 6; multi_table_wl_n*.hip): the Wang-Landau kernel with TableFlip proposals (update_period 1; see
+// mc_table_kernel): the accept rule S[bin] - S[new bin] + a-priori factor (wanglandau.py:197-198), the per-walker
+// state of mc_lean_multi_kernel's WLK variant in place of the accumulator cells.
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool WLT = false>
 __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P) {
+    static_assert(!(WLT && REPLAY), "Wang-Landau TableFlip replays take the universal kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1103,15 +1107,24 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     int *s_tf = (int *)(s_tfw + 16);
     MultiRec *s_rec = (MultiRec *)(s_tfw + 16 + 64);
     const int nrec = NC * NSLOT * 64;
+    // (WLT) feature scale and feature index of every slot record, read on accepted steps only
+    double *s_fs = (double *)(s_rec + nrec);
+    uint32_t *s_ft = (uint32_t *)(s_fs + (WLT ? nrec : 0));
+    unsigned char *shared_end = (unsigned char *)(s_ft + (WLT ? ((nrec + 3) & ~3) : 0));
     // per wave: occupancy | 64 B (species counts) | feature scratch [64] | acc cells | pending cells | phi
+    // (WLT: S [L] | counted steps [L] | log of finished runs [SMOLMC_WLM_LOG][F] instead of the acc cells)
     constexpr bool phi_lds = EWM == 1;
-    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + (size_t)nrec * 16 + (phi_lds ? (size_t)P.ew_nact * 8 : 0);
-    unsigned char *wbase = (unsigned char *)(s_rec + nrec) + (size_t)wave * per_wave;
+    const size_t state_bytes = WLT ? wl_multi_wave_bytes(P.wl.L, P.F, 1) : (size_t)nrec * 8;
+    const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + state_bytes + (size_t)nrec * 8 + (phi_lds ? (size_t)P.ew_nact * 8 : 0);
+    unsigned char *wbase = shared_end + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
     int *s_cnt = (int *)(wbase + P.Nlds);
     double *s_feat = (double *)(wbase + P.Nlds + 64);
     double *s_acc = s_feat + 64;
-    double *s_pend = s_acc + nrec;
+    double *wl_S = s_acc;                                                   // WLT
+    uint32_t *wl_cnt = (uint32_t *)(wl_S + (WLT ? P.wl.L : 0));
+    double *s_rows = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *s_pend = (double *)((unsigned char *)s_acc + state_bytes);
     double *phi = phi_lds ? s_pend + nrec : P.ew_phi + (size_t)r * P.ew_nact;
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     const int D = P.m_ndims;
@@ -1130,6 +1143,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         rec.st8[0] = sl.stride8[0]; rec.st8[1] = sl.stride8[1]; rec.st8[2] = sl.stride8[2];
         rec.w = sl.w;
         s_rec[i] = rec;
+        if (WLT) {
+            s_fs[i] = sl.live ? sl.fs : 0.0;
+            s_ft[i] = sl.feat;
+        }
     }
     const bool live = r < P.R;
     if (live) {
@@ -1138,7 +1155,15 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             *(uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb)) = src[i];
         s_feat[lane] = 0.0;
         if (lane < 16) s_cnt[lane] = 0;
-        for (int i = lane; i < 2 * nrec; i += 64) s_acc[i] = 0.0; // acc + pending cells
+        if (WLT) {
+            for (int i = lane; i < nrec; i += 64) s_pend[i] = 0.0;
+            for (int i = lane; i < P.wl.L; i += 64) {
+                wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
+                wl_cnt[i] = 0u;
+            }
+        } else {
+            for (int i = lane; i < 2 * nrec; i += 64) s_acc[i] = 0.0; // acc + pending cells
+        }
         if (phi_lds)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
     }
@@ -1212,6 +1237,42 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     double acc_mu = 0.0, acc_ew = 0.0;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
+    // ---- Wang-Landau state (WLT; mc_lean_multi_kernel's WLK with update_period 1: see there) ----
+    double fcur = base_feat;  // lane f < F: the walker's current feature vector; H is carried as _current_enthalpy
+    double wl_m = WLT ? P.wl.m[r] : 0.0;
+    int wb = 0;
+    if (WLT) wb = min(max(uni((int)floordiv_exact(H - P.wl.vmin, P.wl.bin)), 0), P.wl.L - 1);
+    const long long wl_counter0 = WLT ? P.wl.counter[r] : 0;
+    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u;
+    uint32_t wl_rem_check = (WLT && wl_check) ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_check)) : 1u; // (0 = no check)
+    uint32_t wl_run_n = 0;
+    int vtag = -1, wl_nlog = 0;
+    const int wl_F = WLT ? P.F : 1;
+    const int wl_k = max(1, min(8, 63 / max(wl_F, 1)));
+    const uint32_t wl_shadow = (uint32_t)((lane % wl_k) * wl_F);
+    const int wl_rd0 = lane < wl_F ? lane : 63, wl_rdstep = lane < wl_F ? wl_F : 0;
+    const bool wl_zero_lane = lane < wl_k * wl_F;
+    const int wl_epi = max(1, 64 / max(wl_F, 1)), wl_lane_e = lane / max(wl_F, 1), wl_lane_f = lane - wl_lane_e * wl_F;
+    auto wl_log_flush = [&]() {
+        const LeanParamsKernarg Q = rare_params();
+        double *grows = Q->wl.meanf + (size_t)r * Q->wl.L * Q->F;
+        const int qF = Q->F;
+        for (int base = 0; base < wl_nlog; base += wl_epi) {
+            const int e = base + wl_lane_e;
+            const int bin = __shfl(vtag, e & 63); // (uniform control flow)
+            if (wl_lane_e < wl_epi && e < wl_nlog)
+                unsafeAtomicAdd(grows + (size_t)bin * qF + wl_lane_f, s_rows[(uint32_t)base * (uint32_t)qF + lane]);
+        }
+        wl_nlog = 0;
+    };
+    auto wl_flush_run = [&]() {
+        if (wl_run_n != 0u) {
+            if (lane < wl_F) s_rows[(uint32_t)wl_nlog * (uint32_t)wl_F + lane] = (double)wl_run_n * fcur;
+            vtag = lane == wl_nlog ? wb : vtag;
+            wl_run_n = 0u;
+            if (++wl_nlog == WLM_LOG) wl_log_flush();
+        }
+    };
     uint32_t smp_countdown = P.smp.every ? (uint32_t)P.smp.every : 0xffffffffu; // (off: cannot reach zero in a launch)
     uint32_t smp_index = 0;
     uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0;
@@ -1907,12 +1968,26 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         const double dEw = has_ew ? ew_uni : 0.0;
         if (has_ew) dH += P.ew_coef * dEw;
         if (has_mu) dH -= dMu;
-        const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
         const double lu = REPLAY ? lu_rp
                                  : __hiloint2double((int)rdlane((uint32_t)__double2hiint(q_logu), l6),
                                                     (int)rdlane((uint32_t)__double2loint(q_logu), l6));
-        const bool accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        bool accepted;
+        int wnb = wb;
+        if (WLT) { // WangLandau._accept_step (wanglandau.py:186-202): exact float64 delta, exact floor division
+            const LeanParamsKernarg Q = rare_params();
+            const double new_h = H + dH, vmin = Q->wl.vmin;
+            accepted = false;
+            if (__ballot(!(new_h < vmin || new_h >= Q->wl.vmax)) != 0ull) {
+                wnb = uni((int)floordiv_exact(new_h - vmin, Q->wl.bin));
+                const double ex = wl_S[wb] - wl_S[wnb] + log_priori; // (:197-198)
+                accepted = __ballot((ex >= 0.0) || (ex > lu)) != 0ull;
+            }
+        } else {
+            const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+            accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        }
         nacc_before = nacc_add;
+        if (WLT && accepted) wl_flush_run(); // the state (bin, features) ends here: its post-steps go to the bin's row
         if (REPLAY) { // what smolmc_replay returns per step (the enthalpy follows the accepted changes)
             if (accepted) H_rp += dH;
             if (lane == 0) {
@@ -1930,7 +2005,12 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 double *cell = s_acc + ((size_t)cls * NSLOT) * 64 + lane;
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it) {
-                    if (accepted) cell[it * 64] += pend[it * 64];
+                    if (WLT) { // (the feature deltas of the step: into the shadow cells, see below)
+                        if (accepted)
+                            __hip_atomic_fetch_add(&s_feat[s_ft[((size_t)cls * NSLOT + it) * 64 + lane] + wl_shadow],
+                                                   s_fs[((size_t)cls * NSLOT + it) * 64 + lane] * pend[it * 64], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    } else if (accepted) cell[it * 64] += pend[it * 64];
                     pend[it * 64] = 0.0;
                 }
             }
@@ -1940,8 +2020,25 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 if (f < nfl) {
                     double *cell = s_acc + ((size_t)tpcls[f] * NSLOT) * 64 + lane;
 #pragma unroll
-                    for (int it = 0; it < NSLOT; ++it) cell[it * 64] += tpd[f][it];
+                    for (int it = 0; it < NSLOT; ++it) {
+                        if (WLT)
+                            __hip_atomic_fetch_add(&s_feat[s_ft[((size_t)tpcls[f] * NSLOT + it) * 64 + lane] + wl_shadow],
+                                                   s_fs[((size_t)tpcls[f] * NSLOT + it) * 64 + lane] * tpd[f][it], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        else cell[it * 64] += tpd[f][it];
+                    }
                 }
+        }
+        if (WLT && accepted) { // _do_accept_step (wanglandau.py:204-220): features, enthalpy and bin follow the step
+            double df = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) df += s_feat[k < wl_k ? wl_rd0 + k * wl_rdstep : 63];
+            if (wl_zero_lane) s_feat[lane] = 0.0;
+            if (has_ew) df += lane == P.Fce ? dEw : 0.0;
+            if (has_mu) df += lane == P.Fce + (has_ew ? 1 : 0) ? dMu : 0.0;
+            fcur += df;
+            H += dH;
+            wb = wnb;
         }
         if (accepted) {
             if (dir >= 0) {
@@ -1975,6 +2072,20 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 occ[lean_swz(s, swa, swm, swb)] = (uint8_t)od;
             }
         }
+        if (WLT) { // WangLandau._do_post_step (wanglandau.py:222-266), accepted or not
+            wl_run_n++;
+            if (lane == 0) { // entropy, histogram and occurrences of the bin (:241-245, update_period 1)
+                __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (++wl_rem_check == wl_check) wl_rem_check = 0u;
+            if (wl_rem_check == 0u) {
+                const LeanParamsKernarg Q = rare_params();
+                const size_t o = (size_t)r * Q->wl.L;
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, nullptr, Q->wl.hist + o, Q->wl.occur + o, Q->wl.L, Q->wl.flat,
+                                               Q->wl.div, wl_m, lane);
+            }
+        }
 
 #ifdef SMOLMC_EXP_PHASES
         { const long long tn = clock64(); ph_acc[4] += tn - ph_t; ph_t = tn; }
@@ -1984,11 +2095,16 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             smp_countdown = (uint32_t)Q->smp.every;
             const size_t row = (size_t)smp_index * Q->R + r;
             smp_index++;
+            const int qF = Q->F, qFce = Q->Fce;
+            double *const q_feat = Q->smp.feat;
+            double Hnow;
+            if (WLT) {
+                if (lane < qF) q_feat[row * qF + lane] = fcur;
+                Hnow = H;
+            } else {
             s_feat[lane] = 0.0;
             double lane_e = 0.0;
             const LeanSlot *q_slots = Q->slots;
-            const int qF = Q->F, qFce = Q->Fce;
-            double *const q_feat = Q->smp.feat;
             for (int i = lane; i < nrec; i += 64) {
                 const LeanSlot sl = q_slots[i];
                 const double v = s_acc[i];
@@ -1999,7 +2115,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             if (lane < qFce) q_feat[row * qF + lane] = base_feat + s_feat[lane];
             if (has_ew && lane == qFce) q_feat[row * qF + lane] = base_feat + acc_ew;
             if (has_mu && lane == qFce + (has_ew ? 1 : 0)) q_feat[row * qF + lane] = base_feat + acc_mu;
-            const double Hnow = H + (wave_sum_all(lane_e) - acc_mu + (has_ew ? Q->ew_coef * acc_ew : 0.0));
+            Hnow = H + (wave_sum_all(lane_e) - acc_mu + (has_ew ? Q->ew_coef * acc_ew : 0.0));
+            }
             if (lane == 0) {
                 Q->smp.H[row] = Hnow;
                 Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
@@ -2026,6 +2143,21 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         for (int i = lane; i < P.Npad / 4; i += 64)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
+    if (WLT) {
+        wl_flush_run(); // the unfinished run of the current state
+        wl_log_flush();
+        for (int i = lane; i < P.wl.L; i += 64) {
+            const size_t o = (size_t)r * P.wl.L + i;
+            P.wl.entropy[o] = wl_S[i];
+            P.wl.hist[o] += (long long)wl_cnt[i];
+            P.wl.occur[o] += (long long)wl_cnt[i];
+        }
+        if (lane < P.F) featp[lane] = fcur;
+        if (lane == 0) {
+            P.wl.m[r] = wl_m;
+            P.wl.counter[r] = wl_counter0 + (long long)nsteps32;
+        }
+    } else {
     s_feat[lane] = 0.0;
     double lane_e = 0.0;
     for (int i = lane; i < nrec; i += 64) {
@@ -2037,9 +2169,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     }
     if (lane < P.Fce) featp[lane] = base_feat + s_feat[lane];
     H += wave_sum_all(lane_e) - acc_mu + (has_ew ? P.ew_coef * acc_ew : 0.0);
+    }
     if (lane == 0) {
-        if (has_ew) featp[P.Fce] += acc_ew;
-        if (has_mu) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
+        if (has_ew && !WLT) featp[P.Fce] += acc_ew;
+        if (has_mu && !WLT) featp[P.Fce + (has_ew ? 1 : 0)] += acc_mu;
         P.enthalpy[r] = H;
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
@@ -2049,11 +2182,11 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 
 #undef key0
 #undef key1
-template <int NSLOT, int MM, bool REPLAY = false> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, bool REPLAY = false, bool WLT = false> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1, REPLAY>
-                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2, REPLAY> : mc_table_multi_kernel<NSLOT, MM, 0, REPLAY>);
+    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1, REPLAY, WLT>
+                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2, REPLAY, WLT> : mc_table_multi_kernel<NSLOT, MM, 0, REPLAY, WLT>);
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -2065,6 +2198,10 @@ template <int NSLOT, int MM, bool REPLAY = false> static int launch_table_multi_
     return 0;
 }
 
+// (instantiated in multi_table_wl_n*.hip only)
+template <int NSLOT> static int launch_table_multi_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2, false, true>(h, lp) : launch_table_multi_inst<NSLOT, 3, false, true>(h, lp);
+}
 // (instantiated in multi_table_replay_n*.hip only)
 template <int NSLOT> static int launch_table_multi_replay_nslot(smolmc_handle *h, const LeanParams &lp) {
     return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2, true>(h, lp) : launch_table_multi_inst<NSLOT, 3, true>(h, lp);

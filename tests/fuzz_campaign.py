@@ -122,8 +122,8 @@ def build_case(rng, profile="any"):
     if table_ok:
         steps += ["table-flip", "table-flip"] + (["table-flip"] * 2 if fast else [])
     step = pick(rng, steps)
-    if fast:  # (Wang-Landau TableFlip runs on the universal kernel: not this profile's subject)
-        kernel = "metropolis" if step == "table-flip" else pick(rng, ["metropolis", "wang-landau", "wang-landau"])
+    if fast:  # (Wang-Landau TableFlip: on the lean table kernel since round 6, part of this profile)
+        kernel = pick(rng, ["metropolis", "wang-landau", "wang-landau"])
     desc.update(kernel=kernel, step=step)
     R = int(rng.integers(1, 4 if big else 7))
     P = sc.size

@@ -36,7 +36,7 @@ def test_pmc_entries_name_kernels_of_this_library():
 
 
 def test_isa_stale_follows_the_machine_code_not_the_comments():
-    name, dig = codeobj.find_kernel("void mc_table_kernel<2, 2, 2, false, false>(LeanParams)")
+    name, dig = codeobj.find_kernel("void mc_table_kernel<2, 2, 2, false, false, false>(LeanParams)")
     fresh = dict(kernel_symbol=name, isa_sha256=dig, csrc_sha256="0" * 64)  # (another tree, same kernel bytes)
     assert not codeobj.isa_stale(fresh)
     assert codeobj.isa_stale(dict(fresh, isa_sha256="1" * 64))

@@ -309,3 +309,113 @@ def test_two_sublattice_table_flip_detailed_balance():
     for k in top:
         p = w[k] / tot_w
         assert counts.get(k, 0) / tot_c == pytest.approx(p, abs=max(0.012, 5 * np.sqrt(p / tot_c)))
+
+
+def _wl_window(tab, occ, seeds, R, nbins=23.5):
+    """A Wang-Landau window the walkers start inside and try to leave: a third of the enthalpy range a hot
+    Metropolis chain of the oracle covers, on either side of the starting enthalpies."""
+    from oracle import oracle as orc
+
+    probe = orc.OracleMC(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP))
+    probe.set_state(occ, seeds, 1.0e4)
+    h0 = probe.get_state()["enthalpy"]
+    probe.run(300)
+    h1 = probe.get_state()["enthalpy"]
+    pad = (max(h0.max(), h1.max()) - min(h0.min(), h1.min())) / 3 + 1e-3
+    lo, hi = h0.min() - pad, h0.max() + pad
+    return capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_TABLE_FLIP, min_enthalpy=lo, max_enthalpy=hi,
+                            bin_size=(hi - lo) / nbins, check_period=97, flatness=0.2)
+
+
+def _wl_table_chain(tab, cfg, occ, seeds, family, monkeypatch):
+    """The lean kernel of `family`, the oracle and the universal kernel (SMOLMC_NO_TABLE_WL) on one Wang-Landau
+    TableFlip chain: occupancies, accept flags, entropies, histograms, occurrences bit-exact, enthalpies / features /
+    per-bin mean features to 1e-10; then a sampled trace against the oracle's states at the sample times."""
+    from oracle import oracle as orc
+    from smol_amd.engine import Engine
+
+    monkeypatch.delenv("SMOLMC_NO_TABLE_WL", raising=False)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    monkeypatch.setenv("SMOLMC_NO_TABLE_WL", "1")
+    univ = Engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_TABLE_WL")
+    assert eng.kernel_info().startswith(family[0]) and family[1] in eng.kernel_info(), eng.kernel_info()
+    assert univ.kernel_info().startswith("universal"), univ.kernel_info()
+    for e in (eng, ora, univ):
+        e.set_state(occ, seeds, 0.0)
+    for chunk in (1, 62, 3, 700, 129, 1105):
+        for e in (eng, ora, univ):
+            e.run(chunk)
+        a, b, c = eng.get_state(), ora.get_state(), univ.get_state()
+        x, y, z = eng.get_wl(), ora.get_wl(), univ.get_wl()
+        for s, w in ((b, y), (c, z)):
+            assert np.array_equal(a["occupancy"], s["occupancy"])
+            assert np.array_equal(a["n_accepted"], s["n_accepted"])
+            assert np.array_equal(a["accepted"], s["accepted"])
+            np.testing.assert_allclose(a["enthalpy"], s["enthalpy"], rtol=1e-10, atol=1e-8)
+            np.testing.assert_allclose(a["features"], s["features"], rtol=1e-10, atol=1e-8)
+            assert np.array_equal(x["histogram"], w["histogram"])
+            assert np.array_equal(x["occurrences"], w["occurrences"])
+            np.testing.assert_allclose(x["entropy"], w["entropy"], rtol=0, atol=0)
+            np.testing.assert_allclose(x["mean_features"], w["mean_features"], rtol=1e-10, atol=1e-8)
+            np.testing.assert_allclose(x["mod_factor"], w["mod_factor"])
+    acc = a["n_accepted"].sum() / a["n_steps"].sum()
+    assert 0.05 < acc < 0.98, acc
+    assert (x["mod_factor"] < 1.0).any()  # the flatness branch fired
+    np.testing.assert_allclose(a["features"], eng.eval_full(a["occupancy"]), rtol=1e-10, atol=1e-7)
+    rows = eng.run_sampled(5, 40)
+    for k in range(5):
+        ora.run(40)
+        b = ora.get_state()
+        assert np.array_equal(rows["accepted"][k], b["accepted"])
+        np.testing.assert_allclose(rows["enthalpy"][k], b["enthalpy"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(rows["features"][k], b["features"], rtol=1e-10, atol=1e-8)
+    y, x = ora.get_wl(), eng.get_wl()
+    assert np.array_equal(x["histogram"], y["histogram"])
+    np.testing.assert_allclose(x["mean_features"], y["mean_features"], rtol=1e-10, atol=1e-8)
+    eng.close()
+    univ.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(coef_scale=0.05),
+    dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05]),
+    dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=True),
+], ids=["ce", "ce+mu", "ce+mu+ewald"])
+@pytest.mark.parametrize("dim", [3, 6])
+def test_wang_landau_table_flip_on_the_lean_table_kernel(dim, kw, monkeypatch):
+    """Wang-Landau with TableFlip proposals (the reference composes any usher with any kernel, kernel/base.py:192-239;
+    the accept rule takes the step's a-priori factor, wanglandau.py:197-198) on mc_table_kernel<..., WLT> (round 6;
+    the universal kernel until then): the oracle's chain on the native stream in launches that start and end inside
+    the 64-step proposal blocks, with flatness checks that fire, steps that leave the window, a sampled trace, and the
+    same chain again from the universal kernel."""
+    sc, tab = _model(dim, **kw)
+    R = 6
+    rng = np.random.default_rng(31)
+    occ = np.array([_neutral_occ(sc, (sc.size & 1) + 2 * (r % 3 + 1), rng) for r in range(R)])
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(7100)
+    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R), occ, seeds, ("lean ", "wl=table"), monkeypatch)
+
+
+@pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
+def test_wang_landau_table_flip_across_two_sublattices(ewald, monkeypatch):
+    """... and with flip vectors that span the cation and the anion sublattice (the shape of the reference's own
+    TableFlip tests, tests/test_moca/test_mcushers.py:199-319) on mc_table_multi_kernel<..., WLT>."""
+    from smol_amd import moca, synth
+
+    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=8, scale=0.02),
+                                               ewald_coefficient=0.05 if ewald else None)
+    table = np.asarray(ens.composition_space(optimize_basis=True, table_ergodic=True).flip_table)
+    tab = ens.make_tables(flip_table=table, swap_weight=0.15)
+    R, P = 6, sc.size
+    rng = np.random.default_rng(13)
+    occ = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # 17 Li+ + 8 Mn3+ + 2 Ti4+ = +49, 22 O2- + 5 F- = -49
+        perm = rng.permutation(P)
+        occ[r, perm[:8]] = 1
+        occ[r, perm[8:10]] = 2
+        occ[r, P + rng.permutation(P)[:5]] = 1
+    seeds = np.arange(R, dtype=np.uint64) + np.uint64(1900)
+    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R), occ, seeds, ("lean-multi", "wl=multi"), monkeypatch)
