@@ -664,6 +664,11 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
         size_t tlen = (size_t)SMAX * SMAX * NTP;
         if ((tlen & 1) == 0) tlen += 1;
         std::vector<double> dt(tlen, 0.0); // table 0 = zeros, used by padded slots
+        // Entries the LDS copy of the tables may take.  8000 (64 KB, two workgroups per CU) until round 6; models between
+        // that and what one workgroup's LDS holds beside the walkers' state (the layouts below decide) ran on mc_kernel
+        // with the tables in L2: measured on five quaternary triplet / quadruplet models of the fuzz campaign at 2048
+        // walkers, 0.39-1.05e9 steps/s there against 0.99-2.43e9 here (tools/time_fuzz_case.py).  SMOLMC_LEAN_DT_MAX: A/B hook.
+        const size_t dt_max = getenv("SMOLMC_LEAN_DT_MAX") ? (size_t)atol(getenv("SMOLMC_LEAN_DT_MAX")) : (size_t)18000;
         std::vector<double> dtk; // KF: correlation-function tables (global memory), see LeanParams::dtk
         std::vector<LeanSlot> ls((size_t)NCLS * NSL * 64);
         memset(ls.data(), 0, ls.size() * sizeof(LeanSlot));
@@ -758,7 +763,7 @@ static int build_mc_tables(smolmc_handle *h, const smolmc_tables *t) {
             L.live = (uint32_t)K;
             L.w = (corr_kf || corr_lazy) ? scale : t->ce_coefs[feat] * scale; // (KF / lazy: the coefficients are folded into the table)
             L.fs = scale;
-            if (dt.size() > 8000u) { ok = false; h->lean_reason = "delta tables beyond 8000 entries (species^(cluster size - 1) x species^2 per distinct table)"; } // keep the LDS tables within budget
+            if (dt.size() > dt_max) { ok = false; h->lean_reason = "delta tables beyond 18000 entries (species^(cluster size - 1) x species^2 per distinct table)"; } // keep the LDS tables within budget
             double dmax = 0.0;
             {
                 const double *D = dt.data() + doff_of[key];
@@ -1702,9 +1707,9 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         h->lean = lean;
         // ---- several classes / sublattices (or > 256 clusters per site): mc_lean_multi_kernel
         const bool table = cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
-        // (MCBias: Fugacity / SquareCharge with flips or swaps; the hyperplane bias and biased
-        // TableFlip take the general kernel)
-        const bool multi_bias_ok = !t->bias_type || cfg->step_type != SMOLMC_STEP_TABLE_FLIP;
+        // (MCBias: every bias type with flips or swaps, and since round 6 with TableFlip: mc_table_multi_kernel<..., BIAS>;
+        // SMOLMC_NO_TABLE_BIAS: A/B switch)
+        const bool multi_bias_ok = !t->bias_type || cfg->step_type != SMOLMC_STEP_TABLE_FLIP || getenv("SMOLMC_NO_TABLE_BIAS") == nullptr;
         // Wang-Landau on this layout (round 5; mc_lean_multi_kernel<..., WLK>): any number of classes the
         // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves.  The
         // Wang-Landau TableFlip: mc_table_multi_kernel<..., WLT> (round 6) with update_period 1 and one correlation
@@ -1717,7 +1722,7 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         if (!lean && h->lean_tables)
             h->lean_reason = (h->lean_kf && !wl) ? "several correlation functions per orbit (KF kernel) on a model outside the single-class lean shape"
                              : !multi_wl_ok ? "Wang-Landau with more than 63 features, or with TableFlip and update_period > 1 / several correlation functions per orbit"
-                             : !multi_bias_ok ? "a bias term with TableFlip"
+                             : !multi_bias_ok ? "environment override (SMOLMC_NO_TABLE_BIAS)"
                              : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
                              : (t->has_ewald && !kp.ew_field) ? "Ewald matrix that does not factorise into site charges (no potential field)"
@@ -2614,6 +2619,9 @@ static int launch_lean(smolmc_handle *h, LeanParams lp, int64_t nsteps) {
     if (h->lean_multi_wl)
         return h->lean_nslot == 2 ? smolmc_launch_multi_wl_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_wl_4(h, lp) : smolmc_launch_multi_wl_8(h, lp));
+    if (h->lean_multi && lp.bias_type && h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP)
+        return h->lean_nslot == 2 ? smolmc_launch_multi_table_bias_2(h, lp)
+                                  : (h->lean_nslot == 4 ? smolmc_launch_multi_table_bias_4(h, lp) : smolmc_launch_multi_table_bias_8(h, lp));
     if (h->lean_multi && lp.bias_type)
         return h->lean_nslot == 2 ? smolmc_launch_multi_bias_2(h, lp)
                                   : (h->lean_nslot == 4 ? smolmc_launch_multi_bias_4(h, lp) : smolmc_launch_multi_bias_8(h, lp));
@@ -3085,7 +3093,7 @@ extern "C" int smolmc_replay(smolmc_handle *h, int64_t nsteps, const int32_t *st
     // site -- valid for the boundary -- takes the universal kernel, which evaluates it flip by flip)
     // (a biased or Wang-Landau TableFlip handle has no REPLAY instantiation: the universal kernel replays its records)
     const bool lean_table_replay = h->lean && table && smolmc_table_replay_available() && nsteps < ((int64_t)1 << 30) && !repeated_site &&
-                                   !(h->lp.bias_type && !h->lean_multi) && h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU;
+                                   !h->lp.bias_type && h->cfg.kernel_type != SMOLMC_KERNEL_WANGLANDAU;
     // (a Flip handle's own kernel takes single flips: records of two flips go to mc_kernel / the universal kernel)
     const bool lean_shape_ok = two_flip_ok && (h->cfg.step_type != SMOLMC_STEP_FLIP || max_flips <= 1);
     const bool lean_replay = h->lean && !want_general && nsteps < ((int64_t)1 << 30) && getenv("SMOLMC_REPLAY_UNIVERSAL") == nullptr &&

@@ -1088,9 +1088,13 @@ template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const 
 // WLT (round 6; multi_table_wl_n*.hip): the Wang-Landau kernel with TableFlip proposals (update_period 1; see
 // mc_table_kernel): the accept rule S[bin] - S[new bin] + a-priori factor (wanglandau.py:197-198), the per-walker
 // state of mc_lean_multi_kernel's WLK variant in place of the accumulator cells.
-template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool WLT = false>
+// BIAS (round 6; multi_table_bias_n*.hip): an MCBias term in the exponent (metropolis.py:43-44), one pair table per
+// sublattice and bias row, bias_pair[row][sublattice][old * 8 + new] (see mc_table_kernel).
+template <int NSLOT, int MM, int EWM, bool REPLAY = false, bool WLT = false, bool BIAS = false>
 __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P) {
     static_assert(!(WLT && REPLAY), "Wang-Landau TableFlip replays take the universal kernel");
+    static_assert(!(WLT && BIAS), "Cannot apply bias to Wang-Landau simulation (wanglandau.py:127-128)");
+    static_assert(!(BIAS && REPLAY), "biased TableFlip replays take the universal kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1235,6 +1239,12 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
 #define key0 opaque_u32(key0_)
 #define key1 opaque_u32(key1_)
     double acc_mu = 0.0, acc_ew = 0.0;
+    // MCBias: running bias and, for the square biases, the running A_k . n - b_k of every hyperplane
+    const int tb_type = BIAS ? P.bias_type : 0;
+    const int tb_rows = (tb_type && tb_type != SMOLMC_BIAS_FUGACITY) ? P.bias_rows : 0;
+    double tb_acc = 0.0, tb_chg[SMOLMC_MAX_BIAS_ROWS];
+#pragma unroll
+    for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] = (BIAS && k < tb_rows) ? P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] : 0.0;
     double *featp = P.features + (size_t)r * P.F;
     const double base_feat = lane < P.F ? featp[lane] : 0.0;
     // ---- Wang-Landau state (WLT; mc_lean_multi_kernel's WLK with update_period 1: see there) ----
@@ -1973,6 +1983,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                                                     (int)rdlane((uint32_t)__double2loint(q_logu), l6));
         bool accepted;
         int wnb = wb;
+        double dB = 0.0, dQ[SMOLMC_MAX_BIAS_ROWS] = {0.0, 0.0, 0.0, 0.0};
         if (WLT) { // WangLandau._accept_step (wanglandau.py:186-202): exact float64 delta, exact floor division
             const LeanParamsKernarg Q = rare_params();
             const double new_h = H + dH, vmin = Q->wl.vmin;
@@ -1983,8 +1994,41 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
                 accepted = __ballot((ex >= 0.0) || (ex > lu)) != 0ull;
             }
         } else {
-            const double exponent = nbeta * dH + log_priori; // metropolis.py:41-42
+            // compute_bias_change of the step against the occupancy before it (kernel/base.py:307-311, bias.py:75-93):
+            // the flips of a table step touch distinct sites; lane f reads the pair entry of flip f
+            if (BIAS && tb_type && nfl >= 1) {
+                const LeanParamsKernarg Q = rare_params();
+                const uint32_t pidx = lane < nfl ? (uint32_t)(vfsub * 64 + vold * 8 + vnew) : 0u;
+                if (tb_type == SMOLMC_BIAS_FUGACITY) {
+                    const double x = Q->bias_pair[pidx];
+                    for (int f = 0; f < nfl; ++f) // (in the order of the flips, as the reference adds them)
+                        dB += __hiloint2double((int)rdlane((uint32_t)__double2hiint(x), f), (int)rdlane((uint32_t)__double2loint(x), f));
+                } else {
+                    double sq_new = 0.0, sq_old = 0.0;
+                    const double pen = Q->bias_pen;
+                    const int stride = Q->bias_row_stride;
+#pragma unroll
+                    for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                        if (k < tb_rows) {
+                            const double x = Q->bias_pair[(size_t)k * stride + pidx];
+                            double xs = 0.0;
+                            for (int f = 0; f < nfl; ++f)
+                                xs += __hiloint2double((int)rdlane((uint32_t)__double2hiint(x), f), (int)rdlane((uint32_t)__double2loint(x), f));
+                            dQ[k] = xs;
+                            const double cn = tb_chg[k] + xs;
+                            sq_old += tb_chg[k] * tb_chg[k];
+                            sq_new += cn * cn;
+                        }
+                    dB = -pen * sq_new - (-pen * sq_old);
+                }
+            }
+            const double exponent = nbeta * dH + log_priori + dB; // metropolis.py:41-44
             accepted = __ballot((exponent >= 0.0) || (exponent > lu)) != 0ull;
+        }
+        if (BIAS && accepted) {
+            tb_acc += dB;
+#pragma unroll
+            for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] += dQ[k];
         }
         nacc_before = nacc_add;
         if (WLT && accepted) wl_flush_run(); // the state (bin, features) ends here: its post-steps go to the bin's row
@@ -2120,6 +2164,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             if (lane == 0) {
                 Q->smp.H[row] = Hnow;
                 Q->smp.acc[row] = (uint8_t)(nacc_add != nacc_before);
+                if (BIAS && Q->smp_bias_off) (Q->smp.H + Q->smp_bias_off)[row] = Q->bias[r] + tb_acc; // trace.bias
             }
             if (Q->smp.occ) {
                 const int qNpad = Q->Npad;
@@ -2177,16 +2222,22 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
         P.nsteps[r] = step;
         P.nacc[r] += nacc_add;
         if (nsteps32) P.last_acc[r] = (uint8_t)(nacc_add != nacc_before);
+        if (BIAS && tb_type) {
+            P.bias[r] += tb_acc;
+#pragma unroll
+            for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k)
+                if (k < tb_rows) P.charge[(size_t)r * SMOLMC_MAX_BIAS_ROWS + k] = tb_chg[k];
+        }
     }
 }
 
 #undef key0
 #undef key1
-template <int NSLOT, int MM, bool REPLAY = false, bool WLT = false> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
+template <int NSLOT, int MM, bool REPLAY = false, bool WLT = false, bool BIAS = false> static int launch_table_multi_inst(smolmc_handle *h, const LeanParams &lp) {
     const unsigned wpb = (unsigned)h->waves_per_block_lean;
     const unsigned grid = (unsigned)((h->R + wpb - 1) / wpb);
-    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1, REPLAY, WLT>
-                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2, REPLAY, WLT> : mc_table_multi_kernel<NSLOT, MM, 0, REPLAY, WLT>);
+    auto kern = lp.ew_field == 1 ? mc_table_multi_kernel<NSLOT, MM, 1, REPLAY, WLT, BIAS>
+                                 : (lp.ew_field == 2 ? mc_table_multi_kernel<NSLOT, MM, 2, REPLAY, WLT, BIAS> : mc_table_multi_kernel<NSLOT, MM, 0, REPLAY, WLT, BIAS>);
     if (h->lean_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lean_lds));
@@ -2198,6 +2249,10 @@ template <int NSLOT, int MM, bool REPLAY = false, bool WLT = false> static int l
     return 0;
 }
 
+// (instantiated in multi_table_bias_n*.hip only)
+template <int NSLOT> static int launch_table_multi_bias_nslot(smolmc_handle *h, const LeanParams &lp) {
+    return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2, false, false, true>(h, lp) : launch_table_multi_inst<NSLOT, 3, false, false, true>(h, lp);
+}
 // (instantiated in multi_table_wl_n*.hip only)
 template <int NSLOT> static int launch_table_multi_wl_nslot(smolmc_handle *h, const LeanParams &lp) {
     return h->lean_mm == 2 ? launch_table_multi_inst<NSLOT, 2, false, true>(h, lp) : launch_table_multi_inst<NSLOT, 3, false, true>(h, lp);

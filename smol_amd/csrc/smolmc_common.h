@@ -771,6 +771,9 @@ int smolmc_launch_table_wl_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_table_wl_2(smolmc_handle *h, const LeanParams &lp); // ... on the multi-class layout (multi_table_wl_n*.hip)
 int smolmc_launch_multi_table_wl_4(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_multi_table_wl_8(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_table_bias_2(smolmc_handle *h, const LeanParams &lp); // TableFlip + MCBias on the multi-class layout (multi_table_bias_n*.hip)
+int smolmc_launch_multi_table_bias_4(smolmc_handle *h, const LeanParams &lp);
+int smolmc_launch_multi_table_bias_8(smolmc_handle *h, const LeanParams &lp);
 int smolmc_launch_lean_4(smolmc_handle *h, const LeanParams &lp);
 // replay instantiations of the TableFlip / biased lean kernels (0: those replays take the universal / general kernel)
 #ifndef SMOLMC_HAVE_TABLE_REPLAY

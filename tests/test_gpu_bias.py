@@ -353,3 +353,78 @@ def test_table_flip_with_a_bias_on_the_lean_table_kernel(rocksalt, kind, ewald, 
     np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
     eng.close()
     univ.close()
+
+
+@pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
+@pytest.mark.parametrize("kind", ["fugacity", "square-charge", "square-hyperplane"])
+def test_table_flip_with_a_bias_across_two_sublattices(kind, ewald, monkeypatch):
+    """... and with a flip table that spans the cation and the anion sublattice (the shape of the reference's own
+    TableFlip tests, tests/test_moca/test_mcushers.py:199-319): mc_table_multi_kernel<..., BIAS> (round 6), one pair
+    table per sublattice and bias row.  Same chain as the oracle and as the universal kernel, trace.bias equals a
+    recomputation, the bias column of the device ring is recorded in-kernel."""
+    from oracle import oracle as orc
+
+    for k in ("SMOLMC_FORCE_GENERAL", "SMOLMC_FORCE_UNIVERSAL", "SMOLMC_NO_TABLE_BIAS"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.build_cluster_model(synth.rocksalt_prim(anion_charges=(-2.0, -1.0)), {2: 4.5})
+    sc = synth.build_supercell(model, [3, 3, 3])
+    ens = moca.Ensemble.from_cluster_expansion(sc, synth.random_coefs(model, seed=8, scale=0.02),
+                                               ewald_coefficient=0.05 if ewald else None)
+    cat, ani = (sl.species for sl in ens.active_sublattices)
+    if kind == "fugacity":
+        bias = moca.FugacityBias(ens.sublattices, [{cat[0]: 0.15, cat[1]: 0.25, cat[2]: 0.6}, {ani[0]: 0.7, ani[1]: 0.3}])
+    elif kind == "square-charge":
+        bias = moca.SquareChargeBias(ens.sublattices, penalty=0.05)
+    else:
+        bias = moca.SquareHyperplaneBias(ens.sublattices, [[0, 1, 0, 0, 0], [1, 0, -1, 0, 1]], [sc.size // 3, 1], penalty=0.05)
+    table = np.asarray(ens.composition_space(optimize_basis=True, table_ergodic=True).flip_table)
+    tab = ens.make_tables(flip_table=table, swap_weight=0.15)
+    tab.set_bias(bias.bias_type, bias._table, bias.penalty, intercepts=getattr(bias, "intercepts", None))
+    R, P = 6, sc.size
+    rng = np.random.default_rng(13)
+    occ0 = np.zeros((R, sc.num_sites), dtype=np.int32)
+    for r in range(R):  # 17 Li+ + 8 Mn3+ + 2 Ti4+ = +49, 22 O2- + 5 F- = -49
+        perm = rng.permutation(P)
+        occ0[r, perm[:8]] = 1
+        occ0[r, perm[8:10]] = 2
+        occ0[r, P + rng.permutation(P)[:5]] = 1
+    cfg = capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP)
+    seeds = np.arange(1, R + 1, dtype=np.uint64) * np.uint64(7919)
+    temps = np.linspace(1500.0, 9000.0, R)
+    eng, ora = Engine(tab, cfg), orc.OracleMC(tab, cfg)
+    assert eng.kernel_info().startswith("lean-multi"), eng.kernel_info()
+    monkeypatch.setenv("SMOLMC_NO_TABLE_BIAS", "1")
+    univ = Engine(tab, cfg)
+    monkeypatch.delenv("SMOLMC_NO_TABLE_BIAS")
+    assert univ.kernel_info().startswith("universal"), univ.kernel_info()
+    for e in (eng, ora, univ):
+        e.set_state(occ0, seeds, temps)
+    np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    for chunk in (1, 16, 62, 400, 700):
+        for e in (eng, ora, univ):
+            e.run(chunk)
+        a, b, c = eng.get_state(), ora.get_state(), univ.get_state()
+        assert np.array_equal(a["occupancy"], b["occupancy"])
+        assert np.array_equal(a["n_accepted"], b["n_accepted"])
+        np.testing.assert_allclose(a["enthalpy"], b["enthalpy"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(a["features"], b["features"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+        assert np.array_equal(a["occupancy"], c["occupancy"])
+    np.testing.assert_allclose(eng.get_bias(), [bias.compute_bias(o) for o in a["occupancy"]], rtol=RTOL, atol=1e-8)
+    assert 0 < a["n_accepted"].sum() < a["n_steps"].sum()
+    s = eng.run_sampled(3, 40, occupancy=True, bias=True)
+    for j in range(3):
+        ora.run(40)
+        assert np.array_equal(s["occupancy"][j], ora.get_state()["occupancy"])
+        np.testing.assert_allclose(s["bias"][j], ora.get_bias(), rtol=RTOL, atol=ATOL)
+    st = np.full((R, 1, capi.STEP_ROW), -1, dtype=np.int32)  # (a replayed record: the universal kernel takes it)
+    acc_r, H_r = eng.replay(st, np.full((R, 1), 0.5))
+    acc_o, H_o = ora.replay(st, np.full((R, 1), 0.5))
+    assert np.array_equal(acc_r, acc_o)
+    np.testing.assert_allclose(H_r, H_o, rtol=RTOL, atol=1e-8)
+    eng.run(50)
+    ora.run(50)
+    assert np.array_equal(eng.get_state()["occupancy"], ora.get_state()["occupancy"])
+    np.testing.assert_allclose(eng.get_bias(), ora.get_bias(), rtol=RTOL, atol=ATOL)
+    eng.close()
+    univ.close()
