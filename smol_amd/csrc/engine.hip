@@ -1479,9 +1479,12 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         if (h->lazy_tables) {
             if (dev_alloc(h, (size_t)h->R * 2, &h->d_lazy_scal)) return bail(1);
         }
+        // (... the Wang-Landau TableFlip kernel, mc_table_kernel<..., WLT>, also keeps running means: any update_period)
+        const bool wl_table = wl && cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         bool lean = h->lean_tables && Fk <= 64 &&
-                    (!wl || (cfg->wl_update_period == 1 && h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
-                             getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr && (getenv("SMOLMC_WL_PLAIN_ONLY") == nullptr || (!t->has_ewald && !t->has_mu)))) &&
+                    (!wl || (((cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) || (wl_table && cfg->wl_update_period < (1ll << 31))) &&
+                             h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
+                             (getenv("SMOLMC_WL_PLAIN_ONLY") == nullptr || (!t->has_ewald && !t->has_mu)))) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
                     h->lean_nslot <= 4 && getenv("SMOLMC_FORCE_GENERAL") == nullptr;
         int sbase = -1, nact = 0, nc = 0;
@@ -1604,12 +1607,12 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
                 lp.wl.check = kp.wl_check; lp.wl.update = kp.wl_update;
                 lp.wl.entropy = kp.wl_entropy; lp.wl.hist = kp.wl_hist; lp.wl.occur = kp.wl_occur;
                 lp.wl.meanf = kp.wl_meanf; lp.wl.m = kp.wl_m; lp.wl.counter = kp.wl_counter;
-                lp.wl.sum_mode = 1;
+                lp.wl.sum_mode = table_wl ? kp.wl_sum_mode : 1;
             }
             // (Wang-Landau: per-bin records and the cached rows of per-bin feature sums, mc_wl.h)
             h->lean_lds = ((size_t)lp.dt_len + 24) * 8 +
                           (size_t)4 * (lp.Nlds + 64 * 8 + 64 +
-                                       (table_wl ? wl_multi_wave_bytes(h->L, h->F, 1) // (mc_table_kernel<..., WLT>: the multi-class kernel's state)
+                                       (table_wl ? wl_multi_wave_bytes(h->L, h->F, kp.wl_sum_mode) // (mc_table_kernel<..., WLT>: the multi-class kernel's state)
                                         : wl     ? std::max(wl_lean_bins_bytes(h->L) + (size_t)SMOLMC_WL_ROWS * h->F * 8,
                                                             // (round 2's variant inside mc_lean_kernel, A/B switch: 24-byte records)
                                                             getenv("SMOLMC_WL_V2") ? (size_t)h->L * 24 : (size_t)0)
@@ -1712,16 +1715,16 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         const bool multi_bias_ok = !t->bias_type || cfg->step_type != SMOLMC_STEP_TABLE_FLIP || getenv("SMOLMC_NO_TABLE_BIAS") == nullptr;
         // Wang-Landau on this layout (round 5; mc_lean_multi_kernel<..., WLK>): any number of classes the
         // layout takes and any update_period -- what mc_wl_kernel (one class, update_period 1) leaves.  The
-        // Wang-Landau TableFlip: mc_table_multi_kernel<..., WLT> (round 6) with update_period 1 and one correlation
-        // function per orbit, the universal kernel otherwise.  SMOLMC_NO_WL_MULTI, SMOLMC_NO_TABLE_WL: A/B switches.
+        // Wang-Landau TableFlip: mc_table_multi_kernel<..., WLT> (round 6) with one correlation function per orbit, the
+        // universal kernel otherwise.  SMOLMC_NO_WL_MULTI, SMOLMC_NO_TABLE_WL: A/B switches.
         const int wl_sum_mode = (cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) ? 1 : 0;
-        const bool multi_table_wl_ok = wl_sum_mode && !h->lean_kf && getenv("SMOLMC_NO_TABLE_WL") == nullptr;
+        const bool multi_table_wl_ok = !h->lean_kf && getenv("SMOLMC_NO_TABLE_WL") == nullptr;
         const bool multi_wl_ok = !wl || ((!table || multi_table_wl_ok) && h->F <= 63 && cfg->wl_check_period < (1ll << 31) &&
                                          cfg->wl_update_period < (1ll << 31) && getenv("SMOLMC_NO_WL_MULTI") == nullptr);
         // (why a model with lean tables runs neither lean family: the first condition that fails, for smolmc_kernel_info)
         if (!lean && h->lean_tables)
             h->lean_reason = (h->lean_kf && !wl) ? "several correlation functions per orbit (KF kernel) on a model outside the single-class lean shape"
-                             : !multi_wl_ok ? "Wang-Landau with more than 63 features, or with TableFlip and update_period > 1 / several correlation functions per orbit"
+                             : !multi_wl_ok ? "Wang-Landau with more than 63 features, or with TableFlip and several correlation functions per orbit"
                              : !multi_bias_ok ? "environment override (SMOLMC_NO_TABLE_BIAS)"
                              : Fk > 64 ? "more than 64 features"
                              : t->n_sublattices > 4 ? "more than 4 active sublattices"
@@ -2414,7 +2417,7 @@ extern "C" int smolmc_kernel_info(const smolmc_handle *h, char *buf, int n) {
             snprintf(buf + used, (size_t)n - used, (h->lean_multi_wl || h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP) ? "" : (getenv("SMOLMC_WL_V2") ? " wl=v2" : " wl=v3"));
         if (h->lean && !h->lean_multi && h->cfg.kernel_type == SMOLMC_KERNEL_WANGLANDAU && h->cfg.step_type == SMOLMC_STEP_TABLE_FLIP &&
             strlen(buf) + 16 < (size_t)n) // (mc_table_kernel<..., WLT>)
-            strncat(buf, " wl=table", (size_t)n - strlen(buf) - 1);
+            strncat(buf, h->lp.wl.sum_mode ? " wl=table" : " wl=table-mean", (size_t)n - strlen(buf) - 1);
         if (is_lazy(h) && strlen(buf) + 16 < (size_t)n) strncat(buf, " lazy-features", (size_t)n - strlen(buf) - 1);
         if (h->lean_multi_wl && strlen(buf) + 24 < (size_t)n) // (the Wang-Landau variant of the multi-class kernel)
             snprintf(buf + strlen(buf), (size_t)n - strlen(buf), h->lp.wl.sum_mode ? " wl=multi" : " wl=multi-mean");

@@ -1348,6 +1348,9 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
     return tot;
 }
 
+// (defined in mc_lean_multi.h, which the translation units of the Wang-Landau table kernels include)
+__device__ __noinline__ void wl_multi_row_swap(double *grows, double *crow, int old_bin, int new_bin, int F, int lane, int sum_mode);
+
 // ----------------------------------------------------------------------------
 // TableFlip kernel (charge-neutral semigrand steps, smol/moca/kernel/mcusher.py:397-711)
 // for lean-eligible models: one site class, one contiguous active sublattice, interaction
@@ -1372,7 +1375,7 @@ __device__ __forceinline__ double table_log_count_ratio(const double *lnt, int u
 // usher with any bias (kernel/base.py:192-239) and until now TableFlip with a bias ran on the universal kernel.  The
 // pair tables of the biased lean kernels (bias_pair[row][old * 8 + new]) are read lane-parallel, lane f = flip f; the
 // flips of a table step touch distinct sites, so "the last flip of a site counts" (bias.py:75-93) is every flip.
-// WLT (round 6; table_wl_n*.hip): the Wang-Landau kernel (kernel/wanglandau.py:175-266, update_period 1) with TableFlip
+// WLT (round 6; table_wl_n*.hip): the Wang-Landau kernel (kernel/wanglandau.py:175-266, any update_period) with TableFlip
 // proposals -- the reference composes any usher with any kernel and until now this pair ran on the universal kernel.
 // The accept rule is S[bin] - S[new bin] + the a-priori factor of the step (wanglandau.py:197-198); the per-walker
 // state (entropies, counted steps, the log of finished runs) is mc_lean_multi_kernel's (mc_lean_multi.h: WLK) behind
@@ -1393,7 +1396,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     double *s_dt = (double *)smem;
     double *s_mu = s_dt + P.dt_len; // 8 doubles
     const size_t per_wave = (size_t)P.Nlds + 64 * 8 + 64 + (ew_field ? (size_t)P.ew_nact * 8 : 0) +
-                            (WLT ? wl_multi_wave_bytes(P.wl.L, P.F, 1) : 0);
+                            (WLT ? wl_multi_wave_bytes(P.wl.L, P.F, P.wl.sum_mode) : 0);
     double *s_q = s_mu + 8, *s_dg = s_mu + 16; // field mode: charge / diagonal term per code
     // block-shared copies of the flip table (<= 8 vectors x 8 codes), its weights and ln(k)
     double *s_tfw = s_mu + 24;
@@ -1404,10 +1407,13 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     double *s_feat = (double *)(wbase + P.Nlds);
     int *s_cnt = (int *)(s_feat + 64); // species counts of the walker [<= 8]
     double *phi = (double *)(wbase + P.Nlds + 64 * 8 + 64); // Ewald potential field [ew_nact]
-    // WLT: S f64 [L] | counted steps u32 [L] | log of SMOLMC_WLM_LOG finished runs [F] (wl_multi_wave_bytes)
+    // WLT: S f64 [L] | counted steps u32 [L] | update_period 1 (sums): log of SMOLMC_WLM_LOG finished runs [F] -- else
+    // (running means): occurrences at launch start f64 [L] and SMOLMC_WL_ROWS cached rows [F] (wl_multi_wave_bytes)
+    const int wl_sum_mode = WLT ? P.wl.sum_mode : 1;
     double *wl_S = phi + (ew_field ? P.ew_nact : 0);
     uint32_t *wl_cnt = (uint32_t *)(wl_S + (WLT ? P.wl.L : 0));
-    double *s_rows = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *wl_occb = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *s_rows = wl_occb + ((WLT && !wl_sum_mode) ? P.wl.L : 0);
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
     const bool has_mu = P.mu_row != nullptr;
     for (int i = threadIdx.x; i < P.dt_len; i += blockDim.x) s_dt[i] = P.dt[i];
@@ -1428,11 +1434,15 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
         if (lane < 16) s_cnt[lane] = 0;
         if (ew_field)
             for (int j = lane; j < P.ew_nact; j += 64) phi[j] = P.ew_phi[(size_t)r * P.ew_nact + j];
-        if (WLT)
+        if (WLT) {
             for (int i = lane; i < P.wl.L; i += 64) {
                 wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
                 wl_cnt[i] = 0u;
+                if (!wl_sum_mode) wl_occb[i] = (double)P.wl.occur[(size_t)r * P.wl.L + i];
             }
+            if (!wl_sum_mode)
+                for (int i = lane; i < SMOLMC_WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
+        }
     }
     __syncthreads();
     if (!live) return;
@@ -1551,12 +1561,25 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
     int wb = 0;               // current bin (walkers start inside the window: smolmc_set_state)
     if (WLT) wb = min(max(uni((int)floordiv_exact(H - P.wl.vmin, P.wl.bin)), 0), P.wl.L - 1);
     const long long wl_counter0 = WLT ? P.wl.counter[r] : 0;
-    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u;
+    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u, wl_upd = WLT ? (uint32_t)P.wl.update : 1u;
     // (check period 0 = no device-side check: the remainder starts at 1 and cannot wrap to 0 inside a launch of < 2^30 steps)
     uint32_t wl_rem_check = (WLT && wl_check) ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_check)) : 1u;
-    uint32_t wl_run_n = 0;    // post-steps of the current (bin, features) state not yet in its row
-    int vtag = -1;            // lane i < SMOLMC_WLM_LOG: the bin of log entry i
+    uint32_t wl_rem_upd = WLT ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_upd)) : 0u;
+    uint32_t wl_run_n = 0;    // sums: post-steps of the current (bin, features) state not yet in its row
+    int vtag = -1;            // sums: lane i < SMOLMC_WLM_LOG: the bin of log entry i; means: lane i < SMOLMC_WL_ROWS: the bin cached in row i
     int wl_nlog = 0;
+    // running means (update_period > 1): the cached row of a bin (direct-mapped; the row a slot held goes back to HBM)
+    auto wl_row_of = [&](const int bin) -> double * {
+        const int slot = bin & (SMOLMC_WL_ROWS - 1);
+        const int tag = (int)rdlane((uint32_t)vtag, slot);
+        double *crow = s_rows + (uint32_t)slot * (uint32_t)P.F;
+        if (tag != bin) {
+            const LeanParamsKernarg Q = rare_params();
+            wl_multi_row_swap(Q->wl.meanf + (size_t)r * Q->wl.L * Q->F, crow, tag, bin, Q->F, lane, 0);
+            vtag = lane == slot ? bin : vtag;
+        }
+        return crow;
+    };
     // shadow copies of the feature cells for the accepted steps' deltas (see mc_wl.h): lane l adds into copy l % wl_k,
     // a reader sums the copies; cell 63 is never written (the address of "no copy")
     const int wl_F = WLT ? P.F : 1;
@@ -2402,7 +2425,7 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             if (WLT) {
                 // the state (bin, features) ends here: its post-steps go to the bin's row; then features and bin follow
                 // the step (_do_accept_step, wanglandau.py:204-220; the enthalpy below with the Metropolis kernels')
-                wl_flush_run();
+                if (wl_sum_mode) wl_flush_run();
 #pragma unroll
                 for (int it = 0; it < NSLOT; ++it)
                     __hip_atomic_fetch_add(&s_feat[sfeat[it] + wl_shadow], sfs[it] * pend[it], __ATOMIC_RELAXED,
@@ -2464,17 +2487,27 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
 #endif
         last_acc = accepted ? 1 : 0;
         if (WLT) { // WangLandau._do_post_step (wanglandau.py:222-266), accepted or not
-            wl_run_n++;
-            if (lane == 0) { // entropy, histogram and occurrences of the bin (:241-245, update_period 1)
-                __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (wl_sum_mode) {
+                wl_run_n++;
+            } else { // running mean with total = occurrences[bin] as they are now (:233-239)
+                double *crow = wl_row_of(wb);
+                const double total = wl_occb[wb] + (double)wl_cnt[wb];
+                const double inv = 1.0 / (total + 1.0);
+                if (lane < P.F) crow[lane] = inv * (fcur + total * crow[lane]);
+            }
+            if (++wl_rem_upd == wl_upd) { // entropy, histogram, occurrences every update_period steps (:241-245)
+                wl_rem_upd = 0u;
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
             if (++wl_rem_check == wl_check) wl_rem_check = 0u;
             if (wl_rem_check == 0u) {
                 const LeanParamsKernarg Q = rare_params();
                 const size_t o = (size_t)r * Q->wl.L;
-                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, nullptr, Q->wl.hist + o, Q->wl.occur + o, Q->wl.L, Q->wl.flat,
-                                               Q->wl.div, wl_m, lane);
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, wl_sum_mode ? nullptr : wl_occb, Q->wl.hist + o, Q->wl.occur + o,
+                                               Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
             }
         }
 #ifndef SMOLMC_NO_SETPRIO
@@ -2546,8 +2579,16 @@ __global__ void __launch_bounds__(512) mc_table_kernel(const LeanParams P) { // 
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
     if (WLT) {
-        wl_flush_run(); // the unfinished run of the current state
-        wl_log_flush();
+        if (wl_sum_mode) {
+            wl_flush_run(); // the unfinished run of the current state
+            wl_log_flush();
+        } else {
+            for (int slot = 0; slot < SMOLMC_WL_ROWS; ++slot) { // cached rows (running means) back to HBM
+                const int tag = (int)rdlane((uint32_t)vtag, slot);
+                if (tag >= 0 && lane < P.F)
+                    P.wl.meanf[((size_t)r * P.wl.L + tag) * P.F + lane] = s_rows[(uint32_t)slot * (uint32_t)P.F + lane];
+            }
+        }
         for (int i = lane; i < P.wl.L; i += 64) {
             const size_t o = (size_t)r * P.wl.L + i;
             P.wl.entropy[o] = wl_S[i];

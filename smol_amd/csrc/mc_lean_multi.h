@@ -1085,7 +1085,7 @@ template <int NSLOT> static int launch_multi_bias_nslot(smolmc_handle *h, const 
 // ----------------------------------------------------------------------------
 // EWM: 0 = no Ewald term, 1 = potential field in LDS, 2 = in HBM (compile time, see mc_lean_multi_kernel)
 // REPLAY: host-provided step records (see mc_table_kernel)
-// WLT (round 6; multi_table_wl_n*.hip): the Wang-Landau kernel with TableFlip proposals (update_period 1; see
+// WLT (round 6; multi_table_wl_n*.hip): the Wang-Landau kernel with TableFlip proposals (any update_period; see
 // mc_table_kernel): the accept rule S[bin] - S[new bin] + a-priori factor (wanglandau.py:197-198), the per-walker
 // state of mc_lean_multi_kernel's WLK variant in place of the accumulator cells.
 // BIAS (round 6; multi_table_bias_n*.hip): an MCBias term in the exponent (metropolis.py:43-44), one pair table per
@@ -1118,7 +1118,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     // per wave: occupancy | 64 B (species counts) | feature scratch [64] | acc cells | pending cells | phi
     // (WLT: S [L] | counted steps [L] | log of finished runs [SMOLMC_WLM_LOG][F] instead of the acc cells)
     constexpr bool phi_lds = EWM == 1;
-    const size_t state_bytes = WLT ? wl_multi_wave_bytes(P.wl.L, P.F, 1) : (size_t)nrec * 8;
+    const int wl_sum_mode = WLT ? P.wl.sum_mode : 1;
+    const size_t state_bytes = WLT ? wl_multi_wave_bytes(P.wl.L, P.F, wl_sum_mode) : (size_t)nrec * 8;
     const size_t per_wave = (size_t)P.Nlds + 64 + 64 * 8 + state_bytes + (size_t)nrec * 8 + (phi_lds ? (size_t)P.ew_nact * 8 : 0);
     unsigned char *wbase = shared_end + (size_t)wave * per_wave;
     uint8_t *occ = wbase;
@@ -1127,7 +1128,8 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     double *s_acc = s_feat + 64;
     double *wl_S = s_acc;                                                   // WLT
     uint32_t *wl_cnt = (uint32_t *)(wl_S + (WLT ? P.wl.L : 0));
-    double *s_rows = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *wl_occb = (double *)((unsigned char *)wl_cnt + (WLT ? (((size_t)P.wl.L * 4 + 7) & ~(size_t)7) : 0));
+    double *s_rows = wl_occb + ((WLT && !wl_sum_mode) ? P.wl.L : 0);
     double *s_pend = (double *)((unsigned char *)s_acc + state_bytes);
     double *phi = phi_lds ? s_pend + nrec : P.ew_phi + (size_t)r * P.ew_nact;
     const int swa = P.swz_a, swm = P.swz_m, swb = P.swz_b;
@@ -1164,7 +1166,10 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             for (int i = lane; i < P.wl.L; i += 64) {
                 wl_S[i] = P.wl.entropy[(size_t)r * P.wl.L + i];
                 wl_cnt[i] = 0u;
+                if (!wl_sum_mode) wl_occb[i] = (double)P.wl.occur[(size_t)r * P.wl.L + i];
             }
+            if (!wl_sum_mode)
+                for (int i = lane; i < SMOLMC_WL_ROWS * P.F; i += 64) s_rows[i] = 0.0;
         } else {
             for (int i = lane; i < 2 * nrec; i += 64) s_acc[i] = 0.0; // acc + pending cells
         }
@@ -1253,10 +1258,22 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
     int wb = 0;
     if (WLT) wb = min(max(uni((int)floordiv_exact(H - P.wl.vmin, P.wl.bin)), 0), P.wl.L - 1);
     const long long wl_counter0 = WLT ? P.wl.counter[r] : 0;
-    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u;
+    const uint32_t wl_check = WLT ? (uint32_t)P.wl.check : 0u, wl_upd = WLT ? (uint32_t)P.wl.update : 1u;
     uint32_t wl_rem_check = (WLT && wl_check) ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_check)) : 1u; // (0 = no check)
+    uint32_t wl_rem_upd = WLT ? (uint32_t)uni((int)(wl_counter0 % (long long)wl_upd)) : 0u;
     uint32_t wl_run_n = 0;
     int vtag = -1, wl_nlog = 0;
+    auto wl_row_of = [&](const int bin) -> double * { // running means: the cached row of a bin (see mc_lean_multi_kernel)
+        const int slot = bin & (SMOLMC_WL_ROWS - 1);
+        const int tag = (int)rdlane((uint32_t)vtag, slot);
+        double *crow = s_rows + (uint32_t)slot * (uint32_t)P.F;
+        if (tag != bin) {
+            const LeanParamsKernarg Q = rare_params();
+            wl_multi_row_swap(Q->wl.meanf + (size_t)r * Q->wl.L * Q->F, crow, tag, bin, Q->F, lane, 0);
+            vtag = lane == slot ? bin : vtag;
+        }
+        return crow;
+    };
     const int wl_F = WLT ? P.F : 1;
     const int wl_k = max(1, min(8, 63 / max(wl_F, 1)));
     const uint32_t wl_shadow = (uint32_t)((lane % wl_k) * wl_F);
@@ -2031,7 +2048,7 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             for (int k = 0; k < SMOLMC_MAX_BIAS_ROWS; ++k) tb_chg[k] += dQ[k];
         }
         nacc_before = nacc_add;
-        if (WLT && accepted) wl_flush_run(); // the state (bin, features) ends here: its post-steps go to the bin's row
+        if (WLT && accepted && wl_sum_mode) wl_flush_run(); // the state (bin, features) ends here: its post-steps go to the bin's row
         if (REPLAY) { // what smolmc_replay returns per step (the enthalpy follows the accepted changes)
             if (accepted) H_rp += dH;
             if (lane == 0) {
@@ -2117,17 +2134,27 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             }
         }
         if (WLT) { // WangLandau._do_post_step (wanglandau.py:222-266), accepted or not
-            wl_run_n++;
-            if (lane == 0) { // entropy, histogram and occurrences of the bin (:241-245, update_period 1)
-                __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (wl_sum_mode) {
+                wl_run_n++;
+            } else { // running mean with total = occurrences[bin] as they are now (:233-239)
+                double *crow = wl_row_of(wb);
+                const double total = wl_occb[wb] + (double)wl_cnt[wb];
+                const double inv = 1.0 / (total + 1.0);
+                if (lane < P.F) crow[lane] = inv * (fcur + total * crow[lane]);
+            }
+            if (++wl_rem_upd == wl_upd) { // entropy, histogram, occurrences every update_period steps (:241-245)
+                wl_rem_upd = 0u;
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(&wl_S[wb], wl_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&wl_cnt[wb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
             if (++wl_rem_check == wl_check) wl_rem_check = 0u;
             if (wl_rem_check == 0u) {
                 const LeanParamsKernarg Q = rare_params();
                 const size_t o = (size_t)r * Q->wl.L;
-                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, nullptr, Q->wl.hist + o, Q->wl.occur + o, Q->wl.L, Q->wl.flat,
-                                               Q->wl.div, wl_m, lane);
+                wl_m = wl_multi_flatness_check(wl_S, wl_cnt, wl_sum_mode ? nullptr : wl_occb, Q->wl.hist + o, Q->wl.occur + o,
+                                               Q->wl.L, Q->wl.flat, Q->wl.div, wl_m, lane);
             }
         }
 
@@ -2189,8 +2216,16 @@ __global__ void __launch_bounds__(512) mc_table_multi_kernel(const LeanParams P)
             dst[i] = *(const uint32_t *)(occ + lean_swz(4 * i, swa, swm, swb));
     }
     if (WLT) {
-        wl_flush_run(); // the unfinished run of the current state
-        wl_log_flush();
+        if (wl_sum_mode) {
+            wl_flush_run(); // the unfinished run of the current state
+            wl_log_flush();
+        } else {
+            for (int slot = 0; slot < SMOLMC_WL_ROWS; ++slot) { // cached rows (running means) back to HBM
+                const int tag = (int)rdlane((uint32_t)vtag, slot);
+                if (tag >= 0 && lane < P.F)
+                    P.wl.meanf[((size_t)r * P.wl.L + tag) * P.F + lane] = s_rows[(uint32_t)slot * (uint32_t)P.F + lane];
+            }
+        }
         for (int i = lane; i < P.wl.L; i += 64) {
             const size_t o = (size_t)r * P.wl.L + i;
             P.wl.entropy[o] = wl_S[i];

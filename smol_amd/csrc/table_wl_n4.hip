@@ -1,5 +1,5 @@
 // mc_table_kernel<4, MM, EWM, false, false, WLT = true>: Wang-Landau with TableFlip proposals on the single-class lean layout
-#include "mc_lean.h"
+#include "mc_lean_multi.h"
 
 int smolmc_launch_table_wl_4(smolmc_handle *h, const LeanParams &lp) {
     return launch_table_wl_nslot<4>(h, lp);

@@ -311,7 +311,7 @@ def test_two_sublattice_table_flip_detailed_balance():
         assert counts.get(k, 0) / tot_c == pytest.approx(p, abs=max(0.012, 5 * np.sqrt(p / tot_c)))
 
 
-def _wl_window(tab, occ, seeds, R, nbins=23.5):
+def _wl_window(tab, occ, seeds, R, nbins=23.5, update_period=1):
     """A Wang-Landau window the walkers start inside and try to leave: a third of the enthalpy range a hot
     Metropolis chain of the oracle covers, on either side of the starting enthalpies."""
     from oracle import oracle as orc
@@ -324,7 +324,7 @@ def _wl_window(tab, occ, seeds, R, nbins=23.5):
     pad = (max(h0.max(), h1.max()) - min(h0.min(), h1.min())) / 3 + 1e-3
     lo, hi = h0.min() - pad, h0.max() + pad
     return capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_TABLE_FLIP, min_enthalpy=lo, max_enthalpy=hi,
-                            bin_size=(hi - lo) / nbins, check_period=97, flatness=0.2)
+                            bin_size=(hi - lo) / nbins, check_period=97, flatness=0.2, update_period=update_period)
 
 
 def _wl_table_chain(tab, cfg, occ, seeds, family, monkeypatch):
@@ -382,23 +382,26 @@ def _wl_table_chain(tab, cfg, occ, seeds, family, monkeypatch):
     dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05]),
     dict(coef_scale=0.05, mu=[0.1, -0.2, 0.05], ewald=True),
 ], ids=["ce", "ce+mu", "ce+mu+ewald"])
-@pytest.mark.parametrize("dim", [3, 6])
-def test_wang_landau_table_flip_on_the_lean_table_kernel(dim, kw, monkeypatch):
+@pytest.mark.parametrize("dim,update_period", [(3, 1), (6, 1), (3, 3), (6, 2)], ids=["3^3", "6^3", "3^3-update3", "6^3-update2"])
+def test_wang_landau_table_flip_on_the_lean_table_kernel(dim, update_period, kw, monkeypatch):
     """Wang-Landau with TableFlip proposals (the reference composes any usher with any kernel, kernel/base.py:192-239;
     the accept rule takes the step's a-priori factor, wanglandau.py:197-198) on mc_table_kernel<..., WLT> (round 6;
     the universal kernel until then): the oracle's chain on the native stream in launches that start and end inside
     the 64-step proposal blocks, with flatness checks that fire, steps that leave the window, a sampled trace, and the
-    same chain again from the universal kernel."""
+    same chain again from the universal kernel.  update_period > 1: entropies / histograms every few steps and the
+    per-bin mean features as running means in a cache of rows (wanglandau.py:233-245), as mc_lean_multi_kernel's WLK."""
     sc, tab = _model(dim, **kw)
     R = 6
     rng = np.random.default_rng(31)
     occ = np.array([_neutral_occ(sc, (sc.size & 1) + 2 * (r % 3 + 1), rng) for r in range(R)])
     seeds = np.arange(R, dtype=np.uint64) + np.uint64(7100)
-    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R), occ, seeds, ("lean ", "wl=table"), monkeypatch)
+    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R, update_period=update_period), occ, seeds,
+                    ("lean ", "wl=table" + ("-mean" if update_period > 1 else "")), monkeypatch)
 
 
+@pytest.mark.parametrize("update_period", [1, 3])
 @pytest.mark.parametrize("ewald", [False, True], ids=["ce", "ce+ewald"])
-def test_wang_landau_table_flip_across_two_sublattices(ewald, monkeypatch):
+def test_wang_landau_table_flip_across_two_sublattices(ewald, update_period, monkeypatch):
     """... and with flip vectors that span the cation and the anion sublattice (the shape of the reference's own
     TableFlip tests, tests/test_moca/test_mcushers.py:199-319) on mc_table_multi_kernel<..., WLT>."""
     from smol_amd import moca, synth
@@ -418,4 +421,5 @@ def test_wang_landau_table_flip_across_two_sublattices(ewald, monkeypatch):
         occ[r, perm[8:10]] = 2
         occ[r, P + rng.permutation(P)[:5]] = 1
     seeds = np.arange(R, dtype=np.uint64) + np.uint64(1900)
-    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R), occ, seeds, ("lean-multi", "wl=multi"), monkeypatch)
+    _wl_table_chain(tab, _wl_window(tab, occ, seeds, R, update_period=update_period), occ, seeds,
+                    ("lean-multi", "wl=multi" + ("-mean" if update_period > 1 else "")), monkeypatch)
