@@ -277,3 +277,71 @@ def test_config5_full_size_properties(record_property):
     assert_enthalpy_rel(sa["enthalpy"], full @ a.natural_parameters, "config5_running_vs_from_scratch", record_property)
     # neighbouring rungs of a 2048-step geometric ladder overlap almost completely
     assert 0.8 < rex_a.acceptance.mean() <= 1.0
+
+
+def test_config5_model_under_wang_landau_table_flip(record_property):
+    """The model of BASELINE configs[4] (12^3 ternary rocksalt, 3456 sites, Ewald, charge-neutral TableFlip) under the
+    Wang-Landau kernel -- the usher x kernel pair the reference composes (kernel/base.py:192-239, wanglandau.py:186-266)
+    and round 6 moved onto mc_table_kernel<..., WLT>: 256 walkers at full size.  An oracle spot check of four walkers
+    (occupancies, accept flags, entropies, histograms bit-exact; enthalpies to 1e-10 relative), then the size-independent
+    identities of every walker: histogram == occurrences == steps counted while no flatness check fired, entropy == m x
+    occurrences, charge neutrality, the composition on the flip direction, the running trace against a from-scratch
+    evaluation, chunking invariance."""
+    from oracle import oracle as orc
+    from smol_amd import workloads
+
+    wl = workloads.config5()
+    sc, tab, N = wl.sc, wl.tables, wl.sc.num_sites
+    R, P = 256, sc.size
+    occ, seeds = wl.occupancy[:R], wl.seeds[:R]
+    probe = Engine(tab, capi.make_config(R, capi.KERNEL_METROPOLIS, capi.STEP_TABLE_FLIP))
+    probe.set_state(occ, seeds, 2000.0)
+    h0 = probe.get_state()["enthalpy"]
+    probe.close()
+    lo, hi = h0.min() - 40.0, h0.max() + 40.0
+    cfg = capi.make_config(R, capi.KERNEL_WANGLANDAU, capi.STEP_TABLE_FLIP, min_enthalpy=lo, max_enthalpy=hi,
+                           bin_size=(hi - lo) / 200.0, check_period=10 ** 9)
+    a, b = Engine(tab, cfg), Engine(tab, cfg)
+    assert a.kernel_info().startswith("lean ") and "wl=table" in a.kernel_info(), a.kernel_info()
+    pick = np.array([0, 85, 170, R - 1])
+    ora = orc.OracleMC(tab, capi.make_config(len(pick), capi.KERNEL_WANGLANDAU, capi.STEP_TABLE_FLIP, min_enthalpy=lo,
+                                             max_enthalpy=hi, bin_size=(hi - lo) / 200.0, check_period=10 ** 9))
+    for e in (a, b):
+        e.set_state(occ, seeds, 0.0)
+    ora.set_state(occ[pick], seeds[pick], 0.0)
+    a.run(500)
+    ora.run(500)
+    sa, so = a.get_state(), ora.get_state()
+    wa, wo = a.get_wl(), ora.get_wl()
+    assert np.array_equal(sa["occupancy"][pick], so["occupancy"])
+    assert np.array_equal(sa["n_accepted"][pick], so["n_accepted"])
+    assert_enthalpy_rel(sa["enthalpy"][pick], so["enthalpy"], "config5_wl_table_vs_oracle", record_property)
+    assert np.array_equal(wa["histogram"][pick], wo["histogram"])
+    np.testing.assert_allclose(wa["entropy"][pick], wo["entropy"], rtol=0, atol=0)
+    np.testing.assert_allclose(wa["mean_features"][pick], wo["mean_features"], rtol=1e-10, atol=1e-6)
+    a.run(2956)  # one sweep in all
+    for chunk in (1, 1455, 2000):
+        b.run(chunk)
+    sa, sb = a.get_state(), b.get_state()
+    wa, wb = a.get_wl(), b.get_wl()
+    assert checksum(sa["occupancy"]) == checksum(sb["occupancy"])
+    assert checksum(wa["histogram"]) == checksum(wb["histogram"])
+    np.testing.assert_allclose(wa["entropy"], wb["entropy"], rtol=0, atol=0)
+    assert np.all(sa["n_steps"] == 3456)
+    assert np.all(wa["histogram"].sum(axis=1) == 3456) and np.array_equal(wa["histogram"], wa["occurrences"])
+    np.testing.assert_allclose(wa["entropy"], wa["mod_factor"][:, None] * wa["occurrences"], rtol=1e-12)
+    charge = np.array([1.0, 3.0, 4.0])
+    assert np.all(charge[sa["occupancy"][:, :P]].sum(axis=1) == 2.0 * P)
+    assert np.all(sa["occupancy"][:, P:] == 0)
+    n1 = np.stack([(sa["occupancy"][:, :P] == c).sum(axis=1) for c in range(3)], axis=1)
+    n0 = np.stack([(occ[:, :P] == c).sum(axis=1) for c in range(3)], axis=1)
+    kdir = (n1 - n0)[:, 0]
+    assert np.array_equal(n1 - n0, kdir[:, None] * np.array([[1, -3, 2]]))
+    acc = sa["n_accepted"].sum() / sa["n_steps"].sum()
+    assert 0.05 < acc < 0.99, acc
+    full = a.eval_full(sa["occupancy"])
+    np.testing.assert_allclose(sa["features"], full, rtol=RTOL, atol=1e-6)
+    assert_enthalpy_rel(sa["enthalpy"], full @ a.natural_parameters, "config5_wl_table_running_vs_from_scratch", record_property)
+    assert np.all((sa["enthalpy"] >= lo) & (sa["enthalpy"] < hi))
+    a.close()
+    b.close()
