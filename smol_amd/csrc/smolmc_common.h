@@ -326,11 +326,49 @@ __device__ __forceinline__ void field_sweep_gx_groups(double *pp, const uint32_t
         pp[64 * u] = x;
     }
 }
+// A lattice of fewer than U full groups (na < 64 U: fewer than 576 changeable sites for the batches of nine) in masked
+// batches of US slots, entry 64 (g0 + u) + lane where it exists (the other lanes re-read the last entry and store
+// nothing): three round trips -- E8, table entries, phi -- per batch.  Until round 6 such lattices went group by group, two
+// dependent round trips each (the reference's LiNiO2 model in a 6^3 cell, seven groups: 3.4e8 Wang-Landau steps/s against
+// 5.1e8 in the 8^3 cell; the 8^3 ternary rocksalt of config 3, eight groups: 7 % behind 12^3 instead of ahead).  Batches of
+// FOUR slots in a loop: one batch of nine, inlined beside the large lattices' batches, cost THEIR kernels registers (config 5
+// at 12^3: 4 -> 30 vector spills, 10.27 -> 10.58 ms per sweep; out of line the call convention cost more still).
+template <int NF, int US>
+__device__ __forceinline__ void field_sweep_gx_small(double *phi, const uint32_t *E8, const unsigned char *gx, int lane, int na,
+                                                     const uint32_t (&s8)[NF], const double (&dq)[NF]) {
+    for (int j0 = lane; j0 - lane < na; j0 += 64 * US) { // (uniform trip count)
+        uint32_t e[US];
+        double v[US][NF], pv[US];
+#pragma unroll
+        for (int u = 0; u < US; ++u) e[u] = E8[min(j0 + 64 * u, na - 1)];
+#pragma unroll
+        for (int u = 0; u < US; ++u)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) v[u][f] = *(const double *)(gx + (size_t)(e[u] + s8[f]));
+#pragma unroll
+        for (int u = 0; u < US; ++u) pv[u] = phi[min(j0 + 64 * u, na - 1)];
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            double x = pv[u];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) x = fma(dq[f], v[u][f], x);
+            if (j0 + 64 * u < na) phi[j0 + 64 * u] = x;
+        }
+    }
+}
 template <int NF, int U, int NB>
 __device__ __forceinline__ void field_sweep_gx_sized(double *phi, const uint32_t *E8, const unsigned char *gx, int lane,
                                                      int na, const uint32_t (&s8)[NF], const double (&dq)[NF], int gstart = 0) {
     const int ngf = na >> 6; // full groups of 64 entries
     int g = gstart;          // (groups below gstart: done by the caller, see field_sweep_gx_pre27)
+#ifndef SMOLMC_NO_SMALL_SWEEP // A/B switch (tools/build_variant.sh)
+    // (flips and swaps only: the three- and four-flip sweeps of the TableFlip kernels keep the group-by-group form -- those
+    // kernels sit at 256 VGPRs, and the extra batch moved their spills: config 5 at 12^3 lost 1 % for 23 % at 8^3)
+    if (NF <= 2 && __builtin_expect(gstart == 0 && ngf < U, 0)) { // (uniform)
+        field_sweep_gx_small<NF, 4>(phi, E8, gx, lane, na, s8, dq);
+        return;
+    }
+#endif
     // Chunks of up to NB batches of U groups: the E8 entries of the whole chunk are fetched first, then the
     // batches run, each one round trip to the tables.  When fewer than U groups are left the last batch is
     // shifted back so that it ends on the last full group; the groups it shares with the batch before are
