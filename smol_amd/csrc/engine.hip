@@ -1480,9 +1480,9 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
             if (dev_alloc(h, (size_t)h->R * 2, &h->d_lazy_scal)) return bail(1);
         }
         // (... the Wang-Landau TableFlip kernel, mc_table_kernel<..., WLT>, also keeps running means: any update_period)
-        const bool wl_table = wl && cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
+        const bool table_wl = wl && cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         bool lean = h->lean_tables && Fk <= 64 &&
-                    (!wl || (((cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) || (wl_table && cfg->wl_update_period < (1ll << 31))) &&
+                    (!wl || (((cfg->wl_update_period == 1 && getenv("SMOLMC_WL_RUNNING_MEAN") == nullptr) || (table_wl && cfg->wl_update_period < (1ll << 31))) &&
                              h->F <= 63 && cfg->wl_check_period < (1ll << 31) && // (cell 63 of the feature scratch is the kernel's zero)
                              (getenv("SMOLMC_WL_PLAIN_ONLY") == nullptr || (!t->has_ewald && !t->has_mu)))) &&
                     (!t->has_ewald || kp.ew_compact) && t->n_sublattices == 1 && h->lean_ncls == 1 &&
@@ -1523,7 +1523,6 @@ static int create_impl(const smolmc_tables *t, const smolmc_config *cfg, smolmc_
         std::vector<double> bias_pair((size_t)64 * SMOLMC_MAX_BIAS_ROWS, 0.0);
         // the table kernels take at most 8 flip vectors: larger tables run on the universal kernel
         // (Wang-Landau TableFlip: mc_table_kernel<..., WLT> since round 6; SMOLMC_NO_TABLE_WL: A/B switch)
-        const bool table_wl = wl && cfg->step_type == SMOLMC_STEP_TABLE_FLIP;
         if (lean && cfg->step_type == SMOLMC_STEP_TABLE_FLIP && (t->n_flip_vectors > 8 || (wl && getenv("SMOLMC_NO_TABLE_WL") != nullptr)))
             lean = false;
         // several correlation functions per orbit: plain Metropolis flip / swap variants only
